@@ -1,0 +1,278 @@
+/*
+ * recnn_hip.h -- C ABI of librecnn_hip.so: the MI355X (gfx950) implementation of the RecNN
+ * DDPG/TD3 inner training step.
+ *
+ * The reference (awarebayes/RecNN) is pure Python and has no FFI; the "drop-in boundary" is
+ * its Python API, mirrored by the `recnn_amd` package.  This header is the native boundary
+ * underneath: every entry point below replaces one group of reference Python/ATen calls and
+ * is what a maintainer of the reference would bind with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative RECNN_E_* code or a positive hipError_t;
+ *     `recnn_last_error()` returns a human-readable message for the calling thread.
+ *   - all pointers are DEVICE pointers unless the parameter name starts with `h_`.
+ *   - `stream` is a `hipStream_t` passed as void* (NULL = the null stream).  All work is
+ *     stream-ordered; nothing synchronises the host unless stated.
+ *   - no ownership is transferred: callers allocate every buffer (the Python host uses torch
+ *     for device memory); the engine object only records pointers.
+ *   - "tc" buffers hold the compute type of the engine: float (RECNN_F32) or bfloat16
+ *     (RECNN_BF16, fp32 accumulate, fp32 master weights).
+ *
+ * Reference lines each group replaces are cited as `recnn/...py:lines` (relative to the
+ * upstream repository root).
+ */
+#ifndef RECNN_HIP_H
+#define RECNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RECNN_ABI_VERSION 1
+
+enum {
+  RECNN_OK = 0,
+  RECNN_E_INVALID = -1,   /* bad argument (null pointer, unsupported size, misalignment) */
+  RECNN_E_STATE = -2,     /* call order violated (e.g. step before bind) */
+  RECNN_E_UNSUPPORTED = -3
+};
+
+enum { RECNN_F32 = 0, RECNN_BF16 = 1 };
+
+/* dropout mask source for the train-mode networks */
+enum {
+  RECNN_MASK_NONE = 0,     /* no dropout (eval) */
+  RECNN_MASK_HASH = 1,     /* in-kernel counter-based generator keyed by (seed, step, stream, row, col) */
+  RECNN_MASK_EXTERNAL = 2  /* uint8 keep-masks supplied by the caller (parity tests) */
+};
+
+int recnn_abi_version(void);
+const char* recnn_last_error(void);
+/* sizeof() of an ABI struct: 0 recnn_gemm_args, 1 recnn_engine_config, 2 recnn_hyper,
+ * 3 recnn_engine_sizes (lets a binding verify its declarations); -1 if unknown. */
+int64_t recnn_abi_sizeof(int which);
+/* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
+void recnn_tune_gather_rows(int rows_per_workgroup);
+
+/* =====================================================================================
+ * 1. Replay sampler + embedding gather
+ *    replaces recnn/data/utils.py:161-187 (prepare_batch_static_size: rolling_window +
+ *    concatenate) and recnn/data/utils.py:51-81 (batch_tensor_embeddings: emb[items], view,
+ *    cat, done scatter).  Integer/copy work: bit-exact.
+ *
+ *    Replay store (device resident CSR): items int32[sum L] (dense item ids, time-sorted per
+ *    user), ratings float[sum L], user_off int64[n_store_users+1].
+ * ===================================================================================== */
+
+/* row_off[0..n_users] = exclusive prefix sum of max(L_u - frame, 0) over the batch's users.
+ * row_off[n_users] is the total row count of the batch. */
+int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_users, int frame,
+                     int32_t* row_off, void* stream);
+
+/* Builds rows [0, rows) of the batch.  Output row r of user u at window t:
+ *   state[r]      = [emb(i_t .. i_{t+F-1}) | r_t .. r_{t+F-1}]          (F*E + F floats)
+ *   next_state[r] = [emb(i_{t+1} .. i_{t+F}) | r_{t+1} .. r_{t+F}]
+ *   action[r]     = emb(i_{t+F}),  reward[r] = r_{t+F},  done[r] = (t == L_u - F - 1)
+ * ld_* are row strides in floats (>= row width); rows must be 8-byte aligned, 16-byte
+ * aligned rows take the vector path.  `rows` may be smaller than row_off[n_users]
+ * (fixed-row batches). */
+int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
+                       const int32_t* batch_users, const int32_t* row_off, int n_users, int rows,
+                       int frame, int emb_dim, const float* table,
+                       float* state, int64_t ld_state, float* next_state, int64_t ld_next,
+                       float* action, int64_t ld_action, float* reward, float* done, void* stream);
+
+/* Packs a caller-made canonical batch (reference layout, utils.py:265-276 get_base_batch)
+ * into the engine's packed rows: xs[r] = [action | state | 0-pad], xn[r] = [<next action
+ * slot> | next_state | 0-pad].  Used when the batch did not come from recnn_frame_gather. */
+int recnn_pack_batch(const float* state, int64_t ld_state, const float* action, int64_t ld_action,
+                     const float* next_state, int64_t ld_next, int rows, int state_dim, int action_dim,
+                     float* xs, float* xn, int64_t ld_x, void* stream);
+
+/* =====================================================================================
+ * 2. Dense layers (MFMA GEMMs) -- single-problem launchers used by the module-level
+ *    forward/backward and by the kernel unit tests.  The fused step (section 4) launches
+ *    the same kernels through grouped descriptors.
+ *    replaces recnn/nn/models.py:66-73 and :207-213 (addmm/relu/dropout) and their autograd
+ *    backward (mm, threshold_backward, dropout mul, bias sum).
+ * ===================================================================================== */
+
+typedef struct recnn_gemm_args {
+  int dtype;              /* RECNN_F32 | RECNN_BF16: compute type tc */
+  int M, N;               /* output rows / cols */
+  /* contraction segment 0 and optional segment 1 (accumulated into the same tile) */
+  const void* A[2];       /* fwd/dx: [M, lda] (k contiguous).  dw: [Kc, lda] (m = row index) */
+  const void* B[2];       /* fwd: [N, ldb] (k contiguous).  dx/dw: [Kc, ldb]                 */
+  int64_t lda[2], ldb[2];
+  int K[2];               /* contraction length per segment; K[1] = 0 if unused.  Must be a
+                             multiple of 64 for fwd/dx (zero padded operands); for dw it is the
+                             number of valid rows (any value). */
+  int a_f32[2];           /* segment's A operand is float in memory although tc is bf16 */
+  int b_f32[2];           /* same for B (dw of layer 1: B = packed fp32 batch rows) */
+  /* epilogue */
+  void* C; int64_t ldc; int c_f32;
+  const float* bias;      /* fwd: [N] or NULL */
+  int relu;               /* fwd */
+  int mask_mode;          /* fwd: RECNN_MASK_* */
+  const uint8_t* mask; int64_t ld_mask;      /* external keep mask [M, ld_mask] */
+  uint32_t seed, stream_id; const int32_t* step_ptr;   /* hash mask key (step read from device) */
+  const float* addend; int64_t ld_add; float add_clip; /* fwd: C += clamp(addend, +-add_clip) (TD3 noise) */
+  const void* yref; int64_t ldy; float dx_scale;       /* dx: C = acc * dx_scale * [yref > 0]; yref NULL = plain */
+  float* colsum;          /* dx: per-row-tile column sums, float[ceil(M/64)][N] (bias gradients) */
+  int dw_splits;          /* dw: number of K splits; slab s written at C + s*dw_slab_stride */
+  int64_t dw_slab_stride;
+  int dw_valid_cols;      /* dw: columns >= this are not stored */
+  int dw_col_rot;         /* dw: stored column = (col + rot) mod valid_cols */
+} recnn_gemm_args;
+
+/* C[M,N] = epi( sum_seg A_seg[M,K] * B_seg[N,K]^T ) */
+int recnn_gemm_fwd(const recnn_gemm_args* h_args, void* stream);
+/* C[M,N] = epi( A[M,Kc] * B[Kc,N] )            (dX = dZ * W) */
+int recnn_gemm_dx(const recnn_gemm_args* h_args, void* stream);
+/* C[M,N] = A[Kc,M]^T * B[Kc,N], split over Kc  (dW = dZ^T * X) */
+int recnn_gemm_dw(const recnn_gemm_args* h_args, void* stream);
+
+/* Writes the keep-mask the RECNN_MASK_HASH generator produces for (seed, step, stream_id)
+ * into out[M, N] (uint8).  Lets tests feed the in-kernel masks to the CPU oracle. */
+int recnn_hash_mask_dump(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N,
+                         uint8_t* out, void* stream);
+
+/* =====================================================================================
+ * 3. Flat-arena optimizer / soft-update kernels
+ *    replaces torch.optim.Adam.step (the optimizer the reference's users inject,
+ *    recnn/nn/update/misc.py:44, ddpg.py:93, td3.py:97,101,134), the clip quirk
+ *    torch.nn.utils.clip_grad_norm_(params, -1, 1) (ddpg.py:92, td3.py:133) and
+ *    recnn/utils/misc.py:1-5 (soft_update).
+ * ===================================================================================== */
+
+/* target = target*(1-tau) + net*tau over n floats (operand order as the reference). */
+int recnn_soft_update_flat(float* target, const float* net, int64_t n, float tau, void* stream);
+
+/* One Adam step over a flat fp32 arena: p, m, v updated in place from g * grad_scale.
+ * step_t is the 1-based step count (bias correction). */
+int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step_t, float grad_scale, void* stream);
+
+/* out[0] = sum |g| over n floats (deterministic two-pass reduction; scratch >= 1024 floats). */
+int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, float* out, void* stream);
+
+/* =====================================================================================
+ * 4. The fused DDPG / TD3 step engine
+ *    replaces recnn/nn/update/ddpg.py:8-104, recnn/nn/update/misc.py:10-55,
+ *    recnn/nn/update/td3.py:8-150 for nets = Actor/Critic (recnn/nn/models.py) and the
+ *    Adam optimizer, including the soft target update.
+ * ===================================================================================== */
+
+typedef struct recnn_engine recnn_engine;
+
+enum { RECNN_ALGO_DDPG = 0, RECNN_ALGO_TD3 = 1 };
+
+/* network slots inside an engine */
+enum {
+  RECNN_NET_POLICY = 0, RECNN_NET_TARGET_POLICY = 1,
+  RECNN_NET_VALUE1 = 2, RECNN_NET_TARGET_VALUE1 = 3,
+  RECNN_NET_VALUE2 = 4, RECNN_NET_TARGET_VALUE2 = 5,
+  RECNN_NET_COUNT = 6
+};
+
+typedef struct recnn_engine_config {
+  int algo;            /* RECNN_ALGO_* */
+  int dtype;           /* RECNN_F32 | RECNN_BF16 */
+  int state_dim;       /* S = F*E + F (1290) */
+  int action_dim;      /* A (128) */
+  int hidden;          /* H (256) */
+  int max_rows;        /* batch capacity */
+  int mask_mode;       /* RECNN_MASK_* for the learning nets */
+  uint32_t seed;
+  int device;          /* hip device ordinal */
+} recnn_engine_config;
+
+typedef struct recnn_hyper {
+  float gamma, min_value, max_value;   /* DDPG clamps the TD target; TD3 passes -inf/+inf */
+  float soft_tau;
+  int policy_every;                    /* policy_step / policy_update */
+  float noise_std, noise_clip;         /* TD3 */
+  /* Adam, [0] = policy optimizer, [1] = value optimizer(s) */
+  float lr[2], beta1[2], beta2[2], eps[2], weight_decay[2];
+} recnn_hyper;
+
+/* Sizes (in bytes) of the buffers the caller must allocate for an engine. */
+typedef struct recnn_engine_sizes {
+  int64_t master_floats_actor, master_floats_critic;  /* canonical flat parameter arenas */
+  int64_t workspace_bytes;                            /* everything else, one allocation */
+  int64_t ld_x;                                       /* packed batch row stride (floats) */
+  int64_t x_rows;                                     /* rows to allocate for xs / xn */
+} recnn_engine_sizes;
+
+int recnn_engine_query(const recnn_engine_config* h_cfg, recnn_engine_sizes* h_out);
+
+/* `workspace` must be zero-initialised, 256-byte aligned, workspace_bytes long. */
+int recnn_engine_create(const recnn_engine_config* h_cfg, void* workspace, recnn_engine** h_out);
+void recnn_engine_destroy(recnn_engine* e);
+
+/* Bind the canonical fp32 arenas of one network: params / grads / Adam moments, each a flat
+ * array laid out [w1 | b1 | w2 | b2 | w3 | b3] in torch's [out,in] row-major layout.
+ * grads/m/v may be NULL for target networks. */
+int recnn_engine_bind_net(recnn_engine* e, int net, float* params, float* grads, float* adam_m, float* adam_v);
+
+/* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
+int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);
+
+/* External inputs for parity runs: masks uint8[n_masks][max_rows][hidden] (6 DDPG, 8 TD3, in the
+ * reference's consumption order), noise float[max_rows][action_dim] (TD3, unclipped). */
+int recnn_engine_bind_external(recnn_engine* e, const uint8_t* masks, const float* noise);
+
+int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h_hyper);
+
+/* Re-derive the compute-layout shadow of a network from its canonical arena (call after the
+ * canonical parameters were changed by anything other than the engine). */
+int recnn_engine_refresh(recnn_engine* e, int net, void* stream);
+
+/* Set optimizer step counters (1-based count of steps already taken). */
+int recnn_engine_set_counters(recnn_engine* e, int policy_t, int value1_t, int value2_t, int step);
+
+/* One full update on the bound batch (rows valid rows).
+ *   learn      : 0 = losses only (reference learn=False), 1 = update
+ *   step       : the caller's step counter (policy step iff step % policy_every == 0)
+ *   fused_optim: 1 = run Adam + soft update inside; 0 = stop after gradients (phases below)
+ * Losses are written to the device loss buffer; fetch with recnn_engine_read_losses. */
+int recnn_engine_step(recnn_engine* e, int rows, int learn, int step, void* stream);
+
+/* Phase API (external optimizers, data-parallel all-reduce between phases):
+ *   value_grads  : TD target, critic forward/backward -> value grads in the bound grad arenas
+ *   value_apply  : Adam on the critic(s) (+ fused soft update when `soft`), shadows refreshed
+ *   policy_grads : actor forward, critic forward, policy loss; with `backward` also the actor
+ *                  gradient (reduced into the bound grad arena, NOT yet clipped)
+ *   policy_apply : L1 clip quirk + Adam on the actor (+ soft update when `soft`)
+ * grad_scale multiplies gradients inside the apply phases (1/world_size after an all-reduce). */
+int recnn_engine_value_grads(recnn_engine* e, int rows, int learn, void* stream);
+int recnn_engine_value_apply(recnn_engine* e, int soft, float grad_scale, void* stream);
+int recnn_engine_policy_grads(recnn_engine* e, int rows, int backward, void* stream);
+int recnn_engine_policy_apply(recnn_engine* e, int soft, float grad_scale, void* stream);
+/* the same pieces for callers that run their own optimizer: */
+int recnn_engine_clip_policy_grads(recnn_engine* e, float grad_scale, void* stream);  /* g *= coef */
+int recnn_engine_soft_update(recnn_engine* e, int net, int target_net, float tau, void* stream);
+/* closes a step driven through the phase API: reduces the loss partials into the loss buffer
+ * and advances the device step / optimizer counters. */
+int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy_stepped, void* stream);
+
+/* Capture `recnn_engine_step` for a fixed row count into two hipGraphs (policy / non-policy
+ * step) and replay `n_steps` consecutive steps starting at `first_step`. */
+int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
+int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream);
+
+/* Host copy of the last step's losses (synchronises `stream`):
+ * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */
+int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream);
+
+/* Debug / test access to intermediate device buffers by name
+ * ("next_action", "expected", "q1", "gen_action", ...).  Returns NULL if unknown. */
+const void* recnn_engine_buffer(recnn_engine* e, const char* name, int64_t* h_rows, int64_t* h_cols,
+                                int64_t* h_ld, int* h_is_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECNN_HIP_H */

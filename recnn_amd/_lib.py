@@ -1,0 +1,160 @@
+"""ctypes binding of librecnn_hip.so (the C ABI declared in include/recnn_hip.h).
+
+The library is the product: there is NO fallback.  If it has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C recnn_amd/csrc`) every
+entry point raises `RecnnHipMissing`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librecnn_hip.so")
+
+F32, BF16 = 0, 1
+MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
+ALGO_DDPG, ALGO_TD3 = 0, 1
+NET_POLICY, NET_TARGET_POLICY, NET_VALUE1, NET_TARGET_VALUE1, NET_VALUE2, NET_TARGET_VALUE2 = range(6)
+
+
+class RecnnHipMissing(RuntimeError):
+    pass
+
+
+class RecnnHipError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int),
+        ("A", C.c_void_p * 2), ("B", C.c_void_p * 2),
+        ("lda", C.c_int64 * 2), ("ldb", C.c_int64 * 2),
+        ("K", C.c_int * 2), ("a_f32", C.c_int * 2), ("b_f32", C.c_int * 2),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_int),
+        ("bias", C.c_void_p), ("relu", C.c_int), ("mask_mode", C.c_int),
+        ("mask", C.c_void_p), ("ld_mask", C.c_int64),
+        ("seed", C.c_uint32), ("stream_id", C.c_uint32), ("step_ptr", C.c_void_p),
+        ("addend", C.c_void_p), ("ld_add", C.c_int64), ("add_clip", C.c_float),
+        ("yref", C.c_void_p), ("ldy", C.c_int64), ("dx_scale", C.c_float),
+        ("colsum", C.c_void_p),
+        ("dw_splits", C.c_int), ("dw_slab_stride", C.c_int64),
+        ("dw_valid_cols", C.c_int), ("dw_col_rot", C.c_int),
+    ]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [
+        ("algo", C.c_int), ("dtype", C.c_int), ("state_dim", C.c_int), ("action_dim", C.c_int),
+        ("hidden", C.c_int), ("max_rows", C.c_int), ("mask_mode", C.c_int), ("seed", C.c_uint32),
+        ("device", C.c_int),
+    ]
+
+
+class Hyper(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_float), ("min_value", C.c_float), ("max_value", C.c_float),
+        ("soft_tau", C.c_float), ("policy_every", C.c_int),
+        ("noise_std", C.c_float), ("noise_clip", C.c_float),
+        ("lr", C.c_float * 2), ("beta1", C.c_float * 2), ("beta2", C.c_float * 2),
+        ("eps", C.c_float * 2), ("weight_decay", C.c_float * 2),
+    ]
+
+
+class EngineSizes(C.Structure):
+    _fields_ = [
+        ("master_floats_actor", C.c_int64), ("master_floats_critic", C.c_int64),
+        ("workspace_bytes", C.c_int64), ("ld_x", C.c_int64), ("x_rows", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_U = C.c_uint32
+
+# name -> (restype, argtypes).  Mirrors include/recnn_hip.h one to one.
+SIGNATURES = {
+    "recnn_abi_version": (_I, []),
+    "recnn_last_error": (C.c_char_p, []),
+    "recnn_abi_sizeof": (_L, [_I]),
+    "recnn_tune_gather_rows": (None, [_I]),
+    "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P]),
+    "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P]),
+    "recnn_pack_batch": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P]),
+    "recnn_gemm_fwd": (_I, [C.POINTER(GemmArgs), _P]),
+    "recnn_gemm_dx": (_I, [C.POINTER(GemmArgs), _P]),
+    "recnn_gemm_dw": (_I, [C.POINTER(GemmArgs), _P]),
+    "recnn_hash_mask_dump": (_I, [_U, C.c_int32, _U, _I, _I, _P, _P]),
+    "recnn_soft_update_flat": (_I, [_P, _P, _L, _F, _P]),
+    "recnn_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "recnn_l1_norm_flat": (_I, [_P, _L, _P, _P, _P]),
+    "recnn_engine_query": (_I, [C.POINTER(EngineConfig), C.POINTER(EngineSizes)]),
+    "recnn_engine_create": (_I, [C.POINTER(EngineConfig), _P, C.POINTER(_P)]),
+    "recnn_engine_destroy": (None, [_P]),
+    "recnn_engine_bind_net": (_I, [_P, _I, _P, _P, _P, _P]),
+    "recnn_engine_bind_batch": (_I, [_P, _P, _P, _P, _P]),
+    "recnn_engine_bind_external": (_I, [_P, _P, _P]),
+    "recnn_engine_set_hyper": (_I, [_P, C.POINTER(Hyper)]),
+    "recnn_engine_refresh": (_I, [_P, _I, _P]),
+    "recnn_engine_set_counters": (_I, [_P, _I, _I, _I, _I]),
+    "recnn_engine_step": (_I, [_P, _I, _I, _I, _P]),
+    "recnn_engine_value_grads": (_I, [_P, _I, _I, _P]),
+    "recnn_engine_value_apply": (_I, [_P, _I, _F, _P]),
+    "recnn_engine_policy_grads": (_I, [_P, _I, _I, _P]),
+    "recnn_engine_policy_apply": (_I, [_P, _I, _F, _P]),
+    "recnn_engine_clip_policy_grads": (_I, [_P, _F, _P]),
+    "recnn_engine_soft_update": (_I, [_P, _I, _I, _F, _P]),
+    "recnn_engine_finish": (_I, [_P, _I, _I, _I, _P]),
+    "recnn_engine_graph_build": (_I, [_P, _I, _P]),
+    "recnn_engine_graph_run": (_I, [_P, _I, _I, _P]),
+    "recnn_engine_read_losses": (_I, [_P, _P, _P]),
+    "recnn_engine_buffer": (_P, [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librecnn_hip.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RecnnHipMissing(
+            f"{LIB_PATH} not found: build it with `make -C recnn_amd/csrc` "
+            "(or __graft_entry__.build()).  recnn_amd has no CPU or PyTorch fallback.")
+    import torch  # noqa: F401  -- loads libamdhip64.so.7 first; ours must bind to the same runtime
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for which, st in enumerate((GemmArgs, EngineConfig, Hyper, EngineSizes)):
+        if lib.recnn_abi_sizeof(which) != C.sizeof(st):
+            raise RecnnHipError(f"ABI mismatch for {st.__name__}: C={lib.recnn_abi_sizeof(which)} py={C.sizeof(st)}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().recnn_last_error()
+        raise RecnnHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on a non-zero code."""
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,96 @@
+// common.h -- shared device helpers for librecnn_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/recnn_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint16_t bf16_t;  // storage type of a bfloat16
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- error plumbing (host)
+void recnn_set_error(const char* fmt, ...);
+int recnn_check_hip(hipError_t e, const char* what);
+#define RECNN_HIP(expr)                                   \
+  do {                                                    \
+    int _rc = recnn_check_hip((expr), #expr);             \
+    if (_rc) return _rc;                                  \
+  } while (0)
+#define RECNN_REQUIRE(cond, ...)                          \
+  do {                                                    \
+    if (!(cond)) {                                        \
+      recnn_set_error(__VA_ARGS__);                       \
+      return RECNN_E_INVALID;                             \
+    }                                                     \
+  } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__host__ __device__ inline bf16_t f2bf(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
+  return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf2f(bf16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  return __builtin_bit_cast(float, u);
+}
+__device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <class T> struct TcTraits;
+template <> struct TcTraits<float> {
+  static constexpr int VEC = 4;    // elements per 16-byte chunk
+  static constexpr int BK = 32;    // k elements per LDS stage
+  static constexpr int KSTEP = 16; // k elements consumed per fragment read
+  static constexpr int DT = RECNN_F32;
+};
+template <> struct TcTraits<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int BK = 64;
+  static constexpr int KSTEP = 32;
+  static constexpr int DT = RECNN_BF16;
+};
+
+__device__ inline float tc_load(const float* p) { return *p; }
+__device__ inline float tc_load(const bf16_t* p) { return bf2f(*p); }
+__device__ inline void tc_store(float* p, float v) { *p = v; }
+__device__ inline void tc_store(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---------------------------------------------------------------- dropout keep-mask generator
+// Counter-based: the keep bit of element (row, col) of mask stream `stream_id` at step `step` is a
+// pure function of (seed, step, stream_id, row, col) -- independent of tiling, so
+// recnn_hash_mask_dump reproduces exactly what the GEMM epilogues used.  One 32-bit word serves the
+// 4 consecutive rows (row & ~3 .. +3) of a column: that is what one lane of a 16x16 MFMA tile owns.
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t mask_key(uint32_t seed, int32_t step, uint32_t stream_id) {
+  return mix32(seed ^ mix32((uint32_t)step * 0x9E3779B1u + stream_id * 0x7F4A7C15u + 0x1234567u));
+}
+__host__ __device__ inline uint32_t mask_word(uint32_t key, uint32_t row4, uint32_t col) {
+  return mix32((row4 * 0x9E3779B1u) ^ mix32(col * 0x85EBCA77u + key));
+}
+// keep bit for row (row4*4 + r)
+__host__ __device__ inline bool mask_keep(uint32_t word, int r) { return (word >> (7 + 8 * r)) & 1u; }
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on one XCD
+// (hardware places block b on XCD b % 8), so tiles that share an operand panel share an L2.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nwg / NX, r = nwg % NX;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

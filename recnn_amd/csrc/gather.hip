@@ -1,0 +1,264 @@
+// gather.hip -- replay sampler + embedding gather (gfx950).
+//
+// Replaces, bit-exactly, the collate of the reference:
+//   recnn/data/utils.py:7-10     rolling_window        (sliding windows of length F+1 per user)
+//   recnn/data/utils.py:161-187  prepare_batch_static_size (concatenate windows over users)
+//   recnn/data/utils.py:51-81    batch_tensor_embeddings   (emb[items], view, cat, done scatter)
+// The [B, F+1] item/rating windows are never materialised: a batch row r is located by a binary
+// search over the per-user row prefix sum, and the window is read straight from the CSR store.
+//
+// HBM-bound copy kernel.  One workgroup builds R consecutive batch rows.  Consecutive rows of one
+// user share F of their F+1 embedding rows (sliding window) and state / next_state / action of one
+// row share all of them, so each distinct (row, slot) embedding line is fetched ONCE into LDS
+// ((R+F)..R*(F+1) lines of E floats) with 16-byte coalesced loads and then streamed out to the
+// three outputs with the widest store the output alignment allows.
+#include "common.h"
+
+// ------------------------------------------------------------------ plan: row prefix sums
+__global__ __launch_bounds__(1024) void frame_plan_kernel(const int64_t* __restrict__ user_off,
+                                                          const int32_t* __restrict__ users, int n, int frame,
+                                                          int32_t* __restrict__ row_off) {
+  __shared__ int sc[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry = 0; row_off[0] = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    int v = 0;
+    if (i < n) {
+      int u = users[i];
+      int len = (int)(user_off[u + 1] - user_off[u]);
+      v = max(len - frame, 0);
+    }
+    sc[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+      int t = tid >= o ? sc[tid - o] : 0;
+      __syncthreads();
+      sc[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) row_off[i + 1] = carry + sc[tid];
+    __syncthreads();
+    if (tid == 0) carry += sc[1023];
+    __syncthreads();
+  }
+}
+
+extern "C" int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_users, int frame,
+                                int32_t* row_off, void* stream) {
+  RECNN_REQUIRE(user_off && batch_users && row_off && n_users >= 0 && frame > 0, "frame_plan: bad arguments");
+  hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, user_off, batch_users, n_users, frame,
+                     row_off);
+  return recnn_check_hip(hipGetLastError(), "frame_plan");
+}
+
+// ------------------------------------------------------------------ gather
+struct GatherArgs {
+  const int32_t* items;
+  const float* ratings;
+  const int64_t* user_off;
+  const int32_t* users;
+  const int32_t* row_off;
+  int n_users, rows, frame, emb;
+  const float* table;
+  float* state; int64_t ld_state;
+  float* next_state; int64_t ld_next;
+  float* action; int64_t ld_action;
+  float* reward;
+  float* done;
+};
+
+template <int W> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<1> { using type = float; };
+
+// R rows per workgroup; W = floats per output store (4/2/1 by output alignment).
+template <int R, int W>
+__global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
+  using V = typename VecT<W>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int F = a.frame, E = a.emb, F1 = F + 1;
+  float* lines = (float*)smem_raw;                 // [R*F1][E]
+  float* rat = lines + (size_t)R * F1 * E;         // [R*F1]
+  int* meta = (int*)(rat + R * F1);                // per row: base line, cont flag, done flag; + src offset (2 ints)
+  int* m_base = meta;
+  int* m_cont = meta + R;
+  int* m_done = meta + 2 * R;
+  int* m_valid = meta + 3 * R;
+  long long* m_src = (long long*)(meta + 4 * R);   // CSR offset of the window start
+
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * R;
+
+  if (tid < R) {
+    const int r = row0 + tid;
+    int valid = r < a.rows;
+    int u = 0, t = 0, len = 0;
+    long long src = 0;
+    if (valid) {
+      // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
+      int lo = 0, hi = a.n_users;
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (a.row_off[mid] <= r) lo = mid; else hi = mid;
+      }
+      u = lo;
+      t = r - a.row_off[lo];
+      const int su = a.users[u];
+      const long long o0 = a.user_off[su];
+      len = (int)(a.user_off[su + 1] - o0);
+      src = o0 + t;
+    }
+    m_valid[tid] = valid;
+    m_src[tid] = src;
+    m_done[tid] = valid && (t == len - F - 1);
+    // continuation of the previous row's window (same user => shifted by one)
+    m_cont[tid] = 0;
+    m_base[tid] = u;  // temporarily the user index
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int base = 0, prev_u = -1, prev_valid = 0;
+    for (int r = 0; r < R; ++r) {
+      int u = m_base[r];
+      int cont = r > 0 && prev_valid && m_valid[r] && u == prev_u;
+      if (r > 0) base += cont ? 1 : F1;
+      m_cont[r] = cont;
+      prev_u = u;
+      prev_valid = m_valid[r];
+      m_base[r] = base;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage the distinct embedding lines + ratings into LDS
+  const int E4 = E >> 2;
+  for (int idx = tid; idx < R * F1 * E4; idx += 256) {
+    const int pair = idx / E4, e4 = idx - pair * E4;
+    const int r = pair / F1, j = pair - r * F1;
+    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
+    const int item = a.items[m_src[r] + j];
+    const float4 v = *(const float4*)(a.table + (int64_t)item * E + e4 * 4);
+    *(float4*)(lines + (size_t)(m_base[r] + j) * E + e4 * 4) = v;
+  }
+  for (int pair = tid; pair < R * F1; pair += 256) {
+    const int r = pair / F1, j = pair - r * F1;
+    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
+    rat[m_base[r] + j] = a.ratings[m_src[r] + j];
+  }
+  __syncthreads();
+
+  // ---- stream out: state / next_state embedding parts and the action
+  const int FE = F * E;
+  const int per_row = FE / W;
+  for (int idx = tid; idx < R * per_row; idx += 256) {
+    const int r = idx / per_row, q = idx - r * per_row;
+    if (!m_valid[r]) continue;
+    const float* src = lines + (size_t)m_base[r] * E + q * W;
+    *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
+    *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
+  }
+  const int per_act = E / W;
+  for (int idx = tid; idx < R * per_act; idx += 256) {
+    const int r = idx / per_act, q = idx - r * per_act;
+    if (!m_valid[r]) continue;
+    *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)(lines + (size_t)(m_base[r] + F) * E + q * W);
+  }
+  // ---- ratings tails, reward, done
+  for (int idx = tid; idx < R * F; idx += 256) {
+    const int r = idx / F, j = idx - r * F;
+    if (!m_valid[r]) continue;
+    a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
+    a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
+  }
+  if (tid < R && m_valid[tid]) {
+    a.reward[row0 + tid] = rat[m_base[tid] + F];
+    a.done[row0 + tid] = m_done[tid] ? 1.f : 0.f;
+  }
+}
+
+template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_t s) {
+  const int F1 = a.frame + 1;
+  size_t lds = (size_t)R * F1 * a.emb * 4 + (size_t)R * F1 * 4 + 4 * R * 4 + R * 8 + 16;
+  if (lds > 160 * 1024) { recnn_set_error("frame_gather: tile does not fit LDS (%zu bytes)", lds); return RECNN_E_UNSUPPORTED; }
+  dim3 grid((a.rows + R - 1) / R), block(256);
+  hipError_t e = hipSuccess;
+  if (W == 4) {
+    if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)frame_gather_kernel<R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((frame_gather_kernel<R, 4>), grid, block, lds, s, a);
+  } else if (W == 2) {
+    if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)frame_gather_kernel<R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((frame_gather_kernel<R, 2>), grid, block, lds, s, a);
+  } else {
+    if (lds > 48 * 1024) e = hipFuncSetAttribute((const void*)frame_gather_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((frame_gather_kernel<R, 1>), grid, block, lds, s, a);
+  }
+  if (e != hipSuccess) return recnn_check_hip(e, "frame_gather attr");
+  return recnn_check_hip(hipGetLastError(), "frame_gather");
+}
+
+static int g_gather_rows_per_wg = 4;
+extern "C" void recnn_tune_gather_rows(int r) { g_gather_rows_per_wg = r; }
+
+extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
+                                  const int32_t* batch_users, const int32_t* row_off, int n_users, int rows, int frame,
+                                  int emb_dim, const float* table, float* state, int64_t ld_state, float* next_state,
+                                  int64_t ld_next, float* action, int64_t ld_action, float* reward, float* done, void* stream) {
+  RECNN_REQUIRE(items && ratings && user_off && batch_users && row_off && table, "frame_gather: null input");
+  RECNN_REQUIRE(state && next_state && action && reward && done, "frame_gather: null output");
+  RECNN_REQUIRE(frame > 0 && emb_dim > 0 && (emb_dim % 4) == 0, "frame_gather: emb_dim must be a positive multiple of 4");
+  RECNN_REQUIRE(((uintptr_t)table & 15) == 0, "frame_gather: table must be 16-byte aligned");
+  RECNN_REQUIRE(n_users >= 0 && rows >= 0, "frame_gather: negative sizes");
+  if (rows == 0) return 0;
+  RECNN_REQUIRE(n_users > 0, "frame_gather: rows requested from an empty user list");
+  GatherArgs a;
+  a.items = items; a.ratings = ratings; a.user_off = user_off; a.users = batch_users; a.row_off = row_off;
+  a.n_users = n_users; a.rows = rows; a.frame = frame; a.emb = emb_dim; a.table = table;
+  a.state = state; a.ld_state = ld_state; a.next_state = next_state; a.ld_next = ld_next;
+  a.action = action; a.ld_action = ld_action; a.reward = reward; a.done = done;
+  // widest store every output row start supports
+  auto al = [](const void* p, int64_t ld) {
+    uintptr_t x = (uintptr_t)p | (uintptr_t)(ld * 4);
+    return (x & 15) == 0 ? 4 : ((x & 7) == 0 ? 2 : 1);
+  };
+  int W = al(state, ld_state);
+  int w2 = al(next_state, ld_next); if (w2 < W) W = w2;
+  int w3 = al(action, ld_action); if (w3 < W) W = w3;
+  if (emb_dim % W) W = 1;
+  switch (g_gather_rows_per_wg) {
+    case 2: return launch_gather<2>(a, W, (hipStream_t)stream);
+    case 8: return launch_gather<8>(a, W, (hipStream_t)stream);
+    default: return launch_gather<4>(a, W, (hipStream_t)stream);
+  }
+}
+
+// ------------------------------------------------------------------ pack a canonical batch
+__global__ __launch_bounds__(256) void pack_batch_kernel(const float* __restrict__ state, int64_t ld_state,
+                                                         const float* __restrict__ action, int64_t ld_action,
+                                                         const float* __restrict__ next_state, int64_t ld_next, int rows, int S,
+                                                         int A, float* __restrict__ xs, float* __restrict__ xn, int64_t ld_x) {
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;  // column in the packed row
+  if (r >= rows || c >= A + S) return;
+  if (c < A) {
+    xs[(int64_t)r * ld_x + c] = action[(int64_t)r * ld_action + c];
+  } else {
+    xs[(int64_t)r * ld_x + c] = state[(int64_t)r * ld_state + (c - A)];
+    xn[(int64_t)r * ld_x + c] = next_state[(int64_t)r * ld_next + (c - A)];
+  }
+}
+
+extern "C" int recnn_pack_batch(const float* state, int64_t ld_state, const float* action, int64_t ld_action,
+                                const float* next_state, int64_t ld_next, int rows, int state_dim, int action_dim, float* xs,
+                                float* xn, int64_t ld_x, void* stream) {
+  RECNN_REQUIRE(state && action && next_state && xs && xn, "pack_batch: null pointer");
+  RECNN_REQUIRE(rows >= 0 && state_dim > 0 && action_dim > 0 && ld_x >= state_dim + action_dim, "pack_batch: bad sizes");
+  if (rows == 0) return 0;
+  dim3 grid((state_dim + action_dim + 255) / 256, rows), block(256);
+  hipLaunchKernelGGL(pack_batch_kernel, grid, block, 0, (hipStream_t)stream, state, ld_state, action, ld_action, next_state,
+                     ld_next, rows, state_dim, action_dim, xs, xn, ld_x);
+  return recnn_check_hip(hipGetLastError(), "pack_batch");
+}

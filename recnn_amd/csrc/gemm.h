@@ -1,0 +1,61 @@
+// gemm.h -- grouped MFMA GEMM descriptors shared by gemm.hip and engine.hip.
+#pragma once
+#include "common.h"
+
+enum { GEMM_FWD = 0, GEMM_DX = 1, GEMM_DW = 2 };
+
+struct GemmSeg {
+  const void* A;
+  const void* B;
+  int64_t lda, ldb;
+  int K;
+};
+
+// One GEMM problem.  Passed BY VALUE inside GemmBatch (kernel argument): no device-side
+// descriptor memory, and hipGraph capture freezes it with the launch.
+struct GemmProb {
+  GemmSeg seg[2];
+  int nseg;
+  int M, N;
+  void* C;
+  int64_t ldc;
+  int c_f32;
+  // forward epilogue
+  const float* bias;
+  int relu;
+  int mask_mode;
+  const uint8_t* mask;
+  int64_t ld_mask;
+  uint32_t seed, stream_id;
+  const int32_t* step_ptr;
+  const float* addend;
+  int64_t ld_add;
+  float add_clip;
+  // dX epilogue
+  const void* yref;
+  int64_t ldy;
+  float dx_scale;
+  float* colsum;
+  // dW epilogue
+  int dw_splits;
+  int64_t dw_slab_stride;
+  int dw_valid_cols;
+  int dw_col_rot;
+  // filled by the launcher
+  int tiles_m, tiles_n;
+};
+
+constexpr int GEMM_MAX_GROUP = 6;
+struct GemmBatch {
+  GemmProb p[GEMM_MAX_GROUP];
+};
+
+// All problems of one launch share (dtype, mode, a_f32, b_f32).
+struct GemmLaunch {
+  int dtype, mode, a_f32, b_f32, nprob;
+  GemmBatch batch;
+};
+
+void gemm_prob_init(GemmProb* p);
+int gemm_launch(GemmLaunch* L, hipStream_t stream);
+int gemm_from_args(const recnn_gemm_args* a, int mode, GemmLaunch* L);

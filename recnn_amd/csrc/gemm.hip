@@ -1,0 +1,489 @@
+// gemm.hip -- grouped MFMA GEMM kernels for the actor/critic MLPs (gfx950).
+//
+// Replaces the ATen op groups K4/K5 of SURVEY.md 2.3:
+//   forward   addmm + relu + dropout                recnn/nn/models.py:66-73, :207-213
+//   backward  mm (dX, dW), threshold_backward, dropout mul, bias sum   (autograd of the above)
+//
+// One kernel template, three operand-layout modes (all accumulate in fp32 MFMA):
+//   FWD  C[m,n] = epi( sum_k A[m,k] * W[n,k] )          A, W k-contiguous           (X * W^T)
+//   DX   C[m,j] = epi( sum_n dZ[m,n] * W[n,j] )         dZ k-contiguous, W k-strided (dZ * W)
+//   DW   C[i,j] =      sum_m dZ[m,i] * X[m,j]           both k-strided, split over m (dZ^T * X)
+// k-strided operands are transposed in registers while they are staged into LDS, so the LDS
+// image is always [tile_row][k] with k contiguous and the MFMA inner loop is identical for the
+// three modes.  fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32), bf16 mode
+// v_mfma_f32_16x16x32_bf16; an fp32-in-memory operand can be converted to bf16 on the fly
+// (the packed fp32 batch rows feed layer 1 directly).
+//
+// Tile: 256 threads = 4 waves as 2x2, wave tile (16*TM) x (16*TN), block tile (32*TM) x (32*TN).
+// LDS: double buffered, row pitch 144 B (128 B of k + 16 B pad).  One barrier per k-tile; the
+// global loads of tile t+1 are in flight while tile t is multiplied.
+#include <type_traits>
+#include "gemm.h"
+
+template <class TC> struct LdsCfg {
+  static constexpr int VEC = TcTraits<TC>::VEC;
+  static constexpr int BK = TcTraits<TC>::BK;
+  static constexpr int BKP = BK + VEC;  // padded pitch in elements (144 bytes)
+};
+
+// ------------------------------------------------------------------ staging: k-contiguous
+template <class TC, bool MEM32, int R> struct KCLoader {
+  static constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+  static constexpr int CPR = BK / VEC;          // 16-byte LDS chunks per row (8)
+  static constexpr int NCH = R * CPR / 256;     // chunks per thread
+  static constexpr bool CVT = MEM32 && (sizeof(TC) == 2);
+  uint4 raw[NCH][CVT ? 2 : 1];
+
+  __device__ inline void load(const void* base, int64_t ld, int row0, int row_max, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = tid + i * 256;
+      int row = c / CPR, kc = c % CPR;
+      int gr = min(row0 + row, row_max);  // clamp: rows past the end re-read the last valid row
+      if constexpr (CVT) {
+        const float* p = (const float*)base + (int64_t)gr * ld + k0 + kc * 8;
+        raw[i][0] = *(const uint4*)p;
+        raw[i][1] = *(const uint4*)(p + 4);
+      } else if constexpr (sizeof(TC) == 4) {
+        const float* p = (const float*)base + (int64_t)gr * ld + k0 + kc * 4;
+        raw[i][0] = *(const uint4*)p;
+      } else {
+        const bf16_t* p = (const bf16_t*)base + (int64_t)gr * ld + k0 + kc * 8;
+        raw[i][0] = *(const uint4*)p;
+      }
+    }
+  }
+  __device__ inline void store(TC* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = tid + i * 256;
+      int row = c / CPR, kc = c % CPR;
+      uint4 v;
+      if constexpr (CVT) {
+        const float* f0 = (const float*)&raw[i][0];
+        const float* f1 = (const float*)&raw[i][1];
+        v.x = pack_bf2(f0[0], f0[1]); v.y = pack_bf2(f0[2], f0[3]);
+        v.z = pack_bf2(f1[0], f1[1]); v.w = pack_bf2(f1[2], f1[3]);
+      } else {
+        v = raw[i][0];
+      }
+      *(uint4*)&lds[row * BKP + kc * VEC] = v;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ staging: k-strided (transpose)
+// Source is [Kc, ld] with the tile dimension contiguous.  A unit = 4 consecutive k rows x one
+// 16-byte load along the tile dimension (NE elements); it is transposed in registers and written
+// as NE small vectors of 4 k values.
+template <class TC, bool MEM32, int R> struct KSLoader {
+  static constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+  static constexpr bool SRC32 = MEM32 || (sizeof(TC) == 4);
+  static constexpr int NE = SRC32 ? 4 : 8;      // tile elements per 16-byte load
+  static constexpr int KG = BK / 4;             // k groups per stage
+  static constexpr int UNITS = (R / NE) * KG;
+  static constexpr int UPT = (UNITS + 255) / 256;
+  uint4 raw[UPT][4];
+
+  __device__ inline void load(const void* base, int64_t ld, int tile0, int k0, int k_end, int tid) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      int u = tid + i * 256;
+      if (UNITS % 256 == 0 || u < UNITS) {
+        int kg = u % KG, tg = u / KG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int kr = k0 + kg * 4 + j;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (kr < k_end) {
+            if constexpr (SRC32) v = *(const uint4*)((const float*)base + (int64_t)kr * ld + tile0 + tg * NE);
+            else v = *(const uint4*)((const bf16_t*)base + (int64_t)kr * ld + tile0 + tg * NE);
+          }
+          raw[i][j] = v;
+        }
+      }
+    }
+  }
+  __device__ inline void store(TC* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      int u = tid + i * 256;
+      if (UNITS % 256 == 0 || u < UNITS) {
+        int kg = u % KG, tg = u / KG;
+        if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float4 v;
+            v.x = ((const float*)&raw[i][0])[e]; v.y = ((const float*)&raw[i][1])[e];
+            v.z = ((const float*)&raw[i][2])[e]; v.w = ((const float*)&raw[i][3])[e];
+            *(float4*)&lds[(tg * 4 + e) * BKP + kg * 4] = v;
+          }
+        } else if constexpr (SRC32) {  // fp32 in memory -> bf16 in LDS
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint2 v;
+            v.x = pack_bf2(((const float*)&raw[i][0])[e], ((const float*)&raw[i][1])[e]);
+            v.y = pack_bf2(((const float*)&raw[i][2])[e], ((const float*)&raw[i][3])[e]);
+            *(uint2*)&lds[(tg * 4 + e) * BKP + kg * 4] = v;
+          }
+        } else {  // bf16 in memory
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            uint2 v;
+            uint32_t h0 = ((const uint16_t*)&raw[i][0])[e], h1 = ((const uint16_t*)&raw[i][1])[e];
+            uint32_t h2 = ((const uint16_t*)&raw[i][2])[e], h3 = ((const uint16_t*)&raw[i][3])[e];
+            v.x = h0 | (h1 << 16);
+            v.y = h2 | (h3 << 16);
+            *(uint2*)&lds[(tg * 8 + e) * BKP + kg * 4] = v;
+          }
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ MFMA on one LDS stage
+template <class TC, int TM, int TN>
+__device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+  constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP, KSTEP = TcTraits<TC>::KSTEP;
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < BK / KSTEP; ++ks) {
+    uint4 a[TM], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = *(const uint4*)&As[(wm0 + tm * 16 + fr) * BKP + ks * KSTEP + fg * VEC];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)&Bs[(wn0 + tn * 16 + fr) * BKP + ks * KSTEP + fg * VEC];
+    if constexpr (sizeof(TC) == 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[tm])[j], ((const float*)&b[tn])[j],
+                                                               acc[tm][tn], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]),
+                                                                __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+  constexpr bool A_KS = (MODE == GEMM_DW);
+  constexpr bool B_KS = (MODE != GEMM_FWD);
+  const GemmProb& P = batch.p[blockIdx.y];
+
+  const int splits = (MODE == GEMM_DW) ? P.dw_splits : 1;
+  const int nwg = P.tiles_m * P.tiles_n * splits;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % P.tiles_n;
+  const int tile_m = (lid / P.tiles_n) % P.tiles_m;
+  const int split = lid / (P.tiles_n * P.tiles_m);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  __shared__ __attribute__((aligned(16))) TC smem[2 * (BM + BN) * BKP];
+  constexpr int STAGE = (BM + BN) * BKP;  // one LDS stage: A tile then B tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 16 * TM, wn0 = (wave & 1) * 16 * TN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // contraction schedule
+  int nt0, nt1 = 0, kbeg = 0, kend = 0;
+  if constexpr (MODE == GEMM_DW) {
+    const int Kc = P.seg[0].K;
+    int chunk = (((Kc + splits - 1) / splits) + BK - 1) / BK * BK;
+    kbeg = split * chunk;
+    kend = min(Kc, kbeg + chunk);
+    nt0 = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  } else {
+    nt0 = P.seg[0].K / BK;
+    nt1 = P.nseg > 1 ? P.seg[1].K / BK : 0;
+    kend = P.seg[0].K;
+  }
+  const int nt = nt0 + nt1;
+
+  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM>, KCLoader<TC, A32, BM>>::type;
+  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN>, KCLoader<TC, B32, BN>>::type;
+  ALoader la;
+  BLoader lb;
+
+  auto issue = [&](int t) {
+    const int s = (t < nt0) ? 0 : 1;
+    const GemmSeg& G = P.seg[s];
+    const int k0 = kbeg + (s == 0 ? t : t - nt0) * BK;
+    const int ke = (MODE == GEMM_DW) ? kend : G.K;
+    if constexpr (A_KS) la.load(G.A, G.lda, m0, k0, ke, tid);
+    else la.load(G.A, G.lda, m0, P.M - 1, k0, tid);
+    if constexpr (B_KS) lb.load(G.B, G.ldb, n0, k0, ke, tid);
+    else lb.load(G.B, G.ldb, n0, P.N - 1, k0, tid);
+  };
+
+  if (nt > 0) {
+    issue(0);
+    la.store(smem, tid);
+    lb.store(smem + BM * BKP, tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) issue(t + 1);
+    TC* sa = smem + cur * STAGE;
+    TC* sn = smem + (cur ^ 1) * STAGE;
+    mma_stage<TC, TM, TN>(sa, sa + BM * BKP, acc, wm0, wn0, lane);
+    if (t + 1 < nt) {
+      la.store(sn, tid);
+      lb.store(sn + BM * BKP, tid);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int fr = lane & 15, fg = lane >> 4;
+  if constexpr (MODE == GEMM_FWD) {
+    uint32_t key = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, P.step_ptr ? *P.step_ptr : 0, P.stream_id);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 16 + fr;
+        const int mb = m0 + wm0 + tm * 16 + fg * 4;
+        if (n < P.N) {
+          const float bv = P.bias ? P.bias[n] : 0.f;
+          uint32_t word = 0;
+          if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mb + r;
+            if (m < P.M) {
+              float v = acc[tm][tn][r] + bv;
+              if (P.addend) {
+                float z = P.addend[(int64_t)m * P.ld_add + n];
+                v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+              }
+              if (P.relu) v = fmaxf(v, 0.f);
+              if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
+              else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
+              if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
+              else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, v);
+            }
+          }
+        }
+      }
+  } else if constexpr (MODE == GEMM_DX) {
+    float cs[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) cs[tn] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 16 + fr;
+        const int mb = m0 + wm0 + tm * 16 + fg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mb + r;
+          if (m < P.M && n < P.N) {
+            float v = acc[tm][tn][r] * P.dx_scale;
+            if (P.yref) {
+              float y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
+              v = y > 0.f ? v : 0.f;
+            }
+            cs[tn] += v;
+            if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
+            else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, v);
+          }
+        }
+      }
+    if (P.colsum) {
+      // column sums of this row tile -> colsum[tile_m][n]  (deterministic: fixed summation tree)
+      float* red = (float*)smem;  // [2 (wave row)][BN]
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        float v = cs[tn];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (fg == 0) red[(wave >> 1) * BN + wn0 + tn * 16 + fr] = v;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < P.N) P.colsum[(int64_t)tile_m * P.N + n0 + tid] = red[tid] + red[BN + tid];
+    }
+  } else {  // GEMM_DW
+    float* Cs = (float*)P.C + (int64_t)split * P.dw_slab_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 16 + fr;
+        const int mb = m0 + wm0 + tm * 16 + fg * 4;
+        if (n < P.dw_valid_cols) {
+          int cc = n + P.dw_col_rot;
+          if (cc >= P.dw_valid_cols) cc -= P.dw_valid_cols;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mb + r;
+            if (m < P.M) Cs[(int64_t)m * P.ldc + cc] = acc[tm][tn][r];
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+void gemm_prob_init(GemmProb* p) {
+  memset(p, 0, sizeof(*p));
+  p->nseg = 1;
+  p->dx_scale = 1.f;
+  p->dw_splits = 1;
+}
+
+template <class TC, int MODE, bool A32, bool B32>
+static int launch_t(GemmLaunch* L, hipStream_t stream) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    int splits = (MODE == GEMM_DW) ? p.dw_splits : 1;
+    int nwg = p.tiles_m * p.tiles_n * splits;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  dim3 grid(maxwg, L->nprob, 1), block(256, 1, 1);
+  hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN>), grid, block, 0, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
+}
+
+template <class TC, int MODE> static int launch_m(GemmLaunch* L, hipStream_t s) {
+  if (sizeof(TC) == 4) return launch_t<TC, MODE, false, false>(L, s);
+  // bf16: operands may be fp32 in memory.  Only the combinations the engine uses are built.
+  if (MODE == GEMM_FWD) {
+    if (L->b_f32) { recnn_set_error("gemm fwd: B must be tc"); return RECNN_E_UNSUPPORTED; }
+    return L->a_f32 ? launch_t<TC, MODE, true, false>(L, s) : launch_t<TC, MODE, false, false>(L, s);
+  }
+  if (MODE == GEMM_DX) {
+    if (L->a_f32 || L->b_f32) { recnn_set_error("gemm dx: operands must be tc"); return RECNN_E_UNSUPPORTED; }
+    return launch_t<TC, MODE, false, false>(L, s);
+  }
+  if (L->a_f32) { recnn_set_error("gemm dw: A must be tc"); return RECNN_E_UNSUPPORTED; }
+  return L->b_f32 ? launch_t<TC, MODE, false, true>(L, s) : launch_t<TC, MODE, false, false>(L, s);
+}
+
+int gemm_launch(GemmLaunch* L, hipStream_t stream) {
+  if (L->nprob <= 0) return 0;
+  if (L->nprob > GEMM_MAX_GROUP) { recnn_set_error("gemm group too large"); return RECNN_E_INVALID; }
+  const int BK = L->dtype == RECNN_F32 ? 32 : 64;
+  for (int i = 0; i < L->nprob; ++i) {
+    const GemmProb& p = L->batch.p[i];
+    for (int s = 0; s < p.nseg; ++s) {
+      const GemmSeg& g = p.seg[s];
+      if (!g.A || !g.B) { recnn_set_error("gemm: null operand"); return RECNN_E_INVALID; }
+      if (L->mode != GEMM_DW && (g.K % BK)) { recnn_set_error("gemm: K=%d not a multiple of %d", g.K, BK); return RECNN_E_INVALID; }
+      if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) { recnn_set_error("gemm: operand not 16-byte aligned"); return RECNN_E_INVALID; }
+      const int64_t ea = (L->a_f32 || L->dtype == RECNN_F32) ? 4 : 2, eb = (L->b_f32 || L->dtype == RECNN_F32) ? 4 : 2;
+      if ((g.lda * ea) % 16 || (g.ldb * eb) % 16) { recnn_set_error("gemm: leading dimension not 16-byte aligned"); return RECNN_E_INVALID; }
+    }
+    if (!p.C) { recnn_set_error("gemm: null output"); return RECNN_E_INVALID; }
+  }
+  if (L->dtype == RECNN_F32) {
+    switch (L->mode) {
+      case GEMM_FWD: return launch_m<float, GEMM_FWD>(L, stream);
+      case GEMM_DX: return launch_m<float, GEMM_DX>(L, stream);
+      case GEMM_DW: return launch_m<float, GEMM_DW>(L, stream);
+    }
+  } else if (L->dtype == RECNN_BF16) {
+    switch (L->mode) {
+      case GEMM_FWD: return launch_m<bf16_t, GEMM_FWD>(L, stream);
+      case GEMM_DX: return launch_m<bf16_t, GEMM_DX>(L, stream);
+      case GEMM_DW: return launch_m<bf16_t, GEMM_DW>(L, stream);
+    }
+  }
+  recnn_set_error("gemm: bad dtype/mode");
+  return RECNN_E_INVALID;
+}
+
+int gemm_from_args(const recnn_gemm_args* a, int mode, GemmLaunch* L) {
+  if (!a) { recnn_set_error("null args"); return RECNN_E_INVALID; }
+  memset(L, 0, sizeof(*L));
+  L->dtype = a->dtype;
+  L->mode = mode;
+  L->nprob = 1;
+  L->a_f32 = a->a_f32[0];
+  L->b_f32 = a->b_f32[0];
+  GemmProb& p = L->batch.p[0];
+  gemm_prob_init(&p);
+  p.nseg = (mode == GEMM_FWD && a->K[1] > 0) ? 2 : 1;
+  for (int s = 0; s < p.nseg; ++s) {
+    p.seg[s].A = a->A[s]; p.seg[s].B = a->B[s];
+    p.seg[s].lda = a->lda[s]; p.seg[s].ldb = a->ldb[s];
+    p.seg[s].K = a->K[s];
+    if (a->a_f32[s] != a->a_f32[0] || a->b_f32[s] != a->b_f32[0]) {
+      recnn_set_error("gemm: segments must share operand memory types");
+      return RECNN_E_UNSUPPORTED;
+    }
+  }
+  p.M = a->M; p.N = a->N;
+  p.C = a->C; p.ldc = a->ldc; p.c_f32 = a->c_f32;
+  p.bias = a->bias; p.relu = a->relu; p.mask_mode = a->mask_mode;
+  p.mask = a->mask; p.ld_mask = a->ld_mask;
+  p.seed = a->seed; p.stream_id = a->stream_id; p.step_ptr = a->step_ptr;
+  p.addend = a->addend; p.ld_add = a->ld_add; p.add_clip = a->add_clip;
+  p.yref = a->yref; p.ldy = a->ldy; p.dx_scale = a->dx_scale; p.colsum = a->colsum;
+  p.dw_splits = a->dw_splits > 0 ? a->dw_splits : 1;
+  p.dw_slab_stride = a->dw_slab_stride;
+  p.dw_valid_cols = a->dw_valid_cols > 0 ? a->dw_valid_cols : a->N;
+  p.dw_col_rot = a->dw_col_rot;
+  if (mode == GEMM_DW) p.c_f32 = 1;
+  return 0;
+}
+
+extern "C" int recnn_gemm_fwd(const recnn_gemm_args* a, void* stream) {
+  GemmLaunch L;
+  int rc = gemm_from_args(a, GEMM_FWD, &L);
+  return rc ? rc : gemm_launch(&L, (hipStream_t)stream);
+}
+extern "C" int recnn_gemm_dx(const recnn_gemm_args* a, void* stream) {
+  GemmLaunch L;
+  int rc = gemm_from_args(a, GEMM_DX, &L);
+  return rc ? rc : gemm_launch(&L, (hipStream_t)stream);
+}
+extern "C" int recnn_gemm_dw(const recnn_gemm_args* a, void* stream) {
+  GemmLaunch L;
+  int rc = gemm_from_args(a, GEMM_DW, &L);
+  return rc ? rc : gemm_launch(&L, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ mask dump (tests)
+__global__ void hash_mask_dump_kernel(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N, uint8_t* out) {
+  const uint32_t key = mask_key(seed, step, stream_id);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  int m = (int)(i / N), n = (int)(i % N);
+  out[i] = mask_keep(mask_word(key, (uint32_t)(m >> 2), (uint32_t)n), m & 3) ? 1 : 0;
+}
+extern "C" int recnn_hash_mask_dump(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N, uint8_t* out, void* stream) {
+  RECNN_REQUIRE(out && M > 0 && N > 0, "hash_mask_dump: bad args");
+  int64_t n = (int64_t)M * N;
+  hipLaunchKernelGGL(hash_mask_dump_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, step,
+                     stream_id, M, N, out);
+  return recnn_check_hip(hipGetLastError(), "hash_mask_dump");
+}

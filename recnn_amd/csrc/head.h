@@ -1,0 +1,61 @@
+// head.h -- argument blocks of the critic-head / loss kernels (head.hip).
+#pragma once
+#include "common.h"
+
+constexpr int HEAD_MAX_CRITIC = 2;
+constexpr int HEAD_ROWS_PER_BLOCK = 16;
+constexpr int HEADB_ROWS_PER_BLOCK = 16;
+
+struct HeadArgs {
+  int rows, H, tc_bf16;
+  int64_t ld_h;
+  // TD target side (n_target = 0: none, 1: DDPG, 2: TD3 min of twins)
+  int n_target;
+  const void* th2[2];
+  const float* tw3[2];
+  const float* tb3[2];
+  const float* reward;
+  const float* done;
+  float gamma, lo, hi;
+  float* expected;  // y[rows]
+  float* target_q;  // optional debug: target critic value before the TD formula
+  // learning critics
+  int n_critic;
+  const void* ch2[2];
+  const float* cw3[2];
+  const float* cb3[2];
+  float* q[2];
+  float* delta[2];      // 2 (q - y) / rows
+  float* loss_part[2];  // per block partial sums: (q-y)^2, or q in policy mode
+  int policy_mode;
+};
+
+struct HeadBwdArgs {
+  int rows, H, train;
+  int64_t ld_h;
+  const float* delta;  // [rows] or NULL -> delta_const
+  float delta_const;
+  const float* w3;     // canonical fp32 [H]
+  const void* h2;      // tc [rows, ld_h]
+  void* dz2;           // tc [rows, ld_h]
+  float* dw3_part;     // [nblk][H] or NULL (no parameter gradients needed)
+  float* db2_part;     // [nblk][H]
+  float* db3_part;     // [nblk]
+};
+struct HeadBwdBatch {
+  HeadBwdArgs p[2];
+};
+
+struct LossFinalizeArgs {
+  int n;
+  const float* part[4];
+  int n_part[4];
+  float scale[4];
+  float* out;  // [4]
+  int n_tick;
+  int32_t* tick[6];
+};
+
+int head_launch(const HeadArgs& a, hipStream_t s);
+int head_bwd_launch(const HeadBwdBatch& b, int n, int tc_bf16, hipStream_t s);
+int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s);

@@ -1,0 +1,178 @@
+// head.hip -- the critic's N=1 output layer, TD target, losses and their backward seed (gfx950).
+//
+// Replaces:
+//   recnn/nn/models.py:212      value = linear3(h2)            (row dot, not an MFMA shape)
+//   recnn/nn/update/misc.py:6-7 temporal_difference
+//   recnn/nn/update/misc.py:33-39  clamp + mean((V - y)^2)
+//   recnn/nn/update/td3.py:83-93   min of twin targets, MSELoss x2
+//   recnn/nn/update/ddpg.py:79,87 / td3.py:117-127   policy_loss = -Q.mean()
+// and the first step of autograd's backward through linear3 of the critic.
+#include "head.h"
+
+// ---------------------------------------------------------------- row dot: one wave per row
+template <class TC> __device__ inline float row_dot(const TC* __restrict__ h, const float* __restrict__ w, int H, int lane) {
+  float s = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    float4 wv = *(const float4*)(w + c);
+    float x0, x1, x2, x3;
+    if constexpr (sizeof(TC) == 4) {
+      float4 hv = *(const float4*)(h + c);
+      x0 = hv.x; x1 = hv.y; x2 = hv.z; x3 = hv.w;
+    } else {
+      uint2 hv = *(const uint2*)(h + c);
+      x0 = bf2f((bf16_t)(hv.x & 0xFFFF)); x1 = bf2f((bf16_t)(hv.x >> 16));
+      x2 = bf2f((bf16_t)(hv.y & 0xFFFF)); x3 = bf2f((bf16_t)(hv.y >> 16));
+    }
+    s += x0 * wv.x + x1 * wv.y + x2 * wv.z + x3 * wv.w;
+  }
+  return wave_sum(s);
+}
+
+// 16 rows per block (4 waves x 4 rows).  partial sums of the loss terms per block.
+template <class TC> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+  __shared__ float part[4][HEAD_MAX_CRITIC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[HEAD_MAX_CRITIC];
+#pragma unroll
+  for (int c = 0; c < HEAD_MAX_CRITIC; ++c) acc[c] = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int r = blockIdx.x * HEAD_ROWS_PER_BLOCK + wave * 4 + i;
+    if (r >= a.rows) break;  // wave-uniform
+    float y = 0.f;
+    if (a.n_target > 0) {
+      float tq = row_dot<TC>((const TC*)a.th2[0] + (int64_t)r * a.ld_h, a.tw3[0], a.H, lane) + a.tb3[0][0];
+      if (a.n_target > 1) {
+        float t2 = row_dot<TC>((const TC*)a.th2[1] + (int64_t)r * a.ld_h, a.tw3[1], a.H, lane) + a.tb3[1][0];
+        tq = fminf(tq, t2);
+      }
+      y = a.reward[r] + (1.0f - a.done[r]) * a.gamma * tq;
+      y = fminf(fmaxf(y, a.lo), a.hi);
+      if (lane == 0) {
+        if (a.expected) a.expected[r] = y;
+        if (a.target_q) a.target_q[r] = tq;
+      }
+    }
+    for (int c = 0; c < a.n_critic; ++c) {
+      float q = row_dot<TC>((const TC*)a.ch2[c] + (int64_t)r * a.ld_h, a.cw3[c], a.H, lane) + a.cb3[c][0];
+      if (a.policy_mode) {
+        acc[c] += q;
+        if (lane == 0 && a.q[c]) a.q[c][r] = q;
+      } else {
+        const float d = q - y;
+        acc[c] += d * d;
+        if (lane == 0) {
+          if (a.q[c]) a.q[c][r] = q;
+          a.delta[c][r] = d * (2.0f / (float)a.rows);
+        }
+      }
+    }
+  }
+  if (lane == 0)
+    for (int c = 0; c < a.n_critic; ++c) part[wave][c] = acc[c];
+  __syncthreads();
+  if (threadIdx.x < a.n_critic) {
+    const int c = threadIdx.x;
+    a.loss_part[c][blockIdx.x] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  }
+}
+
+int head_launch(const HeadArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return 0;
+  if (a.H % 4) { recnn_set_error("head: hidden size must be a multiple of 4"); return RECNN_E_INVALID; }
+  dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK), block(256);
+  if (a.tc_bf16) hipLaunchKernelGGL(head_kernel<bf16_t>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, a);
+  return recnn_check_hip(hipGetLastError(), "head_kernel");
+}
+
+// ---------------------------------------------------------------- backward seed of the critic head
+// dz2[m,n] = delta[m] * w3[n] * 2 * [h2[m,n] > 0]      (dropout p=0.5 folded: h2 > 0 <=> kept & relu'd)
+// partial sums over the block's rows:  dw3[n] += delta[m] * h2[m,n],  db3 += delta[m],  db2[n] += dz2[m,n]
+template <class TC> __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdBatch batch) {
+  const HeadBwdArgs& a = batch.p[blockIdx.y];
+  __shared__ float sdelta[HEADB_ROWS_PER_BLOCK];
+  const int r0 = blockIdx.x * HEADB_ROWS_PER_BLOCK;
+  const int nr = min(HEADB_ROWS_PER_BLOCK, a.rows - r0);
+  if (nr <= 0) return;
+  if (threadIdx.x < HEADB_ROWS_PER_BLOCK)
+    sdelta[threadIdx.x] = threadIdx.x < nr ? (a.delta ? a.delta[r0 + threadIdx.x] : a.delta_const) : 0.f;
+  __syncthreads();
+  const float scale = a.train ? 2.0f : 1.0f;
+  for (int n = threadIdx.x; n < a.H; n += 256) {
+    const float w = a.w3[n];
+    float sw = 0.f, sb = 0.f;
+    for (int i = 0; i < nr; ++i) {
+      const int64_t off = (int64_t)(r0 + i) * a.ld_h + n;
+      const float h = tc_load((const TC*)a.h2 + off);
+      const float d = sdelta[i];
+      const float dz = h > 0.f ? d * w * scale : 0.f;
+      tc_store((TC*)a.dz2 + off, dz);
+      sw += d * h;
+      sb += dz;
+    }
+    if (a.dw3_part) {
+      a.dw3_part[(int64_t)blockIdx.x * a.H + n] = sw;
+      a.db2_part[(int64_t)blockIdx.x * a.H + n] = sb;
+    }
+  }
+  if (a.db3_part && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nr; ++i) s += sdelta[i];
+    a.db3_part[blockIdx.x] = s;
+  }
+}
+
+int head_bwd_launch(const HeadBwdBatch& b, int n, int tc_bf16, hipStream_t s) {
+  int rows = 0;
+  for (int i = 0; i < n; ++i) rows = b.p[i].rows > rows ? b.p[i].rows : rows;
+  if (rows <= 0 || n <= 0) return 0;
+  dim3 grid((rows + HEADB_ROWS_PER_BLOCK - 1) / HEADB_ROWS_PER_BLOCK, n), block(256);
+  if (tc_bf16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, grid, block, 0, s, b);
+  else hipLaunchKernelGGL(head_bwd_kernel<float>, grid, block, 0, s, b);
+  return recnn_check_hip(hipGetLastError(), "head_bwd_kernel");
+}
+
+// ---------------------------------------------------------------- loss finalize (+ step tick)
+// losses[c] = scale[c] * sum(part[c][0..n)) ; then the device counters advance.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {
+  __shared__ float red[4];
+  for (int c = 0; c < a.n; ++c) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.n_part[c]; i += 256) s += a.part[c][i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.out[c] = ((red[0] + red[1]) + (red[2] + red[3])) * a.scale[c];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < a.n_tick; ++i) *a.tick[i] += 1;
+  }
+}
+
+int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, a);
+  return recnn_check_hip(hipGetLastError(), "loss_finalize_kernel");
+}
+
+// ---------------------------------------------------------------- TD3 target-policy noise (perf mode)
+// out[i] ~ N(0, stddev^2), counter-based (Box-Muller over two hashed uniforms), keyed by (seed, step).
+// The parity tests bypass it with the reference's own CPU draw (td3.py:74).
+__global__ __launch_bounds__(256) void noise_fill_kernel(float* __restrict__ out, int64_t n, float stddev, uint32_t seed,
+                                                         const int32_t* __restrict__ step_ptr) {
+  const uint32_t key = mask_key(seed, step_ptr ? *step_ptr : 0, 0xA511CEu);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t a = mix32((uint32_t)i * 0x9E3779B1u + key);
+    const uint32_t b = mix32(a ^ 0x68E31DA4u ^ (uint32_t)(i >> 32));
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    out[i] = stddev * sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+  }
+}
+int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s) {
+  if (n <= 0) return 0;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(noise_fill_kernel, dim3(grid), dim3(256), 0, s, out, n, stddev, seed, step_ptr);
+  return recnn_check_hip(hipGetLastError(), "noise_fill_kernel");
+}

@@ -1,0 +1,213 @@
+"""StepEngine: Python owner of the device buffers behind the fused HIP DDPG/TD3 step.
+
+Host plumbing only (torch allocates device memory, ctypes calls the C ABI); all arithmetic of
+the step runs in librecnn_hip.so.  Mirrors the data the reference's update functions touch
+(recnn/nn/update/ddpg.py:8-104, td3.py:8-150): four (DDPG) or six (TD3) networks, their
+optimizer state, one batch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .. import _lib as L
+
+PARAM_NAMES = ("w1", "b1", "w2", "b2", "w3", "b3")
+NET_NAMES_DDPG = {"policy_net": L.NET_POLICY, "target_policy_net": L.NET_TARGET_POLICY,
+                  "value_net": L.NET_VALUE1, "target_value_net": L.NET_TARGET_VALUE1}
+NET_NAMES_TD3 = {"policy_net": L.NET_POLICY, "target_policy_net": L.NET_TARGET_POLICY,
+                 "value_net1": L.NET_VALUE1, "target_value_net1": L.NET_TARGET_VALUE1,
+                 "value_net2": L.NET_VALUE2, "target_value_net2": L.NET_TARGET_VALUE2}
+LEARNING = (L.NET_POLICY, L.NET_VALUE1, L.NET_VALUE2)
+
+
+def _require_gpu(device: torch.device):
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise L.RecnnHipError(
+            "recnn_amd runs on an AMD GPU through librecnn_hip.so only; got device "
+            f"{device} (torch.cuda.is_available()={torch.cuda.is_available()}). There is no CPU fallback.")
+
+
+class StepEngine:
+    def __init__(self, algo: str, state_dim: int, action_dim: int, hidden: int, max_rows: int,
+                 dtype: str = "fp32", mask_mode: str = "hash", seed: int = 0,
+                 device: Optional[torch.device] = None):
+        device = torch.device("cuda") if device is None else torch.device(device)
+        _require_gpu(device)
+        self.lib = L.load()
+        self.device = device
+        self.algo = algo
+        self.td3 = algo == "td3"
+        self.S, self.A, self.H = state_dim, action_dim, hidden
+        self.max_rows = max_rows
+        self.dtype = dtype
+        self.mask_mode = {"none": L.MASK_NONE, "hash": L.MASK_HASH, "external": L.MASK_EXTERNAL}[mask_mode]
+        cfg = L.EngineConfig(L.ALGO_TD3 if self.td3 else L.ALGO_DDPG, {"fp32": L.F32, "bf16": L.BF16}[dtype],
+                             state_dim, action_dim, hidden, max_rows, self.mask_mode, seed & 0xFFFFFFFF,
+                             device.index or 0)
+        self.cfg = cfg
+        sz = L.EngineSizes()
+        L.call("recnn_engine_query", C.byref(cfg), C.byref(sz))
+        self.sizes = sz
+        self.ld_x = int(sz.ld_x)
+        with torch.cuda.device(device):
+            self.workspace = torch.zeros(int(sz.workspace_bytes), dtype=torch.uint8, device=device)
+            self.xs = torch.zeros(int(sz.x_rows), self.ld_x, dtype=torch.float32, device=device)
+            self.xn = torch.zeros(int(sz.x_rows), self.ld_x, dtype=torch.float32, device=device)
+            self.reward = torch.zeros(max_rows, dtype=torch.float32, device=device)
+            self.done = torch.zeros(max_rows, dtype=torch.float32, device=device)
+            h = C.c_void_p()
+            L.call("recnn_engine_create", C.byref(cfg), L.ptr(self.workspace), C.byref(h))
+            self.handle = h
+            self.nets = sorted((NET_NAMES_TD3 if self.td3 else NET_NAMES_DDPG).values())
+            self.params: Dict[int, torch.Tensor] = {}
+            self.grads: Dict[int, torch.Tensor] = {}
+            self.adam_m: Dict[int, torch.Tensor] = {}
+            self.adam_v: Dict[int, torch.Tensor] = {}
+            for ni in self.nets:
+                n = int(sz.master_floats_critic if ni >= L.NET_VALUE1 else sz.master_floats_actor)
+                self.params[ni] = torch.zeros(n, dtype=torch.float32, device=device)
+                if ni in LEARNING:
+                    self.grads[ni] = torch.zeros(n, dtype=torch.float32, device=device)
+                    self.adam_m[ni] = torch.zeros(n, dtype=torch.float32, device=device)
+                    self.adam_v[ni] = torch.zeros(n, dtype=torch.float32, device=device)
+                L.call("recnn_engine_bind_net", h, ni, L.ptr(self.params[ni]), L.ptr(self.grads.get(ni)),
+                       L.ptr(self.adam_m.get(ni)), L.ptr(self.adam_v.get(ni)))
+            L.call("recnn_engine_bind_batch", h, L.ptr(self.xs), L.ptr(self.xn), L.ptr(self.reward), L.ptr(self.done))
+            self.n_masks = 8 if self.td3 else 6
+            self.ext_masks = None
+            self.ext_noise = None
+            if self.mask_mode == L.MASK_EXTERNAL:
+                self.ext_masks = torch.ones(self.n_masks, max_rows, hidden, dtype=torch.uint8, device=device)
+            self._bind_external()
+        self._losses_host = (C.c_float * 4)()
+
+    # ------------------------------------------------------------------ plumbing
+    def _bind_external(self):
+        L.call("recnn_engine_bind_external", self.handle, L.ptr(self.ext_masks), L.ptr(self.ext_noise))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.recnn_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return L.current_stream()
+
+    def in_dim(self, ni: int) -> int:
+        return self.S + self.A if ni >= L.NET_VALUE1 else self.S
+
+    def out_dim(self, ni: int) -> int:
+        return 1 if ni >= L.NET_VALUE1 else self.A
+
+    def param_views(self, ni: int, arena: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Views [out,in]/[out] into a flat canonical arena laid out [w1|b1|w2|b2|w3|b3]."""
+        a = self.params[ni] if arena is None else arena
+        H, i, o = self.H, self.in_dim(ni), self.out_dim(ni)
+        shapes = [(H, i), (H,), (H, H), (H,), (o, H), (o,)]
+        out, off = {}, 0
+        for name, shp in zip(PARAM_NAMES, shapes):
+            n = 1
+            for d in shp:
+                n *= d
+            out[name] = a[off:off + n].view(*shp)
+            off += n
+        return out
+
+    def load_params(self, ni: int, p: Dict[str, torch.Tensor]):
+        views = self.param_views(ni)
+        with torch.no_grad():
+            for k in PARAM_NAMES:
+                views[k].copy_(p[k].to(self.device, torch.float32))
+        self.refresh(ni)
+
+    def refresh(self, ni: int):
+        L.call("recnn_engine_refresh", self.handle, ni, self._stream())
+
+    def set_hyper(self, gamma=0.99, min_value=-10.0, max_value=10.0, soft_tau=0.001, policy_every=10,
+                  noise_std=0.5, noise_clip=3.0, policy_opt=None, value_opt=None):
+        def opt(d):
+            d = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, **(d or {}))
+            return d
+        po, vo = opt(policy_opt), opt(value_opt)
+        h = L.Hyper()
+        h.gamma, h.min_value, h.max_value = gamma, min_value, max_value
+        h.soft_tau, h.policy_every = soft_tau, int(policy_every)
+        h.noise_std, h.noise_clip = noise_std, noise_clip
+        for i, o in enumerate((po, vo)):
+            h.lr[i], h.beta1[i], h.beta2[i], h.eps[i], h.weight_decay[i] = o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"]
+        self.hyper = h
+        L.call("recnn_engine_set_hyper", self.handle, C.byref(h))
+
+    def set_counters(self, policy_t=0, value1_t=0, value2_t=0, step=0):
+        L.call("recnn_engine_set_counters", self.handle, policy_t, value1_t, value2_t, step)
+
+    # ------------------------------------------------------------------ batch
+    def pack_batch(self, state, action, reward, next_state, done) -> int:
+        """Copy a canonical (reference-layout) batch into the packed rows."""
+        rows = state.shape[0]
+        if rows > self.max_rows:
+            raise ValueError(f"batch has {rows} rows, engine capacity is {self.max_rows}")
+        f = lambda t: t.to(self.device, torch.float32)
+        state, action, next_state = f(state), f(action), f(next_state)
+        for t in (state, action, next_state):
+            assert t.stride(-1) == 1
+        L.call("recnn_pack_batch", L.ptr(state), state.stride(0), L.ptr(action), action.stride(0),
+               L.ptr(next_state), next_state.stride(0), rows, self.S, self.A,
+               L.ptr(self.xs), L.ptr(self.xn), self.ld_x, self._stream())
+        self.reward[:rows].copy_(f(reward).reshape(-1))
+        self.done[:rows].copy_(f(done).reshape(-1))
+        return rows
+
+    def set_external(self, masks: Optional[Sequence[torch.Tensor]] = None, noise: Optional[torch.Tensor] = None):
+        if masks is not None:
+            assert self.ext_masks is not None, "engine was not created with mask_mode='external'"
+            for i, m in enumerate(masks):
+                self.ext_masks[i, :m.shape[0]].copy_(m.to(self.device, torch.uint8))
+        if noise is not None:
+            if self.ext_noise is None:
+                self.ext_noise = torch.zeros(self.max_rows, self.A, dtype=torch.float32, device=self.device)
+                self._bind_external()
+            self.ext_noise[:noise.shape[0]].copy_(noise.to(self.device, torch.float32))
+
+    # ------------------------------------------------------------------ stepping
+    def step(self, rows: int, learn: bool, step: int):
+        L.call("recnn_engine_step", self.handle, rows, int(learn), int(step), self._stream())
+
+    def graph_build(self, rows: int):
+        L.call("recnn_engine_graph_build", self.handle, rows, self._stream())
+
+    def graph_run(self, first_step: int, n_steps: int):
+        L.call("recnn_engine_graph_run", self.handle, first_step, n_steps, self._stream())
+
+    def losses(self):
+        """Synchronises the stream and returns the last step's losses as python floats."""
+        L.call("recnn_engine_read_losses", self.handle, self._losses_host, self._stream())
+        v = list(self._losses_host)
+        if self.td3:
+            return {"value1": v[0], "value2": v[1], "policy": v[2]}
+        return {"value": v[0], "policy": v[1]}
+
+    def buffer(self, name: str, rows: Optional[int] = None) -> torch.Tensor:
+        """Copy of an intermediate device buffer (debug / tests)."""
+        r, c, ld, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        p = self.lib.recnn_engine_buffer(self.handle, name.encode(), C.byref(r), C.byref(c), C.byref(ld), C.byref(f))
+        if not p:
+            raise KeyError(name)
+        rows = int(r.value) if rows is None else rows
+        esz = 4 if f.value else (2 if self.dtype == "bf16" else 4)
+        off = p - self.workspace.data_ptr()
+        if 0 <= off < self.workspace.numel():
+            raw = self.workspace[off: off + rows * ld.value * esz]
+        elif name == "next_action":
+            return self.xn[:rows, :self.A].clone()
+        else:
+            raise KeyError(name)
+        dt = torch.float32 if esz == 4 else torch.bfloat16
+        t = raw.view(dt).view(rows, ld.value)[:, :c.value]
+        return t.float().clone()
