@@ -90,7 +90,7 @@ def snap(mod):
 
 
 def pack(prefix, p):
-    return {f"{prefix}.{k}": v.numpy() for k, v in p.items()}
+    return {f"{prefix}.{k}": v.numpy().copy() for k, v in p.items()}   # copy: the oracle updates in place
 
 
 def check_params(tag, oracle_p, module, tol):

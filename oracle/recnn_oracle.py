@@ -410,11 +410,15 @@ def td3_step(st: TD3State, batch, noise: torch.Tensor, masks: Sequence[Optional[
         g1, _, _ = mlp_backward(st.value1, c1, d1 * (2.0 / B), train=m[0] is not None)
         adam_step(st.value1, g1, st.value_opt1)                                  # td3.py:95-97
         g2, _, _ = mlp_backward(st.value2, c2, d2 * (2.0 / B), train=m[2] is not None)
+        if trace is not None:
+            trace.update(value1_grads=g1, value2_grads=g2)
         adam_step(st.value2, g2, st.value_opt2)                                  # td3.py:99-101
 
     gen_action, pcache = actor_forward(st.policy, s, m[4], m[5])
     q_pi, qcache = critic_forward(st.value1, s, gen_action, m[6], m[7])
     policy_loss = -(q_pi.mean())
+    if trace is not None:
+        trace.update(gen_action=gen_action, q_pi=q_pi)
 
     if step % P["policy_update"] == 0 and learn:                                 # td3.py:130
         dq_pi = torch.full_like(q_pi, -1.0 / B)
@@ -422,6 +426,8 @@ def td3_step(st: TD3State, batch, noise: torch.Tensor, masks: Sequence[Optional[
         dact = dxa[:, s.shape[1]:]
         gp, _, _ = mlp_backward(st.policy, pcache, dact, train=m[4] is not None)
         coef = clip_grad_quirk_scale(gp)
+        if trace is not None:
+            trace.update(policy_grads=gp, clip_coef=coef, dact=dact)
         adam_step(st.policy, gp, st.policy_opt, grad_scale=coef)
         soft_update(st.value1, st.target_value1, P["soft_tau"])
         soft_update(st.value2, st.target_value2, P["soft_tau"])

@@ -909,7 +909,10 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
       {"critic1_h1", e->cv[0].h1, e->H, Hp, 0},    {"critic1_h2", e->cv[0].h2, e->H, Hp, 0},
       {"actor_h1", e->pa.h1, e->H, Hp, 0},         {"actor_h2", e->pa.h2, e->H, Hp, 0},
       {"critic1_dz2", e->dzc2[0], e->H, Hp, 0},    {"critic1_dz1", e->dzc1[0], e->H, Hp, 0},
-      {"dact", e->dag, e->A, e->Ap, 0},            {"noise", e->noise_buf, e->A, e->A, 1},
+      {"dact", e->dag, e->A, e->Ap, 0},
+      {"pc_h1", e->pc.h1, e->H, Hp, 0},            {"pc_h2", e->pc.h2, e->H, Hp, 0},
+      {"dze2", e->dze2, e->H, Hp, 0},              {"dze1", e->dze1, e->H, Hp, 0},
+      {"dzp2", e->dzp2, e->H, Hp, 0},              {"dzp1", e->dzp1, e->H, Hp, 0},            {"noise", e->noise_buf, e->A, e->A, 1},
   };
   for (const Ent& t : tab)
     if (!strcmp(t.n, name)) {

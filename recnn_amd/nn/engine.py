@@ -132,8 +132,7 @@ class StepEngine:
     def set_hyper(self, gamma=0.99, min_value=-10.0, max_value=10.0, soft_tau=0.001, policy_every=10,
                   noise_std=0.5, noise_clip=3.0, policy_opt=None, value_opt=None):
         def opt(d):
-            d = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, **(d or {}))
-            return d
+            return {**dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0), **(d or {})}
         po, vo = opt(policy_opt), opt(value_opt)
         h = L.Hyper()
         h.gamma, h.min_value, h.max_value = gamma, min_value, max_value

@@ -22,3 +22,10 @@ def rel_err(a, b):
     a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=torch.float64)
     b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b), dtype=torch.float64)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def fro_err(a, b):
+    """Relative Frobenius-norm error ||a-b|| / ||b|| (robust to a handful of outlying elements)."""
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-30))
