@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- DDPG update steps/sec (batch 2048 transition rows, frame 10, emb 128) on N MI355X.
+
+One "step" = the whole hot path of BASELINE.json's north_star on one batch of synthetic ML20M-shaped data:
+  replay sampler (row plan) -> embedding gather -> target/actor/critic forward -> critic backward -> Adam ->
+  policy loss through the updated critic -> [every 10th step: actor backward, L1 clip quirk, Adam, soft update]
+all inside librecnn_hip.so (hipGraph replay), inputs resident in HBM.  Nothing is skipped inside the timed region.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+value = total update steps/s over all ranks (weak scaling: every rank runs its own B=2048 step on its own shard
+of the replay users; gradients are all-reduced over RCCL when N > 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ROWS, FRAME, EMB, HIDDEN = 2048, 10, 128, 256
+STATE = FRAME * EMB + FRAME
+N_USERS, N_ITEMS = 138_493, 26_744           # ML20M as processed by the reference
+USERS_PER_BATCH = 256                        # >= 2048 rows guaranteed (every user has >= 10 windows)
+GATHER_BYTES_PER_ROW = 16_604                # 5,632 + 132 read, 10,840 written (fp32 layout)
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def synthetic_store(seed=0):
+    """ML20M-shaped replay store: lognormal history lengths (>= 20), uniform item ids, ratings in {-4..5}."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.round(rng.lognormal(4.22, 1.22, N_USERS)), 20, 9254).astype(np.int64)
+    off = np.zeros(N_USERS + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    items = rng.integers(0, N_ITEMS, size=total, dtype=np.int32)
+    ratings = (2.0 * (rng.integers(1, 11, size=total) * 0.5 - 2.5)).astype(np.float32)
+    return items, ratings, off, lens
+
+
+def init_nets(seed=0):
+    """Actor(1290,128,256,6e-1), Critic(1290,128,256,54e-2) with the reference's constructor RNG order."""
+    torch.manual_seed(seed)
+
+    def mk(inp, out, init_w):
+        l1, l2, l3 = torch.nn.Linear(inp, HIDDEN), torch.nn.Linear(HIDDEN, HIDDEN), torch.nn.Linear(HIDDEN, out)
+        l3.weight.data.uniform_(-init_w, init_w)
+        l3.bias.data.uniform_(-init_w, init_w)
+        return {"w1": l1.weight.data, "b1": l1.bias.data, "w2": l2.weight.data, "b2": l2.bias.data,
+                "w3": l3.weight.data, "b3": l3.bias.data}
+    critic = mk(STATE + EMB, 1, 54e-2)
+    actor = mk(STATE, EMB, 6e-1)
+    return actor, critic
+
+
+def cpu_baseline(items, ratings, off, table, budget_s=12.0):
+    """The CPU restatement of the reference (oracle/, validated against the real reference in the build container)
+    timed on this host: collate (windows + gather) + ddpg_update with Adam, fp32, all cores."""
+    from oracle import recnn_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    actor, critic = init_nets(0)
+    st = O.DDPGState.create(O.clone_params(actor), O.clone_params(critic), O.AdamState(lr=1e-5, weight_decay=1e-2),
+                            O.AdamState(lr=1e-5, weight_decay=1e-2))
+    rng = np.random.default_rng(1)
+    tab = table.numpy()
+
+    def one(step):
+        users = rng.integers(0, N_USERS, size=USERS_PER_BATCH)
+        ui = [items[off[u]:off[u + 1]].astype(np.int64) for u in users]
+        ur = [ratings[off[u]:off[u + 1]].astype(np.float64) for u in users]
+        # only as many users as the 2048 rows need (the reference collates whole users)
+        need, k = 0, 0
+        while need < B_ROWS:
+            need += len(ui[k]) - FRAME
+            k += 1
+        b = O.frame_batch(ui[:k], ur[:k], tab, FRAME, rows=B_ROWS)
+        masks = O.draw_dropout_masks(6, B_ROWS, HIDDEN)
+        O.ddpg_step(st, b, masks, step=step, learn=True)
+    for s in range(2):
+        one(s)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and n >= 10:
+            break
+    return {"value": n / el, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from recnn_amd import _lib as L
+    from recnn_amd.nn.engine import StepEngine
+
+    items, ratings, off, lens = synthetic_store(0)
+    gen = torch.Generator().manual_seed(0)
+    table = torch.randn(N_ITEMS, EMB, generator=gen)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    items_d, ratings_d, off_d, table_d = d(items), d(ratings), d(off), table.to(dev)
+    # epoch permutation of the users, sharded over ranks (rank r owns perm[r::world])
+    perm = torch.randperm(N_USERS, generator=gen)[rank::world].to(torch.int32).to(dev)
+
+    actor, critic = init_nets(0)
+    eng = StepEngine("ddpg", STATE, EMB, HIDDEN, B_ROWS, dtype=args.dtype, mask_mode="hash", seed=1234 + rank, device=dev)
+    for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
+        eng.load_params(ni, p)
+    adam = dict(lr=1e-5, weight_decay=1e-2)            # recnn/nn/algo.py:84-89 lr / weight_decay
+    eng.set_hyper(gamma=0.99, min_value=-10, max_value=10, soft_tau=0.001, policy_every=10, policy_opt=adam, value_opt=adam)
+    eng.set_counters()
+    eng.bind_sampler(items_d, ratings_d, off_d, perm, USERS_PER_BATCH, FRAME, EMB, table_d)
+
+    stream = torch.cuda.Stream(device=dev)
+    if world == 1:
+        with torch.cuda.stream(stream):
+            eng.graph_build(B_ROWS)
+
+            def run(first, n):
+                eng.graph_run(first, n)
+    else:
+        from recnn_amd.parallel import DataParallelStepper
+        dp = DataParallelStepper(eng, B_ROWS)
+
+        def run(first, n):
+            for t in range(first, first + n):
+                dp.step(t)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        run(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.warmup, args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = eng.losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "DDPG update steps/sec (batch 2048, frame 10, emb 128)",
+            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: DDPG, 2048 transition rows/step/GPU, frame_size 10, emb_dim 128, "
+                                   "Actor/Critic hidden 256, Adam, policy+soft update every 10th step, synthetic ML20M-shaped "
+                                   "replay store (138,493 users, 26,744 items, ~20M ratings)",
+                       "rows_per_step_per_gpu": B_ROWS, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "final_losses": losses},
+        }
+        # ---- roofline of the dominant kernel, measured live with HIP events around every launch (eager replays of the same step)
+        with torch.cuda.stream(stream):
+            prof = eng.profile(B_ROWS, policy=False, n_steps=50)
+            prof_pol = eng.profile(B_ROWS, policy=True, n_steps=10)
+        dom = max(prof, key=lambda r: r[1])
+        if dom[2] > 0:
+            ach = dom[2] / (dom[1] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            out["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "avg_ms": dom[1], "flops_per_launch": dom[2]}
+        else:
+            out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": None, "traffic": None, "avg_ms": dom[1]}
+        g = [r for r in prof if r[0] == "frame_gather"]
+        if g:
+            gbs = GATHER_BYTES_PER_ROW * B_ROWS / (g[0][1] * 1e-3) / 1e9
+            out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_ms": g[0][1],
+                                      "bytes_per_launch": GATHER_BYTES_PER_ROW * B_ROWS}
+        gemm_fl = sum(r[2] for r in prof)
+        gemm_ms = sum(r[1] for r in prof if r[2] > 0)
+        out["step_breakdown"] = {"launches": [{"name": n, "ms": round(ms, 5), "gflop": round(fl / 1e9, 4)} for n, ms, fl in prof],
+                                 "sum_kernel_ms": sum(r[1] for r in prof), "gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12,
+                                 "policy_step_sum_kernel_ms": sum(r[1] for r in prof_pol), "policy_step_launches": len(prof_pol)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(items, ratings, off, table)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

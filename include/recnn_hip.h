@@ -51,7 +51,7 @@ enum {
 int recnn_abi_version(void);
 const char* recnn_last_error(void);
 /* sizeof() of an ABI struct: 0 recnn_gemm_args, 1 recnn_engine_config, 2 recnn_hyper,
- * 3 recnn_engine_sizes (lets a binding verify its declarations); -1 if unknown. */
+ * 3 recnn_engine_sizes, 4 recnn_sampler (lets a binding verify its declarations); -1 if unknown. */
 int64_t recnn_abi_sizeof(int which);
 /* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
 void recnn_tune_gather_rows(int rows_per_workgroup);
@@ -67,9 +67,11 @@ void recnn_tune_gather_rows(int rows_per_workgroup);
  * ===================================================================================== */
 
 /* row_off[0..n_users] = exclusive prefix sum of max(L_u - frame, 0) over the batch's users.
- * row_off[n_users] is the total row count of the batch. */
+ * row_off[n_users] is the total row count of the batch.
+ * `cursor` (device int32, may be NULL): the user list actually read is
+ * batch_users + (*cursor) * cursor_stride -- lets a replayed hipGraph walk an epoch permutation. */
 int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_users, int frame,
-                     int32_t* row_off, void* stream);
+                     int32_t* row_off, const int32_t* cursor, int cursor_stride, void* stream);
 
 /* Builds rows [0, rows) of the batch.  Output row r of user u at window t:
  *   state[r]      = [emb(i_t .. i_{t+F-1}) | r_t .. r_{t+F-1}]          (F*E + F floats)
@@ -77,12 +79,13 @@ int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_
  *   action[r]     = emb(i_{t+F}),  reward[r] = r_{t+F},  done[r] = (t == L_u - F - 1)
  * ld_* are row strides in floats (>= row width); rows must be 8-byte aligned, 16-byte
  * aligned rows take the vector path.  `rows` may be smaller than row_off[n_users]
- * (fixed-row batches). */
+ * (fixed-row batches); rows >= row_off[n_users] are left untouched. */
 int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
                        const int32_t* batch_users, const int32_t* row_off, int n_users, int rows,
                        int frame, int emb_dim, const float* table,
                        float* state, int64_t ld_state, float* next_state, int64_t ld_next,
-                       float* action, int64_t ld_action, float* reward, float* done, void* stream);
+                       float* action, int64_t ld_action, float* reward, float* done,
+                       const int32_t* cursor, int cursor_stride, void* stream);
 
 /* Packs a caller-made canonical batch (reference layout, utils.py:265-276 get_base_batch)
  * into the engine's packed rows: xs[r] = [action | state | 0-pad], xn[r] = [<next action
@@ -220,6 +223,24 @@ int recnn_engine_bind_net(recnn_engine* e, int net, float* params, float* grads,
 /* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
 int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);
 
+/* Device-resident replay sampler: when bound, every step first builds its batch on the GPU
+ * (recnn_frame_plan + recnn_frame_gather straight into the packed rows) from
+ * perm[cursor*users_per_batch .. +users_per_batch), cut to the step's `rows`, and then advances
+ * the cursor (mod n_batches).  This makes the whole hot path -- sampler, gather, networks,
+ * optimizer, soft update -- one launch sequence / one hipGraph.
+ *   replaces the DataLoader + collate of recnn/data/env.py:225-252. */
+typedef struct recnn_sampler {
+  const int32_t* items; const float* ratings; const int64_t* user_off;  /* CSR replay store */
+  const int32_t* perm;        /* epoch permutation of store user slots, int32[n_batches*users_per_batch] */
+  int users_per_batch;
+  int n_batches;
+  int frame, emb_dim;
+  const float* table;         /* float[n_items, emb_dim] */
+  int32_t* row_off;           /* scratch int32[users_per_batch + 1] */
+  int32_t* cursor;            /* device int32: next batch index */
+} recnn_sampler;
+int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* h_sampler);  /* NULL unbinds */
+
 /* External inputs for parity runs: masks uint8[n_masks][max_rows][hidden] (6 DDPG, 8 TD3, in the
  * reference's consumption order), noise float[max_rows][action_dim] (TD3, unclipped). */
 int recnn_engine_bind_external(recnn_engine* e, const uint8_t* masks, const float* noise);
@@ -262,6 +283,14 @@ int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy
  * step) and replay `n_steps` consecutive steps starting at `first_step`. */
 int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
 int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream);
+
+/* Runs n_steps eager steps with a hipEvent pair around every kernel launch and returns, per
+ * launch slot, the average device time in milliseconds (h_ms[i]), its name (h_names[i], static
+ * strings) and, for GEMM slots, the algorithmic FLOPs of one launch (h_flops[i], 0 otherwise).
+ * *h_n is in: capacity, out: slots used.  Policy and non-policy steps have different slot
+ * lists; only steps with (step % policy_every == 0) == policy_steps are run and averaged. */
+int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream,
+                         float* h_ms, double* h_flops, const char** h_names, int* h_n);
 
 /* Host copy of the last step's losses (synchronises `stream`):
  * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */

@@ -69,6 +69,14 @@ class EngineSizes(C.Structure):
     ]
 
 
+class Sampler(C.Structure):
+    _fields_ = [
+        ("items", C.c_void_p), ("ratings", C.c_void_p), ("user_off", C.c_void_p), ("perm", C.c_void_p),
+        ("users_per_batch", C.c_int), ("n_batches", C.c_int), ("frame", C.c_int), ("emb_dim", C.c_int),
+        ("table", C.c_void_p), ("row_off", C.c_void_p), ("cursor", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -81,8 +89,8 @@ SIGNATURES = {
     "recnn_last_error": (C.c_char_p, []),
     "recnn_abi_sizeof": (_L, [_I]),
     "recnn_tune_gather_rows": (None, [_I]),
-    "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P]),
-    "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P]),
+    "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
+    "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     "recnn_pack_batch": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P]),
     "recnn_gemm_fwd": (_I, [C.POINTER(GemmArgs), _P]),
     "recnn_gemm_dx": (_I, [C.POINTER(GemmArgs), _P]),
@@ -97,6 +105,8 @@ SIGNATURES = {
     "recnn_engine_bind_net": (_I, [_P, _I, _P, _P, _P, _P]),
     "recnn_engine_bind_batch": (_I, [_P, _P, _P, _P, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
+    "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),
+    "recnn_engine_profile": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(_I)]),
     "recnn_engine_set_hyper": (_I, [_P, C.POINTER(Hyper)]),
     "recnn_engine_refresh": (_I, [_P, _I, _P]),
     "recnn_engine_set_counters": (_I, [_P, _I, _I, _I, _I]),
@@ -132,7 +142,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((GemmArgs, EngineConfig, Hyper, EngineSizes)):
+    for which, st in enumerate((GemmArgs, EngineConfig, Hyper, EngineSizes, Sampler)):
         if lib.recnn_abi_sizeof(which) != C.sizeof(st):
             raise RecnnHipError(f"ABI mismatch for {st.__name__}: C={lib.recnn_abi_sizeof(which)} py={C.sizeof(st)}")
     _lib = lib

@@ -88,11 +88,36 @@ struct recnn_engine {
   float* coef_out;                         // device float[1]
   int32_t* counters;                       // device int32[8]: step, t_policy, t_value1, t_value2
   float* l1_scratch;
+  // device-resident sampler (optional)
+  recnn_sampler smp;
+  bool has_sampler = false;
+  // per-launch profiler (recnn_engine_profile)
+  bool prof_on = false;
+  int prof_n = 0;
+  static constexpr int PROF_MAX = 48;
+  hipEvent_t prof_ev[2 * PROF_MAX];
+  const char* prof_name[PROF_MAX];
+  double prof_flops[PROF_MAX];
+  bool prof_ready = false;
   // graphs
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
   int graph_rows = 0;
   bool hyper_set = false;
 };
+
+// Every kernel launch of the step goes through slot(): a no-op wrapper normally, a hipEvent pair in profile mode.
+template <class F> int slot(recnn_engine* e, const char* name, double flops, hipStream_t s, F&& launch) {
+  if (!e->prof_on) return launch();
+  const int i = e->prof_n;
+  if (i >= recnn_engine::PROF_MAX) return launch();
+  e->prof_name[i] = name;
+  e->prof_flops[i] = flops;
+  (void)hipEventRecord(e->prof_ev[2 * i], s);
+  int rc = launch();
+  (void)hipEventRecord(e->prof_ev[2 * i + 1], s);
+  e->prof_n = i + 1;
+  return rc;
+}
 
 // ------------------------------------------------------------------------------------ sizing
 namespace {
@@ -285,6 +310,21 @@ extern "C" int recnn_engine_bind_external(recnn_engine* e, const uint8_t* masks,
   return 0;
 }
 
+extern "C" int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* m) {
+  RECNN_REQUIRE(e, "bind_sampler: null engine");
+  for (int i = 0; i < 2; ++i)
+    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  if (!m) { e->has_sampler = false; return 0; }
+  RECNN_REQUIRE(m->items && m->ratings && m->user_off && m->perm && m->table && m->row_off && m->cursor, "bind_sampler: null pointer");
+  RECNN_REQUIRE(m->users_per_batch > 0 && m->n_batches > 0 && m->frame > 0, "bind_sampler: bad sizes");
+  RECNN_REQUIRE(m->frame * m->emb_dim + m->frame == e->S && m->emb_dim == e->A,
+                "bind_sampler: frame*emb+frame=%d / emb=%d do not match the engine's state_dim=%d / action_dim=%d",
+                m->frame * m->emb_dim + m->frame, m->emb_dim, e->S, e->A);
+  e->smp = *m;
+  e->has_sampler = true;
+  return 0;
+}
+
 extern "C" int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h) {
   RECNN_REQUIRE(e && h, "set_hyper: null pointer");
   RECNN_REQUIRE(h->policy_every > 0, "set_hyper: policy_every must be positive");
@@ -379,7 +419,7 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
     a.tgt_shadow = e->net[target_ni].shadow;
     a.tau = tau;
   }
-  return apply_launch(L, a, s);
+  return slot(e, do_adam ? (n.critic ? "adam_critic" : "adam_actor") : "shadow_refresh", 0, s, [&] { return apply_launch(L, a, s); });
 }
 
 // ---- GEMM problem builders ---------------------------------------------------------------
@@ -395,7 +435,7 @@ struct FwdSpec {
   const float* addend = nullptr; int64_t ld_add = 0; float add_clip = 0.f;
 };
 
-void fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) {
+double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) {
   const Net& n = e->net[f.ni];
   gemm_prob_init(p);
   const int wi = f.layer == 1 ? W1 : (f.layer == 2 ? W2 : W3);
@@ -428,11 +468,15 @@ void fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) {
     }
   }
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
+  const double kreal = f.layer == 1 ? n.in_dim : e->H;
+  return 2.0 * rows * p->N * kreal;
 }
 
 struct Group {
   GemmLaunch L;
-  Group(const recnn_engine* e, int mode, int a_f32, int b_f32) {
+  double flops = 0.0;
+  recnn_engine* eng;
+  Group(recnn_engine* e, int mode, int a_f32, int b_f32) : eng(e) {
     memset(&L, 0, sizeof(L));
     L.dtype = e->cfg.dtype; L.mode = mode;
     L.a_f32 = e->bf16 ? a_f32 : 0;
@@ -440,11 +484,14 @@ struct Group {
     L.nprob = 0;
   }
   GemmProb* add() { return &L.batch.p[L.nprob++]; }
-  int run(hipStream_t s) { return gemm_launch(&L, s); }
+  GemmProb* add(double fl) { flops += fl; return &L.batch.p[L.nprob++]; }
+  int run(hipStream_t s, const char* name = "gemm") {
+    return slot(eng, name, flops, s, [&] { return gemm_launch(&L, s); });
+  }
 };
 
 // dX problem: C[rows, N] = (A[rows, Kc] * Wshadow[Kc, N(+col0)]) * scale*[yref>0]
-void fill_dx(const recnn_engine* e, GemmProb* p, int rows, const void* A, int64_t lda, int Kc, int ni, int which, int col0,
+double fill_dx(const recnn_engine* e, GemmProb* p, int rows, const void* A, int64_t lda, int Kc, int ni, int which, int col0,
              int N, void* C, int64_t ldc, const void* yref, int64_t ldy, float* colsum) {
   const Net& n = e->net[ni];
   gemm_prob_init(p);
@@ -456,10 +503,12 @@ void fill_dx(const recnn_engine* e, GemmProb* p, int rows, const void* A, int64_
   p->yref = yref; p->ldy = ldy;
   p->dx_scale = yref ? (e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f) : 1.0f;
   p->colsum = colsum;
+  const double kreal = (which == W3) ? n.out_dim : e->H;
+  return 2.0 * rows * N * kreal;
 }
 
 // dW problem: slabs[s][M, valid] = dZ[rows, M]^T * X[rows, N]
-void fill_dw(const recnn_engine* e, GemmProb* p, int rows, const void* dz, int64_t ldz, int M, const void* X, int64_t ldx_,
+double fill_dw(const recnn_engine* e, GemmProb* p, int rows, const void* dz, int64_t ldz, int M, const void* X, int64_t ldx_,
              int valid_cols, int rot, float* slabs, int splits, int64_t slab_stride) {
   gemm_prob_init(p);
   p->seg[0].A = dz; p->seg[0].lda = ldz; p->seg[0].K = rows;
@@ -468,6 +517,7 @@ void fill_dw(const recnn_engine* e, GemmProb* p, int rows, const void* dz, int64
   p->C = slabs; p->ldc = valid_cols; p->c_f32 = 1;
   p->dw_splits = splits; p->dw_slab_stride = slab_stride;
   p->dw_valid_cols = valid_cols; p->dw_col_rot = rot;
+  return 2.0 * rows * M * valid_cols;
 }
 
 int check_ready(recnn_engine* e, int rows) {
@@ -494,41 +544,41 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipS
     if (value_side) {
       FwdSpec f{TPOL, 1, e->xn + A, e->ldx, 1, e->K1a};
       f.C = e->tp.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
       for (int c = 0; c < nc; ++c) {
         FwdSpec fc{VAL[c], 1, e->xs, e->ldx, 1, e->K1c};
         fc.C = e->cv[c].h1; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c;
-        fill_fwd(e, fc, rows, g.add());
+        g.flops += fill_fwd(e, fc, rows, g.add());
       }
     }
     if (actor_side) {
       FwdSpec f{POL, 1, e->xs + A, e->ldx, 1, e->K1a};
       f.C = e->pa.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1;
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
     }
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "fwd_l1"))) return rc;
   }
   {  // layer 2
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
       FwdSpec f{TPOL, 2, e->tp.h1, Hp, 0, Hp};
       f.C = e->tp.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
       for (int c = 0; c < nc; ++c) {
         FwdSpec fc{VAL[c], 2, e->cv[c].h1, Hp, 0, Hp};
         fc.C = e->cv[c].h2; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c + 1;
-        fill_fwd(e, fc, rows, g.add());
+        g.flops += fill_fwd(e, fc, rows, g.add());
       }
     }
     if (actor_side) {
       FwdSpec f{POL, 2, e->pa.h1, Hp, 0, Hp};
       f.C = e->pa.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1 + 1;
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
     }
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "fwd_l2"))) return rc;
   }
   if (value_side && e->td3 && !e->ext_noise) {
-    if ((rc = noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s))) return rc;
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s); }))) return rc;
   }
   {  // layer 3 of the actors: fp32 outputs (next_action into the packed xn rows, gen_action)
     Group g(e, GEMM_FWD, 0, 0);
@@ -540,14 +590,14 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipS
         f.ld_add = A;
         f.add_clip = e->hy.noise_clip;
       }
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
     }
     if (actor_side) {
       FwdSpec f{POL, 3, e->pa.h2, Hp, 0, Hp};
       f.C = e->gen_action; f.ldc = e->Ap; f.c_f32 = 1; f.relu = 0; f.mask_idx = -1;
-      fill_fwd(e, f, rows, g.add());
+      g.flops += fill_fwd(e, f, rows, g.add());
     }
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
   }
   if (value_side) {
     {  // target critics on [next_action | next_state]
@@ -555,18 +605,18 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipS
       for (int c = 0; c < nc; ++c) {
         FwdSpec f{TVAL[c], 1, e->xn, e->ldx, 1, e->K1c};
         f.C = e->tq[c].h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-        fill_fwd(e, f, rows, g.add());
+        g.flops += fill_fwd(e, f, rows, g.add());
       }
-      if ((rc = g.run(s))) return rc;
+      if ((rc = g.run(s, "fwd_l1_target_critic"))) return rc;
     }
     {
       Group g(e, GEMM_FWD, 0, 0);
       for (int c = 0; c < nc; ++c) {
         FwdSpec f{TVAL[c], 2, e->tq[c].h1, Hp, 0, Hp};
         f.C = e->tq[c].h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-        fill_fwd(e, f, rows, g.add());
+        g.flops += fill_fwd(e, f, rows, g.add());
       }
-      if ((rc = g.run(s))) return rc;
+      if ((rc = g.run(s, "fwd_l2_target_critic"))) return rc;
     }
     // heads: TD target, Q, dQ, loss partials
     HeadArgs h;
@@ -587,7 +637,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipS
     h.expected = e->expected; h.target_q = e->target_q;
     h.n_critic = nc;
     h.policy_mode = 0;
-    if ((rc = head_launch(h, s))) return rc;
+    if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
   }
   return 0;
 }
@@ -609,34 +659,34 @@ int ph_value_backward(recnn_engine* e, int rows, hipStream_t s) {
     a.h2 = e->cv[c].h2; a.dz2 = e->dzc2[c];
     a.dw3_part = v.gp[W3]; a.db2_part = v.gp[B2]; a.db3_part = v.gp[B3];
   }
-  if ((rc = head_bwd_launch(hb, nc, e->bf16, s))) return rc;
+  if ((rc = slot(e, "head_bwd_critic", 0, s, [&] { return head_bwd_launch(hb, nc, e->bf16, s); }))) return rc;
   {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
-      fill_dx(e, g.add(), rows, e->dzc2[c], Hp, Hp, VAL[c], W2, 0, H, e->dzc1[c], Hp, e->cv[c].h1, Hp, e->net[VAL[c]].gp[B1]);
-    if ((rc = g.run(s))) return rc;
+      g.flops += fill_dx(e, g.add(), rows, e->dzc2[c], Hp, Hp, VAL[c], W2, 0, H, e->dzc1[c], Hp, e->cv[c].h1, Hp, e->net[VAL[c]].gp[B1]);
+    if ((rc = g.run(s, "dx_critic_l2"))) return rc;
   }
   NetLayout L0 = make_layout(e, VAL[0], rows);
   {
     Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1   (tc x tc)
     for (int c = 0; c < nc; ++c)
-      fill_dw(e, g.add(), rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab, L0.t[W2].slab_stride);
+      g.flops += fill_dw(e, g.add(), rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab, L0.t[W2].slab_stride);
     if (!e->bf16)  // fp32: same operand memory types, share the launch with dW1
       for (int c = 0; c < nc; ++c)
-        fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
+        g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
                 L0.t[W1].slab_stride);
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "dw_critic"))) return rc;
   }
   if (e->bf16) {
     Group g(e, GEMM_DW, 0, 1);  // dW1 = dz1^T [a|s]   (tc x fp32 packed rows)
     for (int c = 0; c < nc; ++c)
-      fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
+      g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
               L0.t[W1].slab_stride);
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "dw_critic_l1"))) return rc;
   }
   for (int c = 0; c < nc; ++c) {
     NetLayout L = make_layout(e, VAL[c], rows);
-    if ((rc = grad_reduce_launch(L, e->net[VAL[c]].g, nullptr, s))) return rc;
+    if ((rc = slot(e, "grad_reduce_critic", 0, s, [&] { return grad_reduce_launch(L, e->net[VAL[c]].g, nullptr, s); }))) return rc;
   }
   return 0;
 }
@@ -656,15 +706,15 @@ int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
     f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
     // gen_action is zero padded to Ap columns, so segment 0 may run over the padded width: the W1
     // shadow columns it meets there (the first state columns) are multiplied by zeros.
-    fill_fwd(e, f, rows, g.add());
-    if ((rc = g.run(s))) return rc;
+    g.flops += fill_fwd(e, f, rows, g.add());
+    if ((rc = g.run(s, "fwd_l1_pcritic"))) return rc;
   }
   {
     Group g(e, GEMM_FWD, 0, 0);
     FwdSpec f{V1, 2, e->pc.h1, Hp, 0, Hp};
     f.C = e->pc.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0 + 1;
-    fill_fwd(e, f, rows, g.add());
-    if ((rc = g.run(s))) return rc;
+    g.flops += fill_fwd(e, f, rows, g.add());
+    if ((rc = g.run(s, "fwd_l2_pcritic"))) return rc;
   }
   {
     HeadArgs h;
@@ -674,7 +724,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
     h.n_target = 0; h.n_critic = 1; h.policy_mode = 1;
     h.ch2[0] = e->pc.h2; h.cw3[0] = v.p + v.off[W3]; h.cb3[0] = v.p + v.off[B3];
     h.q[0] = e->qpi; h.loss_part[0] = e->loss_part[2];
-    if ((rc = head_launch(h, s))) return rc;
+    if ((rc = slot(e, "head_policy_loss", 0, s, [&] { return head_launch(h, s); }))) return rc;
   }
   if (!backward) return 0;
   Net& pn = e->net[POL];
@@ -687,34 +737,34 @@ int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
     a.rows = rows; a.H = H; a.train = train; a.ld_h = Hp;
     a.delta = nullptr; a.delta_const = -1.0f / (float)rows;
     a.w3 = v.p + v.off[W3]; a.h2 = e->pc.h2; a.dz2 = e->dze2;
-    if ((rc = head_bwd_launch(hb, 1, e->bf16, s))) return rc;
+    if ((rc = slot(e, "head_bwd_policy", 0, s, [&] { return head_bwd_launch(hb, 1, e->bf16, s); }))) return rc;
   }
-  auto dx1 = [&](const void* Ain, int64_t lda, int Kc, int ni, int which, int N, void* C, int64_t ldc, const void* yref,
+  auto dx1 = [&](const char* nm, const void* Ain, int64_t lda, int Kc, int ni, int which, int N, void* C, int64_t ldc, const void* yref,
                  float* colsum) {
     Group g(e, GEMM_DX, 0, 0);
-    fill_dx(e, g.add(), rows, Ain, lda, Kc, ni, which, 0, N, C, ldc, yref, Hp, colsum);
-    return g.run(s);
+    g.flops += fill_dx(e, g.add(), rows, Ain, lda, Kc, ni, which, 0, N, C, ldc, yref, Hp, colsum);
+    return g.run(s, nm);
   };
   // critic: dz_e1 = (dz_e2 W2) * 2[e1>0];   dact = dz_e1 * W1[:, action columns]  (shadow columns 0..A-1)
-  if ((rc = dx1(e->dze2, Hp, Hp, V1, W2, H, e->dze1, Hp, e->pc.h1, nullptr))) return rc;
-  if ((rc = dx1(e->dze1, Hp, Hp, V1, W1, A, e->dag, Ap, nullptr, pn.gp[B3]))) return rc;
+  if ((rc = dx1("dx_pcritic_l2", e->dze2, Hp, Hp, V1, W2, H, e->dze1, Hp, e->pc.h1, nullptr))) return rc;
+  if ((rc = dx1("dx_pcritic_action", e->dze1, Hp, Hp, V1, W1, A, e->dag, Ap, nullptr, pn.gp[B3]))) return rc;
   // actor: dz_p2 = (dact W3) * 2[p2>0];  dz_p1 = (dz_p2 W2) * 2[p1>0]
-  if ((rc = dx1(e->dag, Ap, Ap, POL, W3, H, e->dzp2, Hp, e->pa.h2, pn.gp[B2]))) return rc;
-  if ((rc = dx1(e->dzp2, Hp, Hp, POL, W2, H, e->dzp1, Hp, e->pa.h1, pn.gp[B1]))) return rc;
+  if ((rc = dx1("dx_actor_l3", e->dag, Ap, Ap, POL, W3, H, e->dzp2, Hp, e->pa.h2, pn.gp[B2]))) return rc;
+  if ((rc = dx1("dx_actor_l2", e->dzp2, Hp, Hp, POL, W2, H, e->dzp1, Hp, e->pa.h1, pn.gp[B1]))) return rc;
   NetLayout L = make_layout(e, POL, rows);
   {
     Group g(e, GEMM_DW, 0, 0);
-    fill_dw(e, g.add(), rows, e->dag, Ap, A, e->pa.h2, Hp, H, 0, pn.gp[W3], L.t[W3].nslab, L.t[W3].slab_stride);
-    fill_dw(e, g.add(), rows, e->dzp2, Hp, H, e->pa.h1, Hp, H, 0, pn.gp[W2], L.t[W2].nslab, L.t[W2].slab_stride);
+    g.flops += fill_dw(e, g.add(), rows, e->dag, Ap, A, e->pa.h2, Hp, H, 0, pn.gp[W3], L.t[W3].nslab, L.t[W3].slab_stride);
+    g.flops += fill_dw(e, g.add(), rows, e->dzp2, Hp, H, e->pa.h1, Hp, H, 0, pn.gp[W2], L.t[W2].nslab, L.t[W2].slab_stride);
     if (!e->bf16) fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
-    if ((rc = g.run(s))) return rc;
+    if ((rc = g.run(s, "dw_actor"))) return rc;
   }
   if (e->bf16) {
     Group g(e, GEMM_DW, 0, 1);
-    fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
-    if ((rc = g.run(s))) return rc;
+    g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
+    if ((rc = g.run(s, "dw_actor_l1"))) return rc;
   }
-  return grad_reduce_launch(L, pn.g, nullptr, s);
+  return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, pn.g, nullptr, s); });
 }
 
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
@@ -734,7 +784,8 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
     if (e->td3) a.tick[a.n_tick++] = e->net[RECNN_NET_VALUE2].t_ptr;
   }
   if (ticked_policy) a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr;
-  return loss_finalize_launch(a, s);
+  if (e->has_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; }
+  return slot(e, "loss_finalize", 0, s, [&] { return loss_finalize_launch(a, s); });
 }
 
 }  // namespace
@@ -760,8 +811,10 @@ namespace {
 int ph_policy_l1(recnn_engine* e, hipStream_t s) {
   Net& pn = e->net[RECNN_NET_POLICY];
   NetLayout L = make_layout(e, RECNN_NET_POLICY, 0);
-  hipLaunchKernelGGL(l1_rows_kernel, dim3(L.nblk), dim3(256), 0, s, L, pn.g, pn.l1part);
-  return recnn_check_hip(hipGetLastError(), "l1_rows_kernel");
+  return slot(e, "l1_norm_actor", 0, s, [&] {
+    hipLaunchKernelGGL(l1_rows_kernel, dim3(L.nblk), dim3(256), 0, s, L, pn.g, pn.l1part);
+    return recnn_check_hip(hipGetLastError(), "l1_rows_kernel");
+  });
 }
 
 int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s) {
@@ -780,9 +833,23 @@ int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s) {
   return apply_net(e, RECNN_NET_POLICY, 0, true, 0, grad_scale, true, tgt, e->hy.soft_tau, s);
 }
 
+int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
+  const recnn_sampler& m = e->smp;
+  int rc = slot(e, "frame_plan", 0, s, [&] {
+    return recnn_frame_plan(m.user_off, m.perm, m.users_per_batch, m.frame, m.row_off, m.cursor, m.users_per_batch, s);
+  });
+  if (rc) return rc;
+  return slot(e, "frame_gather", 0, s, [&] {
+    return recnn_frame_gather(m.items, m.ratings, m.user_off, m.perm, m.row_off, m.users_per_batch, rows, m.frame, m.emb_dim,
+                              m.table, e->xs + e->A, e->ldx, e->xn + e->A, e->ldx, e->xs, e->ldx, e->reward, e->done, m.cursor,
+                              m.users_per_batch, s);
+  });
+}
+
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s) {
   int rc;
+  if (e->has_sampler && (rc = frame_gather_packed(e, rows, s))) return rc;
   if ((rc = ph_forward(e, rows, true, true, s))) return rc;
   if (learn) {
     if ((rc = ph_value_backward(e, rows, s))) return rc;
@@ -859,6 +926,45 @@ extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* str
   RECNN_REQUIRE(e && h_out, "read_losses: null pointer");
   RECNN_HIP(hipMemcpyAsync(h_out, e->losses, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ per-launch profile
+extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream, float* h_ms,
+                                    double* h_flops, const char** h_names, int* h_n) {
+  int rc = check_ready(e, rows);
+  if (rc) return rc;
+  RECNN_REQUIRE(h_ms && h_flops && h_names && h_n && n_steps > 0, "profile: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (!e->prof_ready) {
+    for (int i = 0; i < 2 * recnn_engine::PROF_MAX; ++i) RECNN_HIP(hipEventCreate(&e->prof_ev[i]));
+    e->prof_ready = true;
+  }
+  double acc[recnn_engine::PROF_MAX];
+  for (int i = 0; i < recnn_engine::PROF_MAX; ++i) acc[i] = 0.0;
+  int nslots = 0;
+  for (int it = 0; it < n_steps; ++it) {
+    e->prof_on = true;
+    e->prof_n = 0;
+    rc = step_impl(e, rows, true, policy_steps != 0, s);
+    e->prof_on = false;
+    if (rc) return rc;
+    RECNN_HIP(hipStreamSynchronize(s));
+    nslots = e->prof_n;
+    for (int i = 0; i < nslots; ++i) {
+      float ms = 0.f;
+      RECNN_HIP(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+      acc[i] += ms;
+    }
+  }
+  const int cap = *h_n;
+  const int n = nslots < cap ? nslots : cap;
+  for (int i = 0; i < n; ++i) {
+    h_ms[i] = (float)(acc[i] / n_steps);
+    h_flops[i] = e->prof_flops[i];
+    h_names[i] = e->prof_name[i];
+  }
+  *h_n = n;
   return 0;
 }
 

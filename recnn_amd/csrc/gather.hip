@@ -17,10 +17,12 @@
 // ------------------------------------------------------------------ plan: row prefix sums
 __global__ __launch_bounds__(1024) void frame_plan_kernel(const int64_t* __restrict__ user_off,
                                                           const int32_t* __restrict__ users, int n, int frame,
-                                                          int32_t* __restrict__ row_off) {
+                                                          int32_t* __restrict__ row_off, const int32_t* __restrict__ cursor,
+                                                          int cursor_stride) {
   __shared__ int sc[1024];
   __shared__ int carry;
   const int tid = threadIdx.x;
+  if (cursor) users += (int64_t)(*cursor) * cursor_stride;  // device-side batch cursor (graph replay)
   if (tid == 0) { carry = 0; row_off[0] = 0; }
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
@@ -47,10 +49,10 @@ __global__ __launch_bounds__(1024) void frame_plan_kernel(const int64_t* __restr
 }
 
 extern "C" int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_users, int frame,
-                                int32_t* row_off, void* stream) {
+                                int32_t* row_off, const int32_t* cursor, int cursor_stride, void* stream) {
   RECNN_REQUIRE(user_off && batch_users && row_off && n_users >= 0 && frame > 0, "frame_plan: bad arguments");
   hipLaunchKernelGGL(frame_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, user_off, batch_users, n_users, frame,
-                     row_off);
+                     row_off, cursor, cursor_stride);
   return recnn_check_hip(hipGetLastError(), "frame_plan");
 }
 
@@ -68,6 +70,8 @@ struct GatherArgs {
   float* action; int64_t ld_action;
   float* reward;
   float* done;
+  const int32_t* cursor;
+  int cursor_stride;
 };
 
 template <int W> struct VecT;
@@ -92,10 +96,13 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
 
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
+  const int32_t* users = a.users;
+  if (a.cursor) users += (int64_t)(*a.cursor) * a.cursor_stride;
 
   if (tid < R) {
     const int r = row0 + tid;
-    int valid = r < a.rows;
+    // rows past the planned total (fewer windows than requested) are left untouched
+    int valid = r < a.rows && r < a.row_off[a.n_users];
     int u = 0, t = 0, len = 0;
     long long src = 0;
     if (valid) {
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
       }
       u = lo;
       t = r - a.row_off[lo];
-      const int su = a.users[u];
+      const int su = users[u];
       const long long o0 = a.user_off[su];
       len = (int)(a.user_off[su + 1] - o0);
       src = o0 + t;
@@ -206,7 +213,8 @@ extern "C" void recnn_tune_gather_rows(int r) { g_gather_rows_per_wg = r; }
 extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
                                   const int32_t* batch_users, const int32_t* row_off, int n_users, int rows, int frame,
                                   int emb_dim, const float* table, float* state, int64_t ld_state, float* next_state,
-                                  int64_t ld_next, float* action, int64_t ld_action, float* reward, float* done, void* stream) {
+                                  int64_t ld_next, float* action, int64_t ld_action, float* reward, float* done,
+                                  const int32_t* cursor, int cursor_stride, void* stream) {
   RECNN_REQUIRE(items && ratings && user_off && batch_users && row_off && table, "frame_gather: null input");
   RECNN_REQUIRE(state && next_state && action && reward && done, "frame_gather: null output");
   RECNN_REQUIRE(frame > 0 && emb_dim > 0 && (emb_dim % 4) == 0, "frame_gather: emb_dim must be a positive multiple of 4");
@@ -219,6 +227,7 @@ extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, co
   a.n_users = n_users; a.rows = rows; a.frame = frame; a.emb = emb_dim; a.table = table;
   a.state = state; a.ld_state = ld_state; a.next_state = next_state; a.ld_next = ld_next;
   a.action = action; a.ld_action = ld_action; a.reward = reward; a.done = done;
+  a.cursor = cursor; a.cursor_stride = cursor_stride;
   // widest store every output row start supports
   auto al = [](const void* p, int64_t ld) {
     uintptr_t x = (uintptr_t)p | (uintptr_t)(ld * 4);

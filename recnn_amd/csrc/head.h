@@ -54,6 +54,8 @@ struct LossFinalizeArgs {
   float* out;  // [4]
   int n_tick;
   int32_t* tick[6];
+  int32_t* wrap_ptr;  // sampler cursor: *wrap_ptr = (*wrap_ptr + 1) % wrap_mod
+  int wrap_mod;
 };
 
 int head_launch(const HeadArgs& a, hipStream_t s);

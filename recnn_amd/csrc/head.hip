@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
   }
   if (threadIdx.x == 0) {
     for (int i = 0; i < a.n_tick; ++i) *a.tick[i] += 1;
+    if (a.wrap_ptr) {
+      int c = *a.wrap_ptr + 1;
+      *a.wrap_ptr = c >= a.wrap_mod ? 0 : c;
+    }
   }
 }
 

@@ -27,6 +27,7 @@ extern "C" int64_t recnn_abi_sizeof(int which) {
     case 1: return (int64_t)sizeof(recnn_engine_config);
     case 2: return (int64_t)sizeof(recnn_hyper);
     case 3: return (int64_t)sizeof(recnn_engine_sizes);
+    case 4: return (int64_t)sizeof(recnn_sampler);
     default: return -1;
   }
 }

@@ -174,6 +174,34 @@ class StepEngine:
                 self._bind_external()
             self.ext_noise[:noise.shape[0]].copy_(noise.to(self.device, torch.float32))
 
+    def bind_sampler(self, items, ratings, user_off, perm, users_per_batch: int, frame: int, emb_dim: int, table):
+        """Attach a device-resident replay store: every step then builds its own batch on the GPU."""
+        dev = self.device
+        assert items.dtype == torch.int32 and ratings.dtype == torch.float32 and user_off.dtype == torch.int64
+        assert perm.dtype == torch.int32 and table.dtype == torch.float32
+        n_batches = perm.numel() // users_per_batch
+        assert n_batches >= 1, "permutation shorter than one batch of users"
+        self._row_off = torch.zeros(users_per_batch + 1, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._smp_keep = (items, ratings, user_off, perm, table)
+        m = L.Sampler(items.data_ptr(), ratings.data_ptr(), user_off.data_ptr(), perm.data_ptr(), users_per_batch,
+                      n_batches, frame, emb_dim, table.data_ptr(), self._row_off.data_ptr(), self.cursor.data_ptr())
+        L.call("recnn_engine_bind_sampler", self.handle, C.byref(m))
+        self.n_batches = n_batches
+
+    def unbind_sampler(self):
+        L.call("recnn_engine_bind_sampler", self.handle, None)
+
+    def profile(self, rows: int, policy: bool, n_steps: int = 20):
+        """Per-launch average device time of an eager step: [(name, ms, flops)]."""
+        cap = 48
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        names = (C.c_char_p * cap)()
+        n = C.c_int(cap)
+        L.call("recnn_engine_profile", self.handle, rows, int(policy), n_steps, self._stream(), ms, fl, names, C.byref(n))
+        return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
+
     # ------------------------------------------------------------------ stepping
     def step(self, rows: int, learn: bool, step: int):
         L.call("recnn_engine_step", self.handle, rows, int(learn), int(step), self._stream())

@@ -30,7 +30,7 @@ def _gather(L, dev, items, ratings, table, users, frame, rows=None, packed=False
     it_d, rt_d, off_d, tab_d = d(it), d(rt), d(off), d(table)
     users_d = torch.tensor(users, dtype=torch.int32, device=dev)
     row_off = torch.zeros(len(users) + 1, dtype=torch.int32, device=dev)
-    L.call("recnn_frame_plan", L.ptr(off_d), L.ptr(users_d), len(users), frame, L.ptr(row_off), L.current_stream())
+    L.call("recnn_frame_plan", L.ptr(off_d), L.ptr(users_d), len(users), frame, L.ptr(row_off), None, 0, L.current_stream())
     total = int(row_off[-1].item())
     B = total if rows is None else rows
     if rows_per_wg:
@@ -51,7 +51,7 @@ def _gather(L, dev, items, ratings, table, users, frame, rows=None, packed=False
     done = torch.full((B,), 7.0, device=dev)
     L.call("recnn_frame_gather", L.ptr(it_d), L.ptr(rt_d), L.ptr(off_d), L.ptr(users_d), L.ptr(row_off), len(users), B,
            frame, E, L.ptr(tab_d), L.ptr(state), lds, L.ptr(nstate), ldn, L.ptr(action), lda, L.ptr(reward), L.ptr(done),
-           L.current_stream())
+           None, 0, L.current_stream())
     torch.cuda.synchronize()
     L.load().recnn_tune_gather_rows(4)
     return dict(state=state.cpu().numpy(), next_state=nstate.cpu().numpy(), action=action.cpu().numpy(),
