@@ -4,7 +4,7 @@
 
 constexpr int HEAD_MAX_CRITIC = 2;
 constexpr int HEAD_ROWS_PER_BLOCK = 16;
-constexpr int HEADB_ROWS_PER_BLOCK = 16;
+constexpr int HEADB_ROWS_PER_BLOCK = 32;
 
 struct HeadArgs {
   int rows, H, tc_bf16;

@@ -36,8 +36,16 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const NetLayout L, flo
   float l1 = 0.f;
   for (int c = threadIdx.x; c < T.cols; c += 256) {
     const int64_t e = (int64_t)row * T.cols + c;
+    // fixed summation order (deterministic); 8 independent loads in flight per thread
     float g = 0.f;
-    for (int s = 0; s < T.nslab; ++s) g += T.gpart[(int64_t)s * T.slab_stride + e];
+    int s = 0;
+    for (; s + 8 <= T.nslab; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+      g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; s < T.nslab; ++s) g += T.gpart[(int64_t)s * T.slab_stride + e];
     gflat[T.p_off + e] = g;
     l1 += fabsf(g);
   }
