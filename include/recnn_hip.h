@@ -246,6 +246,8 @@ int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* h_sampler); 
 int recnn_engine_bind_external(recnn_engine* e, const uint8_t* masks, const float* noise);
 
 int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h_hyper);
+/* switch the dropout-mask source of the learning nets (RECNN_MASK_*); invalidates built graphs. */
+int recnn_engine_set_mask_mode(recnn_engine* e, int mask_mode);
 
 /* Re-derive the compute-layout shadow of a network from its canonical arena (call after the
  * canonical parameters were changed by anything other than the engine). */
@@ -262,7 +264,8 @@ int recnn_engine_set_counters(recnn_engine* e, int policy_t, int value1_t, int v
 int recnn_engine_step(recnn_engine* e, int rows, int learn, int step, void* stream);
 
 /* Phase API (external optimizers, data-parallel all-reduce between phases):
- *   value_grads  : TD target, critic forward/backward -> value grads in the bound grad arenas
+ *   value_grads  : [sampler gather if bound,] TD target, critic forward/backward -> value grads in the bound
+ *                  grad arenas
  *   value_apply  : Adam on the critic(s) (+ fused soft update when `soft`), shadows refreshed
  *   policy_grads : actor forward, critic forward, policy loss; with `backward` also the actor
  *                  gradient (reduced into the bound grad arena, NOT yet clipped)

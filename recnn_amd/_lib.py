@@ -108,6 +108,7 @@ SIGNATURES = {
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),
     "recnn_engine_profile": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(_I)]),
     "recnn_engine_set_hyper": (_I, [_P, C.POINTER(Hyper)]),
+    "recnn_engine_set_mask_mode": (_I, [_P, _I]),
     "recnn_engine_refresh": (_I, [_P, _I, _P]),
     "recnn_engine_set_counters": (_I, [_P, _I, _I, _I, _I]),
     "recnn_engine_step": (_I, [_P, _I, _I, _I, _P]),

@@ -335,6 +335,14 @@ extern "C" int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h) {
   return 0;
 }
 
+extern "C" int recnn_engine_set_mask_mode(recnn_engine* e, int mask_mode) {
+  RECNN_REQUIRE(e && mask_mode >= RECNN_MASK_NONE && mask_mode <= RECNN_MASK_EXTERNAL, "set_mask_mode: bad arguments");
+  e->cfg.mask_mode = mask_mode;
+  for (int i = 0; i < 2; ++i)
+    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  return 0;
+}
+
 extern "C" int recnn_engine_set_counters(recnn_engine* e, int policy_t, int value1_t, int value2_t, int step) {
   RECNN_REQUIRE(e, "set_counters: null engine");
   int32_t h[4] = {step, policy_t, value1_t, value2_t};
@@ -880,6 +888,7 @@ extern "C" int recnn_engine_step(recnn_engine* e, int rows, int learn, int step,
 extern "C" int recnn_engine_value_grads(recnn_engine* e, int rows, int learn, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
+  if (e->has_sampler && (rc = frame_gather_packed(e, rows, (hipStream_t)stream))) return rc;
   if ((rc = ph_forward(e, rows, true, false, (hipStream_t)stream))) return rc;
   if (learn) return ph_value_backward(e, rows, (hipStream_t)stream);
   return 0;

@@ -1,0 +1,103 @@
+"""Algo / DDPG / TD3 facades (reference: recnn/nn/algo.py:15-179).
+
+Same public attributes (nets, optimizers, params, _step, debug, writer, device, loss_layout, algorithm) and
+methods (update, to, step).  Targets are deep copies put in eval mode and hard-synced (soft_tau = 1.0) exactly
+as the reference does; the sync itself happens when the networks reach the GPU if they were built on the CPU.
+
+Default optimizers: the reference builds `torch_optimizer.Ranger(lr=1e-5, weight_decay=1e-2)` -- a third-party
+package that is neither vendored nor pinned by the reference.  Here the default is the fused
+`recnn_amd.optim.Adam(lr=1e-5, weight_decay=1e-2)` (the optimizer north_star names and the substitution the
+reference's own docs show, `algo.optimizers[...] = torch.optim.Adam(...)`).  `recnn_amd.optim.Ranger` is
+available as an explicitly unverified restatement; any torch optimizer can be assigned to `algo.optimizers[...]`.
+"""
+import copy
+
+import torch
+
+from .. import optim, utils
+from . import update
+
+__all__ = ["Algo", "DDPG", "TD3"]
+
+
+def _hard_sync(net, target):
+    """soft_update with tau = 1.0 (algo.py:80-81).  CPU-resident freshly built nets are synced by value copy:
+    tau = 1 makes the lerp an exact copy, no arithmetic is involved."""
+    if next(net.parameters()).is_cuda:
+        utils.soft_update(net, target, soft_tau=1.0)
+    else:
+        with torch.no_grad():
+            for tp, p in zip(target.parameters(), net.parameters()):
+                tp.data.copy_(p.data)
+
+
+class Algo:
+    def __init__(self):
+        self.nets = {"value_net": None, "policy_net": None}
+        self.optimizers = {"policy_optimizer": None, "value_optimizer": None}
+        self.params = {"Some parameters here": None}
+        self._step = 0
+        self.debug = {}
+        self.writer = utils.misc.DummyWriter()
+        self.device = torch.device("cpu")
+        self.loss_layout = {"test": {"value": [], "policy": [], "step": []},
+                            "train": {"value": [], "policy": [], "step": []}}
+        self.algorithm = None
+
+    def update(self, batch, learn=True):
+        return self.algorithm(batch, self.params, self.nets, self.optimizers, device=self.device, debug=self.debug,
+                              writer=self.writer, learn=learn, step=self._step)
+
+    def to(self, device):
+        self.nets = {k: v.to(device) for k, v in self.nets.items()}
+        self.device = device
+        return self
+
+    def step(self):
+        self._step += 1
+
+
+class DDPG(Algo):
+    def __init__(self, policy_net, value_net):
+        super().__init__()
+        self.algorithm = update.ddpg_update
+        target_policy_net = copy.deepcopy(policy_net)
+        target_value_net = copy.deepcopy(value_net)
+        target_policy_net.eval()
+        target_value_net.eval()
+        _hard_sync(value_net, target_value_net)
+        _hard_sync(policy_net, target_policy_net)
+        value_optimizer = optim.Adam(value_net.parameters(), lr=1e-5, weight_decay=1e-2)
+        policy_optimizer = optim.Adam(policy_net.parameters(), lr=1e-5, weight_decay=1e-2)
+        self.nets = {"value_net": value_net, "target_value_net": target_value_net, "policy_net": policy_net,
+                     "target_policy_net": target_policy_net}
+        self.optimizers = {"policy_optimizer": policy_optimizer, "value_optimizer": value_optimizer}
+        self.params = {"gamma": 0.99, "min_value": -10, "max_value": 10, "policy_step": 10, "soft_tau": 0.001}
+        self.loss_layout = {"test": {"value": [], "policy": [], "step": []},
+                            "train": {"value": [], "policy": [], "step": []}}
+
+
+class TD3(Algo):
+    def __init__(self, policy_net, value_net1, value_net2):
+        super().__init__()
+        self.algorithm = update.td3_update
+        target_policy_net = copy.deepcopy(policy_net)
+        target_value_net1 = copy.deepcopy(value_net1)
+        target_value_net2 = copy.deepcopy(value_net2)
+        for t in (target_policy_net, target_value_net1, target_value_net2):
+            t.eval()
+        _hard_sync(value_net1, target_value_net1)
+        _hard_sync(value_net2, target_value_net2)
+        _hard_sync(policy_net, target_policy_net)
+        value_optimizer1 = optim.Adam(value_net1.parameters(), lr=1e-5, weight_decay=1e-2)
+        value_optimizer2 = optim.Adam(value_net2.parameters(), lr=1e-5, weight_decay=1e-2)
+        policy_optimizer = optim.Adam(policy_net.parameters(), lr=1e-5, weight_decay=1e-2)
+        self.nets = {"value_net1": value_net1, "target_value_net1": target_value_net1, "value_net2": value_net2,
+                     "target_value_net2": target_value_net2, "policy_net": policy_net,
+                     "target_policy_net": target_policy_net}
+        self.optimizers = {"policy_optimizer": policy_optimizer, "value_optimizer1": value_optimizer1,
+                           "value_optimizer2": value_optimizer2}
+        self.params = {"gamma": 0.99, "noise_std": 0.5, "noise_clip": 3, "soft_tau": 0.001, "policy_update": 10,
+                       "policy_lr": 1e-5, "value_lr": 1e-5, "actor_weight_init": 25e-2, "critic_weight_init": 6e-1}
+        self.loss_layout = {"test": {"value1": [], "value2": [], "policy": [], "step": []},
+                            "train": {"value1": [], "value2": [], "policy": [], "step": []}}

@@ -206,6 +206,32 @@ class StepEngine:
     def step(self, rows: int, learn: bool, step: int):
         L.call("recnn_engine_step", self.handle, rows, int(learn), int(step), self._stream())
 
+    # phase API (external optimizers, data parallel all-reduce between phases); see include/recnn_hip.h
+    def value_grads(self, rows: int, learn: bool = True):
+        L.call("recnn_engine_value_grads", self.handle, rows, int(learn), self._stream())
+
+    def value_apply(self, soft: bool, grad_scale: float = 1.0):
+        L.call("recnn_engine_value_apply", self.handle, int(soft), float(grad_scale), self._stream())
+
+    def policy_grads(self, rows: int, backward: bool):
+        L.call("recnn_engine_policy_grads", self.handle, rows, int(backward), self._stream())
+
+    def policy_apply(self, soft: bool, grad_scale: float = 1.0):
+        L.call("recnn_engine_policy_apply", self.handle, int(soft), float(grad_scale), self._stream())
+
+    def finish(self, rows: int, value_stepped: bool, policy_stepped: bool):
+        L.call("recnn_engine_finish", self.handle, rows, int(value_stepped), int(policy_stepped), self._stream())
+
+    @property
+    def policy_every(self) -> int:
+        return int(self.hyper.policy_every)
+
+    def value_nets(self):
+        return (L.NET_VALUE1, L.NET_VALUE2) if self.td3 else (L.NET_VALUE1,)
+
+    def grad_arena(self, ni: int) -> torch.Tensor:
+        return self.grads[ni]
+
     def graph_build(self, rows: int):
         L.call("recnn_engine_graph_build", self.handle, rows, self._stream())
 

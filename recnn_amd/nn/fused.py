@@ -1,0 +1,255 @@
+"""Binding of the reference-shaped objects (nets / optimizer dicts of nn.Modules and torch optimizers) to the
+fused HIP step engine.
+
+`ddpg_update(batch, params, nets, optimizer, ...)` keeps the reference's signature and in-place semantics
+(recnn/nn/update/ddpg.py:8-18): the modules in `nets` stay the owners of the weights.  On first use their
+parameter tensors are *adopted*: copied into the engine's flat fp32 arenas and re-pointed (`param.data`) at
+views of those arenas, so that optimizers, `state_dict()`, `torch.save` and user code keep seeing live values
+while the kernels read and write the same memory.  External in-place changes (load_state_dict, a user
+optimizer) are detected through the tensors' version counters and the compute-layout shadows are refreshed.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib as L
+from ..optim import adam_config
+from .engine import NET_NAMES_DDPG, NET_NAMES_TD3, PARAM_NAMES, StepEngine
+
+_MODULE_PARAMS = (("linear1", "weight"), ("linear1", "bias"), ("linear2", "weight"), ("linear2", "bias"),
+                  ("linear3", "weight"), ("linear3", "bias"))
+
+# process-wide defaults for engines created by the update functions
+DEFAULTS = {"dtype": "bf16", "mask_mode": "hash", "seed": None, "min_capacity": 256}
+
+_contexts: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_by_module: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def set_defaults(**kw):
+    """dtype='bf16'|'fp32', mask_mode='hash'|'none', seed=int|None, min_capacity=rows."""
+    for k, v in kw.items():
+        if k not in DEFAULTS:
+            raise KeyError(k)
+        DEFAULTS[k] = v
+
+
+def notify_params_changed(module):
+    ctx = _by_module.get(module)
+    if ctx is not None:
+        ctx.dirty.add(id(module))
+
+
+def _module_params(m):
+    return [getattr(getattr(m, a), b) for a, b in _MODULE_PARAMS]
+
+
+class FusedContext:
+    def __init__(self, algo: str, nets: Dict[str, torch.nn.Module]):
+        self.algo = algo
+        self.names = NET_NAMES_TD3 if algo == "td3" else NET_NAMES_DDPG
+        missing = [k for k in self.names if k not in nets]
+        if missing:
+            raise KeyError(f"{algo}_update: nets is missing {missing}")
+        pol = nets["policy_net"]
+        self.S = pol.linear1.in_features
+        self.A = pol.linear3.out_features
+        self.H = pol.linear1.out_features
+        self.engine: Optional[StepEngine] = None
+        self.modules: Dict[int, torch.nn.Module] = {}
+        self.versions: Dict[int, list] = {}
+        self.dirty = set()
+        self.opt_t = {L.NET_POLICY: 0, L.NET_VALUE1: 0, L.NET_VALUE2: 0}
+        self.hyper_key = None
+        self.external = None        # (masks, noise) for the next update (parity runs)
+        self.dtype = DEFAULTS["dtype"]
+        self.mask_mode = DEFAULTS["mask_mode"]
+        self.seed = DEFAULTS["seed"]
+        self.sampler_env = None
+
+    # ------------------------------------------------------------------ engine lifetime
+    def _check_modules(self, nets):
+        for name, ni in self.names.items():
+            m = nets[name]
+            p = m.linear1.weight
+            if not p.is_cuda:
+                raise L.RecnnHipError(
+                    f"{self.algo}_update: network '{name}' lives on {p.device}; recnn_amd runs on the GPU only "
+                    "(no CPU fallback) -- call algo.to(torch.device('cuda')) / net.to('cuda') first")
+            want_in = self.S + self.A if ni >= L.NET_VALUE1 else self.S
+            if m.linear1.in_features != want_in or m.linear1.out_features != self.H or m.linear2.in_features != self.H:
+                raise L.RecnnHipError(f"network '{name}' does not have the Actor/Critic shape the engine was built for")
+
+    def ensure(self, nets, rows: int):
+        self._check_modules(nets)
+        dev = nets["policy_net"].linear1.weight.device
+        if self.engine is None or rows > self.engine.max_rows or self.engine.device != dev:
+            cap = max(DEFAULTS["min_capacity"], 1 << (max(rows, 1) - 1).bit_length())
+            old = self.engine
+            seed = self.seed if self.seed is not None else (torch.initial_seed() & 0x7FFFFFFF)
+            eng = StepEngine(self.algo, self.S, self.A, self.H, cap, dtype=self.dtype,
+                             mask_mode="hash" if self.mask_mode == "hash" else "none", seed=seed, device=dev)
+            if old is not None and old.device == dev:       # carry optimizer state over to the bigger engine
+                for ni in eng.adam_m:
+                    eng.adam_m[ni].copy_(old.adam_m[ni])
+                    eng.adam_v[ni].copy_(old.adam_v[ni])
+            self.engine = eng
+            self.modules = {}
+            self.hyper_key = None
+            eng.set_counters(self.opt_t[L.NET_POLICY], self.opt_t[L.NET_VALUE1], self.opt_t[L.NET_VALUE2], 0)
+        for name, ni in self.names.items():
+            m = nets[name]
+            if self.modules.get(ni) is not m or not self._is_adopted(ni, m):
+                self._adopt(ni, m)
+        self._sync_versions()
+
+    def _is_adopted(self, ni, m):
+        views = self.engine.param_views(ni)
+        return all(p.data.data_ptr() == views[k].data_ptr() for p, k in zip(_module_params(m), PARAM_NAMES))
+
+    def _adopt(self, ni, m):
+        eng = self.engine
+        views = eng.param_views(ni)
+        gviews = eng.param_views(ni, eng.grads[ni]) if ni in eng.grads else None
+        with torch.no_grad():
+            for p, k in zip(_module_params(m), PARAM_NAMES):
+                views[k].copy_(p.data.to(torch.float32))
+                p.data = views[k]
+                if gviews is not None:
+                    p.grad = gviews[k]
+        self.modules[ni] = m
+        _by_module[m] = self
+        self.versions[ni] = [p._version for p in _module_params(m)]
+        eng.refresh(ni)
+
+    def _sync_versions(self):
+        """Refresh the shadows of every net whose parameters were modified behind the engine's back."""
+        for ni, m in self.modules.items():
+            cur = [p._version for p in _module_params(m)]
+            if cur != self.versions.get(ni) or id(m) in self.dirty:
+                self.engine.refresh(ni)
+                self.versions[ni] = cur
+                self.dirty.discard(id(m))
+
+    def attach_grads(self, ni):
+        m = self.modules[ni]
+        gviews = self.engine.param_views(ni, self.engine.grads[ni])
+        for p, k in zip(_module_params(m), PARAM_NAMES):
+            if p.grad is None or p.grad.data_ptr() != gviews[k].data_ptr():
+                p.grad = gviews[k]
+
+    # ------------------------------------------------------------------ per-step inputs
+    def load_batch(self, batch) -> int:
+        eng = self.engine
+        packed = getattr(batch, "packed", None)
+        if packed is not None and packed[5] == eng.ld_x and packed[0].device == eng.device \
+                and batch["state"].data_ptr() == packed[0].data_ptr() + 4 * self.A:
+            xs, xn, reward, done, rows, _ = packed
+            L.call("recnn_engine_bind_batch", eng.handle, L.ptr(xs), L.ptr(xn), L.ptr(reward), L.ptr(done))
+            self._bound_external_batch = (xs, xn, reward, done)   # keep alive while the kernels run
+            return rows
+        if getattr(self, "_bound_external_batch", None) is not None:
+            L.call("recnn_engine_bind_batch", eng.handle, L.ptr(eng.xs), L.ptr(eng.xn), L.ptr(eng.reward), L.ptr(eng.done))
+            self._bound_external_batch = None
+        for k in ("state", "action", "reward", "next_state", "done"):
+            if k not in batch:
+                raise KeyError(f"batch has no '{k}'")
+        return eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+
+    def set_hyper(self, algo_params: dict, pol_cfg: Optional[dict], val_cfg: Optional[dict]):
+        P = algo_params
+        if self.algo == "ddpg":
+            key = ("ddpg", P["gamma"], P["min_value"], P["max_value"], P["soft_tau"], P["policy_step"])
+            kw = dict(gamma=P["gamma"], min_value=P["min_value"], max_value=P["max_value"], soft_tau=P["soft_tau"],
+                      policy_every=P["policy_step"])
+        else:
+            key = ("td3", P["gamma"], P["noise_std"], P["noise_clip"], P["soft_tau"], P["policy_update"])
+            kw = dict(gamma=P["gamma"], soft_tau=P["soft_tau"], policy_every=P["policy_update"], noise_std=P["noise_std"],
+                      noise_clip=P["noise_clip"])
+        key = key + (tuple(sorted((pol_cfg or {}).items())), tuple(sorted((val_cfg or {}).items())))
+        if key != self.hyper_key:
+            self.engine.set_hyper(policy_opt=pol_cfg, value_opt=val_cfg, **kw)
+            self.hyper_key = key
+
+    def apply_external(self, rows):
+        """Parity runs: dropout masks / TD3 noise supplied by the caller for exactly one update."""
+        eng = self.engine
+        if self.external is None:
+            want = L.MASK_HASH if self.mask_mode == "hash" else L.MASK_NONE
+            if eng.mask_mode != want:
+                L.call("recnn_engine_set_mask_mode", eng.handle, want)
+                eng.mask_mode = want
+            return
+        masks, noise = self.external
+        self.external = None
+        if masks is not None:
+            if eng.ext_masks is None:
+                eng.ext_masks = torch.ones(eng.n_masks, eng.max_rows, eng.H, dtype=torch.uint8, device=eng.device)
+                eng._bind_external()
+            if eng.mask_mode != L.MASK_EXTERNAL:
+                L.call("recnn_engine_set_mask_mode", eng.handle, L.MASK_EXTERNAL)
+                eng.mask_mode = L.MASK_EXTERNAL
+        eng.set_external(masks=masks, noise=noise)
+
+    # ------------------------------------------------------------------ optimizer state mirrors
+    def mirror_optimizer_state(self, opt, ni):
+        """Expose the engine's Adam moments through `opt.state` (state_dict compatibility)."""
+        eng = self.engine
+        mv = eng.param_views(ni, eng.adam_m[ni])
+        vv = eng.param_views(ni, eng.adam_v[ni])
+        t = self.opt_t[ni]
+        is_torch = type(opt) is torch.optim.Adam
+        for p, k in zip(_module_params(self.modules[ni]), PARAM_NAMES):
+            st = opt.state[p]
+            if st.get("exp_avg") is not None and st["exp_avg"].data_ptr() != mv[k].data_ptr():
+                mv[k].copy_(st["exp_avg"])            # state that existed before adoption
+                vv[k].copy_(st["exp_avg_sq"])
+                t = max(t, int(st.get("step", 0)))
+            st["exp_avg"], st["exp_avg_sq"] = mv[k], vv[k]
+            st["step"] = torch.tensor(float(t)) if is_torch else t
+        if t != self.opt_t[ni]:
+            self.opt_t[ni] = t
+            eng.set_counters(self.opt_t[L.NET_POLICY], self.opt_t[L.NET_VALUE1], self.opt_t[L.NET_VALUE2], 0)
+
+    def bump(self, opt, ni):
+        self.opt_t[ni] += 1
+        t = self.opt_t[ni]
+        is_torch = type(opt) is torch.optim.Adam
+        for p in _module_params(self.modules[ni]):
+            st = opt.state[p]
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(t)) if is_torch else t
+
+
+def context_for(algo: str, nets) -> FusedContext:
+    anchor = nets["policy_net"]
+    ctx = _contexts.get(anchor)
+    if ctx is None or ctx.algo != algo:
+        ctx = FusedContext(algo, nets)
+        _contexts[anchor] = ctx
+    return ctx
+
+
+class external_randomness:
+    """Context manager for parity tests: the next update of `algo_or_nets` uses these dropout keep-masks
+    (uint8 [B, H] each, reference consumption order) and, for TD3, this unclipped noise draw."""
+
+    def __init__(self, nets, masks=None, noise=None, algo="ddpg"):
+        self.ctx = context_for(algo, nets)
+        self.payload = (masks, noise)
+
+    def __enter__(self):
+        self.ctx.external = self.payload
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.external = None
+        return False
+
+
+def fused_adam_configs(optimizer: dict, keys):
+    cfgs = [adam_config(optimizer.get(k)) for k in keys]
+    return cfgs if all(c is not None for c in cfgs) else None

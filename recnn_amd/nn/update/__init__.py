@@ -1,0 +1,5 @@
+from .misc import temporal_difference, value_update  # noqa: F401
+from .ddpg import ddpg_update  # noqa: F401
+from .td3 import td3_update  # noqa: F401
+
+__all__ = ["temporal_difference", "value_update", "ddpg_update", "td3_update"]

@@ -1,0 +1,124 @@
+"""Optimizers.
+
+`Adam`  -- torch.optim.Optimizer whose step() is the fused HIP kernel `recnn_adam_flat` (arithmetic of
+           torch.optim.Adam: L2 weight decay, bias correction, eps outside the sqrt).  When both optimizers of
+           an update are (this or torch's) plain Adam, `ddpg_update` / `td3_update` run Adam INSIDE the fused
+           step engine (one launch per network, fused with the shadow refresh and the soft target update).
+`Ranger`-- RAdam + Lookahead in plain torch ops.  The reference's default `torch_optimizer.Ranger`
+           (recnn/nn/algo.py:84-89) is an absent, un-pinned third-party package; this restatement follows its
+           published algorithm from memory and is NOT verified against it ("parity unpinned").
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+__all__ = ["Adam", "Ranger", "adam_config"]
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        stream = None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise L.RecnnHipError("recnn_amd.optim.Adam: parameters must live on the GPU (no CPU fallback)")
+                if p.dtype != torch.float32 or not p.data.is_contiguous():
+                    raise L.RecnnHipError("recnn_amd.optim.Adam: parameters must be contiguous float32")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+                st["step"] = int(st["step"]) + 1
+                g = p.grad.data if p.grad.data.is_contiguous() else p.grad.data.contiguous()
+                stream = stream or L.current_stream()
+                L.call("recnn_adam_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                       int(st["step"]), 1.0, stream)
+        return loss
+
+
+def adam_config(opt):
+    """Hyper-parameters if `opt` is an Adam the fused engine reproduces exactly, else None."""
+    if opt is None or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if type(opt) is Adam:
+        pass
+    elif type(opt) is torch.optim.Adam:
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return None
+        if g.get("decoupled_weight_decay"):
+            return None
+        if isinstance(g["lr"], torch.Tensor):
+            return None
+    else:
+        return None
+    return dict(lr=float(g["lr"]), beta1=float(g["betas"][0]), beta2=float(g["betas"][1]), eps=float(g["eps"]),
+                weight_decay=float(g["weight_decay"]))
+
+
+class Ranger(torch.optim.Optimizer):
+    """RAdam (variance rectified Adam) + Lookahead(k, alpha).  UNVERIFIED restatement, see module docstring."""
+
+    def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5, weight_decay=0):
+        super().__init__(params, dict(lr=lr, alpha=alpha, k=k, N_sma_threshhold=N_sma_threshhold, betas=betas, eps=eps,
+                                      weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            n_max = 2.0 / (1.0 - b2) - 1.0
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad.data.float()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+                    st["slow_buffer"] = p.data.clone()
+                st["step"] += 1
+                t = st["step"]
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                b2t = b2 ** t
+                n_sma = n_max - 2 * t * b2t / (1 - b2t)
+                if n_sma > group["N_sma_threshhold"]:
+                    step_size = math.sqrt((1 - b2t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) \
+                        / (1 - b1 ** t)
+                else:
+                    step_size = 1.0 / (1 - b1 ** t)
+                if group["weight_decay"] != 0:
+                    p.data.add_(p.data, alpha=-group["weight_decay"] * group["lr"])
+                if n_sma > group["N_sma_threshhold"]:
+                    p.data.addcdiv_(m, v.sqrt().add_(group["eps"]), value=-step_size * group["lr"])
+                else:
+                    p.data.add_(m, alpha=-step_size * group["lr"])
+                if t % group["k"] == 0:
+                    slow = st["slow_buffer"]
+                    slow.add_(p.data - slow, alpha=group["alpha"])
+                    p.data.copy_(slow)
+        return loss

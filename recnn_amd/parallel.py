@@ -1,0 +1,66 @@
+"""Data-parallel replicas of the update step over RCCL (new functionality; the reference has no distributed code).
+
+Weak scaling, one process per GPU: every rank owns a shard of the replay users (rank r takes perm[r::W]), builds
+its own batch and runs the forward/backward phases locally; the only exchange is one all-reduce(sum) of the flat
+fp32 gradient arena per optimizer step -- critic(s) every step (1.7 MB each), actor every `policy_step`-th step.
+The L1 clip quirk is evaluated on the REDUCED actor gradient, optimizer / soft update run replicated, so all
+ranks hold identical weights without any broadcast (`check_replicas` verifies).
+
+N ranks x B/N rows with the matching slices of the dropout masks == 1 rank x B rows up to fp32 summation order
+(tests/test_parallel_gloo.py proves the orchestration with the CPU oracle standing in for the engine).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+__all__ = ["DataParallelStepper", "shard_users"]
+
+
+def shard_users(perm: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank r's share of an epoch permutation of user slots."""
+    return perm[rank::world].contiguous()
+
+
+class DataParallelStepper:
+    """Drives any engine exposing the phase API of recnn_amd.nn.engine.StepEngine
+    (value_grads / value_apply / policy_grads / policy_apply / finish / grad_arena / value_nets / policy_every)."""
+
+    def __init__(self, engine, rows: int, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallelStepper needs an initialised torch.distributed process group "
+                               "(backend 'nccl' = RCCL on ROCm)")
+        self.engine = engine
+        self.rows = rows
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.scale = 1.0 / self.world
+
+    def _allreduce(self, t: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def step(self, t: int, learn: bool = True):
+        e = self.engine
+        policy = learn and (t % e.policy_every == 0)
+        e.value_grads(self.rows, learn)
+        if learn:
+            for ni in e.value_nets():
+                self._allreduce(e.grad_arena(ni))
+            e.value_apply(policy, self.scale)
+        e.policy_grads(self.rows, policy)
+        if policy:
+            self._allreduce(e.grad_arena(L.NET_POLICY))
+            e.policy_apply(True, self.scale)
+        e.finish(self.rows, learn, policy)
+
+    def check_replicas(self, tensors) -> float:
+        """max |x - mean over ranks| over the given parameter tensors (0 when replicas agree bit for bit)."""
+        worst = 0.0
+        for t in tensors:
+            ref = t.detach().clone()
+            self._allreduce(ref)
+            worst = max(worst, float((ref * self.scale - t).abs().max()))
+        return worst

@@ -1,0 +1,65 @@
+"""CPU checks of the native boundary: the shared library loads without a GPU, exports every symbol that
+include/recnn_hip.h declares, the ctypes struct declarations match sizeof() on the C side, and the product
+path refuses to run without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "recnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(recnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from recnn_amd import _lib as L
+    lib = L.load()
+    assert lib.recnn_abi_version() == 1
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/recnn_hip.h but not exported"
+    for n in names:
+        assert n in L.SIGNATURES, f"{n} has no ctypes signature in recnn_amd/_lib.py"
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from recnn_amd import _lib as L
+    lib = L.load()
+    assert lib.recnn_engine_query(None, None) == -1
+    assert b"null" in lib.recnn_last_error()
+    cfg = L.EngineConfig(0, 0, 1290, 126, 256, 2048, 1, 0, 0)      # action_dim not a multiple of 8
+    sz = L.EngineSizes()
+    import ctypes as C
+    assert lib.recnn_engine_query(C.byref(cfg), C.byref(sz)) == -1
+    cfg.action_dim = 128
+    assert lib.recnn_engine_query(C.byref(cfg), C.byref(sz)) == 0
+    assert sz.ld_x == 1472 and sz.master_floats_actor == 429_184 and sz.master_floats_critic == 429_313
+    assert sz.workspace_bytes > 0 and sz.workspace_bytes % 256 == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_fallback():
+    from recnn_amd import _lib as L
+    from recnn_amd.nn.engine import StepEngine
+    with pytest.raises(L.RecnnHipError):
+        StepEngine("ddpg", 1290, 128, 256, 32, device=torch.device("cpu"))
+    import recnn_amd
+    with pytest.raises(L.RecnnHipError):
+        recnn_amd.utils.soft_update(recnn_amd.nn.Actor(27, 8, 16), recnn_amd.nn.Actor(27, 8, 16), 1.0)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "recnn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
