@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,13 +122,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from recnn_amd import _lib as L
     from recnn_amd.nn.engine import StepEngine
+    if os.environ.get("RECNN_GEMM_VARIANT"):
+        L.load().recnn_tune_gemm_variant(int(os.environ["RECNN_GEMM_VARIANT"]))
+    if os.environ.get("RECNN_GATHER_ROWS"):
+        L.load().recnn_tune_gather_rows(int(os.environ["RECNN_GATHER_ROWS"]))
 
     items, ratings, off, lens = synthetic_store(0)
     gen = torch.Generator().manual_seed(0)
@@ -147,7 +158,7 @@ def main():
     eng.bind_sampler(items_d, ratings_d, off_d, perm, USERS_PER_BATCH, FRAME, EMB, table_d)
 
     stream = torch.cuda.Stream(device=dev)
-    if world == 1:
+    if not use_dp:
         with torch.cuda.stream(stream):
             eng.graph_build(B_ROWS)
 
@@ -163,7 +174,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dp:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -174,7 +185,7 @@ def main():
         run(args.warmup, args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -221,7 +232,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(items, ratings, off, table)
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 

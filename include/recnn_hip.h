@@ -53,6 +53,9 @@ const char* recnn_last_error(void);
 /* sizeof() of an ABI struct: 0 recnn_gemm_args, 1 recnn_engine_config, 2 recnn_hyper,
  * 3 recnn_engine_sizes, 4 recnn_sampler (lets a binding verify its declarations); -1 if unknown. */
 int64_t recnn_abi_sizeof(int which);
+/* tuning knob: GEMM tile variant, -1 = per-launch heuristic, 0 = 64x64 tile, 1 = 32x64 tile with a 2x longer
+ * k stage. */
+void recnn_tune_gemm_variant(int variant);
 /* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
 void recnn_tune_gather_rows(int rows_per_workgroup);
 
@@ -79,7 +82,9 @@ int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_users, int n_
  *   action[r]     = emb(i_{t+F}),  reward[r] = r_{t+F},  done[r] = (t == L_u - F - 1)
  * ld_* are row strides in floats (>= row width); rows must be 8-byte aligned, 16-byte
  * aligned rows take the vector path.  `rows` may be smaller than row_off[n_users]
- * (fixed-row batches); rows >= row_off[n_users] are left untouched. */
+ * (fixed-row batches); rows >= row_off[n_users] are left untouched.
+ * row_off may be NULL when n_users <= 1024: the kernel then computes the plan itself (per workgroup, in
+ * LDS) and no recnn_frame_plan launch is needed. */
 int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
                        const int32_t* batch_users, const int32_t* row_off, int n_users, int rows,
                        int frame, int emb_dim, const float* table,
@@ -123,7 +128,7 @@ typedef struct recnn_gemm_args {
   uint32_t seed, stream_id; const int32_t* step_ptr;   /* hash mask key (step read from device) */
   const float* addend; int64_t ld_add; float add_clip; /* fwd: C += clamp(addend, +-add_clip) (TD3 noise) */
   const void* yref; int64_t ldy; float dx_scale;       /* dx: C = acc * dx_scale * [yref > 0]; yref NULL = plain */
-  float* colsum;          /* dx: per-row-tile column sums, float[ceil(M/64)][N] (bias gradients) */
+  float* colsum;          /* dx: column sums per 32-row slab, float[ceil(M/32)][N] (bias gradients) */
   int dw_splits;          /* dw: number of K splits; slab s written at C + s*dw_slab_stride */
   int64_t dw_slab_stride;
   int dw_valid_cols;      /* dw: columns >= this are not stored */

@@ -37,7 +37,7 @@ static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 namespace {
 
 constexpr int W1 = 0, B1 = 1, W2 = 2, B2 = 3, W3 = 4, B3 = 5;
-constexpr int SP_W1 = 4, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
+constexpr int SP_W1 = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
 
 struct Net {
   bool critic = false, bound = false;
@@ -194,8 +194,8 @@ int64_t carve(recnn_engine* e, char* base) {
   e->target_q = (float*)c.take(Bc * 4);
   e->qpi = (float*)c.take(Bc * 4);
   const int64_t nblk_head = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
-  const int64_t nblk_hb = (Bc + HEADB_ROWS_PER_BLOCK - 1) / HEADB_ROWS_PER_BLOCK;
-  const int64_t tiles_m = (Bc + 63) / 64;
+  const int64_t nblk_hb = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
+  const int64_t tiles_m = (Bc + 31) / 32;  // dX column-sum slabs (32 rows each)
   for (int i = 0; i < 2; ++i) {
     e->q[i] = (float*)c.take(Bc * 4);
     e->delta[i] = (float*)c.take(Bc * 4);
@@ -358,8 +358,8 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
   NetLayout L;
   memset(&L, 0, sizeof(L));
   const int H = e->H;
-  const int tiles_m = (rows + 63) / 64;
-  const int nblk_hb = (rows + HEADB_ROWS_PER_BLOCK - 1) / HEADB_ROWS_PER_BLOCK;
+  const int tiles_m = (rows + 31) / 32;
+  const int nblk_hb = (rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int rr[6] = {H, 1, H, 1, n.out_dim, 1};
   const int cc[6] = {n.in_dim, H, H, H, H, n.out_dim};
   int blk = 0;
@@ -403,7 +403,7 @@ inline char* sh_ptr(const recnn_engine* e, int ni, int which) {
 }
 
 int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni,
-              float tau, hipStream_t s) {
+              float tau, hipStream_t s, bool from_slabs = false) {
   Net& n = e->net[ni];
   NetLayout L = make_layout(e, ni, rows);
   ApplyArgs a;
@@ -419,6 +419,8 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
     a.eps = e->hy.eps[opt_idx]; a.weight_decay = e->hy.weight_decay[opt_idx];
   }
   a.grad_scale = grad_scale;
+  a.from_slabs = from_slabs && do_adam && rows > 0;
+  a.g_out = n.g;
   a.l1part = clip ? n.l1part : nullptr;
   a.n_l1 = clip ? L.nblk : 0;
   a.coef_out = clip ? e->coef_out : nullptr;
@@ -541,7 +543,7 @@ int check_ready(recnn_engine* e, int rows) {
 
 // ------------------------------------------------------------------------------------ phases
 // Forward of the value side (+ optionally the actor forward, which is independent of it).
-int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipStream_t s) {
+int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
   const int A = e->A, Hp = e->Hp, nc = e->n_critic;
   const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
@@ -645,29 +647,25 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, hipS
     h.expected = e->expected; h.target_q = e->target_q;
     h.n_critic = nc;
     h.policy_mode = 0;
+    h.do_bwd = value_bwd;
+    h.train = e->cfg.mask_mode != RECNN_MASK_NONE;
+    if (value_bwd) {
+      for (int c = 0; c < nc; ++c) {
+        Net& v = e->net[VAL[c]];
+        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+        h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
+      }
+    }
     if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
   }
   return 0;
 }
 
 // Backward of the critic(s) into gradient slabs, then slab reduction into the bound grad arenas.
-int ph_value_backward(recnn_engine* e, int rows, hipStream_t s) {
+int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
-  const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
-  HeadBwdBatch hb;
-  memset(&hb, 0, sizeof(hb));
-  for (int c = 0; c < nc; ++c) {
-    Net& v = e->net[VAL[c]];
-    RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
-    HeadBwdArgs& a = hb.p[c];
-    a.rows = rows; a.H = H; a.train = train; a.ld_h = Hp;
-    a.delta = e->delta[c]; a.w3 = v.p + v.off[W3];
-    a.h2 = e->cv[c].h2; a.dz2 = e->dzc2[c];
-    a.dw3_part = v.gp[W3]; a.db2_part = v.gp[B2]; a.db3_part = v.gp[B3];
-  }
-  if ((rc = slot(e, "head_bwd_critic", 0, s, [&] { return head_bwd_launch(hb, nc, e->bf16, s); }))) return rc;
   {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
@@ -692,7 +690,7 @@ int ph_value_backward(recnn_engine* e, int rows, hipStream_t s) {
               L0.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_critic_l1"))) return rc;
   }
-  for (int c = 0; c < nc; ++c) {
+  for (int c = 0; c < nc && reduce; ++c) {
     NetLayout L = make_layout(e, VAL[c], rows);
     if ((rc = slot(e, "grad_reduce_critic", 0, s, [&] { return grad_reduce_launch(L, e->net[VAL[c]].g, nullptr, s); }))) return rc;
   }
@@ -700,7 +698,7 @@ int ph_value_backward(recnn_engine* e, int rows, hipStream_t s) {
 }
 
 // Policy loss through the (updated) critic 1; optionally the gradient chain back into the actor.
-int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
+int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s) {
   const int A = e->A, Hp = e->Hp, H = e->H, Ap = e->Ap;
   const int POL = RECNN_NET_POLICY, V1 = RECNN_NET_VALUE1;
   const int m0 = e->td3 ? 6 : 4;
@@ -732,21 +730,15 @@ int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
     h.n_target = 0; h.n_critic = 1; h.policy_mode = 1;
     h.ch2[0] = e->pc.h2; h.cw3[0] = v.p + v.off[W3]; h.cb3[0] = v.p + v.off[B3];
     h.q[0] = e->qpi; h.loss_part[0] = e->loss_part[2];
+    h.do_bwd = backward;          // d(policy_loss)/dQ = -1/B for every row; no critic parameter gradients
+    h.train = train;
+    h.delta_const = -1.0f / (float)rows;
+    h.dz2[0] = e->dze2;
     if ((rc = slot(e, "head_policy_loss", 0, s, [&] { return head_launch(h, s); }))) return rc;
   }
   if (!backward) return 0;
   Net& pn = e->net[POL];
   RECNN_REQUIRE(pn.g, "policy backward: the actor has no gradient arena bound");
-  {  // d(policy_loss)/dQ = -1/B for every row
-    HeadBwdBatch hb;
-    memset(&hb, 0, sizeof(hb));
-    HeadBwdArgs& a = hb.p[0];
-    const Net& v = e->net[V1];
-    a.rows = rows; a.H = H; a.train = train; a.ld_h = Hp;
-    a.delta = nullptr; a.delta_const = -1.0f / (float)rows;
-    a.w3 = v.p + v.off[W3]; a.h2 = e->pc.h2; a.dz2 = e->dze2;
-    if ((rc = slot(e, "head_bwd_policy", 0, s, [&] { return head_bwd_launch(hb, 1, e->bf16, s); }))) return rc;
-  }
   auto dx1 = [&](const char* nm, const void* Ain, int64_t lda, int Kc, int ni, int which, int N, void* C, int64_t ldc, const void* yref,
                  float* colsum) {
     Group g(e, GEMM_DX, 0, 0);
@@ -772,7 +764,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, hipStream_t s) {
     g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_actor_l1"))) return rc;
   }
-  return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, pn.g, nullptr, s); });
+  return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, pn.g, with_l1 ? pn.l1part : nullptr, s); });
 }
 
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
@@ -825,17 +817,19 @@ int ph_policy_l1(recnn_engine* e, hipStream_t s) {
   });
 }
 
-int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s) {
+// rows > 0: fused single-GPU path, Adam sums the gradient slabs itself (no separate reduction launch)
+int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int rows = 0) {
   int rc;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   for (int c = 0; c < e->n_critic; ++c)
-    if ((rc = apply_net(e, VAL[c], 0, true, 1, grad_scale, false, soft ? TVAL[c] : -1, e->hy.soft_tau, s))) return rc;
+    if ((rc = apply_net(e, VAL[c], rows, true, 1, grad_scale, false, soft ? TVAL[c] : -1, e->hy.soft_tau, s, rows > 0)))
+      return rc;
   return 0;
 }
 
-int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s) {
+int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bool have_l1 = false) {
   int rc;
-  if ((rc = ph_policy_l1(e, s))) return rc;
+  if (!have_l1 && (rc = ph_policy_l1(e, s))) return rc;
   // TD3 never soft-updates the target policy (td3.py:136-141); DDPG does (ddpg.py:98-100).
   const int tgt = (soft && !e->td3) ? RECNN_NET_TARGET_POLICY : -1;
   return apply_net(e, RECNN_NET_POLICY, 0, true, 0, grad_scale, true, tgt, e->hy.soft_tau, s);
@@ -843,12 +837,15 @@ int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s) {
 
 int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
   const recnn_sampler& m = e->smp;
-  int rc = slot(e, "frame_plan", 0, s, [&] {
-    return recnn_frame_plan(m.user_off, m.perm, m.users_per_batch, m.frame, m.row_off, m.cursor, m.users_per_batch, s);
-  });
-  if (rc) return rc;
+  const bool inl = m.users_per_batch <= 1024;   // the gather plans its rows itself: one launch less
+  if (!inl) {
+    int rc = slot(e, "frame_plan", 0, s, [&] {
+      return recnn_frame_plan(m.user_off, m.perm, m.users_per_batch, m.frame, m.row_off, m.cursor, m.users_per_batch, s);
+    });
+    if (rc) return rc;
+  }
   return slot(e, "frame_gather", 0, s, [&] {
-    return recnn_frame_gather(m.items, m.ratings, m.user_off, m.perm, m.row_off, m.users_per_batch, rows, m.frame, m.emb_dim,
+    return recnn_frame_gather(m.items, m.ratings, m.user_off, m.perm, inl ? nullptr : m.row_off, m.users_per_batch, rows, m.frame, m.emb_dim,
                               m.table, e->xs + e->A, e->ldx, e->xn + e->A, e->ldx, e->xs, e->ldx, e->reward, e->done, m.cursor,
                               m.users_per_batch, s);
   });
@@ -858,16 +855,16 @@ int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s) {
   int rc;
   if (e->has_sampler && (rc = frame_gather_packed(e, rows, s))) return rc;
-  if ((rc = ph_forward(e, rows, true, true, s))) return rc;
+  if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
-    if ((rc = ph_value_backward(e, rows, s))) return rc;
+    if ((rc = ph_value_backward(e, rows, false, s))) return rc;
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
     // next step, so on policy steps it is fused into the critic's Adam pass (ddpg.py:95-97).
-    if ((rc = value_apply(e, policy_step, 1.0f, s))) return rc;
+    if ((rc = value_apply(e, policy_step, 1.0f, s, rows))) return rc;
   }
   const bool pol = learn && policy_step;
-  if ((rc = ph_policy(e, rows, pol, s))) return rc;
-  if (pol && (rc = policy_apply(e, true, 1.0f, s))) return rc;
+  if ((rc = ph_policy(e, rows, pol, true, s))) return rc;
+  if (pol && (rc = policy_apply(e, true, 1.0f, s, true))) return rc;
   return ph_finish(e, rows, learn, pol, s);
 }
 }  // namespace
@@ -889,8 +886,8 @@ extern "C" int recnn_engine_value_grads(recnn_engine* e, int rows, int learn, vo
   int rc = check_ready(e, rows);
   if (rc) return rc;
   if (e->has_sampler && (rc = frame_gather_packed(e, rows, (hipStream_t)stream))) return rc;
-  if ((rc = ph_forward(e, rows, true, false, (hipStream_t)stream))) return rc;
-  if (learn) return ph_value_backward(e, rows, (hipStream_t)stream);
+  if ((rc = ph_forward(e, rows, true, false, learn != 0, (hipStream_t)stream))) return rc;
+  if (learn) return ph_value_backward(e, rows, true, (hipStream_t)stream);
   return 0;
 }
 
@@ -902,8 +899,8 @@ extern "C" int recnn_engine_value_apply(recnn_engine* e, int soft, float grad_sc
 extern "C" int recnn_engine_policy_grads(recnn_engine* e, int rows, int backward, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
-  if ((rc = ph_forward(e, rows, false, true, (hipStream_t)stream))) return rc;
-  return ph_policy(e, rows, backward != 0, (hipStream_t)stream);
+  if ((rc = ph_forward(e, rows, false, true, false, (hipStream_t)stream))) return rc;
+  return ph_policy(e, rows, backward != 0, false, (hipStream_t)stream);
 }
 
 extern "C" int recnn_engine_policy_apply(recnn_engine* e, int soft, float grad_scale, void* stream) {

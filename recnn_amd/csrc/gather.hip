@@ -72,6 +72,7 @@ struct GatherArgs {
   float* done;
   const int32_t* cursor;
   int cursor_stride;
+  int inline_plan;  // row_off == NULL: every workgroup scans the batch's history lengths itself (n_users <= 1024)
 };
 
 template <int W> struct VecT;
@@ -93,16 +94,55 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
   int* m_done = meta + 2 * R;
   int* m_valid = meta + 3 * R;
   long long* m_src = (long long*)(meta + 4 * R);   // CSR offset of the window start
+  int* s_off = (int*)(m_src + R);                  // inline plan: row prefix sums [n_users + 1]
+  int* s_sc = s_off + a.n_users + 1;               // inline plan: scan scratch [256]
 
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
   const int32_t* users = a.users;
   if (a.cursor) users += (int64_t)(*a.cursor) * a.cursor_stride;
 
+  const int* row_off = a.row_off;
+  if (a.inline_plan) {
+    // exclusive prefix sum of max(L_u - F, 0) over the batch's users, recomputed per workgroup (a few hundred
+    // L2-resident loads) instead of a separate single-workgroup plan launch ahead of the gather
+    const int n = a.n_users;
+    const int per = (n + 255) / 256;
+    int lens[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid * per + j;
+      int v = 0;
+      if (j < per && i < n) {
+        const int su = users[i];
+        v = max((int)(a.user_off[su + 1] - a.user_off[su]) - F, 0);
+      }
+      lens[j] = v;
+      sum += v;
+    }
+    s_sc[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int t = tid >= o ? s_sc[tid - o] : 0;
+      __syncthreads();
+      s_sc[tid] += t;
+      __syncthreads();
+    }
+    int run = s_sc[tid] - sum;
+    if (tid == 0) s_off[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid * per + j;
+      if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; }
+    }
+    __syncthreads();
+    row_off = s_off;
+  }
+
   if (tid < R) {
     const int r = row0 + tid;
     // rows past the planned total (fewer windows than requested) are left untouched
-    int valid = r < a.rows && r < a.row_off[a.n_users];
+    int valid = r < a.rows && r < row_off[a.n_users];
     int u = 0, t = 0, len = 0;
     long long src = 0;
     if (valid) {
@@ -110,10 +150,10 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
       int lo = 0, hi = a.n_users;
       while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
-        if (a.row_off[mid] <= r) lo = mid; else hi = mid;
+        if (row_off[mid] <= r) lo = mid; else hi = mid;
       }
       u = lo;
-      t = r - a.row_off[lo];
+      t = r - row_off[lo];
       const int su = users[u];
       const long long o0 = a.user_off[su];
       len = (int)(a.user_off[su + 1] - o0);
@@ -190,6 +230,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
 template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_t s) {
   const int F1 = a.frame + 1;
   size_t lds = (size_t)R * F1 * a.emb * 4 + (size_t)R * F1 * 4 + 4 * R * 4 + R * 8 + 16;
+  if (a.inline_plan) lds += (size_t)(a.n_users + 1 + 256) * 4;
   if (lds > 160 * 1024) { recnn_set_error("frame_gather: tile does not fit LDS (%zu bytes)", lds); return RECNN_E_UNSUPPORTED; }
   dim3 grid((a.rows + R - 1) / R), block(256);
   hipError_t e = hipSuccess;
@@ -215,7 +256,8 @@ extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, co
                                   int emb_dim, const float* table, float* state, int64_t ld_state, float* next_state,
                                   int64_t ld_next, float* action, int64_t ld_action, float* reward, float* done,
                                   const int32_t* cursor, int cursor_stride, void* stream) {
-  RECNN_REQUIRE(items && ratings && user_off && batch_users && row_off && table, "frame_gather: null input");
+  RECNN_REQUIRE(items && ratings && user_off && batch_users && table, "frame_gather: null input");
+  RECNN_REQUIRE(row_off || n_users <= 1024, "frame_gather: more than 1024 users per batch need a recnn_frame_plan row_off");
   RECNN_REQUIRE(state && next_state && action && reward && done, "frame_gather: null output");
   RECNN_REQUIRE(frame > 0 && emb_dim > 0 && (emb_dim % 4) == 0, "frame_gather: emb_dim must be a positive multiple of 4");
   RECNN_REQUIRE(((uintptr_t)table & 15) == 0, "frame_gather: table must be 16-byte aligned");
@@ -228,6 +270,7 @@ extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, co
   a.state = state; a.ld_state = ld_state; a.next_state = next_state; a.ld_next = ld_next;
   a.action = action; a.ld_action = ld_action; a.reward = reward; a.done = done;
   a.cursor = cursor; a.cursor_stride = cursor_stride;
+  a.inline_plan = row_off == nullptr;
   // widest store every output row start supports
   auto al = [](const void* p, int64_t ld) {
     uintptr_t x = (uintptr_t)p | (uintptr_t)(ld * 4);

@@ -20,26 +20,31 @@
 #include <type_traits>
 #include "gemm.h"
 
-template <class TC> struct LdsCfg {
+template <class TC, int KB> struct LdsCfg {
   static constexpr int VEC = TcTraits<TC>::VEC;
-  static constexpr int BK = TcTraits<TC>::BK;
-  static constexpr int BKP = BK + VEC;  // padded pitch in elements (144 bytes)
+  static constexpr int BK = KB;          // k elements per LDS stage
+  static constexpr int BKP = BK + VEC;   // padded pitch in elements (+16 bytes)
 };
 
 // ------------------------------------------------------------------ staging: k-contiguous
-template <class TC, bool MEM32, int R> struct KCLoader {
-  static constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+template <class TC, bool MEM32, int R, int KB> struct KCLoader {
+  static constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   static constexpr int CPR = BK / VEC;          // 16-byte LDS chunks per row (8)
   static constexpr int NCH = R * CPR / 256;     // chunks per thread
   static constexpr bool CVT = MEM32 && (sizeof(TC) == 2);
   uint4 raw[NCH][CVT ? 2 : 1];
 
-  __device__ inline void load(const void* base, int64_t ld, int row0, int row_max, int k0, int tid) {
+  __device__ inline void load(const void* base, int64_t ld, int row0, int row_max, int k0, int k_end, int tid) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int c = tid + i * 256;
       int row = c / CPR, kc = c % CPR;
       int gr = min(row0 + row, row_max);  // clamp: rows past the end re-read the last valid row
+      if (k0 + kc * VEC >= k_end) {       // k tail of the last stage: zeros
+        raw[i][0] = make_uint4(0, 0, 0, 0);
+        if constexpr (CVT) raw[i][1] = make_uint4(0, 0, 0, 0);
+        continue;
+      }
       if constexpr (CVT) {
         const float* p = (const float*)base + (int64_t)gr * ld + k0 + kc * 8;
         raw[i][0] = *(const uint4*)p;
@@ -76,8 +81,8 @@ template <class TC, bool MEM32, int R> struct KCLoader {
 // Source is [Kc, ld] with the tile dimension contiguous.  A unit = 4 consecutive k rows x one
 // 16-byte load along the tile dimension (NE elements); it is transposed in registers and written
 // as NE small vectors of 4 k values.
-template <class TC, bool MEM32, int R> struct KSLoader {
-  static constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+template <class TC, bool MEM32, int R, int KB> struct KSLoader {
+  static constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   static constexpr bool SRC32 = MEM32 || (sizeof(TC) == 4);
   static constexpr int NE = SRC32 ? 4 : 8;      // tile elements per 16-byte load
   static constexpr int KG = BK / 4;             // k groups per stage
@@ -143,9 +148,9 @@ template <class TC, bool MEM32, int R> struct KSLoader {
 };
 
 // ------------------------------------------------------------------ MFMA on one LDS stage
-template <class TC, int TM, int TN>
+template <class TC, int TM, int TN, int KB>
 __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN], int wm0, int wn0, int lane) {
-  constexpr int VEC = LdsCfg<TC>::VEC, BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP, KSTEP = TcTraits<TC>::KSTEP;
+  constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP, KSTEP = TcTraits<TC>::KSTEP;
   const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < BK / KSTEP; ++ks) {
@@ -175,10 +180,10 @@ __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN
 }
 
 // ------------------------------------------------------------------ the kernel
-template <class TC, int MODE, bool A32, bool B32, int TM, int TN>
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
-  constexpr int BK = LdsCfg<TC>::BK, BKP = LdsCfg<TC>::BKP;
+  constexpr int BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   constexpr bool A_KS = (MODE == GEMM_DW);
   constexpr bool B_KS = (MODE != GEMM_FWD);
   const GemmProb& P = batch.p[blockIdx.y];
@@ -213,14 +218,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
     kend = min(Kc, kbeg + chunk);
     nt0 = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   } else {
-    nt0 = P.seg[0].K / BK;
-    nt1 = P.nseg > 1 ? P.seg[1].K / BK : 0;
+    nt0 = (P.seg[0].K + BK - 1) / BK;
+    nt1 = P.nseg > 1 ? (P.seg[1].K + BK - 1) / BK : 0;
     kend = P.seg[0].K;
   }
   const int nt = nt0 + nt1;
 
-  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM>, KCLoader<TC, A32, BM>>::type;
-  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN>, KCLoader<TC, B32, BN>>::type;
+  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM, KB>, KCLoader<TC, A32, BM, KB>>::type;
+  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN, KB>, KCLoader<TC, B32, BN, KB>>::type;
   ALoader la;
   BLoader lb;
 
@@ -230,9 +235,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
     const int k0 = kbeg + (s == 0 ? t : t - nt0) * BK;
     const int ke = (MODE == GEMM_DW) ? kend : G.K;
     if constexpr (A_KS) la.load(G.A, G.lda, m0, k0, ke, tid);
-    else la.load(G.A, G.lda, m0, P.M - 1, k0, tid);
+    else la.load(G.A, G.lda, m0, P.M - 1, k0, ke, tid);
     if constexpr (B_KS) lb.load(G.B, G.ldb, n0, k0, ke, tid);
-    else lb.load(G.B, G.ldb, n0, P.N - 1, k0, tid);
+    else lb.load(G.B, G.ldb, n0, P.N - 1, k0, ke, tid);
   };
 
   if (nt > 0) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
     if (t + 1 < nt) issue(t + 1);
     TC* sa = smem + cur * STAGE;
     TC* sn = smem + (cur ^ 1) * STAGE;
-    mma_stage<TC, TM, TN>(sa, sa + BM * BKP, acc, wm0, wn0, lane);
+    mma_stage<TC, TM, TN, KB>(sa, sa + BM * BKP, acc, wm0, wn0, lane);
     if (t + 1 < nt) {
       la.store(sn, tid);
       lb.store(sn + BM * BKP, tid);
@@ -323,7 +328,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
         if (fg == 0) red[(wave >> 1) * BN + wn0 + tn * 16 + fr] = v;
       }
       __syncthreads();
-      if (tid < BN && n0 + tid < P.N) P.colsum[(int64_t)tile_m * P.N + n0 + tid] = red[tid] + red[BN + tid];
+      // slab granularity is 32 rows whatever the block tile: a 64-row tile writes two slabs
+      if (tid < BN && n0 + tid < P.N) {
+        if constexpr (BM == 32) {
+          P.colsum[(int64_t)tile_m * P.N + n0 + tid] = red[tid] + red[BN + tid];
+        } else {
+          P.colsum[(int64_t)(2 * tile_m) * P.N + n0 + tid] = red[tid];
+          if (m0 + 32 < P.M) P.colsum[(int64_t)(2 * tile_m + 1) * P.N + n0 + tid] = red[BN + tid];
+        }
+      }
     }
   } else {  // GEMM_DW
     float* Cs = (float*)P.C + (int64_t)split * P.dw_slab_stride;
@@ -354,9 +367,13 @@ void gemm_prob_init(GemmProb* p) {
   p->dw_splits = 1;
 }
 
-template <class TC, int MODE, bool A32, bool B32>
-static int launch_t(GemmLaunch* L, hipStream_t stream) {
-  constexpr int TM = 2, TN = 2;
+// Tile variants: 0 = 64x64 block tile, short k stage; 1 = 32x64 block tile, 2x longer k stage (more, smaller
+// workgroups with more bytes in flight each: these GEMMs have M = batch rows only, so they are latency bound).
+static int g_gemm_variant = -1;  // -1 = choose per launch
+extern "C" void recnn_tune_gemm_variant(int v) { g_gemm_variant = v; }
+
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
+static int launch_v(GemmLaunch* L, hipStream_t stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   int maxwg = 0;
   for (int i = 0; i < L->nprob; ++i) {
@@ -369,8 +386,24 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
   }
   if (maxwg == 0) return 0;
   dim3 grid(maxwg, L->nprob, 1), block(256, 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN>), grid, block, 0, stream, L->batch);
+  hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB>), grid, block, 0, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
+}
+
+template <class TC, int MODE, bool A32, bool B32>
+static int launch_t(GemmLaunch* L, hipStream_t stream) {
+  constexpr int KB0 = TcTraits<TC>::BK;
+  int v = g_gemm_variant;
+  if (v < 0) {  // enough 64x64 tiles to give every CU a few workgroups?  else take the small-tile variant
+    long wg = 0;
+    for (int i = 0; i < L->nprob; ++i) {
+      const GemmProb& p = L->batch.p[i];
+      wg += (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (MODE == GEMM_DW ? p.dw_splits : 1);
+    }
+    v = wg >= 1024 ? 0 : 1;
+  }
+  if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 2, KB0>(L, stream);
+  return launch_v<TC, MODE, A32, B32, 1, 2, 2 * KB0>(L, stream);
 }
 
 template <class TC, int MODE> static int launch_m(GemmLaunch* L, hipStream_t s) {
@@ -391,7 +424,7 @@ template <class TC, int MODE> static int launch_m(GemmLaunch* L, hipStream_t s) 
 int gemm_launch(GemmLaunch* L, hipStream_t stream) {
   if (L->nprob <= 0) return 0;
   if (L->nprob > GEMM_MAX_GROUP) { recnn_set_error("gemm group too large"); return RECNN_E_INVALID; }
-  const int BK = L->dtype == RECNN_F32 ? 32 : 64;
+  const int BK = 64;  // zero-padding granularity of k-contiguous operands (16-byte chunks never straddle it)
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];
     for (int s = 0; s < p.nseg; ++s) {

@@ -28,6 +28,15 @@ struct HeadArgs {
   float* delta[2];      // 2 (q - y) / rows
   float* loss_part[2];  // per block partial sums: (q-y)^2, or q in policy mode
   int policy_mode;
+  // fused backward seed (same rows, same block): dz2 = delta * w3 * scale * [h2 > 0] and the partial sums of
+  // dW3 / db3 / db2 over the block's rows.  do_bwd = 0 skips it.
+  int do_bwd;
+  int train;             // dropout active: scale = 2
+  float delta_const;     // policy mode: d(loss)/dQ = -1/rows for every row
+  void* dz2[2];          // tc [rows, ld_h]
+  float* dw3_part[2];    // [nblk][H] or NULL (no parameter gradients needed)
+  float* db2_part[2];    // [nblk][H]
+  float* db3_part[2];    // [nblk]
 };
 
 struct HeadBwdArgs {

@@ -28,42 +28,61 @@ template <class TC> __device__ inline float row_dot(const TC* __restrict__ h, co
   return wave_sum(s);
 }
 
-// 16 rows per block (4 waves x 4 rows).  partial sums of the loss terms per block.
+// 16 rows per block.  Phase 1: one wave per row (4 rows per wave, loads of all 4 rows issued together): TD target,
+// Q, dQ, loss partial.  Phase 2 (do_bwd): one thread per hidden column walks the block's 16 rows: dz2 and the
+// partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
 template <class TC> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
   __shared__ float part[4][HEAD_MAX_CRITIC];
+  __shared__ float sdelta[HEAD_MAX_CRITIC][HEAD_ROWS_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * HEAD_ROWS_PER_BLOCK;
   float acc[HEAD_MAX_CRITIC];
 #pragma unroll
   for (int c = 0; c < HEAD_MAX_CRITIC; ++c) acc[c] = 0.f;
+  float tq[4], qv[HEAD_MAX_CRITIC][4];
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = blockIdx.x * HEAD_ROWS_PER_BLOCK + wave * 4 + i;
-    if (r >= a.rows) break;  // wave-uniform
-    float y = 0.f;
+    const int r = min(r0 + wave * 4 + i, a.rows - 1);  // clamp: tail rows recompute the last row, results unused
+    tq[i] = 0.f;
     if (a.n_target > 0) {
-      float tq = row_dot<TC>((const TC*)a.th2[0] + (int64_t)r * a.ld_h, a.tw3[0], a.H, lane) + a.tb3[0][0];
-      if (a.n_target > 1) {
-        float t2 = row_dot<TC>((const TC*)a.th2[1] + (int64_t)r * a.ld_h, a.tw3[1], a.H, lane) + a.tb3[1][0];
-        tq = fminf(tq, t2);
-      }
-      y = a.reward[r] + (1.0f - a.done[r]) * a.gamma * tq;
+      tq[i] = row_dot<TC>((const TC*)a.th2[0] + (int64_t)r * a.ld_h, a.tw3[0], a.H, lane) + a.tb3[0][0];
+      if (a.n_target > 1)
+        tq[i] = fminf(tq[i], row_dot<TC>((const TC*)a.th2[1] + (int64_t)r * a.ld_h, a.tw3[1], a.H, lane) + a.tb3[1][0]);
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_CRITIC; ++c)
+      qv[c][i] = c < a.n_critic ? row_dot<TC>((const TC*)a.ch2[c] + (int64_t)r * a.ld_h, a.cw3[c], a.H, lane) + a.cb3[c][0] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + wave * 4 + i;
+    const bool valid = r < a.rows;
+    float y = 0.f;
+    if (a.n_target > 0 && valid) {
+      y = a.reward[r] + (1.0f - a.done[r]) * a.gamma * tq[i];
       y = fminf(fmaxf(y, a.lo), a.hi);
       if (lane == 0) {
         if (a.expected) a.expected[r] = y;
-        if (a.target_q) a.target_q[r] = tq;
+        if (a.target_q) a.target_q[r] = tq[i];
       }
     }
-    for (int c = 0; c < a.n_critic; ++c) {
-      float q = row_dot<TC>((const TC*)a.ch2[c] + (int64_t)r * a.ld_h, a.cw3[c], a.H, lane) + a.cb3[c][0];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_CRITIC; ++c) {
+      if (c >= a.n_critic) continue;
+      const float q = qv[c][i];
+      float d;
       if (a.policy_mode) {
-        acc[c] += q;
-        if (lane == 0 && a.q[c]) a.q[c][r] = q;
+        d = a.delta_const;
+        if (valid) acc[c] += q;
       } else {
-        const float d = q - y;
-        acc[c] += d * d;
-        if (lane == 0) {
-          if (a.q[c]) a.q[c][r] = q;
-          a.delta[c][r] = d * (2.0f / (float)a.rows);
-        }
+        const float e = q - y;
+        d = e * (2.0f / (float)a.rows);
+        if (valid) acc[c] += e * e;
+        if (valid && lane == 0 && a.delta[c]) a.delta[c][r] = d;
+      }
+      if (lane == 0) {
+        sdelta[c][wave * 4 + i] = valid ? d : 0.f;
+        if (valid && a.q[c]) a.q[c][r] = q;
       }
     }
   }
@@ -73,6 +92,38 @@ template <class TC> __global__ __launch_bounds__(256) void head_kernel(const Hea
   if (threadIdx.x < a.n_critic) {
     const int c = threadIdx.x;
     a.loss_part[c][blockIdx.x] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  }
+  if (!a.do_bwd) return;
+  const int nr = min(HEAD_ROWS_PER_BLOCK, a.rows - r0);
+  const float scale = a.train ? 2.0f : 1.0f;
+  for (int c = 0; c < a.n_critic; ++c) {
+    const TC* h2 = (const TC*)a.ch2[c];
+    TC* dz2 = (TC*)a.dz2[c];
+    for (int n = threadIdx.x; n < a.H; n += 256) {
+      const float w = a.cw3[c][n] * scale;
+      float hv[HEAD_ROWS_PER_BLOCK];
+#pragma unroll
+      for (int i = 0; i < HEAD_ROWS_PER_BLOCK; ++i)
+        hv[i] = i < nr ? tc_load(h2 + (int64_t)(r0 + i) * a.ld_h + n) : 0.f;
+      float sw = 0.f, sb = 0.f;
+#pragma unroll
+      for (int i = 0; i < HEAD_ROWS_PER_BLOCK; ++i) {
+        const float d = sdelta[c][i];
+        const float dz = hv[i] > 0.f ? d * w : 0.f;
+        if (i < nr) tc_store(dz2 + (int64_t)(r0 + i) * a.ld_h + n, dz);
+        sw += d * hv[i];
+        sb += dz;
+      }
+      if (a.dw3_part[c]) {
+        a.dw3_part[c][(int64_t)blockIdx.x * a.H + n] = sw;
+        a.db2_part[c][(int64_t)blockIdx.x * a.H + n] = sb;
+      }
+    }
+    if (a.db3_part[c] && threadIdx.x == 0) {
+      float s = 0.f;
+      for (int i = 0; i < nr; ++i) s += sdelta[c][i];
+      a.db3_part[c][blockIdx.x] = s;
+    }
   }
 }
 

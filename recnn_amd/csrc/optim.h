@@ -37,6 +37,8 @@ struct ApplyArgs {
   void* tgt_shadow;
   float tau;
   float* coef_out;      // optional: the clip coefficient (debug)
+  int from_slabs;       // gradient = sum of the layout's partial slabs (fused slab reduction); g_out receives it
+  float* g_out;
 };
 
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);

@@ -26,6 +26,20 @@ __device__ inline float block_sum256(float v, float* red /*[4]*/) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// fixed summation order (deterministic); 8 independent loads in flight per thread
+__device__ inline float sum_slabs(const TensorSeg& T, int64_t e) {
+  float g = 0.f;
+  int s = 0;
+  for (; s + 8 <= T.nslab; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+    g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; s < T.nslab; ++s) g += T.gpart[(int64_t)s * T.slab_stride + e];
+  return g;
+}
+
 // g_flat = sum of partial slabs (split-K slabs of the dW GEMMs, row-tile column sums for biases)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const NetLayout L, float* __restrict__ gflat,
                                                           float* __restrict__ l1part) {
@@ -36,16 +50,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const NetLayout L, flo
   float l1 = 0.f;
   for (int c = threadIdx.x; c < T.cols; c += 256) {
     const int64_t e = (int64_t)row * T.cols + c;
-    // fixed summation order (deterministic); 8 independent loads in flight per thread
-    float g = 0.f;
-    int s = 0;
-    for (; s + 8 <= T.nslab; s += 8) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
-      g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    for (; s < T.nslab; ++s) g += T.gpart[(int64_t)s * T.slab_stride + e];
+    const float g = sum_slabs(T, e);
     gflat[T.p_off + e] = g;
     l1 += fabsf(g);
   }
@@ -92,7 +97,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
     const int64_t e = T.p_off + (int64_t)row * T.cols + c;
     float p = a.p[e];
     if (a.do_adam) {
-      float g = a.g[e] * gs;
+      float graw;
+      if (a.from_slabs) {
+        graw = sum_slabs(T, (int64_t)row * T.cols + c);
+        if (a.g_out) a.g_out[e] = graw;
+      } else {
+        graw = a.g[e];
+      }
+      float g = graw * gs;
       if (a.weight_decay != 0.f) g += a.weight_decay * p;
       float m = a.m[e], v = a.v[e];
       m += (1.0f - a.beta1) * (g - m);

@@ -53,9 +53,12 @@ def gather_frames(items, ratings, user_off, batch_users, row_total, rows, frame_
     S = frame_size * E + frame_size
     n_users = batch_users.numel()
     stream = L.current_stream()
-    if row_off is None:
-        row_off = torch.empty(n_users + 1, dtype=torch.int32, device=dev)
-    L.call("recnn_frame_plan", L.ptr(user_off), L.ptr(batch_users), n_users, frame_size, L.ptr(row_off), None, 0, stream)
+    if n_users > 1024:      # big user lists: explicit plan launch; otherwise the gather kernel plans inline
+        if row_off is None:
+            row_off = torch.empty(n_users + 1, dtype=torch.int32, device=dev)
+        L.call("recnn_frame_plan", L.ptr(user_off), L.ptr(batch_users), n_users, frame_size, L.ptr(row_off), None, 0, stream)
+    else:
+        row_off = None
     out = FrameBatch()
     reward = torch.empty(rows, dtype=torch.float32, device=dev) if reward is None else reward
     done = torch.empty(rows, dtype=torch.float32, device=dev) if done is None else done

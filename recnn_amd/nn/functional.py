@@ -106,7 +106,7 @@ class MLPFunction(torch.autograd.Function):
         B, K, H, O, Kp, Hp, Op = ctx.dims
         dev = dout.device
         scale = 2.0 if ctx.train else 1.0
-        tiles = (B + 63) // 64
+        tiles = (B + 31) // 32
         doutp = _pad(dout, B, Op)
         gw3 = torch.empty(O, H, device=dev)
         _dw(doutp, O, h2, H, gw3)

@@ -22,7 +22,7 @@ def _lib():
     return L
 
 
-def _gather(L, dev, items, ratings, table, users, frame, rows=None, packed=False, rows_per_wg=None):
+def _gather(L, dev, items, ratings, table, users, frame, rows=None, packed=False, rows_per_wg=None, inline_plan=False):
     it, rt, off = csr(items, ratings)
     E = table.shape[1]
     S = frame * E + frame
@@ -49,7 +49,7 @@ def _gather(L, dev, items, ratings, table, users, frame, rows=None, packed=False
         lda = E
     reward = torch.full((B,), 7.0, device=dev)
     done = torch.full((B,), 7.0, device=dev)
-    L.call("recnn_frame_gather", L.ptr(it_d), L.ptr(rt_d), L.ptr(off_d), L.ptr(users_d), L.ptr(row_off), len(users), B,
+    L.call("recnn_frame_gather", L.ptr(it_d), L.ptr(rt_d), L.ptr(off_d), L.ptr(users_d), None if inline_plan else L.ptr(row_off), len(users), B,
            frame, E, L.ptr(tab_d), L.ptr(state), lds, L.ptr(nstate), ldn, L.ptr(action), lda, L.ptr(reward), L.ptr(done),
            None, 0, L.current_stream())
     torch.cuda.synchronize()
@@ -83,9 +83,11 @@ def test_gather_bitexact_vs_oracle_b2048(cuda, rows_per_wg):
     ref = O.frame_batch([items[u] for u in users], [ratings[u] for u in users], table, 10, rows=2048)
     assert ref["state"].shape[0] == 2048
     for packed in (False, True):
-        out = _gather(L, cuda, items, ratings, table, users, 10, rows=2048, packed=packed, rows_per_wg=rows_per_wg)
-        for k in ("state", "next_state", "action", "reward", "done"):
-            assert np.array_equal(out[k], ref[k]), (k, packed)
+        for inline_plan in (False, True):
+            out = _gather(L, cuda, items, ratings, table, users, 10, rows=2048, packed=packed, rows_per_wg=rows_per_wg,
+                          inline_plan=inline_plan)
+            for k in ("state", "next_state", "action", "reward", "done"):
+                assert np.array_equal(out[k], ref[k]), (k, packed, inline_plan)
 
 
 def test_gather_edge_cases(cuda):
@@ -94,9 +96,10 @@ def test_gather_edge_cases(cuda):
     items, ratings, table = make_store(n_users=7, n_items=40, emb_dim=16, min_len=6, max_len=6, seed=5)
     for users, rows in (([3], None), (list(range(7)), None), ([6, 0, 2], 1), ([1, 1, 1], None)):
         ref = O.frame_batch([items[u] for u in users], [ratings[u] for u in users], table, 5, rows=rows)
-        out = _gather(L, cuda, items, ratings, table, users, 5, rows=rows)
-        for k in ("state", "next_state", "action", "reward", "done"):
-            assert np.array_equal(out[k], ref[k]), (k, users)
+        for inline_plan in (False, True):
+            out = _gather(L, cuda, items, ratings, table, users, 5, rows=rows, inline_plan=inline_plan)
+            for k in ("state", "next_state", "action", "reward", "done"):
+                assert np.array_equal(out[k], ref[k]), (k, users, inline_plan)
 
 
 # ------------------------------------------------------------------------------------------- GEMMs
@@ -173,7 +176,7 @@ def test_gemm_dx(cuda, dtype, M, Kc, N):
     y = torch.randn(M, N, generator=g)
     DZ, W, Y = _tc(dz, dtype).to(cuda), _tc(w, dtype).to(cuda), _tc(y, dtype).to(cuda)
     out = torch.zeros(M, N, device=cuda, dtype=DZ.dtype)
-    tiles_m = (M + 63) // 64
+    tiles_m = (M + 31) // 32
     colsum = torch.zeros(tiles_m, N, device=cuda)
     a = _args(L, dtype, M, N)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = DZ.data_ptr(), W.data_ptr(), Kc, N, Kc
