@@ -137,6 +137,8 @@ def main():
     from recnn_amd.nn.engine import StepEngine
     if os.environ.get("RECNN_GEMM_VARIANT"):
         L.load().recnn_tune_gemm_variant(int(os.environ["RECNN_GEMM_VARIANT"]))
+    if os.environ.get("RECNN_GEMM_DMA"):
+        L.load().recnn_tune_gemm_dma(int(os.environ["RECNN_GEMM_DMA"]))
     if os.environ.get("RECNN_GATHER_ROWS"):
         L.load().recnn_tune_gather_rows(int(os.environ["RECNN_GATHER_ROWS"]))
 

@@ -56,6 +56,9 @@ int64_t recnn_abi_sizeof(int which);
 /* tuning knob: GEMM tile variant, -1 = per-launch heuristic, 0 = 64x64 tile, 1 = 32x64 tile with a 2x longer
  * k stage. */
 void recnn_tune_gemm_variant(int variant);
+/* tuning knob: 1 (default) = forward GEMMs whose operands are stored in the compute type use the LDS-DMA
+ * 3-stage pipeline, 0 = always the register-staged kernel. */
+void recnn_tune_gemm_dma(int on);
 /* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
 void recnn_tune_gather_rows(int rows_per_workgroup);
 

@@ -26,11 +26,13 @@
 #include <string>
 #include <vector>
 
+#include "gather.h"
 #include "gemm.h"
 #include "head.h"
 #include "optim.h"
 
 int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s);
+int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s);
 
 static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -80,7 +82,9 @@ struct recnn_engine {
   Acts tp, tq[2], cv[2], pa, pc;           // target policy, target critics, critics, actor, policy-critic
   char *dzc2[2], *dzc1[2];                 // critic backward
   char *dze2, *dze1, *dag, *dzp2, *dzp1;   // policy backward chain
-  float* gen_action;                       // fp32 [Bc, Ap]
+  char *xcs = nullptr, *xcn = nullptr;     // packed rows in the compute type: the bound fp32 rows, or bf16 twins
+  char *xsh = nullptr, *xnh = nullptr;     // bf16 twins (workspace, bf16 mode only)
+  char* gen_action;                        // tc [Bc, Ap]
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
   float *loss_part[3];                     // value1, value2, policy  (per head block)
@@ -188,7 +192,11 @@ int64_t carve(recnn_engine* e, char* base) {
   e->dag = c.take(Bc * Ap * es);
   e->dzp2 = c.take(Bc * Hp * es);
   e->dzp1 = c.take(Bc * Hp * es);
-  e->gen_action = (float*)c.take(Bc * Ap * 4);
+  e->gen_action = c.take(Bc * Ap * es);
+  if (e->bf16) {
+    e->xsh = c.take(Bc * (int64_t)e->ldx * 2);
+    e->xnh = c.take(Bc * (int64_t)e->ldx * 2);
+  }
   e->noise_buf = (float*)c.take(Bc * A * 4);
   e->expected = (float*)c.take(Bc * 4);
   e->target_q = (float*)c.take(Bc * 4);
@@ -233,10 +241,12 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   RECNN_REQUIRE(cfg->action_dim % 8 == 0 && cfg->hidden % 4 == 0, "engine: action_dim must be a multiple of 8, hidden of 4");
   e->cfg = *cfg;
   e->S = cfg->state_dim; e->A = cfg->action_dim; e->H = cfg->hidden;
-  e->Hp = (int)ru(e->H, 64); e->Ap = (int)ru(e->A, 64);
-  e->K1a = (int)ru(e->S, 64);
-  e->K1c = (int)ru(e->S + e->A, 64);
-  e->ldx = (int)ru(e->A + e->K1a, 64);
+  // zero-padding granularity 128 elements: whole 256-byte k stages for the bf16 LDS-DMA pipeline
+  e->Hp = (int)ru(e->H, 128); e->Ap = (int)ru(e->A, 128);
+  e->K1a = (int)ru(e->S, 128);
+  e->K1c = (int)ru(e->S + e->A, 128);
+  e->ldx = (int)ru(e->A + e->K1a, 128);
+  if (e->ldx < e->K1c) e->ldx = e->K1c;
   e->Bc = (int)ru(cfg->max_rows, 64);
   e->bf16 = cfg->dtype == RECNN_BF16;
   e->esz = e->bf16 ? 2 : 4;
@@ -268,6 +278,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   RECNN_REQUIRE(e, "engine_create: out of host memory");
   int rc = setup_dims(e, cfg);
   if (rc) { delete e; return rc; }
+  if ((rc = gemm_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->net[ni].t_ptr = nullptr;
@@ -300,6 +311,10 @@ extern "C" int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, fl
   RECNN_REQUIRE(e && xs && xn && reward && done, "bind_batch: null pointer");
   RECNN_REQUIRE((((uintptr_t)xs | (uintptr_t)xn) & 15) == 0, "bind_batch: packed rows must be 16-byte aligned");
   e->xs = xs; e->xn = xn; e->reward = reward; e->done = done;
+  e->xcs = e->bf16 ? e->xsh : (char*)xs;
+  e->xcn = e->bf16 ? e->xnh : (char*)xn;
+  for (int i = 0; i < 2; ++i)
+    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
   return 0;
 }
 
@@ -549,20 +564,20 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
-  {  // layer 1: fp32 packed rows in, tc hidden out
-    Group g(e, GEMM_FWD, 1, 0);
+  {  // layer 1: packed rows (compute type) in, tc hidden out
+    Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
-      FwdSpec f{TPOL, 1, e->xn + A, e->ldx, 1, e->K1a};
+      FwdSpec f{TPOL, 1, e->xcn + (int64_t)A * e->esz, e->ldx, 0, e->K1a};
       f.C = e->tp.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
       g.flops += fill_fwd(e, f, rows, g.add());
       for (int c = 0; c < nc; ++c) {
-        FwdSpec fc{VAL[c], 1, e->xs, e->ldx, 1, e->K1c};
+        FwdSpec fc{VAL[c], 1, e->xcs, e->ldx, 0, e->K1c};
         fc.C = e->cv[c].h1; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c;
         g.flops += fill_fwd(e, fc, rows, g.add());
       }
     }
     if (actor_side) {
-      FwdSpec f{POL, 1, e->xs + A, e->ldx, 1, e->K1a};
+      FwdSpec f{POL, 1, e->xcs + (int64_t)A * e->esz, e->ldx, 0, e->K1a};
       f.C = e->pa.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1;
       g.flops += fill_fwd(e, f, rows, g.add());
     }
@@ -590,11 +605,11 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   if (value_side && e->td3 && !e->ext_noise) {
     if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s); }))) return rc;
   }
-  {  // layer 3 of the actors: fp32 outputs (next_action into the packed xn rows, gen_action)
+  {  // layer 3 of the actors: next_action into the action slot of the packed next rows, gen_action
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
       FwdSpec f{TPOL, 3, e->tp.h2, Hp, 0, Hp};
-      f.C = e->xn; f.ldc = e->ldx; f.c_f32 = 1; f.relu = 0; f.mask_idx = -1;
+      f.C = e->xcn; f.ldc = e->ldx; f.c_f32 = 0; f.relu = 0; f.mask_idx = -1;
       if (e->td3) {  // td3.py:74-78: next_action += clamp(noise)
         f.addend = e->ext_noise ? e->ext_noise : e->noise_buf;
         f.ld_add = A;
@@ -604,16 +619,16 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     }
     if (actor_side) {
       FwdSpec f{POL, 3, e->pa.h2, Hp, 0, Hp};
-      f.C = e->gen_action; f.ldc = e->Ap; f.c_f32 = 1; f.relu = 0; f.mask_idx = -1;
+      f.C = e->gen_action; f.ldc = e->Ap; f.c_f32 = 0; f.relu = 0; f.mask_idx = -1;
       g.flops += fill_fwd(e, f, rows, g.add());
     }
     if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
   }
   if (value_side) {
     {  // target critics on [next_action | next_state]
-      Group g(e, GEMM_FWD, 1, 0);
+      Group g(e, GEMM_FWD, 0, 0);
       for (int c = 0; c < nc; ++c) {
-        FwdSpec f{TVAL[c], 1, e->xn, e->ldx, 1, e->K1c};
+        FwdSpec f{TVAL[c], 1, e->xcn, e->ldx, 0, e->K1c};
         f.C = e->tq[c].h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
         g.flops += fill_fwd(e, f, rows, g.add());
       }
@@ -674,21 +689,14 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   }
   NetLayout L0 = make_layout(e, VAL[0], rows);
   {
-    Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1   (tc x tc)
+    Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1 and dW1 = dz1^T [a|s], split over the batch into slabs
     for (int c = 0; c < nc; ++c)
-      g.flops += fill_dw(e, g.add(), rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab, L0.t[W2].slab_stride);
-    if (!e->bf16)  // fp32: same operand memory types, share the launch with dW1
-      for (int c = 0; c < nc; ++c)
-        g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
-                L0.t[W1].slab_stride);
+      g.flops += fill_dw(e, g.add(), rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab,
+                         L0.t[W2].slab_stride);
+    for (int c = 0; c < nc; ++c)
+      g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xcs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1],
+                         L0.t[W1].nslab, L0.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_critic"))) return rc;
-  }
-  if (e->bf16) {
-    Group g(e, GEMM_DW, 0, 1);  // dW1 = dz1^T [a|s]   (tc x fp32 packed rows)
-    for (int c = 0; c < nc; ++c)
-      g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1], L0.t[W1].nslab,
-              L0.t[W1].slab_stride);
-    if ((rc = g.run(s, "dw_critic_l1"))) return rc;
   }
   for (int c = 0; c < nc && reduce; ++c) {
     NetLayout L = make_layout(e, VAL[c], rows);
@@ -705,10 +713,10 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
   {  // critic L1 on [gen_action | state]: two contraction segments over the rotated W1 shadow
-    Group g(e, GEMM_FWD, 1, 0);
-    FwdSpec f{V1, 1, e->gen_action, Ap, 1, Ap};
+    Group g(e, GEMM_FWD, 0, 0);
+    FwdSpec f{V1, 1, e->gen_action, Ap, 0, Ap};
     f.b_col = 0;
-    f.A2 = e->xs + A; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
+    f.A2 = e->xcs + (int64_t)A * e->esz; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
     f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
     // gen_action is zero padded to Ap columns, so segment 0 may run over the padded width: the W1
     // shadow columns it meets there (the first state columns) are multiplied by zeros.
@@ -756,13 +764,9 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     Group g(e, GEMM_DW, 0, 0);
     g.flops += fill_dw(e, g.add(), rows, e->dag, Ap, A, e->pa.h2, Hp, H, 0, pn.gp[W3], L.t[W3].nslab, L.t[W3].slab_stride);
     g.flops += fill_dw(e, g.add(), rows, e->dzp2, Hp, H, e->pa.h1, Hp, H, 0, pn.gp[W2], L.t[W2].nslab, L.t[W2].slab_stride);
-    if (!e->bf16) fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
+    g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xcs + (int64_t)A * e->esz, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab,
+                       L.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_actor"))) return rc;
-  }
-  if (e->bf16) {
-    Group g(e, GEMM_DW, 0, 1);
-    g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xs + A, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab, L.t[W1].slab_stride);
-    if ((rc = g.run(s, "dw_actor_l1"))) return rc;
   }
   return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, pn.g, with_l1 ? pn.l1part : nullptr, s); });
 }
@@ -845,16 +849,39 @@ int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
     if (rc) return rc;
   }
   return slot(e, "frame_gather", 0, s, [&] {
-    return recnn_frame_gather(m.items, m.ratings, m.user_off, m.perm, inl ? nullptr : m.row_off, m.users_per_batch, rows, m.frame, m.emb_dim,
-                              m.table, e->xs + e->A, e->ldx, e->xn + e->A, e->ldx, e->xs, e->ldx, e->reward, e->done, m.cursor,
-                              m.users_per_batch, s);
+    GatherArgs g;
+    memset(&g, 0, sizeof(g));
+    g.items = m.items; g.ratings = m.ratings; g.user_off = m.user_off; g.users = m.perm;
+    g.row_off = inl ? nullptr : m.row_off;
+    g.n_users = m.users_per_batch; g.rows = rows; g.frame = m.frame; g.emb = m.emb_dim; g.table = m.table;
+    g.state = e->xs + e->A; g.ld_state = e->ldx;
+    g.next_state = e->xn + e->A; g.ld_next = e->ldx;
+    g.action = e->xs; g.ld_action = e->ldx;
+    g.reward = e->reward; g.done = e->done;
+    g.cursor = m.cursor; g.cursor_stride = m.users_per_batch;
+    g.inline_plan = inl;
+    if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
+      g.state_h = (bf16_t*)e->xsh + e->A; g.next_h = (bf16_t*)e->xnh + e->A; g.action_h = (bf16_t*)e->xsh;
+      g.ld_h = e->ldx;
+    }
+    return frame_gather_launch(g, s);
   });
+}
+
+// Make the step's batch available in the compute type: built by the sampler, or converted from the bound fp32 rows.
+int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
+  if (e->has_sampler) return frame_gather_packed(e, rows, s);
+  if (e->bf16)
+    return slot(e, "rows_to_bf16", 0, s, [&] {
+      return rows_to_bf16_launch(e->xs, e->xn, (bf16_t*)e->xsh, (bf16_t*)e->xnh, rows, e->ldx, s);
+    });
+  return 0;
 }
 
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s) {
   int rc;
-  if (e->has_sampler && (rc = frame_gather_packed(e, rows, s))) return rc;
+  if ((rc = stage_batch(e, rows, s))) return rc;
   if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
     if ((rc = ph_value_backward(e, rows, false, s))) return rc;
@@ -885,7 +912,7 @@ extern "C" int recnn_engine_step(recnn_engine* e, int rows, int learn, int step,
 extern "C" int recnn_engine_value_grads(recnn_engine* e, int rows, int learn, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
-  if (e->has_sampler && (rc = frame_gather_packed(e, rows, (hipStream_t)stream))) return rc;
+  if ((rc = stage_batch(e, rows, (hipStream_t)stream))) return rc;
   if ((rc = ph_forward(e, rows, true, false, learn != 0, (hipStream_t)stream))) return rc;
   if (learn) return ph_value_backward(e, rows, true, (hipStream_t)stream);
   return 0;
@@ -1012,7 +1039,7 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
   struct Ent { const char* n; const void* p; int64_t c, l; int f; };
   const int64_t Hp = e->Hp;
   const Ent tab[] = {
-      {"next_action", e->xn, e->A, e->ldx, 1},   {"gen_action", e->gen_action, e->A, e->Ap, 1},
+      {"next_action", e->xcn, e->A, e->ldx, e->bf16 ? 0 : 1}, {"gen_action", e->gen_action, e->A, e->Ap, 0},
       {"expected", e->expected, 1, 1, 1},          {"target_q", e->target_q, 1, 1, 1},
       {"q1", e->q[0], 1, 1, 1},                    {"q2", e->q[1], 1, 1, 1},
       {"delta1", e->delta[0], 1, 1, 1},            {"delta2", e->delta[1], 1, 1, 1},

@@ -1,0 +1,29 @@
+// gather.h -- argument block of frame_gather_kernel (gather.hip), shared with engine.hip.
+#pragma once
+#include "common.h"
+
+struct GatherArgs {
+  const int32_t* items;
+  const float* ratings;
+  const int64_t* user_off;
+  const int32_t* users;
+  const int32_t* row_off;
+  int n_users, rows, frame, emb;
+  const float* table;
+  float* state; int64_t ld_state;
+  float* next_state; int64_t ld_next;
+  float* action; int64_t ld_action;
+  float* reward;
+  float* done;
+  const int32_t* cursor;
+  int cursor_stride;
+  int inline_plan;  // row_off == NULL: every workgroup scans the batch's history lengths itself (n_users <= 1024)
+  // optional bf16 twins of the packed rows (engine, bf16 compute mode): same columns, row stride ld_h (elements)
+  bf16_t* state_h;
+  bf16_t* next_h;
+  bf16_t* action_h;
+  int64_t ld_h;
+};
+
+
+int frame_gather_launch(GatherArgs a, hipStream_t s);

@@ -12,7 +12,7 @@
 // row share all of them, so each distinct (row, slot) embedding line is fetched ONCE into LDS
 // ((R+F)..R*(F+1) lines of E floats) with 16-byte coalesced loads and then streamed out to the
 // three outputs with the widest store the output alignment allows.
-#include "common.h"
+#include "gather.h"
 
 // ------------------------------------------------------------------ plan: row prefix sums
 __global__ __launch_bounds__(1024) void frame_plan_kernel(const int64_t* __restrict__ user_off,
@@ -57,24 +57,6 @@ extern "C" int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_us
 }
 
 // ------------------------------------------------------------------ gather
-struct GatherArgs {
-  const int32_t* items;
-  const float* ratings;
-  const int64_t* user_off;
-  const int32_t* users;
-  const int32_t* row_off;
-  int n_users, rows, frame, emb;
-  const float* table;
-  float* state; int64_t ld_state;
-  float* next_state; int64_t ld_next;
-  float* action; int64_t ld_action;
-  float* reward;
-  float* done;
-  const int32_t* cursor;
-  int cursor_stride;
-  int inline_plan;  // row_off == NULL: every workgroup scans the batch's history lengths itself (n_users <= 1024)
-};
-
 template <int W> struct VecT;
 template <> struct VecT<4> { using type = float4; };
 template <> struct VecT<2> { using type = float2; };
@@ -207,12 +189,24 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     const float* src = lines + (size_t)m_base[r] * E + q * W;
     *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
     *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
+    if constexpr (W == 4) {
+      if (a.state_h) {
+        *(uint2*)(a.state_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
+        *(uint2*)(a.next_h + (int64_t)(row0 + r) * a.ld_h + q * 4) =
+            make_uint2(pack_bf2(src[E], src[E + 1]), pack_bf2(src[E + 2], src[E + 3]));
+      }
+    }
   }
   const int per_act = E / W;
   for (int idx = tid; idx < R * per_act; idx += 256) {
     const int r = idx / per_act, q = idx - r * per_act;
     if (!m_valid[r]) continue;
-    *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)(lines + (size_t)(m_base[r] + F) * E + q * W);
+    const float* src = lines + (size_t)(m_base[r] + F) * E + q * W;
+    *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)src;
+    if constexpr (W == 4) {
+      if (a.action_h)
+        *(uint2*)(a.action_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
+    }
   }
   // ---- ratings tails, reward, done
   for (int idx = tid; idx < R * F; idx += 256) {
@@ -220,6 +214,10 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     if (!m_valid[r]) continue;
     a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
     a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
+    if (a.state_h) {
+      a.state_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + j]);
+      a.next_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + 1 + j]);
+    }
   }
   if (tid < R && m_valid[tid]) {
     a.reward[row0 + tid] = rat[m_base[tid] + F];
@@ -265,12 +263,20 @@ extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, co
   if (rows == 0) return 0;
   RECNN_REQUIRE(n_users > 0, "frame_gather: rows requested from an empty user list");
   GatherArgs a;
+  memset(&a, 0, sizeof(a));
   a.items = items; a.ratings = ratings; a.user_off = user_off; a.users = batch_users; a.row_off = row_off;
   a.n_users = n_users; a.rows = rows; a.frame = frame; a.emb = emb_dim; a.table = table;
   a.state = state; a.ld_state = ld_state; a.next_state = next_state; a.ld_next = ld_next;
   a.action = action; a.ld_action = ld_action; a.reward = reward; a.done = done;
   a.cursor = cursor; a.cursor_stride = cursor_stride;
   a.inline_plan = row_off == nullptr;
+  return frame_gather_launch(a, (hipStream_t)stream);
+}
+
+int frame_gather_launch(GatherArgs a, hipStream_t stream) {
+  float* state = a.state; float* next_state = a.next_state; float* action = a.action;
+  const int64_t ld_state = a.ld_state, ld_next = a.ld_next, ld_action = a.ld_action;
+  const int emb_dim = a.emb;
   // widest store every output row start supports
   auto al = [](const void* p, int64_t ld) {
     uintptr_t x = (uintptr_t)p | (uintptr_t)(ld * 4);
@@ -280,10 +286,11 @@ extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, co
   int w2 = al(next_state, ld_next); if (w2 < W) W = w2;
   int w3 = al(action, ld_action); if (w3 < W) W = w3;
   if (emb_dim % W) W = 1;
+  if (a.state_h && W != 4) { recnn_set_error("frame_gather: bf16 twin rows need 16-byte aligned fp32 rows"); return RECNN_E_INVALID; }
   switch (g_gather_rows_per_wg) {
-    case 2: return launch_gather<2>(a, W, (hipStream_t)stream);
-    case 8: return launch_gather<8>(a, W, (hipStream_t)stream);
-    default: return launch_gather<4>(a, W, (hipStream_t)stream);
+    case 2: return launch_gather<2>(a, W, stream);
+    case 8: return launch_gather<8>(a, W, stream);
+    default: return launch_gather<4>(a, W, stream);
   }
 }
 
@@ -313,4 +320,23 @@ extern "C" int recnn_pack_batch(const float* state, int64_t ld_state, const floa
   hipLaunchKernelGGL(pack_batch_kernel, grid, block, 0, (hipStream_t)stream, state, ld_state, action, ld_action, next_state,
                      ld_next, rows, state_dim, action_dim, xs, xn, ld_x);
   return recnn_check_hip(hipGetLastError(), "pack_batch");
+}
+
+// ------------------------------------------------------------------ packed fp32 rows -> bf16 twins
+// (engine, bf16 mode, batch not produced by the engine's own sampler): one pass over xs and xn.
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ xs, const float* __restrict__ xn,
+                                                           bf16_t* __restrict__ hs, bf16_t* __restrict__ hn, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = ((const float4*)xs)[i], b = ((const float4*)xn)[i];
+    ((uint2*)hs)[i] = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+    ((uint2*)hn)[i] = make_uint2(pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+  }
+}
+int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s) {
+  const int64_t n4 = (int64_t)rows * ld / 4;
+  if (n4 <= 0) return 0;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid), dim3(256), 0, s, xs, xn, hs, hn, n4);
+  return recnn_check_hip(hipGetLastError(), "rows_to_bf16_kernel");
 }

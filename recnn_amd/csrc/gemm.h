@@ -58,4 +58,5 @@ struct GemmLaunch {
 
 void gemm_prob_init(GemmProb* p);
 int gemm_launch(GemmLaunch* L, hipStream_t stream);
+int gemm_init();  // one-time kernel attribute setup (call outside stream capture)
 int gemm_from_args(const recnn_gemm_args* a, int mode, GemmLaunch* L);

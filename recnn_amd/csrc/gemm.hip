@@ -179,6 +179,44 @@ __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN
   }
 }
 
+// ------------------------------------------------------------------ forward epilogue (shared by both fwd kernels)
+template <class TC, int TM, int TN>
+__device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  {
+    uint32_t key = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, P.step_ptr ? *P.step_ptr : 0, P.stream_id);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 16 + fr;
+        const int mb = m0 + wm0 + tm * 16 + fg * 4;
+        if (n < P.N) {
+          const float bv = P.bias ? P.bias[n] : 0.f;
+          uint32_t word = 0;
+          if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mb + r;
+            if (m < P.M) {
+              float v = acc[tm][tn][r] + bv;
+              if (P.addend) {
+                float z = P.addend[(int64_t)m * P.ld_add + n];
+                v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+              }
+              if (P.relu) v = fmaxf(v, 0.f);
+              if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
+              else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
+              if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
+              else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, v);
+            }
+          }
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------ the kernel
 template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
@@ -262,36 +300,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   // ------------------------------------------------------------------ epilogue
   const int fr = lane & 15, fg = lane >> 4;
   if constexpr (MODE == GEMM_FWD) {
-    uint32_t key = 0;
-    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, P.step_ptr ? *P.step_ptr : 0, P.stream_id);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn0 + tn * 16 + fr;
-        const int mb = m0 + wm0 + tm * 16 + fg * 4;
-        if (n < P.N) {
-          const float bv = P.bias ? P.bias[n] : 0.f;
-          uint32_t word = 0;
-          if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mb + r;
-            if (m < P.M) {
-              float v = acc[tm][tn][r] + bv;
-              if (P.addend) {
-                float z = P.addend[(int64_t)m * P.ld_add + n];
-                v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
-              }
-              if (P.relu) v = fmaxf(v, 0.f);
-              if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
-              else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
-              if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
-              else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, v);
-            }
-          }
-        }
-      }
+    epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane);
   } else if constexpr (MODE == GEMM_DX) {
     float cs[TN];
 #pragma unroll
@@ -359,6 +368,121 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   }
 }
 
+// ------------------------------------------------------------------ forward GEMM, LDS-DMA pipeline
+// C = epi(A W^T) for k-contiguous operands stored in the compute type.  Tiles are copied global -> LDS by
+// `global_load_lds_dwordx4` (no VGPR round trip) into a 3-stage ring: two k stages are in flight while the third
+// is multiplied, one raw s_barrier per stage, counted vmcnt waits (the asm loads are invisible to hipcc's wait
+// insertion, which would otherwise drain every DMA before each ds_read).  A k stage is 256 bytes per tile row;
+// the 16-byte chunk c of row r sits at chunk position c ^ (r & 15) of its LDS row (the DMA writes lane-linear,
+// so the XOR is applied to each lane's SOURCE address), which makes the 16 rows x one chunk of an MFMA fragment
+// read hit 16 different bank quads.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "memory");
+}
+
+template <class TC, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int ES = sizeof(TC), KB = 256 / ES;  // k elements per stage (256-byte rows)
+  constexpr int NS = 3;
+  constexpr int STAGE_BYTES = (BM + BN) * 256;
+  constexpr int NA = BM / 16, NB = BN / 16;  // DMA instructions per wave and stage (4 rows each)
+  constexpr int KSTEP = TcTraits<TC>::KSTEP;
+  const GemmProb& P = batch.p[blockIdx.y];
+  const int nwg = P.tiles_m * P.tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+  const unsigned lds0 = (unsigned)(size_t)dsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 16 * TM, wn0 = (wave & 1) * 16 * TN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt0 = P.seg[0].K / KB;
+  const int nt1 = P.nseg > 1 ? P.seg[1].K / KB : 0;
+  const int nt = nt0 + nt1;
+
+  // per-lane source geometry (constant over the k loop): chunk q = (j*4 + wave)*64 + lane of a tile
+  const int q_row = lane >> 4, q_pos = lane & 15;  // within the 4 rows one wave instruction covers
+
+  auto issue = [&](int t, int stage) {
+    const int sidx = (t < nt0) ? 0 : 1;
+    const GemmSeg& G = P.seg[sidx];
+    const int k0 = (sidx == 0 ? t : t - nt0) * KB;
+    const unsigned sbase = lds0 + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int row = (j * 4 + wave) * 4 + q_row;
+      const int c = q_pos ^ (row & 15);
+      const int gr = min(m0 + row, P.M - 1);
+      const char* src = (const char*)G.A + ((int64_t)gr * G.lda + k0) * ES + c * 16;
+      dma16(src, sbase + (j * 4 + wave) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int row = (j * 4 + wave) * 4 + q_row;
+      const int c = q_pos ^ (row & 15);
+      const int gr = min(n0 + row, P.N - 1);
+      const char* src = (const char*)G.B + ((int64_t)gr * G.ldb + k0) * ES + c * 16;
+      dma16(src, sbase + BM * 256 + (j * 4 + wave) * 1024);
+    }
+  };
+
+  if (nt > 0) issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed once at most the NA+NB loads of tile t+1 are still outstanding
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; every wave is done reading tile t-1
+    if (t + 2 < nt) issue(t + 2, (t + 2) % NS);
+    const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
+    const unsigned char* sb = sa + BM * 256;
+#pragma unroll
+    for (int ks = 0; ks < KB / KSTEP; ++ks) {
+      const int pos = ((ks * 4 + fg) ^ fr) * 16;
+      uint4 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pos);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pos);
+      if constexpr (ES == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[tm])[j], ((const float*)&b[tn])[j],
+                                                                 acc[tm][tn], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]),
+                                                                  __builtin_bit_cast(bf16x8, b[tn]), acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+  epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane);
+}
+
 // ------------------------------------------------------------------ host side
 void gemm_prob_init(GemmProb* p) {
   memset(p, 0, sizeof(*p));
@@ -390,9 +514,58 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
   return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
 }
 
+static int g_gemm_dma = 1;
+extern "C" void recnn_tune_gemm_dma(int on) { g_gemm_dma = on; }
+
+template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
+  constexpr int TM = 1, TN = 2, BM = 32 * TM, BN = 32 * TN;
+  constexpr int LDS = 3 * (BM + BN) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm dma attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel launch");
+}
+
+// the DMA pipeline needs both operands stored in the compute type and whole 256-byte k stages
+template <class TC> static bool dma_eligible(const GemmLaunch* L) {
+  if (!g_gemm_dma || L->mode != GEMM_FWD) return false;
+  if (sizeof(TC) == 2 && (L->a_f32 || L->b_f32)) return false;
+  const int KB = 256 / (int)sizeof(TC);
+  for (int i = 0; i < L->nprob; ++i)
+    for (int s = 0; s < L->batch.p[i].nseg; ++s)
+      if (L->batch.p[i].seg[s].K % KB) return false;
+  return true;
+}
+
+// make the one-time function attribute calls outside of any stream capture
+int gemm_init() {
+  GemmLaunch L;
+  memset(&L, 0, sizeof(L));
+  int rc = launch_dma<float>(&L, nullptr);
+  if (rc) return rc;
+  return launch_dma<bf16_t>(&L, nullptr);
+}
+
 template <class TC, int MODE, bool A32, bool B32>
 static int launch_t(GemmLaunch* L, hipStream_t stream) {
   constexpr int KB0 = TcTraits<TC>::BK;
+  if constexpr (MODE == GEMM_FWD && !A32 && !B32) {
+    if (dma_eligible<TC>(L)) return launch_dma<TC>(L, stream);
+  }
   int v = g_gemm_variant;
   if (v < 0) {  // enough 64x64 tiles to give every CU a few workgroups?  else take the small-tile variant
     long wg = 0;

@@ -29,8 +29,8 @@ def packed_ld(frame_size: int, emb_dim: int) -> int:
     """Row stride (floats) of the packed batch rows [action | state | 0-pad] the MFMA GEMMs read:
     the 16-byte aligned, zero-padded layout shared with the C engine (engine.hip setup_dims)."""
     state = frame_size * emb_dim + frame_size
-    r64 = lambda x: (x + 63) // 64 * 64
-    return r64(emb_dim + r64(state))
+    r128 = lambda x: (x + 127) // 128 * 128
+    return max(r128(emb_dim + r128(state)), r128(emb_dim + state))
 
 
 class FrameBatch(dict):

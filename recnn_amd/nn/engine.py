@@ -163,6 +163,13 @@ class StepEngine:
         self.done[:rows].copy_(f(done).reshape(-1))
         return rows
 
+    def bind_batch(self, xs=None, xn=None, reward=None, done=None):
+        """Bind packed rows owned by someone else (a FrameEnv batch); no arguments = back to the engine's own."""
+        if xs is None:
+            xs, xn, reward, done = self.xs, self.xn, self.reward, self.done
+        self._bound = (xs, xn, reward, done)          # keep alive while kernels may still read them
+        L.call("recnn_engine_bind_batch", self.handle, L.ptr(xs), L.ptr(xn), L.ptr(reward), L.ptr(done))
+
     def set_external(self, masks: Optional[Sequence[torch.Tensor]] = None, noise: Optional[torch.Tensor] = None):
         if masks is not None:
             assert self.ext_masks is not None, "engine was not created with mask_mode='external'"
@@ -254,12 +261,14 @@ class StepEngine:
             raise KeyError(name)
         rows = int(r.value) if rows is None else rows
         esz = 4 if f.value else (2 if self.dtype == "bf16" else 4)
-        off = p - self.workspace.data_ptr()
-        if 0 <= off < self.workspace.numel():
-            raw = self.workspace[off: off + rows * ld.value * esz]
-        elif name == "next_action":
-            return self.xn[:rows, :self.A].clone()
-        else:
+        nbytes = rows * ld.value * esz
+        raw = None
+        for owner in (self.workspace, self.xn, self.xs) + tuple(getattr(self, "_bound", ())[:2]):
+            base = owner.data_ptr()
+            if base <= p < base + owner.numel() * owner.element_size():
+                raw = owner.view(-1).view(torch.uint8)[p - base: p - base + nbytes]
+                break
+        if raw is None:
             raise KeyError(name)
         dt = torch.float32 if esz == 4 else torch.bfloat16
         t = raw.view(dt).view(rows, ld.value)[:, :c.value]

@@ -148,11 +148,11 @@ class FusedContext:
         if packed is not None and packed[5] == eng.ld_x and packed[0].device == eng.device \
                 and batch["state"].data_ptr() == packed[0].data_ptr() + 4 * self.A:
             xs, xn, reward, done, rows, _ = packed
-            L.call("recnn_engine_bind_batch", eng.handle, L.ptr(xs), L.ptr(xn), L.ptr(reward), L.ptr(done))
-            self._bound_external_batch = (xs, xn, reward, done)   # keep alive while the kernels run
+            eng.bind_batch(xs, xn, reward, done)
+            self._bound_external_batch = True
             return rows
-        if getattr(self, "_bound_external_batch", None) is not None:
-            L.call("recnn_engine_bind_batch", eng.handle, L.ptr(eng.xs), L.ptr(eng.xn), L.ptr(eng.reward), L.ptr(eng.done))
+        if getattr(self, "_bound_external_batch", None):
+            eng.bind_batch()
             self._bound_external_batch = None
         for k in ("state", "action", "reward", "next_state", "done"):
             if k not in batch:
