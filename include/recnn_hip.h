@@ -59,6 +59,9 @@ void recnn_tune_gemm_variant(int variant);
 /* tuning knob: 1 (default) = forward GEMMs whose operands are stored in the compute type use the LDS-DMA
  * 3-stage pipeline, 0 = always the register-staged kernel. */
 void recnn_tune_gemm_dma(int on);
+/* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
+ * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
+void recnn_tune_gemm_ks_layout(int tile_fastest);
 /* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
 void recnn_tune_gather_rows(int rows_per_workgroup);
 

@@ -81,7 +81,7 @@ template <class TC, bool MEM32, int R, int KB> struct KCLoader {
 // Source is [Kc, ld] with the tile dimension contiguous.  A unit = 4 consecutive k rows x one
 // 16-byte load along the tile dimension (NE elements); it is transposed in registers and written
 // as NE small vectors of 4 k values.
-template <class TC, bool MEM32, int R, int KB> struct KSLoader {
+template <class TC, bool MEM32, int R, int KB, bool TGF> struct KSLoader {
   static constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   static constexpr bool SRC32 = MEM32 || (sizeof(TC) == 4);
   static constexpr int NE = SRC32 ? 4 : 8;      // tile elements per 16-byte load
@@ -95,7 +95,9 @@ template <class TC, bool MEM32, int R, int KB> struct KSLoader {
     for (int i = 0; i < UPT; ++i) {
       int u = tid + i * 256;
       if (UNITS % 256 == 0 || u < UNITS) {
-        int kg = u % KG, tg = u / KG;
+        // TGF: consecutive lanes walk the (contiguous) tile dimension -> 256-byte runs per k row in global memory
+        // (LDS writes then collide 4-way); otherwise consecutive lanes walk k (conflict-free LDS writes).
+        int kg = TGF ? u / (R / NE) : u % KG, tg = TGF ? u % (R / NE) : u / KG;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           int kr = k0 + kg * 4 + j;
@@ -114,7 +116,7 @@ template <class TC, bool MEM32, int R, int KB> struct KSLoader {
     for (int i = 0; i < UPT; ++i) {
       int u = tid + i * 256;
       if (UNITS % 256 == 0 || u < UNITS) {
-        int kg = u % KG, tg = u / KG;
+        int kg = TGF ? u / (R / NE) : u % KG, tg = TGF ? u % (R / NE) : u / KG;
         if constexpr (sizeof(TC) == 4) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -218,7 +220,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
 }
 
 // ------------------------------------------------------------------ the kernel
-template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB, bool TGF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   constexpr int BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   }
   const int nt = nt0 + nt1;
 
-  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM, KB>, KCLoader<TC, A32, BM, KB>>::type;
-  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN, KB>, KCLoader<TC, B32, BN, KB>>::type;
+  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM, KB, TGF>, KCLoader<TC, A32, BM, KB>>::type;
+  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN, KB, TGF>, KCLoader<TC, B32, BN, KB>>::type;
   ALoader la;
   BLoader lb;
 
@@ -496,6 +498,9 @@ void gemm_prob_init(GemmProb* p) {
 static int g_gemm_variant = -1;  // -1 = choose per launch
 extern "C" void recnn_tune_gemm_variant(int v) { g_gemm_variant = v; }
 
+static int g_gemm_tgf = 0;
+extern "C" void recnn_tune_gemm_ks_layout(int tile_fastest) { g_gemm_tgf = tile_fastest; }
+
 template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
 static int launch_v(GemmLaunch* L, hipStream_t stream) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -510,7 +515,10 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
   }
   if (maxwg == 0) return 0;
   dim3 grid(maxwg, L->nprob, 1), block(256, 1, 1);
-  hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB>), grid, block, 0, stream, L->batch);
+  if (MODE != GEMM_FWD && g_gemm_tgf)
+    hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB, (MODE != GEMM_FWD)>), grid, block, 0, stream, L->batch);
+  else
+    hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB, false>), grid, block, 0, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
 }
 
