@@ -59,6 +59,9 @@ void recnn_tune_gemm_variant(int variant);
 /* tuning knob: 1 (default) = forward GEMMs whose operands are stored in the compute type use the LDS-DMA
  * 3-stage pipeline, 0 = always the register-staged kernel. */
 void recnn_tune_gemm_dma(int on);
+/* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
+ * launch (csrc/mlp.hip); 0 = layer-by-layer GEMM launches. */
+void recnn_tune_fused_mlp(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

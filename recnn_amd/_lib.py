@@ -91,6 +91,7 @@ SIGNATURES = {
     "recnn_tune_gather_rows": (None, [_I]),
     "recnn_tune_gemm_variant": (None, [_I]),
     "recnn_tune_gemm_dma": (None, [_I]),
+    "recnn_tune_fused_mlp": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),

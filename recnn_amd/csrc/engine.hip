@@ -29,6 +29,7 @@
 #include "gather.h"
 #include "gemm.h"
 #include "head.h"
+#include "mlp.h"
 #include "optim.h"
 
 int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s);
@@ -279,6 +280,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   int rc = setup_dims(e, cfg);
   if (rc) { delete e; return rc; }
   if ((rc = gemm_init())) { delete e; return rc; }
+  if ((rc = mlp_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->net[ni].t_ptr = nullptr;
@@ -556,6 +558,56 @@ int check_ready(recnn_engine* e, int rows) {
   return 0;
 }
 
+// ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
+static int g_fused_mlp = 1;
+extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
+
+// g_fused_mlp: 0 = never, 1 = groups of >= 3 networks (a single network only occupies 64 CUs and streams its
+// whole W1 per workgroup: the tiled kernels are faster there), 2 = every forward
+bool fused_mlp_ok(const recnn_engine* e, int nprob) {
+  return g_fused_mlp && e->bf16 && e->Hp == 256 && e->Ap == 128 && (nprob >= 3 || g_fused_mlp >= 2);
+}
+
+struct MlpSpec {
+  int ni;
+  const void* A0; int64_t lda0; int K0; int col0;
+  const void* A1 = nullptr; int64_t lda1 = 0; int K1 = 0; int col1 = 0;
+  void* h1 = nullptr; void* h2 = nullptr;
+  void* out = nullptr; int64_t ldo = 0;
+  int mask_idx = -1;   // external mask index of the first hidden layer (second = +1); -1 = eval mode
+  const float* addend = nullptr; int64_t ld_add = 0; float add_clip = 0.f;
+};
+
+double fill_mlp(const recnn_engine* e, const MlpSpec& f, int rows, MlpProb* p) {
+  const Net& n = e->net[f.ni];
+  memset(p, 0, sizeof(*p));
+  p->A[0] = f.A0; p->lda[0] = f.lda0; p->K[0] = f.K0; p->w1_col[0] = f.col0;
+  p->nseg = 1;
+  if (f.A1) { p->A[1] = f.A1; p->lda[1] = f.lda1; p->K[1] = f.K1; p->w1_col[1] = f.col1; p->nseg = 2; }
+  p->W1 = sh_ptr(e, f.ni, W1); p->ldw1 = n.ld_w1;
+  p->W2 = sh_ptr(e, f.ni, W2); p->ldw2 = n.ld_w2;
+  if (!n.critic) { p->W3 = sh_ptr(e, f.ni, W3); p->ldw3 = n.ld_w3; }
+  p->b1 = n.p + n.off[B1]; p->b2 = n.p + n.off[B2]; p->b3 = n.p + n.off[B3];
+  p->w3row = n.critic ? n.p + n.off[W3] : nullptr;
+  p->rows = rows; p->H = e->H; p->out_dim = n.out_dim;
+  p->mask_mode = RECNN_MASK_NONE;
+  if (f.mask_idx >= 0 && e->cfg.mask_mode != RECNN_MASK_NONE) {
+    p->mask_mode = e->cfg.mask_mode;
+    if (e->cfg.mask_mode == RECNN_MASK_EXTERNAL) {
+      p->mask1 = e->ext_masks + (int64_t)f.mask_idx * e->cfg.max_rows * e->H;
+      p->mask2 = e->ext_masks + (int64_t)(f.mask_idx + 1) * e->cfg.max_rows * e->H;
+      p->ld_mask = e->H;
+    } else {
+      p->seed = e->cfg.seed; p->stream1 = (uint32_t)f.mask_idx; p->stream2 = (uint32_t)f.mask_idx + 1;
+      p->step_ptr = e->counters;
+    }
+  }
+  p->h1 = f.h1; p->h2 = f.h2; p->ldh = e->Hp;
+  p->out = f.out; p->ldo = f.ldo;
+  p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
+  return 2.0 * rows * ((double)e->H * n.in_dim + (double)e->H * e->H + (double)n.out_dim * e->H);
+}
+
 // ------------------------------------------------------------------------------------ phases
 // Forward of the value side (+ optionally the actor forward, which is independent of it).
 int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
@@ -564,6 +616,36 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
+  const int n_first = (value_side ? 1 + nc : 0) + (actor_side ? 1 : 0);
+  if (fused_mlp_ok(e, n_first)) {
+    // whole networks per launch: {target actor, critic(s), actor}
+    if (value_side && e->td3 && !e->ext_noise) {
+      if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s); }))) return rc;
+    }
+    const int64_t aoff = (int64_t)A * e->esz;
+    {
+      MlpBatch mb;
+      int np = 0;
+      double fl = 0;
+      if (value_side) {
+        MlpSpec f{TPOL, e->xcn + aoff, e->ldx, e->K1a, 0};
+        f.out = e->xcn; f.ldo = e->ldx;
+        if (e->td3) { f.addend = e->ext_noise ? e->ext_noise : e->noise_buf; f.ld_add = A; f.add_clip = e->hy.noise_clip; }
+        fl += fill_mlp(e, f, rows, &mb.p[np++]);
+        for (int c = 0; c < nc; ++c) {
+          MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
+          fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
+          fl += fill_mlp(e, fc, rows, &mb.p[np++]);
+        }
+      }
+      if (actor_side) {
+        MlpSpec f{POL, e->xcs + aoff, e->ldx, e->K1a, 0};
+        f.h1 = e->pa.h1; f.h2 = e->pa.h2; f.out = e->gen_action; f.ldo = e->Ap; f.mask_idx = actor_m1;
+        fl += fill_mlp(e, f, rows, &mb.p[np++]);
+      }
+      if ((rc = slot(e, "mlp_fwd_nets", fl, s, [&] { return mlp_launch(mb, np, s); }))) return rc;
+    }
+  } else {
   {  // layer 1: packed rows (compute type) in, tc hidden out
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
@@ -624,7 +706,19 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     }
     if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
   }
-  if (value_side) {
+  }  // first group
+  if (value_side && fused_mlp_ok(e, nc)) {
+    {
+      MlpBatch mb;
+      double fl = 0;
+      for (int c = 0; c < nc; ++c) {
+        MlpSpec f{TVAL[c], e->xcn, e->ldx, e->K1c, 0};
+        f.h2 = e->tq[c].h2;
+        fl += fill_mlp(e, f, rows, &mb.p[c]);
+      }
+      if ((rc = slot(e, "mlp_fwd_target_critic", fl, s, [&] { return mlp_launch(mb, nc, s); }))) return rc;
+    }
+  } else if (value_side) {
     {  // target critics on [next_action | next_state]
       Group g(e, GEMM_FWD, 0, 0);
       for (int c = 0; c < nc; ++c) {
@@ -643,6 +737,8 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       }
       if ((rc = g.run(s, "fwd_l2_target_critic"))) return rc;
     }
+  }
+  if (value_side) {
     // heads: TD target, Q, dQ, loss partials
     HeadArgs h;
     memset(&h, 0, sizeof(h));
@@ -712,6 +808,15 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   const int m0 = e->td3 ? 6 : 4;
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
+  if (fused_mlp_ok(e, 1)) {
+    // critic on [gen_action | state] with the UPDATED weights: one launch, two layer-1 contraction segments
+    MlpBatch mb;
+    MlpSpec f{V1, e->gen_action, Ap, Ap, 0};
+    f.A1 = e->xcs + (int64_t)A * e->esz; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
+    f.h1 = e->pc.h1; f.h2 = e->pc.h2; f.mask_idx = m0;
+    const double fl = fill_mlp(e, f, rows, &mb.p[0]);
+    if ((rc = slot(e, "mlp_fwd_pcritic", fl, s, [&] { return mlp_launch(mb, 1, s); }))) return rc;
+  } else {
   {  // critic L1 on [gen_action | state]: two contraction segments over the rotated W1 shadow
     Group g(e, GEMM_FWD, 0, 0);
     FwdSpec f{V1, 1, e->gen_action, Ap, 0, Ap};
@@ -729,6 +834,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     f.C = e->pc.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0 + 1;
     g.flops += fill_fwd(e, f, rows, g.add());
     if ((rc = g.run(s, "fwd_l2_pcritic"))) return rc;
+  }
   }
   {
     HeadArgs h;

@@ -1,0 +1,41 @@
+// mlp.h -- argument blocks of the fused row-panel MLP forward kernel (mlp.hip).
+#pragma once
+#include "common.h"
+
+constexpr int MLP_MAX_GROUP = 4;
+
+struct MlpProb {
+  // layer-1 input: up to two k-contiguous bf16 segments accumulated into the same pre-activation
+  const void* A[2];
+  int64_t lda[2];
+  int K[2];          // multiples of 128
+  int w1_col[2];     // first W1-shadow column of each segment
+  int nseg;
+  const void* W1; int64_t ldw1;   // bf16 shadow [256 rows, ldw1]
+  const void* W2; int64_t ldw2;   // bf16 shadow [256, 256]
+  const void* W3; int64_t ldw3;   // bf16 shadow [128 rows, 256] (actor) or NULL (critic)
+  const float* b1;
+  const float* b2;
+  const float* b3;
+  const float* w3row;             // critic: canonical fp32 [H]
+  int rows, H, out_dim;
+  // dropout of the two hidden layers
+  int mask_mode;
+  const uint8_t* mask1;
+  const uint8_t* mask2;
+  int64_t ld_mask;
+  uint32_t seed, stream1, stream2;
+  const int32_t* step_ptr;
+  // outputs
+  void* h1; void* h2; int64_t ldh;      // bf16 [rows, ldh]; either may be NULL
+  void* out; int64_t ldo;                // actor output, bf16 [rows, ldo]
+  float* q;                              // critic output, fp32 [rows]
+  const float* addend; int64_t ld_add; float add_clip;
+};
+
+struct MlpBatch {
+  MlpProb p[MLP_MAX_GROUP];
+};
+
+int mlp_init();
+int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s);

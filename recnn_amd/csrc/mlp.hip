@@ -1,0 +1,236 @@
+// mlp.hip -- fused row-panel forward of a whole Actor / Critic MLP (bf16 compute, gfx950).
+//
+// Replaces, in ONE launch per group of network applications, what recnn/nn/models.py:66-73 / :207-213 do with
+// cat + 3 x (addmm, relu, dropout): the three dependent GEMMs of a network are chained inside a workgroup, so the
+// hidden activations never leave the CU between layers and two kernel boundaries per chain disappear
+// (at batch 2048 every boundary costs more than the arithmetic of layers 2 and 3).
+//
+// One workgroup (4 waves) owns 32 batch rows of one network and ALL 256 hidden columns (wave w: columns 64w..64w+63):
+//   layer 1  k loop over the packed input rows: A panel (32 x 128 k) and the full W1 k-slab (256 x 128 k) stream
+//            global -> LDS by global_load_lds (2-stage ring, 72 KB per stage), MFMA 16x16x32 bf16, fp32 accumulate
+//   epilogue bias + relu + dropout -> bf16 panel in LDS (the next layer's A operand) and, if requested, global h1
+//   layer 2  A = LDS panel, W2 (2 k-slabs) by DMA;  same epilogue -> panel, global h2
+//   layer 3  actor: W3 by DMA, 32 x 128 outputs (+ TD3 noise) -> global;   critic: per-row dot with fp32 w3 -> q
+// LDS image of every k-slab row is 256 bytes; 16-byte chunk c of row r sits at chunk position c ^ (r & 15)
+// (applied on the DMA source address / the panel write address), so MFMA fragment reads are bank-conflict free.
+// Whole 160 KiB of LDS per workgroup (1 workgroup per CU): 2 x (8 KB A + 64 KB W) + 16 KB panel.
+#include "mlp.h"
+
+namespace {
+constexpr int BM = 32;            // rows per workgroup
+constexpr int HP = 256;           // hidden width handled (4 waves x 64 columns)
+constexpr int KB = 128;           // bf16 k elements per stage row (256 bytes)
+constexpr int A_BYTES = BM * 256;             // 8 KB
+constexpr int W_BYTES = HP * 256;             // 64 KB
+constexpr int STAGE = A_BYTES + W_BYTES;      // 72 KB
+constexpr int PANEL_OFF = 2 * STAGE;          // 144 KB
+constexpr int PANEL_HALF = BM * 256;          // one k half (128 columns) of the 32 x 256 activation panel
+constexpr int LDS_TOTAL = PANEL_OFF + 2 * PANEL_HALF;  // 160 KB
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "memory");
+}
+
+// DMA `nrows` rows x 256 bytes (k slab [k0, k0+128) of a bf16 matrix with row pitch ld elements) into LDS at
+// lds_dst; rows beyond row_max are clamped (their results are never stored).  4 rows per wave instruction.
+__device__ __forceinline__ void dma_rows(const void* base, int64_t ld, int row0, int row_max, int k0, int nrows,
+                                         unsigned lds_dst, int wave, int lane) {
+  const int q_row = lane >> 4, q_pos = lane & 15;
+  const int ninstr = nrows / 16;  // per wave
+  for (int j = 0; j < ninstr; ++j) {
+    const int row = (j * 4 + wave) * 4 + q_row;
+    const int c = q_pos ^ (row & 15);
+    const int gr = min(row0 + row, row_max);
+    const char* src = (const char*)base + ((int64_t)gr * ld + k0) * 2 + c * 16;
+    dma16(src, lds_dst + (j * 4 + wave) * 1024);
+  }
+}
+
+// acc[tm][tn] += A(32 x 128) * B(rows wn0.. x 128)^T for one k slab already in LDS
+template <int TN>
+__device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned char* sb, f32x4 (&acc)[2][TN], int wn0, int fr,
+                                         int fg) {
+#pragma unroll
+  for (int ks = 0; ks < KB / 32; ++ks) {
+    const int pos = ((ks * 4 + fg) ^ fr) * 16;
+    uint4 a[2], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + pos);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pos);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]), __builtin_bit_cast(bf16x8, b[tn]),
+                                                              acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// hidden-layer epilogue: bias + relu + dropout; bf16 result into the LDS panel and (optionally) global memory
+__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][4], const float* bias, int H, int rows, int m0, int wave, int fr,
+                                                int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
+                                                unsigned char* panel, bf16_t* gout, int64_t ldg) {
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = wave * 64 + tn * 16 + fr;
+    const float bv = n < H ? bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int rb = tm * 16 + fg * 4;
+      uint32_t word = 0;
+      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)((m0 + rb) >> 2), (uint32_t)n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + r, m = m0 + row;
+        float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
+        if (mask_mode == RECNN_MASK_EXTERNAL) v = (m < rows && n < H && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
+        else if (mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
+        if (n >= H) v = 0.f;
+        const bf16_t hv = f2bf(v);
+        // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
+        const int c = ((n & 127) >> 3) ^ (row & 15);
+        *(bf16_t*)(panel + (n >> 7) * PANEL_HALF + row * 256 + c * 16 + (n & 7) * 2) = hv;
+        if (gout && m < rows && n < H) gout[(int64_t)m * ldg + n] = hv;
+      }
+    }
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
+  const MlpProb& P = batch.p[blockIdx.y];
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= P.rows) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int row_max = P.rows - 1;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ------------------------------------------------------------------ layer 1
+  const int nt0 = P.K[0] / KB;
+  const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
+  auto issue1 = [&](int t) {
+    const int sg = t < nt0 ? 0 : 1;
+    const int k0 = (sg == 0 ? t : t - nt0) * KB;
+    const unsigned sb = lds0 + (t & 1) * STAGE;
+    dma_rows(P.A[sg], P.lda[sg], m0, row_max, k0, BM, sb, wave, lane);
+    dma_rows(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, HP, sb + A_BYTES, wave, lane);
+  };
+  issue1(0);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // slab t landed for every wave; slab t-1 is no longer being read
+    if (t + 1 < nt) issue1(t + 1);
+    const unsigned char* st = lds + (t & 1) * STAGE;
+    mma_slab<4>(st, st + A_BYTES, acc, wave * 64, fr, fg);
+  }
+  __builtin_amdgcn_s_barrier();  // ring free
+  // W2: both k slabs straight away (they overlap the epilogue below)
+  dma_rows(P.W2, P.ldw2, 0, HP - 1, 0, HP, lds0 + A_BYTES, wave, lane);
+  dma_rows(P.W2, P.ldw2, 0, HP - 1, KB, HP, lds0 + STAGE + A_BYTES, wave, lane);
+
+  uint32_t key1 = 0, key2 = 0;
+  if (P.mask_mode == RECNN_MASK_HASH) {
+    const int32_t st = P.step_ptr ? *P.step_ptr : 0;
+    key1 = mask_key(P.seed, st, P.stream1);
+    key2 = mask_key(P.seed, st, P.stream2);
+  }
+  unsigned char* panel = lds + PANEL_OFF;
+  hidden_epilogue(acc, P.b1, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh);
+
+  // ------------------------------------------------------------------ layer 2
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // W2 landed, h1 panel complete (LDS writes drained before the raw barrier)
+  mma_slab<4>(panel, lds + A_BYTES, acc, wave * 64, fr, fg);
+  mma_slab<4>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * 64, fr, fg);
+  __builtin_amdgcn_s_barrier();  // everyone is done with W2 and the h1 panel
+  if (P.W3) {                    // actor: W3 (128 rows) k slabs into the two W slots
+    dma_rows(P.W3, P.ldw3, 0, 127, 0, 128, lds0 + A_BYTES, wave, lane);
+    dma_rows(P.W3, P.ldw3, 0, 127, KB, 128, lds0 + STAGE + A_BYTES, wave, lane);
+  }
+  hidden_epilogue(acc, P.b2, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // h2 panel complete (and W3 landed)
+
+  // ------------------------------------------------------------------ layer 3
+  if (P.W3) {
+    f32x4 o[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_slab<2>(panel, lds + A_BYTES, o, wave * 32, fr, fg);
+    mma_slab<2>(panel + PANEL_HALF, lds + STAGE + A_BYTES, o, wave * 32, fr, fg);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = wave * 32 + tn * 16 + fr;
+      if (n >= P.out_dim) continue;
+      const float bv = P.b3[n];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + tm * 16 + fg * 4 + r;
+          if (m >= P.rows) continue;
+          float v = o[tm][tn][r] + bv;
+          if (P.addend) {
+            const float z = P.addend[(int64_t)m * P.ld_add + n];
+            v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+          }
+          ((bf16_t*)P.out)[(int64_t)m * P.ldo + n] = f2bf(v);
+        }
+    }
+  } else if (P.q) {
+    // critic head: q[m] = h2[m, :] . w3 + b3   (8 rows per wave, lanes split the 256 columns)
+    for (int i = 0; i < 8; ++i) {
+      const int row = wave * 8 + i;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = lane * 4 + j;
+        const int c = ((n & 127) >> 3) ^ (row & 15);
+        const bf16_t hv = *(const bf16_t*)(panel + (n >> 7) * PANEL_HALF + row * 256 + c * 16 + (n & 7) * 2);
+        s += n < P.H ? bf2f(hv) * P.w3row[n] : 0.f;
+      }
+      s = wave_sum(s);
+      if (lane == 0 && m0 + row < P.rows) P.q[m0 + row] = s + P.b3[0];
+    }
+  }
+}
+
+int mlp_init() {
+  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                         "mlp_fwd_kernel attr");
+}
+
+int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
+  int rows = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const MlpProb& p = b.p[i];
+    if (p.rows > rows) rows = p.rows;
+    if (p.H > HP || p.out_dim > 128) { recnn_set_error("mlp_fwd: hidden > 256 or out_dim > 128"); return RECNN_E_UNSUPPORTED; }
+    for (int g = 0; g < p.nseg; ++g)
+      if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
+  }
+  if (rows <= 0 || nprob <= 0) return 0;
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b);
+  return recnn_check_hip(hipGetLastError(), "mlp_fwd_kernel");
+}
