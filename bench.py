@@ -215,12 +215,17 @@ def main():
         with torch.cuda.stream(stream):
             prof = eng.profile(B_ROWS, policy=False, n_steps=50)
             prof_pol = eng.profile(B_ROWS, policy=True, n_steps=10)
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(tpath):          # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be
+            traffic = json.load(open(tpath))   # collected from inside this process); absent -> null
         dom = max(prof, key=lambda r: r[1])
         if dom[2] > 0:
             ach = dom[2] / (dom[1] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             out["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "avg_ms": dom[1], "flops_per_launch": dom[2]}
+                               "frac": ach / peak, "traffic": traffic.get(dom[0], {}).get("traffic_bytes"),
+                               "avg_ms": dom[1], "flops_per_launch": dom[2]}
         else:
             out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "avg_ms": dom[1]}
@@ -228,7 +233,8 @@ def main():
         if g:
             gbs = GATHER_BYTES_PER_ROW * B_ROWS / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_ms": g[0][1],
+                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "traffic": traffic.get("frame_gather", {}).get("traffic_bytes"), "avg_ms": g[0][1],
                                       "bytes_per_launch": GATHER_BYTES_PER_ROW * B_ROWS}
         gemm_fl = sum(r[2] for r in prof)
         gemm_ms = sum(r[1] for r in prof if r[2] > 0)

@@ -304,6 +304,8 @@ int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* s
 /* Runs n_steps eager steps with a hipEvent pair around every kernel launch and returns, per
  * launch slot, the average device time in milliseconds (h_ms[i]), its name (h_names[i], static
  * strings) and, for GEMM slots, the algorithmic FLOPs of one launch (h_flops[i], 0 otherwise).
+ * Kernels whose relaunch does not change state (everything but Adam and the loss/counter kernel) are issued
+ * 8 times back to back inside their event pair and the time divided by 8, which amortises the event overhead.
  * *h_n is in: capacity, out: slots used.  Policy and non-policy steps have different slot
  * lists; only steps with (step % policy_every == 0) == policy_steps are run and averaged. */
 int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream,
