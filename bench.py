@@ -172,7 +172,8 @@ def main():
                 eng.graph_run(first, n)
     else:
         from recnn_amd.parallel import DataParallelStepper
-        dp = DataParallelStepper(eng, B_ROWS)
+        with torch.cuda.stream(stream):
+            dp = DataParallelStepper(eng, B_ROWS, always_reduce=args.force_dp)
 
         def run(first, n):
             for t in range(first, first + n):

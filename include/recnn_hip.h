@@ -311,6 +311,16 @@ int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* s
 int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream,
                          float* h_ms, double* h_flops, const char** h_names, int* h_n);
 
+/* Data-parallel replay: the step cut into four hipGraphs around the two gradient all-reduces the caller issues
+ * (torch.distributed / RCCL) on the same stream:
+ *   0: batch, all forwards, critic backward, slab reduction   -> caller all-reduces the critic gradient arena(s)
+ *   1: non-policy step: critic Adam, policy loss, finish
+ *   2: policy step: critic Adam (+soft update), policy loss, actor backward -> caller all-reduces the actor arena
+ *   3: policy step: L1 clip + actor Adam (+soft update), finish
+ * grad_scale (1/world_size) is baked into the graphs. */
+int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, void* stream);
+int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
+
 /* Host copy of the last step's losses (synchronises `stream`):
  * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */
 int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream);

@@ -108,6 +108,7 @@ struct recnn_engine {
   bool prof_ready = false;
   // graphs
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  hipGraphExec_t gdp[4] = {nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
   int graph_rows = 0;
   bool hyper_set = false;
 };
@@ -297,10 +298,16 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   return 0;
 }
 
+static void drop_graphs(recnn_engine* e) {
+  for (int i = 0; i < 2; ++i)
+    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  for (int i = 0; i < 4; ++i)
+    if (e->gdp[i]) { (void)hipGraphExecDestroy(e->gdp[i]); e->gdp[i] = nullptr; }
+}
+
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
   if (!e) return;
-  for (int i = 0; i < 2; ++i)
-    if (e->gexec[i]) (void)hipGraphExecDestroy(e->gexec[i]);
+  drop_graphs(e);
   delete e;
 }
 
@@ -320,8 +327,7 @@ extern "C" int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, fl
   e->xs = xs; e->xn = xn; e->reward = reward; e->done = done;
   e->xcs = e->bf16 ? e->xsh : (char*)xs;
   e->xcn = e->bf16 ? e->xnh : (char*)xn;
-  for (int i = 0; i < 2; ++i)
-    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  drop_graphs(e);
   return 0;
 }
 
@@ -334,8 +340,7 @@ extern "C" int recnn_engine_bind_external(recnn_engine* e, const uint8_t* masks,
 
 extern "C" int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* m) {
   RECNN_REQUIRE(e, "bind_sampler: null engine");
-  for (int i = 0; i < 2; ++i)
-    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  drop_graphs(e);
   if (!m) { e->has_sampler = false; return 0; }
   RECNN_REQUIRE(m->items && m->ratings && m->user_off && m->perm && m->table && m->row_off && m->cursor, "bind_sampler: null pointer");
   RECNN_REQUIRE(m->users_per_batch > 0 && m->n_batches > 0 && m->frame > 0, "bind_sampler: bad sizes");
@@ -352,16 +357,14 @@ extern "C" int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h) {
   RECNN_REQUIRE(h->policy_every > 0, "set_hyper: policy_every must be positive");
   e->hy = *h;
   e->hyper_set = true;
-  for (int i = 0; i < 2; ++i)
-    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  drop_graphs(e);
   return 0;
 }
 
 extern "C" int recnn_engine_set_mask_mode(recnn_engine* e, int mask_mode) {
   RECNN_REQUIRE(e && mask_mode >= RECNN_MASK_NONE && mask_mode <= RECNN_MASK_EXTERNAL, "set_mask_mode: bad arguments");
   e->cfg.mask_mode = mask_mode;
-  for (int i = 0; i < 2; ++i)
-    if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  drop_graphs(e);
   return 0;
 }
 
@@ -1142,6 +1145,46 @@ extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_ste
     const bool pol = ((first_step + i) % e->hy.policy_every) == 0;
     RECNN_HIP(hipGraphLaunch(e->gexec[pol ? 1 : 0], (hipStream_t)stream));
   }
+  return 0;
+}
+
+// Data-parallel phase graphs (see recnn_amd/parallel.py): the gradient all-reduces run between them.
+//   0  batch + all forwards + critic backward + slab reduction            -> all-reduce critic grads
+//   1  [non-policy step] critic Adam, policy loss, finish
+//   2  [policy step]     critic Adam (+soft), policy loss + actor backward -> all-reduce actor grads
+//   3  [policy step]     L1 clip + actor Adam (+soft), finish
+extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, void* stream) {
+  int rc = check_ready(e, rows);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  RECNN_REQUIRE(s != nullptr, "dp_graph_build: capture needs a non-null stream");
+  for (int v = 0; v < 4; ++v) {
+    if (e->gdp[v]) { (void)hipGraphExecDestroy(e->gdp[v]); e->gdp[v] = nullptr; }
+    hipGraph_t graph = nullptr;
+    RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = 0;
+    if (v == 0) {
+      if (!(rc = stage_batch(e, rows, s)) && !(rc = ph_forward(e, rows, true, true, true, s))) rc = ph_value_backward(e, rows, true, s);
+    } else if (v == 1) {
+      if (!(rc = value_apply(e, false, grad_scale, s)) && !(rc = ph_policy(e, rows, false, false, s))) rc = ph_finish(e, rows, true, false, s);
+    } else if (v == 2) {
+      if (!(rc = value_apply(e, true, grad_scale, s))) rc = ph_policy(e, rows, true, false, s);
+    } else {
+      if (!(rc = policy_apply(e, true, grad_scale, s))) rc = ph_finish(e, rows, true, true, s);
+    }
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    RECNN_HIP(ce);
+    hipError_t ie = hipGraphInstantiate(&e->gdp[v], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    RECNN_HIP(ie);
+  }
+  return 0;
+}
+
+extern "C" int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream) {
+  RECNN_REQUIRE(e && which >= 0 && which < 4 && e->gdp[which], "dp_graph_launch: graph %d not built", which);
+  RECNN_HIP(hipGraphLaunch(e->gdp[which], (hipStream_t)stream));
   return 0;
 }
 

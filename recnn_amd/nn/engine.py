@@ -239,6 +239,13 @@ class StepEngine:
     def grad_arena(self, ni: int) -> torch.Tensor:
         return self.grads[ni]
 
+    def dp_graph_build(self, rows: int, grad_scale: float):
+        L.call("recnn_engine_dp_graph_build", self.handle, rows, float(grad_scale), self._stream())
+        self._dp_graphs = True
+
+    def dp_graph_launch(self, which: int):
+        L.call("recnn_engine_dp_graph_launch", self.handle, which, self._stream())
+
     def graph_build(self, rows: int):
         L.call("recnn_engine_graph_build", self.handle, rows, self._stream())
 

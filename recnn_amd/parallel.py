@@ -28,7 +28,7 @@ class DataParallelStepper:
     """Drives any engine exposing the phase API of recnn_amd.nn.engine.StepEngine
     (value_grads / value_apply / policy_grads / policy_apply / finish / grad_arena / value_nets / policy_every)."""
 
-    def __init__(self, engine, rows: int, group=None):
+    def __init__(self, engine, rows: int, group=None, use_graphs: bool = True, always_reduce: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("DataParallelStepper needs an initialised torch.distributed process group "
                                "(backend 'nccl' = RCCL on ROCm)")
@@ -37,14 +37,30 @@ class DataParallelStepper:
         self.group = group
         self.world = dist.get_world_size(group)
         self.scale = 1.0 / self.world
+        self.always_reduce = always_reduce
+        # the phases between the all-reduces replay as hipGraphs when the engine offers them (StepEngine does)
+        self.graphs = bool(use_graphs and hasattr(engine, "dp_graph_build"))
+        if self.graphs:
+            engine.dp_graph_build(rows, self.scale)
 
     def _allreduce(self, t: torch.Tensor):
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, t: int, learn: bool = True):
         e = self.engine
         policy = learn and (t % e.policy_every == 0)
+        if self.graphs and learn:
+            e.dp_graph_launch(0)
+            for ni in e.value_nets():
+                self._allreduce(e.grad_arena(ni))
+            if not policy:
+                e.dp_graph_launch(1)
+            else:
+                e.dp_graph_launch(2)
+                self._allreduce(e.grad_arena(L.NET_POLICY))
+                e.dp_graph_launch(3)
+            return
         e.value_grads(self.rows, learn)
         if learn:
             for ni in e.value_nets():

@@ -39,7 +39,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert lib.recnn_engine_query(C.byref(cfg), C.byref(sz)) == -1
     cfg.action_dim = 128
     assert lib.recnn_engine_query(C.byref(cfg), C.byref(sz)) == 0
-    assert sz.ld_x == 1472 and sz.master_floats_actor == 429_184 and sz.master_floats_critic == 429_313
+    assert sz.ld_x == 1536 and sz.master_floats_actor == 429_184 and sz.master_floats_critic == 429_313
     assert sz.workspace_bytes > 0 and sz.workspace_bytes % 256 == 0
 
 

@@ -299,3 +299,45 @@ def test_graph_replay_equals_eager(cuda):
     for k in O.PARAM_ORDER:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
+def test_data_parallel_stepper_world1_equals_fused_step(cuda):
+    """The DP phase graphs (and the eager phase API) with one rank reproduce the fused step bit for bit."""
+    import os
+    import torch.distributed as dist
+    from recnn_amd import _lib as L
+    from recnn_amd.parallel import DataParallelStepper
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    S, A, H, B = 1290, 128, 256, 256
+    actor, (critic,) = _init_nets(6, S, A, H, 1)
+    gen = torch.Generator().manual_seed(7)
+    batch = _rand_batch(B, S, A, gen)
+    outs = []
+    for mode in ("fused", "dp_graphs", "dp_eager"):
+        eng = _engine("ddpg", S, A, H, B, "bf16", mask_mode="hash", seed=5)
+        eng.load_params(L.NET_POLICY, actor); eng.load_params(L.NET_TARGET_POLICY, actor)
+        eng.load_params(L.NET_VALUE1, critic); eng.load_params(L.NET_TARGET_VALUE1, critic)
+        eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3), policy_every=2)
+        eng.set_counters()
+        eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            if mode == "fused":
+                for t in range(5):
+                    eng.step(B, True, t)
+            else:
+                dp = DataParallelStepper(eng, B, use_graphs=(mode == "dp_graphs"), always_reduce=False)
+                for t in range(5):
+                    dp.step(t)
+        side.synchronize()
+        torch.cuda.synchronize()
+        outs.append((eng.losses(), {k: v.clone() for k, v in eng.param_views(L.NET_POLICY).items()},
+                     {k: v.clone() for k, v in eng.param_views(L.NET_TARGET_VALUE1).items()}))
+    for other in outs[1:]:
+        assert outs[0][0] == other[0]
+        for k in O.PARAM_ORDER:
+            assert torch.equal(outs[0][1][k], other[1][k]), k
+            assert torch.equal(outs[0][2][k], other[2][k]), k
