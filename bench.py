@@ -244,9 +244,15 @@ def main():
                                  "policy_step_sum_kernel_ms": sum(r[1] for r in prof_pol), "policy_step_launches": len(prof_pol)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(items, ratings, off, table)
-        print(json.dumps(out))
     if use_dp:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,86 @@
+"""CPU tests of the host-side FrameEnv logic (csv/pickle ETL contract, cache, loaders): no GPU work involved.
+Reference behaviour: recnn/data/env.py:81-187, recnn/data/dataset_functions.py:84-126, recnn/data/utils.py:203-214."""
+import os
+import pickle
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import recnn_amd
+from recnn_amd.data import env as E
+
+
+@pytest.fixture()
+def toy_dir(tmp_path):
+    """The toy-dataset recipe of the reference docs (docs/source/examples/your_data.rst:57-98), smaller."""
+    rng = np.random.default_rng(0)
+    n_users, n_items, n_rows = 40, 60, 1500
+    df = pd.DataFrame({"userId": rng.integers(1, n_users + 1, n_rows), "movieId": rng.integers(1000, 1000 + n_items, n_rows),
+                       "rating": rng.integers(1, 11, n_rows) * 0.5, "timestamp": rng.permutation(n_rows)})
+    df.to_csv(tmp_path / "ratings.csv", index=False)
+    emb = {int(k): torch.randn(16) for k in range(1000, 1000 + n_items)}
+    with open(tmp_path / "emb.pkl", "wb") as f:
+        pickle.dump(emb, f)
+    return tmp_path, df, emb
+
+
+def test_frame_env_from_csv_builds_the_reference_data_contract(toy_dir):
+    tmp, df, emb = toy_dir
+    path = E.DataPath(base=str(tmp) + "/", ratings="ratings.csv", embeddings="emb.pkl", cache="cache.pkl", use_cache=True)
+    env = E.FrameEnv(path, frame_size=10, batch_size=5)
+    base = env.base
+    assert base.embeddings.shape == (60, 16) and len(base.key_to_id) == 60
+    assert base.key_to_id[1000] == 0 and base.id_to_key[59] == 1059                      # sorted keys -> dense ids
+    assert torch.equal(base.embeddings[base.key_to_id[1017]], emb[1017])
+    ud = base.train_user_dataset.user_dict
+    counts = df.groupby("userId").size()
+    eligible = set(counts[counts > 10].index)
+    users = set(base.train_user_dataset.users) | set(base.test_user_dataset.users)
+    assert users <= eligible and len(users) == len(eligible) - 2                          # env.py:178 drops the 2 longest
+    assert len(base.test_user_dataset) == int(np.ceil(0.05 * len(eligible)))             # test_size = 0.05
+    u = next(iter(users))
+    rows = df[df.userId == u].sort_values("timestamp")
+    assert np.array_equal(ud[u]["items"], rows.movieId.map(base.key_to_id).values)       # time order, dense ids
+    assert np.allclose(ud[u]["ratings"], 2 * (rows.rating.values - 2.5))                 # [0.5,5] -> [-4,5]
+    item = base.train_user_dataset[0]
+    assert set(item) == {"items", "rates", "sizes", "users"} and item["sizes"] == len(item["items"])
+    lens = [len(ud[x]["items"]) for x in base.train_user_dataset.users]
+    assert lens == sorted(lens, reverse=True)                                            # sort_users_itemwise
+    assert len(env.train_dataloader) == -(-len(base.train_user_dataset) // 5)
+    assert env.frame_size == 10 and env.batch_size == 5 and env.num_workers == 1
+    # cache round trip: second construction loads the pickle and yields the same split
+    assert os.path.isfile(tmp / "cache.pkl")
+    env2 = E.FrameEnv(path, frame_size=10, batch_size=5)
+    assert list(env2.base.train_user_dataset.users) == list(base.train_user_dataset.users)
+    # the pickle unpickles under the reference's module name too
+    recnn_amd.install_as("recnn")
+    import recnn.data.env as alias
+    assert alias.EnvBase is E.EnvBase
+
+
+def test_pipeline_helpers(toy_dir):
+    tmp, df, emb = toy_dir
+    from recnn_amd.data import dataset_functions as D
+    kw = D.DataFuncKwargs(frame_size=10)
+    with pytest.raises(AttributeError):
+        kw.get("reduce_items_to")
+    kw.set("reduce_items_to", 20)
+    base = E.EnvBase()
+    base.embeddings, base.key_to_id, base.id_to_key = recnn_amd.data.make_items_tensor(emb)
+    args = D.DataFuncArgsMut(df=df.copy(), base=base, users=None, user_dict=None)
+    D.build_data_pipeline([D.truncate_dataset, D.prepare_dataset], kw, args)
+    assert args.base.embeddings.shape[0] == 20 and len(args.base.key_to_id) == 20
+    assert all(it.max() < 20 for it in (d["items"] for d in args.user_dict.values()))
+
+
+def test_rolling_window_and_get_base_batch_shapes():
+    a = np.arange(7)
+    w = recnn_amd.data.rolling_window(a, 3)
+    assert w.shape == (5, 3) and w[4].tolist() == [4, 5, 6]
+    b = {"state": torch.zeros(4, 6), "action": torch.zeros(4, 2), "reward": torch.zeros(4), "next_state": torch.zeros(4, 6),
+         "done": torch.ones(4)}
+    out = recnn_amd.data.get_base_batch(b, device=torch.device("cpu"))
+    assert [tuple(t.shape) for t in out] == [(4, 6), (4, 2), (4, 1), (4, 6), (4, 1)]
+    assert len(recnn_amd.data.get_base_batch(b, device=torch.device("cpu"), done=False)) == 4
