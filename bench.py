@@ -141,6 +141,8 @@ def main():
         L.load().recnn_tune_gemm_dma(int(os.environ["RECNN_GEMM_DMA"]))
     if os.environ.get("RECNN_FUSED_MLP"):
         L.load().recnn_tune_fused_mlp(int(os.environ["RECNN_FUSED_MLP"]))
+    if os.environ.get("RECNN_DW_SPLITS"):
+        L.load().recnn_tune_dw_splits(int(os.environ["RECNN_DW_SPLITS"]))
     if os.environ.get("RECNN_GEMM_TGF"):
         L.load().recnn_tune_gemm_ks_layout(int(os.environ["RECNN_GEMM_TGF"]))
     if os.environ.get("RECNN_GATHER_ROWS"):

@@ -62,6 +62,8 @@ void recnn_tune_gemm_dma(int on);
 /* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
  * launch (csrc/mlp.hip); 0 = layer-by-layer GEMM launches. */
 void recnn_tune_fused_mlp(int on);
+/* tuning knob: number of batch splits (gradient slabs) of the layer-1 dW GEMM, 1..8. */
+void recnn_tune_dw_splits(int splits);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecnn_hip.so")
+LIB_PATH = os.environ.get("RECNN_HIP_LIB") or os.path.join(_HERE, "csrc", "librecnn_hip.so")   # override: A/B of builds
 
 F32, BF16 = 0, 1
 MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
@@ -92,6 +92,7 @@ SIGNATURES = {
     "recnn_tune_gemm_variant": (None, [_I]),
     "recnn_tune_gemm_dma": (None, [_I]),
     "recnn_tune_fused_mlp": (None, [_I]),
+    "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),

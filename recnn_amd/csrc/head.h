@@ -4,7 +4,6 @@
 
 constexpr int HEAD_MAX_CRITIC = 2;
 constexpr int HEAD_ROWS_PER_BLOCK = 16;
-constexpr int HEADB_ROWS_PER_BLOCK = 32;
 
 struct HeadArgs {
   int rows, H, tc_bf16;
@@ -39,22 +38,6 @@ struct HeadArgs {
   float* db3_part[2];    // [nblk]
 };
 
-struct HeadBwdArgs {
-  int rows, H, train;
-  int64_t ld_h;
-  const float* delta;  // [rows] or NULL -> delta_const
-  float delta_const;
-  const float* w3;     // canonical fp32 [H]
-  const void* h2;      // tc [rows, ld_h]
-  void* dz2;           // tc [rows, ld_h]
-  float* dw3_part;     // [nblk][H] or NULL (no parameter gradients needed)
-  float* db2_part;     // [nblk][H]
-  float* db3_part;     // [nblk]
-};
-struct HeadBwdBatch {
-  HeadBwdArgs p[2];
-};
-
 struct LossFinalizeArgs {
   int n;
   const float* part[4];
@@ -68,5 +51,4 @@ struct LossFinalizeArgs {
 };
 
 int head_launch(const HeadArgs& a, hipStream_t s);
-int head_bwd_launch(const HeadBwdBatch& b, int n, int tc_bf16, hipStream_t s);
 int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s);

@@ -136,53 +136,6 @@ int head_launch(const HeadArgs& a, hipStream_t s) {
   return recnn_check_hip(hipGetLastError(), "head_kernel");
 }
 
-// ---------------------------------------------------------------- backward seed of the critic head
-// dz2[m,n] = delta[m] * w3[n] * 2 * [h2[m,n] > 0]      (dropout p=0.5 folded: h2 > 0 <=> kept & relu'd)
-// partial sums over the block's rows:  dw3[n] += delta[m] * h2[m,n],  db3 += delta[m],  db2[n] += dz2[m,n]
-template <class TC> __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdBatch batch) {
-  const HeadBwdArgs& a = batch.p[blockIdx.y];
-  __shared__ float sdelta[HEADB_ROWS_PER_BLOCK];
-  const int r0 = blockIdx.x * HEADB_ROWS_PER_BLOCK;
-  const int nr = min(HEADB_ROWS_PER_BLOCK, a.rows - r0);
-  if (nr <= 0) return;
-  if (threadIdx.x < HEADB_ROWS_PER_BLOCK)
-    sdelta[threadIdx.x] = threadIdx.x < nr ? (a.delta ? a.delta[r0 + threadIdx.x] : a.delta_const) : 0.f;
-  __syncthreads();
-  const float scale = a.train ? 2.0f : 1.0f;
-  for (int n = threadIdx.x; n < a.H; n += 256) {
-    const float w = a.w3[n];
-    float sw = 0.f, sb = 0.f;
-    for (int i = 0; i < nr; ++i) {
-      const int64_t off = (int64_t)(r0 + i) * a.ld_h + n;
-      const float h = tc_load((const TC*)a.h2 + off);
-      const float d = sdelta[i];
-      const float dz = h > 0.f ? d * w * scale : 0.f;
-      tc_store((TC*)a.dz2 + off, dz);
-      sw += d * h;
-      sb += dz;
-    }
-    if (a.dw3_part) {
-      a.dw3_part[(int64_t)blockIdx.x * a.H + n] = sw;
-      a.db2_part[(int64_t)blockIdx.x * a.H + n] = sb;
-    }
-  }
-  if (a.db3_part && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < nr; ++i) s += sdelta[i];
-    a.db3_part[blockIdx.x] = s;
-  }
-}
-
-int head_bwd_launch(const HeadBwdBatch& b, int n, int tc_bf16, hipStream_t s) {
-  int rows = 0;
-  for (int i = 0; i < n; ++i) rows = b.p[i].rows > rows ? b.p[i].rows : rows;
-  if (rows <= 0 || n <= 0) return 0;
-  dim3 grid((rows + HEADB_ROWS_PER_BLOCK - 1) / HEADB_ROWS_PER_BLOCK, n), block(256);
-  if (tc_bf16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, grid, block, 0, s, b);
-  else hipLaunchKernelGGL(head_bwd_kernel<float>, grid, block, 0, s, b);
-  return recnn_check_hip(hipGetLastError(), "head_bwd_kernel");
-}
-
 // ---------------------------------------------------------------- loss finalize (+ step tick)
 // losses[c] = scale[c] * sum(part[c][0..n)) ; then the device counters advance.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {

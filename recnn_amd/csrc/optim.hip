@@ -30,6 +30,16 @@ __device__ inline float block_sum256(float v, float* red /*[4]*/) {
 __device__ inline float sum_slabs(const TensorSeg& T, int64_t e) {
   float g = 0.f;
   int s = 0;
+  for (; s + 32 <= T.nslab; s += 32) {  // many small slabs (head / column-sum partials): 32 loads in flight
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1)
+#pragma unroll
+      for (int j = 0; j < w; ++j) v[j] += v[j + w];
+    g += v[0];
+  }
   for (; s + 8 <= T.nslab; s += 8) {
     float v[8];
 #pragma unroll
