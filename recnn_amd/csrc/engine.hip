@@ -40,7 +40,8 @@ static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 namespace {
 
 constexpr int W1 = 0, B1 = 1, W2 = 2, B2 = 3, W3 = 4, B3 = 5;
-constexpr int SP_W1 = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
+int SP_W1 = 8;  // batch splits of the layer-1 dW GEMM (tunable)
+constexpr int SP_W1_MAX = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
 
 struct Net {
   bool critic = false, bound = false;
@@ -219,7 +220,7 @@ int64_t carve(recnn_engine* e, char* base) {
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) {
     if (!net_used(e, ni) || !net_learns(ni)) continue;
     Net& n = e->net[ni];
-    n.gp[W1] = (float*)c.take((int64_t)SP_W1 * H * n.in_dim * 4);
+    n.gp[W1] = (float*)c.take((int64_t)SP_W1_MAX * H * n.in_dim * 4);
     n.gp[W2] = (float*)c.take((int64_t)SP_W2 * H * H * 4);
     n.gp[B1] = (float*)c.take(tiles_m * H * 4);
     if (n.critic) {
@@ -568,6 +569,7 @@ int check_ready(recnn_engine* e, int rows) {
 
 // ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
 static int g_fused_mlp = 1;
+extern "C" void recnn_tune_dw_splits(int s) { SP_W1 = s < 1 ? 1 : (s > SP_W1_MAX ? SP_W1_MAX : s); }
 extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 
 // g_fused_mlp: 0 = never, 1 = groups of >= 3 networks (a single network only occupies 64 CUs and streams its
