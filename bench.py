@@ -26,7 +26,8 @@ B_ROWS, FRAME, EMB, HIDDEN = 2048, 10, 128, 256
 STATE = FRAME * EMB + FRAME
 N_USERS, N_ITEMS = 138_493, 26_744           # ML20M as processed by the reference
 USERS_PER_BATCH = 256                        # >= 2048 rows guaranteed (every user has >= 10 windows)
-GATHER_BYTES_PER_ROW = 16_604                # 5,632 + 132 read, 10,840 written (fp32 layout)
+GATHER_BYTES_PER_ROW = {"fp32": 16_604,       # 5,632 + 132 read, 10,840 written (fp32 rows)
+                        "bf16": 11_192}       # same reads, 5,428 written (bf16 rows): what the bf16 engine materialises
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
@@ -112,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="data parallel: overlap the critic all-reduce with the actor forward")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     args = ap.parse_args()
 
@@ -141,6 +143,8 @@ def main():
         L.load().recnn_tune_gemm_dma(int(os.environ["RECNN_GEMM_DMA"]))
     if os.environ.get("RECNN_FUSED_MLP"):
         L.load().recnn_tune_fused_mlp(int(os.environ["RECNN_FUSED_MLP"]))
+    if os.environ.get("RECNN_SAMPLER_F32"):
+        L.load().recnn_tune_sampler_f32_rows(int(os.environ["RECNN_SAMPLER_F32"]))
     if os.environ.get("RECNN_DW_SPLITS"):
         L.load().recnn_tune_dw_splits(int(os.environ["RECNN_DW_SPLITS"]))
     if os.environ.get("RECNN_GEMM_TGF"):
@@ -175,7 +179,7 @@ def main():
     else:
         from recnn_amd.parallel import DataParallelStepper
         with torch.cuda.stream(stream):
-            dp = DataParallelStepper(eng, B_ROWS, always_reduce=args.force_dp)
+            dp = DataParallelStepper(eng, B_ROWS, always_reduce=args.force_dp, overlap=args.overlap)
 
         def run(first, n):
             for t in range(first, first + n):
@@ -234,11 +238,14 @@ def main():
                                "frac": None, "traffic": None, "avg_ms": dom[1]}
         g = [r for r in prof if r[0] == "frame_gather"]
         if g:
-            gbs = GATHER_BYTES_PER_ROW * B_ROWS / (g[0][1] * 1e-3) / 1e9
+            f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
+            per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else "bf16"]
+            gbs = per_row * B_ROWS / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": traffic.get("frame_gather", {}).get("traffic_bytes"), "avg_ms": g[0][1],
-                                      "bytes_per_launch": GATHER_BYTES_PER_ROW * B_ROWS}
+                                      "bytes_per_launch": per_row * B_ROWS,
+                                      "rows_dtype": "fp32+bf16" if (f32_rows and args.dtype == "bf16") else args.dtype}
         gemm_fl = sum(r[2] for r in prof)
         gemm_ms = sum(r[1] for r in prof if r[2] > 0)
         out["step_breakdown"] = {"launches": [{"name": n, "ms": round(ms, 5), "gflop": round(fl / 1e9, 4)} for n, ms, fl in prof],

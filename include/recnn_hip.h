@@ -62,6 +62,9 @@ void recnn_tune_gemm_dma(int on);
 /* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
  * launch (csrc/mlp.hip); 0 = layer-by-layer GEMM launches. */
 void recnn_tune_fused_mlp(int on);
+/* 0 (default): a bf16 engine that samples its own batches (recnn_engine_bind_sampler) writes the batch rows in
+ * bf16 only; 1: it also fills the bound fp32 packed rows. */
+void recnn_tune_sampler_f32_rows(int on);
 /* tuning knob: number of batch splits (gradient slabs) of the layer-1 dW GEMM, 1..8. */
 void recnn_tune_dw_splits(int splits);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
@@ -319,8 +322,10 @@ int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_step
  *   1: non-policy step: critic Adam, policy loss, finish
  *   2: policy step: critic Adam (+soft update), policy loss, actor backward -> caller all-reduces the actor arena
  *   3: policy step: L1 clip + actor Adam (+soft update), finish
+ *   4: (overlap_actor = 1 only) the actor forward alone; graph 0 then omits it, and the caller launches graph 4
+ *      right after starting the critic all-reduce so that the collective's latency hides behind it
  * grad_scale (1/world_size) is baked into the graphs. */
-int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, void* stream);
+int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int overlap_actor, void* stream);
 int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
 
 /* Host copy of the last step's losses (synchronises `stream`):

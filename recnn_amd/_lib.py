@@ -93,6 +93,7 @@ SIGNATURES = {
     "recnn_tune_gemm_dma": (None, [_I]),
     "recnn_tune_fused_mlp": (None, [_I]),
     "recnn_tune_dw_splits": (None, [_I]),
+    "recnn_tune_sampler_f32_rows": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
@@ -126,7 +127,7 @@ SIGNATURES = {
     "recnn_engine_finish": (_I, [_P, _I, _I, _I, _P]),
     "recnn_engine_graph_build": (_I, [_P, _I, _P]),
     "recnn_engine_graph_run": (_I, [_P, _I, _I, _P]),
-    "recnn_engine_dp_graph_build": (_I, [_P, _I, _F, _P]),
+    "recnn_engine_dp_graph_build": (_I, [_P, _I, _F, _I, _P]),
     "recnn_engine_dp_graph_launch": (_I, [_P, _I, _P]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),
     "recnn_engine_buffer": (_P, [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),

@@ -109,7 +109,7 @@ struct recnn_engine {
   bool prof_ready = false;
   // graphs
   hipGraphExec_t gexec[2] = {nullptr, nullptr};
-  hipGraphExec_t gdp[4] = {nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
+  hipGraphExec_t gdp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
   int graph_rows = 0;
   bool hyper_set = false;
 };
@@ -302,7 +302,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
 static void drop_graphs(recnn_engine* e) {
   for (int i = 0; i < 2; ++i)
     if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 5; ++i)
     if (e->gdp[i]) { (void)hipGraphExecDestroy(e->gdp[i]); e->gdp[i] = nullptr; }
 }
 
@@ -569,6 +569,8 @@ int check_ready(recnn_engine* e, int rows) {
 
 // ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
 static int g_fused_mlp = 1;
+static int g_sampler_f32_rows = 0;
+extern "C" void recnn_tune_sampler_f32_rows(int on) { g_sampler_f32_rows = on; }
 extern "C" void recnn_tune_dw_splits(int s) { SP_W1 = s < 1 ? 1 : (s > SP_W1_MAX ? SP_W1_MAX : s); }
 extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 
@@ -979,6 +981,9 @@ int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
     if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
       g.state_h = (bf16_t*)e->xsh + e->A; g.next_h = (bf16_t*)e->xnh + e->A; g.action_h = (bf16_t*)e->xsh;
       g.ld_h = e->ldx;
+      // Nothing reads the fp32 rows when the engine samples its own batches in bf16: materialise the batch in
+      // the compute type only (recnn_tune_sampler_f32_rows(1) restores the fp32 copies, e.g. for inspection).
+      if (!g_sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
     }
     return frame_gather_launch(g, s);
   });
@@ -1155,18 +1160,24 @@ extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_ste
 //   1  [non-policy step] critic Adam, policy loss, finish
 //   2  [policy step]     critic Adam (+soft), policy loss + actor backward -> all-reduce actor grads
 //   3  [policy step]     L1 clip + actor Adam (+soft), finish
-extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, void* stream) {
+//   4  (overlap mode)    actor forward alone: runs while the critic all-reduce is in flight; graph 0 then
+//                        leaves the actor out of its first group
+extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int overlap_actor, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "dp_graph_build: capture needs a non-null stream");
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < 5; ++v) {
     if (e->gdp[v]) { (void)hipGraphExecDestroy(e->gdp[v]); e->gdp[v] = nullptr; }
+    if (v == 4 && !overlap_actor) continue;
     hipGraph_t graph = nullptr;
     RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     rc = 0;
     if (v == 0) {
-      if (!(rc = stage_batch(e, rows, s)) && !(rc = ph_forward(e, rows, true, true, true, s))) rc = ph_value_backward(e, rows, true, s);
+      if (!(rc = stage_batch(e, rows, s)) && !(rc = ph_forward(e, rows, true, !overlap_actor, true, s)))
+        rc = ph_value_backward(e, rows, true, s);
+    } else if (v == 4) {
+      rc = ph_forward(e, rows, false, true, false, s);
     } else if (v == 1) {
       if (!(rc = value_apply(e, false, grad_scale, s)) && !(rc = ph_policy(e, rows, false, false, s))) rc = ph_finish(e, rows, true, false, s);
     } else if (v == 2) {
@@ -1185,7 +1196,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
 }
 
 extern "C" int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream) {
-  RECNN_REQUIRE(e && which >= 0 && which < 4 && e->gdp[which], "dp_graph_launch: graph %d not built", which);
+  RECNN_REQUIRE(e && which >= 0 && which < 5 && e->gdp[which], "dp_graph_launch: graph %d not built", which);
   RECNN_HIP(hipGraphLaunch(e->gdp[which], (hipStream_t)stream));
   return 0;
 }

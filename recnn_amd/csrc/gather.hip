@@ -187,8 +187,10 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     const int r = idx / per_row, q = idx - r * per_row;
     if (!m_valid[r]) continue;
     const float* src = lines + (size_t)m_base[r] * E + q * W;
-    *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
-    *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
+    if (a.state) {
+      *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
+      *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
+    }
     if constexpr (W == 4) {
       if (a.state_h) {
         *(uint2*)(a.state_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     const int r = idx / per_act, q = idx - r * per_act;
     if (!m_valid[r]) continue;
     const float* src = lines + (size_t)(m_base[r] + F) * E + q * W;
-    *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)src;
+    if (a.action) *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)src;
     if constexpr (W == 4) {
       if (a.action_h)
         *(uint2*)(a.action_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
@@ -212,8 +214,10 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
   for (int idx = tid; idx < R * F; idx += 256) {
     const int r = idx / F, j = idx - r * F;
     if (!m_valid[r]) continue;
-    a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
-    a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
+    if (a.state) {
+      a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
+      a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
+    }
     if (a.state_h) {
       a.state_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + j]);
       a.next_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + 1 + j]);
@@ -282,9 +286,15 @@ int frame_gather_launch(GatherArgs a, hipStream_t stream) {
     uintptr_t x = (uintptr_t)p | (uintptr_t)(ld * 4);
     return (x & 15) == 0 ? 4 : ((x & 7) == 0 ? 2 : 1);
   };
-  int W = al(state, ld_state);
-  int w2 = al(next_state, ld_next); if (w2 < W) W = w2;
-  int w3 = al(action, ld_action); if (w3 < W) W = w3;
+  int W = 4;
+  if (state) {  // fp32 rows may be omitted (bf16 twins only) by the engine's own sampler
+    W = al(state, ld_state);
+    int w2 = al(next_state, ld_next); if (w2 < W) W = w2;
+    int w3 = al(action, ld_action); if (w3 < W) W = w3;
+  } else if (!a.state_h) {
+    recnn_set_error("frame_gather: no output rows");
+    return RECNN_E_INVALID;
+  }
   if (emb_dim % W) W = 1;
   if (a.state_h && W != 4) { recnn_set_error("frame_gather: bf16 twin rows need 16-byte aligned fp32 rows"); return RECNN_E_INVALID; }
   switch (g_gather_rows_per_wg) {

@@ -239,8 +239,8 @@ class StepEngine:
     def grad_arena(self, ni: int) -> torch.Tensor:
         return self.grads[ni]
 
-    def dp_graph_build(self, rows: int, grad_scale: float):
-        L.call("recnn_engine_dp_graph_build", self.handle, rows, float(grad_scale), self._stream())
+    def dp_graph_build(self, rows: int, grad_scale: float, overlap_actor: bool = False):
+        L.call("recnn_engine_dp_graph_build", self.handle, rows, float(grad_scale), int(overlap_actor), self._stream())
         self._dp_graphs = True
 
     def dp_graph_launch(self, which: int):

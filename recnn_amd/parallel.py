@@ -28,7 +28,8 @@ class DataParallelStepper:
     """Drives any engine exposing the phase API of recnn_amd.nn.engine.StepEngine
     (value_grads / value_apply / policy_grads / policy_apply / finish / grad_arena / value_nets / policy_every)."""
 
-    def __init__(self, engine, rows: int, group=None, use_graphs: bool = True, always_reduce: bool = False):
+    def __init__(self, engine, rows: int, group=None, use_graphs: bool = True, always_reduce: bool = False,
+                 overlap: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("DataParallelStepper needs an initialised torch.distributed process group "
                                "(backend 'nccl' = RCCL on ROCm)")
@@ -40,8 +41,13 @@ class DataParallelStepper:
         self.always_reduce = always_reduce
         # the phases between the all-reduces replay as hipGraphs when the engine offers them (StepEngine does)
         self.graphs = bool(use_graphs and hasattr(engine, "dp_graph_build"))
+        # overlap (optional): the actor forward does not depend on the critic update, so it can be launched while the
+        # critic gradient all-reduce (issued async on RCCL's own stream) is in flight.  Measured with one rank it costs
+        # +37 us per step (the actor leaves the fused 3-network launch), so it only pays when the collective is slower
+        # than that; off by default until measured on a multi-GPU node.
+        self.overlap = bool(self.graphs and overlap and (self.world > 1 or always_reduce))
         if self.graphs:
-            engine.dp_graph_build(rows, self.scale)
+            engine.dp_graph_build(rows, self.scale, self.overlap)
 
     def _allreduce(self, t: torch.Tensor):
         if self.world > 1 or self.always_reduce:
@@ -52,8 +58,15 @@ class DataParallelStepper:
         policy = learn and (t % e.policy_every == 0)
         if self.graphs and learn:
             e.dp_graph_launch(0)
-            for ni in e.value_nets():
-                self._allreduce(e.grad_arena(ni))
+            if self.overlap:
+                works = [dist.all_reduce(e.grad_arena(ni), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                         for ni in e.value_nets()]
+                e.dp_graph_launch(4)                 # actor forward, concurrent with the collective
+                for w in works:
+                    w.wait()                         # stream-level wait, the host does not block
+            else:
+                for ni in e.value_nets():
+                    self._allreduce(e.grad_arena(ni))
             if not policy:
                 e.dp_graph_launch(1)
             else:

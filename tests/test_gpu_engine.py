@@ -316,7 +316,7 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
     gen = torch.Generator().manual_seed(7)
     batch = _rand_batch(B, S, A, gen)
     outs = []
-    for mode in ("fused", "dp_graphs", "dp_eager"):
+    for mode in ("fused", "dp_graphs", "dp_graphs_overlap", "dp_eager"):
         eng = _engine("ddpg", S, A, H, B, "bf16", mask_mode="hash", seed=5)
         eng.load_params(L.NET_POLICY, actor); eng.load_params(L.NET_TARGET_POLICY, actor)
         eng.load_params(L.NET_VALUE1, critic); eng.load_params(L.NET_TARGET_VALUE1, critic)
@@ -329,7 +329,8 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
                 for t in range(5):
                     eng.step(B, True, t)
             else:
-                dp = DataParallelStepper(eng, B, use_graphs=(mode == "dp_graphs"), always_reduce=False)
+                dp = DataParallelStepper(eng, B, use_graphs=mode.startswith("dp_graphs"),
+                                         always_reduce=(mode == "dp_graphs_overlap"), overlap=(mode == "dp_graphs_overlap"))
                 for t in range(5):
                     dp.step(t)
         side.synchronize()
