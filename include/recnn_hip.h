@@ -62,6 +62,8 @@ void recnn_tune_gemm_dma(int on);
 /* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
  * launch (csrc/mlp.hip); 0 = layer-by-layer GEMM launches. */
 void recnn_tune_fused_mlp(int on);
+/* tuning knob: 1 (default) = single-problem forward GEMM launches use a 5-stage LDS-DMA ring, 0 = always 3. */
+void recnn_tune_gemm_dma_depth(int deep);
 /* 0 (default): a bf16 engine that samples its own batches (recnn_engine_bind_sampler) writes the batch rows in
  * bf16 only; 1: it also fills the bound fp32 packed rows. */
 void recnn_tune_sampler_f32_rows(int on);

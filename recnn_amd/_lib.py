@@ -92,6 +92,7 @@ SIGNATURES = {
     "recnn_tune_gemm_variant": (None, [_I]),
     "recnn_tune_gemm_dma": (None, [_I]),
     "recnn_tune_fused_mlp": (None, [_I]),
+    "recnn_tune_gemm_dma_depth": (None, [_I]),
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),

@@ -387,11 +387,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
       : "memory");
 }
 
-template <class TC, int TM, int TN>
+template <class TC, int TM, int TN, int NS>
 __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   constexpr int ES = sizeof(TC), KB = 256 / ES;  // k elements per stage (256-byte rows)
-  constexpr int NS = 3;
+  constexpr int D = NS - 1;                      // prefetch distance: D k stages are in flight ahead of the MFMAs
   constexpr int STAGE_BYTES = (BM + BN) * 256;
   constexpr int NA = BM / 16, NB = BN / 16;  // DMA instructions per wave and stage (4 rows each)
   constexpr int KSTEP = TcTraits<TC>::KSTEP;
@@ -445,14 +445,18 @@ __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch
     }
   };
 
-  if (nt > 0) issue(0, 0);
-  if (nt > 1) issue(1, 1);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+    if (i < nt) issue(i, i);
   for (int t = 0; t < nt; ++t) {
-    // tile t has landed once at most the NA+NB loads of tile t+1 are still outstanding
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    // tile t has landed once at most the loads of the (up to D-1) younger tiles are still outstanding
+    const int younger = min(D - 1, nt - 1 - t);
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NA + NB)) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; every wave is done reading tile t-1
-    if (t + 2 < nt) issue(t + 2, (t + 2) % NS);
+    if (t + D < nt) issue(t + D, (t + D) % NS);
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
     const unsigned char* sb = sa + BM * 256;
 #pragma unroll
@@ -525,12 +529,15 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
 static int g_gemm_dma = 1;
 extern "C" void recnn_tune_gemm_dma(int on) { g_gemm_dma = on; }
 
-template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
+static int g_dma_deep = 1;
+extern "C" void recnn_tune_gemm_dma_depth(int deep) { g_dma_deep = deep; }
+
+template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
   constexpr int TM = 1, TN = 2, BM = 32 * TM, BN = 32 * TN;
-  constexpr int LDS = 3 * (BM + BN) * 256;
+  constexpr int LDS = NS * (BM + BN) * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN>,
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN, NS>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm dma attr");
     if (rc) return rc;
     attr_done = true;
@@ -544,8 +551,17 @@ template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN, NS>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel launch");
+}
+
+// Ring depth by launch size: a launch with at most ~1 workgroup per CU keeps 4 k stages in flight per workgroup
+// (5-stage ring, 120 KB of LDS); bigger grouped launches use the 3-stage ring so that 2 workgroups share a CU.
+template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
+  long wg = 0;
+  for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
+  if (L->nprob == 0 || (g_dma_deep && wg <= 320)) return launch_dma_ns<TC, 5>(L, stream);
+  return launch_dma_ns<TC, 3>(L, stream);
 }
 
 // the DMA pipeline needs both operands stored in the compute type and whole 256-byte k stages
@@ -563,9 +579,11 @@ template <class TC> static bool dma_eligible(const GemmLaunch* L) {
 int gemm_init() {
   GemmLaunch L;
   memset(&L, 0, sizeof(L));
-  int rc = launch_dma<float>(&L, nullptr);
-  if (rc) return rc;
-  return launch_dma<bf16_t>(&L, nullptr);
+  int rc;
+  if ((rc = launch_dma_ns<float, 3>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_ns<float, 5>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_ns<bf16_t, 3>(&L, nullptr))) return rc;
+  return launch_dma_ns<bf16_t, 5>(&L, nullptr);
 }
 
 template <class TC, int MODE, bool A32, bool B32>
