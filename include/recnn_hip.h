@@ -56,6 +56,8 @@ int64_t recnn_abi_sizeof(int which);
 /* tuning knob: GEMM tile variant, -1 = per-launch heuristic, 0 = 64x64 tile, 1 = 32x64 tile with a 2x longer
  * k stage. */
 void recnn_tune_gemm_variant(int variant);
+/* tuning knob: the per-launch heuristic takes the 64x64 tile when the launch has at least this many 64x64 tiles. */
+void recnn_tune_gemm_v0_threshold(int workgroups);
 /* tuning knob: 1 (default) = forward GEMMs whose operands are stored in the compute type use the LDS-DMA
  * 3-stage pipeline, 0 = always the register-staged kernel. */
 void recnn_tune_gemm_dma(int on);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "recnn_abi_sizeof": (_L, [_I]),
     "recnn_tune_gather_rows": (None, [_I]),
     "recnn_tune_gemm_variant": (None, [_I]),
+    "recnn_tune_gemm_v0_threshold": (None, [_I]),
     "recnn_tune_gemm_dma": (None, [_I]),
     "recnn_tune_fused_mlp": (None, [_I]),
     "recnn_tune_gemm_dma_depth": (None, [_I]),

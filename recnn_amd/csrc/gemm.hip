@@ -500,6 +500,8 @@ void gemm_prob_init(GemmProb* p) {
 // Tile variants: 0 = 64x64 block tile, short k stage; 1 = 32x64 block tile, 2x longer k stage (more, smaller
 // workgroups with more bytes in flight each: these GEMMs have M = batch rows only, so they are latency bound).
 static int g_gemm_variant = -1;  // -1 = choose per launch
+static int g_gemm_v0_min_wg = 512;
+extern "C" void recnn_tune_gemm_v0_threshold(int wg) { g_gemm_v0_min_wg = wg; }
 extern "C" void recnn_tune_gemm_variant(int v) { g_gemm_variant = v; }
 
 static int g_gemm_tgf = 0;
@@ -599,7 +601,7 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
       const GemmProb& p = L->batch.p[i];
       wg += (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (MODE == GEMM_DW ? p.dw_splits : 1);
     }
-    v = wg >= 1024 ? 0 : 1;
+    v = wg >= g_gemm_v0_min_wg ? 0 : 1;
   }
   if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 2, KB0>(L, stream);
   return launch_v<TC, MODE, A32, B32, 1, 2, 2 * KB0>(L, stream);
