@@ -246,7 +246,7 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   RECNN_REQUIRE(cfg->algo == RECNN_ALGO_DDPG || cfg->algo == RECNN_ALGO_TD3, "engine: bad algo");
   RECNN_REQUIRE(cfg->dtype == RECNN_F32 || cfg->dtype == RECNN_BF16, "engine: bad dtype");
   RECNN_REQUIRE(cfg->state_dim > 0 && cfg->action_dim > 0 && cfg->hidden > 0 && cfg->max_rows > 0, "engine: bad dims");
-  RECNN_REQUIRE(cfg->action_dim % 8 == 0 && cfg->hidden % 4 == 0, "engine: action_dim must be a multiple of 8, hidden of 4");
+  RECNN_REQUIRE(cfg->action_dim % 8 == 0 && cfg->hidden % 8 == 0, "engine: action_dim must be a multiple of 8, hidden of 8");
   e->cfg = *cfg;
   e->S = cfg->state_dim; e->A = cfg->action_dim; e->H = cfg->hidden;
   // zero-padding granularity 128 elements: whole 256-byte k stages for the bf16 LDS-DMA pipeline

@@ -94,29 +94,79 @@ template <class TC> __global__ __launch_bounds__(256) void head_kernel(const Hea
     a.loss_part[c][blockIdx.x] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
   }
   if (!a.do_bwd) return;
+  // Phase 2, vectorised: a thread owns 8 consecutive hidden columns (one 16-byte bf16 load/store per row, two for
+  // fp32) of rows {rg, rg+8} of the block (256 threads = 32 column groups x 8 row groups); the per-column sums over the
+  // 16 rows are combined across the 8 row groups through LDS in a fixed order (deterministic).
   const int nr = min(HEAD_ROWS_PER_BLOCK, a.rows - r0);
   const float scale = a.train ? 2.0f : 1.0f;
+  __shared__ float red_w[8][256 + 8];
+  __shared__ float red_b[8][256 + 8];
+  const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
   for (int c = 0; c < a.n_critic; ++c) {
     const TC* h2 = (const TC*)a.ch2[c];
     TC* dz2 = (TC*)a.dz2[c];
-    for (int n = threadIdx.x; n < a.H; n += 256) {
-      const float w = a.cw3[c][n] * scale;
-      float hv[HEAD_ROWS_PER_BLOCK];
+    for (int n0 = 0; n0 < a.H; n0 += 256) {
+      const int n = n0 + cg * 8;
+      float w[8], sw[8], sb[8];
 #pragma unroll
-      for (int i = 0; i < HEAD_ROWS_PER_BLOCK; ++i)
-        hv[i] = i < nr ? tc_load(h2 + (int64_t)(r0 + i) * a.ld_h + n) : 0.f;
-      float sw = 0.f, sb = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        w[j] = (n + j < a.H) ? a.cw3[c][n + j] * scale : 0.f;
+        sw[j] = 0.f;
+        sb[j] = 0.f;
+      }
+      if (n < a.H) {
 #pragma unroll
-      for (int i = 0; i < HEAD_ROWS_PER_BLOCK; ++i) {
-        const float d = sdelta[c][i];
-        const float dz = hv[i] > 0.f ? d * w : 0.f;
-        if (i < nr) tc_store(dz2 + (int64_t)(r0 + i) * a.ld_h + n, dz);
-        sw += d * hv[i];
-        sb += dz;
+        for (int half = 0; half < 2; ++half) {
+          const int i = rg + half * 8;
+          if (i < nr) {
+            const int64_t off = (int64_t)(r0 + i) * a.ld_h + n;
+            float hv[8];
+            if constexpr (sizeof(TC) == 2) {
+              const uint4 raw = *(const uint4*)(h2 + off);
+              const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                hv[2 * j] = bf2f((bf16_t)(u[j] & 0xFFFF));
+                hv[2 * j + 1] = bf2f((bf16_t)(u[j] >> 16));
+              }
+            } else {
+              const float4 x0 = *(const float4*)(h2 + off), x1 = *(const float4*)(h2 + off + 4);
+              hv[0] = x0.x; hv[1] = x0.y; hv[2] = x0.z; hv[3] = x0.w; hv[4] = x1.x; hv[5] = x1.y; hv[6] = x1.z; hv[7] = x1.w;
+            }
+            const float d = sdelta[c][i];
+            float dz[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              dz[j] = hv[j] > 0.f ? d * w[j] : 0.f;
+              sw[j] += d * hv[j];
+              sb[j] += dz[j];
+            }
+            if constexpr (sizeof(TC) == 2) {
+              *(uint4*)(dz2 + off) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]),
+                                                pack_bf2(dz[6], dz[7]));
+            } else {
+              *(float4*)(dz2 + off) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+              *(float4*)(dz2 + off + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
+            }
+          }
+        }
       }
       if (a.dw3_part[c]) {
-        a.dw3_part[c][(int64_t)blockIdx.x * a.H + n] = sw;
-        a.db2_part[c][(int64_t)blockIdx.x * a.H + n] = sb;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red_w[rg][cg * 8 + j] = sw[j];
+          red_b[rg][cg * 8 + j] = sb[j];
+        }
+        __syncthreads();
+        const int col = threadIdx.x;
+        if (n0 + col < a.H) {
+          float tw = 0.f, tb = 0.f;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) { tw += red_w[g][col]; tb += red_b[g][col]; }
+          a.dw3_part[c][(int64_t)blockIdx.x * a.H + n0 + col] = tw;
+          a.db2_part[c][(int64_t)blockIdx.x * a.H + n0 + col] = tb;
+        }
       }
     }
     if (a.db3_part[c] && threadIdx.x == 0) {
@@ -129,7 +179,7 @@ template <class TC> __global__ __launch_bounds__(256) void head_kernel(const Hea
 
 int head_launch(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
-  if (a.H % 4) { recnn_set_error("head: hidden size must be a multiple of 4"); return RECNN_E_INVALID; }
+  if (a.H % 8 || a.ld_h % 8) { recnn_set_error("head: hidden size and pitch must be multiples of 8"); return RECNN_E_INVALID; }
   dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK), block(256);
   if (a.tc_bf16) hipLaunchKernelGGL(head_kernel<bf16_t>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, a);
