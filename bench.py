@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3"], help="td3 --rows 4096 = BASELINE.json configs[2]")
+    ap.add_argument("--rows", type=int, default=B_ROWS, help="transition rows per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="data parallel: overlap the critic all-reduce with the actor forward")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
@@ -122,8 +124,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if os.environ.get("RECNN_BENCH_SINGLE_DEVICE"):      # functional test of the N>1 path on a 1-GPU box (gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rows = args.rows
     use_dp = world > 1 or args.force_dp
     if use_dp:
         import torch.distributed as dist
@@ -133,7 +138,11 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("RECNN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from recnn_amd import _lib as L
     from recnn_amd.nn.engine import StepEngine
@@ -165,25 +174,30 @@ def main():
     perm = torch.randperm(N_USERS, generator=gen)[rank::world].to(torch.int32).to(dev)
 
     actor, critic = init_nets(0)
-    eng = StepEngine("ddpg", STATE, EMB, HIDDEN, B_ROWS, dtype=args.dtype, mask_mode="hash", seed=1234 + rank, device=dev)
-    for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
+    eng = StepEngine(args.algo, STATE, EMB, HIDDEN, rows, dtype=args.dtype, mask_mode="hash", seed=1234 + rank, device=dev)
+    nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)]
+    if args.algo == "td3":
+        _, critic2 = init_nets(1)
+        nets += [(L.NET_VALUE2, critic2), (L.NET_TARGET_VALUE2, critic2)]
+    for ni, p in nets:
         eng.load_params(ni, p)
     adam = dict(lr=1e-5, weight_decay=1e-2)            # recnn/nn/algo.py:84-89 lr / weight_decay
     eng.set_hyper(gamma=0.99, min_value=-10, max_value=10, soft_tau=0.001, policy_every=10, policy_opt=adam, value_opt=adam)
     eng.set_counters()
-    eng.bind_sampler(items_d, ratings_d, off_d, perm, USERS_PER_BATCH, FRAME, EMB, table_d)
+    users_per_batch = max(USERS_PER_BATCH, -(-rows // 10))   # every user has >= 10 windows
+    eng.bind_sampler(items_d, ratings_d, off_d, perm, users_per_batch, FRAME, EMB, table_d)
 
     stream = torch.cuda.Stream(device=dev)
     if not use_dp:
         with torch.cuda.stream(stream):
-            eng.graph_build(B_ROWS)
+            eng.graph_build(rows)
 
             def run(first, n):
                 eng.graph_run(first, n)
     else:
         from recnn_amd.parallel import DataParallelStepper
         with torch.cuda.stream(stream):
-            dp = DataParallelStepper(eng, B_ROWS, always_reduce=args.force_dp, overlap=args.overlap)
+            dp = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=args.overlap)
 
         def run(first, n):
             for t in range(first, first + n):
@@ -212,20 +226,22 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "DDPG update steps/sec (batch 2048, frame 10, emb 128)",
+            "metric": "DDPG update steps/sec (batch 2048, frame 10, emb 128)" if (args.algo, rows) == ("ddpg", B_ROWS)
+                      else f"{args.algo.upper()} update steps/sec (batch {rows}, frame 10, emb 128)",
             "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: DDPG, 2048 transition rows/step/GPU, frame_size 10, emb_dim 128, "
+            "config": {"workload": ("configs[1]: DDPG" if args.algo == "ddpg" else "configs[2]: TD3 (twin critics, delayed actor)")
+                                   + f", {rows} transition rows/step/GPU, frame_size 10, emb_dim 128, "
                                    "Actor/Critic hidden 256, Adam, policy+soft update every 10th step, synthetic ML20M-shaped "
                                    "replay store (138,493 users, 26,744 items, ~20M ratings)",
-                       "rows_per_step_per_gpu": B_ROWS, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "rows_per_step_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single",
                        "final_losses": losses},
         }
         # ---- roofline of the dominant kernel, measured live with HIP events around every launch (eager replays of the same step)
         with torch.cuda.stream(stream):
-            prof = eng.profile(B_ROWS, policy=False, n_steps=50)
-            prof_pol = eng.profile(B_ROWS, policy=True, n_steps=10)
+            prof = eng.profile(rows, policy=False, n_steps=50)
+            prof_pol = eng.profile(rows, policy=True, n_steps=10)
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.isfile(tpath):          # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be
@@ -244,18 +260,18 @@ def main():
         if g:
             f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
             per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else "bf16"]
-            gbs = per_row * B_ROWS / (g[0][1] * 1e-3) / 1e9
+            gbs = per_row * rows / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": traffic.get("frame_gather", {}).get("traffic_bytes"), "avg_ms": g[0][1],
-                                      "bytes_per_launch": per_row * B_ROWS,
+                                      "bytes_per_launch": per_row * rows,
                                       "rows_dtype": "fp32+bf16" if (f32_rows and args.dtype == "bf16") else args.dtype}
         gemm_fl = sum(r[2] for r in prof)
         gemm_ms = sum(r[1] for r in prof if r[2] > 0)
         out["step_breakdown"] = {"launches": [{"name": n, "ms": round(ms, 5), "gflop": round(fl / 1e9, 4)} for n, ms, fl in prof],
                                  "sum_kernel_ms": sum(r[1] for r in prof), "gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12,
                                  "policy_step_sum_kernel_ms": sum(r[1] for r in prof_pol), "policy_step_launches": len(prof_pol)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (args.algo, rows) == ("ddpg", B_ROWS):
             out["cpu_baseline"] = cpu_baseline(items, ratings, off, table)
     if use_dp:
         dist.barrier()
