@@ -145,7 +145,6 @@ def main():
             dist.init_process_group(backend)
 
     from recnn_amd import _lib as L
-    from recnn_amd.nn.engine import StepEngine
     if os.environ.get("RECNN_GEMM_VARIANT"):
         L.load().recnn_tune_gemm_variant(int(os.environ["RECNN_GEMM_VARIANT"]))
     if os.environ.get("RECNN_GEMM_DMA"):
@@ -165,35 +164,33 @@ def main():
     if os.environ.get("RECNN_GATHER_ROWS"):
         L.load().recnn_tune_gather_rows(int(os.environ["RECNN_GATHER_ROWS"]))
 
+    import recnn_amd
+    from recnn_amd.nn import fused
     items, ratings, off, lens = synthetic_store(0)
     gen = torch.Generator().manual_seed(0)
     table = torch.randn(N_ITEMS, EMB, generator=gen)
-    d = lambda a: torch.from_numpy(a).to(dev)
-    items_d, ratings_d, off_d, table_d = d(items), d(ratings), d(off), table.to(dev)
-    # epoch permutation of the users, sharded over ranks (rank r owns perm[r::world])
-    perm = torch.randperm(N_USERS, generator=gen)[rank::world].to(torch.int32).to(dev)
-
-    actor, critic = init_nets(0)
-    eng = StepEngine(args.algo, STATE, EMB, HIDDEN, rows, dtype=args.dtype, mask_mode="hash", seed=1234 + rank, device=dev)
-    nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)]
+    # ---- the reference's objects: FrameEnv (device-resident replay store) + Actor/Critic + DDPG/TD3 facade
+    env = recnn_amd.data.env.FrameEnv.from_store(table, items, ratings, off, frame_size=FRAME, batch_size=25, device=dev,
+                                                 test_fraction=0.0)
+    fused.set_defaults(dtype=args.dtype, mask_mode="hash", seed=1234 + rank)
+    torch.manual_seed(0)                                   # same seed on every rank: replicas start identical
+    value_net = recnn_amd.nn.Critic(STATE, EMB, HIDDEN, 54e-2)
+    policy_net = recnn_amd.nn.Actor(STATE, EMB, HIDDEN, 6e-1)
     if args.algo == "td3":
-        _, critic2 = init_nets(1)
-        nets += [(L.NET_VALUE2, critic2), (L.NET_TARGET_VALUE2, critic2)]
-    for ni, p in nets:
-        eng.load_params(ni, p)
-    adam = dict(lr=1e-5, weight_decay=1e-2)            # recnn/nn/algo.py:84-89 lr / weight_decay
-    eng.set_hyper(gamma=0.99, min_value=-10, max_value=10, soft_tau=0.001, policy_every=10, policy_opt=adam, value_opt=adam)
-    eng.set_counters()
-    users_per_batch = max(USERS_PER_BATCH, -(-rows // 10))   # every user has >= 10 windows
-    eng.bind_sampler(items_d, ratings_d, off_d, perm, users_per_batch, FRAME, EMB, table_d)
+        value_net2 = recnn_amd.nn.Critic(STATE, EMB, HIDDEN, 54e-2)
+        algo = recnn_amd.nn.TD3(policy_net, value_net, value_net2).to(dev)
+    else:
+        algo = recnn_amd.nn.DDPG(policy_net, value_net).to(dev)   # default optimizers: fused Adam(lr=1e-5, wd=1e-2)
+    users_per_batch = max(USERS_PER_BATCH, -(-rows // 10))        # every user has >= 10 windows: always >= `rows` rows
+    torch.manual_seed(100 + rank)                                 # epoch permutations differ per rank
+    algo.attach_env(env, rows_per_batch=rows, users_per_batch=users_per_batch, shard=(rank, world))
+    ctx = algo._fused_ctx
+    eng = ctx.engine
 
     stream = torch.cuda.Stream(device=dev)
     if not use_dp:
-        with torch.cuda.stream(stream):
-            eng.graph_build(rows)
-
-            def run(first, n):
-                eng.graph_run(first, n)
+        def run(first, n):
+            algo.run(n)                                   # hipGraph replays; ends with one loss read-back
     else:
         from recnn_amd.parallel import DataParallelStepper
         with torch.cuda.stream(stream):

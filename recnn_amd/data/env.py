@@ -167,6 +167,22 @@ class FrameEnv(Env):
         self._make_loaders()
         return self
 
+    @classmethod
+    def from_store(cls, embeddings: torch.Tensor, items, ratings, user_off, frame_size=10, batch_size=25, test_fraction=0.05,
+                   **kwargs):
+        """Build an env straight from CSR arrays (items int[sum L], ratings float[sum L], user_off int64[U+1]): the
+        replay-store form of the reference's `user_dict`, for data that never existed as per-user python objects."""
+        self = cls(None, frame_size, batch_size, **kwargs)
+        self.base.embeddings = embeddings
+        n_users = len(user_off) - 1
+        n_test = int(n_users * test_fraction)
+        ids = list(range(n_users))
+        self._csr = (np.asarray(items), np.asarray(ratings), np.asarray(user_off, dtype=np.int64))
+        self.base.train_user_dataset = UserDataset(ids[: n_users - n_test], None)
+        self.base.test_user_dataset = UserDataset(ids[n_users - n_test:], None)
+        self._make_loaders()
+        return self
+
     def _make_loaders(self):
         self.train_dataloader = FrameLoader(self, self.base.train_user_dataset, self.batch_size, shuffle=True)
         self.test_dataloader = FrameLoader(self, self.base.test_user_dataset, self.batch_size, shuffle=True)
@@ -179,9 +195,12 @@ class FrameEnv(Env):
                 from .. import _lib as L
                 raise L.RecnnHipError(f"FrameEnv batches are built on the GPU; device {self.device} is not usable "
                                       "(no CPU fallback)")
-            user_dict = self.base.train_user_dataset.user_dict
-            ids = list(self.base.train_user_dataset.users) + list(self.base.test_user_dataset.users)
-            self._store = ReplayStore(ids, user_dict, self.device)
+            if getattr(self, "_csr", None) is not None:
+                self._store = ReplayStore.from_arrays(*self._csr, self.device)
+            else:
+                user_dict = self.base.train_user_dataset.user_dict
+                ids = list(self.base.train_user_dataset.users) + list(self.base.test_user_dataset.users)
+                self._store = ReplayStore(ids, user_dict, self.device)
             self._table = self.base.embeddings.to(self.device, torch.float32).contiguous()
         return self._store
 

@@ -56,6 +56,47 @@ class Algo:
     def step(self):
         self._step += 1
 
+    # ---- extension: fused training on a device-resident FrameEnv (no reference counterpart) --------------------
+    def attach_env(self, env, rows_per_batch: int, users_per_batch: int = None, shard=(0, 1)):
+        """Let the engine sample its own batches from `env`'s TRAIN users: `run(n)` then executes n update steps
+        (sampler, gather, update, step()) as hipGraph replays with no Python or host work per step.  Equivalent to
+        `for batch in env.train_dataloader: self.update(batch); self.step()` with fixed `rows_per_batch`-row batches.
+        Needs Adam optimizers (recnn_amd.optim.Adam / torch.optim.Adam) in `self.optimizers`.
+        `shard=(rank, world)` restricts the sampler to this data-parallel rank's share of the train users."""
+        from . import fused
+        from ..optim import adam_config
+        algo = "td3" if "value_net1" in self.nets else "ddpg"
+        keys = ("policy_optimizer", "value_optimizer1", "value_optimizer2") if algo == "td3" else ("policy_optimizer", "value_optimizer")
+        cfgs = [adam_config(self.optimizers[k]) for k in keys]
+        if any(c is None for c in cfgs) or (algo == "td3" and cfgs[1] != cfgs[2]):
+            raise ValueError("attach_env needs plain Adam optimizers (recnn_amd.optim.Adam or torch.optim.Adam)")
+        ctx = fused.context_for(algo, self.nets)
+        ctx.ensure(self.nets, rows_per_batch)
+        ctx.set_hyper(self.params, cfgs[0], cfgs[1])
+        ctx.apply_external(rows_per_batch)
+        for k, ni in zip(keys, (fused.L.NET_POLICY, fused.L.NET_VALUE1, fused.L.NET_VALUE2)):
+            ctx.mirror_optimizer_state(self.optimizers[k], ni)
+        ctx.attach_sampler(env, rows_per_batch, users_per_batch, shard)
+        self._fused_ctx, self._fused_keys = ctx, keys
+        return self
+
+    def run(self, n_steps: int):
+        """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync)."""
+        ctx = getattr(self, "_fused_ctx", None)
+        if ctx is None:
+            raise RuntimeError("call attach_env(env, rows_per_batch) first")
+        every = self.params["policy_update" if "value_net1" in self.nets else "policy_step"]
+        first = self._step
+        ctx.run_steps(first, n_steps)
+        self._step += n_steps
+        n_policy = len(range(first + (-first) % every, first + n_steps, every))
+        from . import fused
+        for k, ni in zip(self._fused_keys, (fused.L.NET_POLICY, fused.L.NET_VALUE1, fused.L.NET_VALUE2)):
+            ctx.bump(self.optimizers[k], ni, n_policy if ni == fused.L.NET_POLICY else n_steps)
+        losses = ctx.engine.losses()
+        losses["step"] = self._step - 1
+        return losses
+
 
 class DDPG(Algo):
     def __init__(self, policy_net, value_net):

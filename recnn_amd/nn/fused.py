@@ -13,6 +13,7 @@ from __future__ import annotations
 import weakref
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from .. import _lib as L
@@ -194,6 +195,55 @@ class FusedContext:
                 eng.mask_mode = L.MASK_EXTERNAL
         eng.set_external(masks=masks, noise=noise)
 
+    # ------------------------------------------------------------------ fused training loop on a device-resident env
+    def attach_sampler(self, env, rows: int, users_per_batch: int = None, shard=(0, 1)):
+        """Bind `env`'s replay store to the engine: every step then builds its own `rows`-row batch on the GPU from an
+        epoch permutation of the env's TRAIN users, `users_per_batch` users per batch."""
+        eng = self.engine
+        st = env.store
+        train = np.asarray(st.slots(env.base.train_user_dataset.users), dtype=np.int64)
+        train = train[shard[0]::shard[1]]          # data parallel: rank r of W owns every W-th train user
+        lens = st.lengths[train] - env.frame_size
+        if users_per_batch is None:       # enough users that even the shortest histories fill `rows` rows
+            k = np.sort(lens)
+            users_per_batch = int(np.searchsorted(np.cumsum(k), rows) + 1)
+        users_per_batch = min(users_per_batch, len(train))
+        self.sampler = dict(env=env, rows=rows, upb=users_per_batch, train=torch.from_numpy(train).to(eng.device),
+                            n_batches=len(train) // users_per_batch, cursor=0)
+        self.perm = torch.empty(self.sampler["n_batches"] * users_per_batch, dtype=torch.int32, device=eng.device)
+        self._reshuffle()
+        eng.bind_sampler(st.items, st.ratings, st.user_off, self.perm, users_per_batch, env.frame_size, self.A, env.table)
+        self.graph_rows = None
+
+    def _reshuffle(self):
+        sm = self.sampler
+        order = torch.randperm(sm["train"].numel())[: self.perm.numel()].to(sm["train"].device)   # CPU generator, as RandomSampler
+        self.perm.copy_(sm["train"][order].to(torch.int32))
+
+    def run_steps(self, first_step: int, n_steps: int):
+        """`n_steps` consecutive learn steps by hipGraph replay; the permutation is redrawn at every epoch boundary."""
+        eng, sm = self.engine, self.sampler
+        # hipGraph capture/replay needs a real (non-null) stream: use a private one, ordered after and before
+        # the caller's current stream
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=eng.device)
+        cur = torch.cuda.current_stream(eng.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            if self.graph_rows != sm["rows"]:
+                eng.graph_build(sm["rows"])
+                self.graph_rows = sm["rows"]
+            done = 0
+            while done < n_steps:
+                chunk = min(n_steps - done, sm["n_batches"] - sm["cursor"])
+                eng.graph_run(first_step + done, chunk)
+                done += chunk
+                sm["cursor"] += chunk
+                if sm["cursor"] >= sm["n_batches"]:      # epoch finished (the device cursor wrapped to 0 by itself)
+                    sm["cursor"] = 0
+                    self._reshuffle()
+        cur.wait_stream(self._side)
+
     # ------------------------------------------------------------------ optimizer state mirrors
     def mirror_optimizer_state(self, opt, ni):
         """Expose the engine's Adam moments through `opt.state` (state_dict compatibility)."""
@@ -214,8 +264,8 @@ class FusedContext:
             self.opt_t[ni] = t
             eng.set_counters(self.opt_t[L.NET_POLICY], self.opt_t[L.NET_VALUE1], self.opt_t[L.NET_VALUE2], 0)
 
-    def bump(self, opt, ni):
-        self.opt_t[ni] += 1
+    def bump(self, opt, ni, inc: int = 1):
+        self.opt_t[ni] += inc
         t = self.opt_t[ni]
         is_torch = type(opt) is torch.optim.Adam
         for p in _module_params(self.modules[ni]):

@@ -280,3 +280,43 @@ def test_install_as_recnn(recnn, cuda):
     import recnn.nn as alias_nn
     from recnn.data.env import FrameEnv
     assert alias is recnn and alias_nn.DDPG is recnn.nn.DDPG and FrameEnv is recnn.data.env.FrameEnv
+
+
+def test_fused_run_equals_update_loop(recnn, cuda):
+    """algo.attach_env(env, rows).run(n) == n x (update(batch); step()) on the same batches, bit for bit.
+
+    The reference loop is driven with the batches the fused sampler would build: same epoch permutation (taken from the
+    fused context), same fixed row count, hash dropout masks keyed by the same device step counter."""
+    from recnn_amd.nn import fused
+    fused.set_defaults(dtype="bf16", mask_mode="hash", seed=21)
+    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=60, seed=8)
+    results = []
+    for mode in ("fused", "loop"):
+        torch.manual_seed(12)
+        ddpg = recnn.nn.DDPG(recnn.nn.Actor(1290, 128, 256, 6e-1), recnn.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+        ddpg.params["policy_step"] = 2
+        torch.manual_seed(99)                       # the epoch permutation is drawn from the CPU generator
+        ddpg.attach_env(env, rows_per_batch=96, users_per_batch=12)
+        ctx = ddpg._fused_ctx
+        n = ctx.sampler["n_batches"]
+        assert n == len(env.base.train_user_dataset.users) // 12
+        if mode == "fused":
+            out = ddpg.run(n)
+            assert out["step"] == n - 1 and ddpg._step == n
+        else:
+            perm = ctx.perm.cpu().numpy()
+            ids = env.store.user_ids
+            ctx.engine.unbind_sampler()
+            for i in range(n):
+                users = [ids[j] for j in perm[i * 12:(i + 1) * 12]]
+                batch = env.collate_users(users)
+                assert batch["state"].shape[0] == 96
+                out = ddpg.update(batch, learn=True)
+                ddpg.step()
+        torch.cuda.synchronize()
+        results.append((out["value"], out["policy"], {k: v.detach().clone() for k, v in ddpg.nets["policy_net"].state_dict().items()},
+                        int(ddpg.optimizers["value_optimizer"].state[ddpg.nets["value_net"].linear1.weight]["step"])))
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    for k in results[0][2]:
+        assert torch.equal(results[0][2][k], results[1][2][k]), k
+    assert results[0][3] == results[1][3] == n
