@@ -94,6 +94,8 @@ SIGNATURES = {
     "recnn_tune_gemm_dma": (None, [_I]),
     "recnn_tune_fused_mlp": (None, [_I]),
     "recnn_tune_gemm_dma_depth": (None, [_I]),
+    "recnn_tune_gemm_dma_waves": (None, [_I]),
+    "recnn_tune_mlp_waves": (None, [_I]),
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),

@@ -387,13 +387,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
       : "memory");
 }
 
-template <class TC, int TM, int TN, int NS>
-__global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
+template <class TC, int TM, int TN, int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch batch) {
+  // NW waves arranged (NW/2) x 2 ... 4 waves: 2x2 wave tiles of (16 TM) x (16 TN); 8 waves: 2x4 wave tiles
+  constexpr int WCOLS = NW / 2;
+  constexpr int BM = 32 * TM, BN = 16 * TN * WCOLS;
   constexpr int ES = sizeof(TC), KB = 256 / ES;  // k elements per stage (256-byte rows)
   constexpr int D = NS - 1;                      // prefetch distance: D k stages are in flight ahead of the MFMAs
   constexpr int STAGE_BYTES = (BM + BN) * 256;
-  constexpr int NA = BM / 16, NB = BN / 16;  // DMA instructions per wave and stage (4 rows each)
+  constexpr int NA = BM / (4 * NW), NB = BN / (4 * NW);  // DMA instructions per wave and stage (4 rows each)
   constexpr int KSTEP = TcTraits<TC>::KSTEP;
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch
   const unsigned lds0 = (unsigned)(size_t)dsmem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * 16 * TM, wn0 = (wave & 1) * 16 * TN;
+  const int wm0 = (wave / WCOLS) * 16 * TM, wn0 = (wave % WCOLS) * 16 * TN;
   const int fr = lane & 15, fg = lane >> 4;
 
   f32x4 acc[TM][TN];
@@ -429,19 +431,19 @@ __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const GemmBatch batch
     const unsigned sbase = lds0 + stage * STAGE_BYTES;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int row = (j * 4 + wave) * 4 + q_row;
+      const int row = (j * NW + wave) * 4 + q_row;
       const int c = q_pos ^ (row & 15);
       const int gr = min(m0 + row, P.M - 1);
       const char* src = (const char*)G.A + ((int64_t)gr * G.lda + k0) * ES + c * 16;
-      dma16(src, sbase + (j * 4 + wave) * 1024);
+      dma16(src, sbase + (j * NW + wave) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int row = (j * 4 + wave) * 4 + q_row;
+      const int row = (j * NW + wave) * 4 + q_row;
       const int c = q_pos ^ (row & 15);
       const int gr = min(n0 + row, P.N - 1);
       const char* src = (const char*)G.B + ((int64_t)gr * G.ldb + k0) * ES + c * 16;
-      dma16(src, sbase + BM * 256 + (j * 4 + wave) * 1024);
+      dma16(src, sbase + BM * 256 + (j * NW + wave) * 1024);
     }
   };
 
@@ -534,12 +536,15 @@ extern "C" void recnn_tune_gemm_dma(int on) { g_gemm_dma = on; }
 static int g_dma_deep = 1;
 extern "C" void recnn_tune_gemm_dma_depth(int deep) { g_dma_deep = deep; }
 
-template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
-  constexpr int TM = 1, TN = 2, BM = 32 * TM, BN = 32 * TN;
+static int g_dma_waves = 8;
+extern "C" void recnn_tune_gemm_dma_waves(int w) { g_dma_waves = (w == 8) ? 8 : 4; }
+
+template <class TC, int NS, int NW> static int launch_dma_nw(GemmLaunch* L, hipStream_t stream) {
+  constexpr int TM = 1, TN = (NW == 8 ? 1 : 2), BM = 32 * TM, BN = 16 * TN * (NW / 2);
   constexpr int LDS = NS * (BM + BN) * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN, NS>,
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN, NS, NW>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm dma attr");
     if (rc) return rc;
     attr_done = true;
@@ -553,8 +558,13 @@ template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t 
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN, NS>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN, NS, NW>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel launch");
+}
+
+template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
+  if (g_dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
+  return launch_dma_nw<TC, NS, 4>(L, stream);
 }
 
 // Ring depth by launch size: a launch with at most ~1 workgroup per CU keeps 4 k stages in flight per workgroup
@@ -582,10 +592,14 @@ int gemm_init() {
   GemmLaunch L;
   memset(&L, 0, sizeof(L));
   int rc;
-  if ((rc = launch_dma_ns<float, 3>(&L, nullptr))) return rc;
-  if ((rc = launch_dma_ns<float, 5>(&L, nullptr))) return rc;
-  if ((rc = launch_dma_ns<bf16_t, 3>(&L, nullptr))) return rc;
-  return launch_dma_ns<bf16_t, 5>(&L, nullptr);
+  if ((rc = launch_dma_nw<float, 3, 4>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<float, 5, 4>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<bf16_t, 3, 4>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<bf16_t, 5, 4>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<float, 3, 8>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<float, 5, 8>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_nw<bf16_t, 3, 8>(&L, nullptr))) return rc;
+  return launch_dma_nw<bf16_t, 5, 8>(&L, nullptr);
 }
 
 template <class TC, int MODE, bool A32, bool B32>

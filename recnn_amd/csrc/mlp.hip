@@ -38,16 +38,17 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 
 // DMA `nrows` rows x 256 bytes (k slab [k0, k0+128) of a bf16 matrix with row pitch ld elements) into LDS at
 // lds_dst; rows beyond row_max are clamped (their results are never stored).  4 rows per wave instruction.
+template <int NW>
 __device__ __forceinline__ void dma_rows(const void* base, int64_t ld, int row0, int row_max, int k0, int nrows,
                                          unsigned lds_dst, int wave, int lane) {
   const int q_row = lane >> 4, q_pos = lane & 15;
-  const int ninstr = nrows / 16;  // per wave
+  const int ninstr = nrows / (4 * NW);  // per wave
   for (int j = 0; j < ninstr; ++j) {
-    const int row = (j * 4 + wave) * 4 + q_row;
+    const int row = (j * NW + wave) * 4 + q_row;
     const int c = q_pos ^ (row & 15);
     const int gr = min(row0 + row, row_max);
     const char* src = (const char*)base + ((int64_t)gr * ld + k0) * 2 + c * 16;
-    dma16(src, lds_dst + (j * 4 + wave) * 1024);
+    dma16(src, lds_dst + (j * NW + wave) * 1024);
   }
 }
 
@@ -73,12 +74,13 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
 }
 
 // hidden-layer epilogue: bias + relu + dropout; bf16 result into the LDS panel and (optionally) global memory
-__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][4], const float* bias, int H, int rows, int m0, int wave, int fr,
+template <int TNH>
+__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const float* bias, int H, int rows, int m0, int wave, int fr,
                                                 int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
                                                 unsigned char* panel, bf16_t* gout, int64_t ldg) {
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int n = wave * 64 + tn * 16 + fr;
+  for (int tn = 0; tn < TNH; ++tn) {
+    const int n = wave * (16 * TNH) + tn * 16 + fr;
     const float bv = n < H ? bias[n] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -103,7 +105,11 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][4], const float*
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) {
+  constexpr int TNH = HP / (16 * NW);   // 16-column MFMA tiles per wave in the hidden layers (4 waves: 4, 8 waves: 2)
+  constexpr int TNO = 128 / (16 * NW);  // same for the actor's 128 outputs
+  constexpr int RW = BM / NW;           // critic head rows per wave
   const MlpProb& P = batch.p[blockIdx.y];
   const int m0 = blockIdx.x * BM;
   if (m0 >= P.rows) return;
@@ -114,11 +120,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
   const int fr = lane & 15, fg = lane >> 4;
   const int row_max = P.rows - 1;
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][TNH];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ------------------------------------------------------------------ layer 1
   const int nt0 = P.K[0] / KB;
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
     const int sg = t < nt0 ? 0 : 1;
     const int k0 = (sg == 0 ? t : t - nt0) * KB;
     const unsigned sb = lds0 + (t & 1) * STAGE;
-    dma_rows(P.A[sg], P.lda[sg], m0, row_max, k0, BM, sb, wave, lane);
-    dma_rows(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, HP, sb + A_BYTES, wave, lane);
+    dma_rows<NW>(P.A[sg], P.lda[sg], m0, row_max, k0, BM, sb, wave, lane);
+    dma_rows<NW>(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, HP, sb + A_BYTES, wave, lane);
   };
   issue1(0);
   for (int t = 0; t < nt; ++t) {
@@ -136,12 +142,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
     __builtin_amdgcn_s_barrier();  // slab t landed for every wave; slab t-1 is no longer being read
     if (t + 1 < nt) issue1(t + 1);
     const unsigned char* st = lds + (t & 1) * STAGE;
-    mma_slab<4>(st, st + A_BYTES, acc, wave * 64, fr, fg);
+    mma_slab<TNH>(st, st + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   }
   __builtin_amdgcn_s_barrier();  // ring free
   // W2: both k slabs straight away (they overlap the epilogue below)
-  dma_rows(P.W2, P.ldw2, 0, HP - 1, 0, HP, lds0 + A_BYTES, wave, lane);
-  dma_rows(P.W2, P.ldw2, 0, HP - 1, KB, HP, lds0 + STAGE + A_BYTES, wave, lane);
+  dma_rows<NW>(P.W2, P.ldw2, 0, HP - 1, 0, HP, lds0 + A_BYTES, wave, lane);
+  dma_rows<NW>(P.W2, P.ldw2, 0, HP - 1, KB, HP, lds0 + STAGE + A_BYTES, wave, lane);
 
   uint32_t key1 = 0, key2 = 0;
   if (P.mask_mode == RECNN_MASK_HASH) {
@@ -150,38 +156,38 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
     key2 = mask_key(P.seed, st, P.stream2);
   }
   unsigned char* panel = lds + PANEL_OFF;
-  hidden_epilogue(acc, P.b1, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh);
+  hidden_epilogue<TNH>(acc, P.b1, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh);
 
   // ------------------------------------------------------------------ layer 2
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // W2 landed, h1 panel complete (LDS writes drained before the raw barrier)
-  mma_slab<4>(panel, lds + A_BYTES, acc, wave * 64, fr, fg);
-  mma_slab<4>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * 64, fr, fg);
+  mma_slab<TNH>(panel, lds + A_BYTES, acc, wave * (16 * TNH), fr, fg);
+  mma_slab<TNH>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   __builtin_amdgcn_s_barrier();  // everyone is done with W2 and the h1 panel
   if (P.W3) {                    // actor: W3 (128 rows) k slabs into the two W slots
-    dma_rows(P.W3, P.ldw3, 0, 127, 0, 128, lds0 + A_BYTES, wave, lane);
-    dma_rows(P.W3, P.ldw3, 0, 127, KB, 128, lds0 + STAGE + A_BYTES, wave, lane);
+    dma_rows<NW>(P.W3, P.ldw3, 0, 127, 0, 128, lds0 + A_BYTES, wave, lane);
+    dma_rows<NW>(P.W3, P.ldw3, 0, 127, KB, 128, lds0 + STAGE + A_BYTES, wave, lane);
   }
-  hidden_epilogue(acc, P.b2, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
+  hidden_epilogue<TNH>(acc, P.b2, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // h2 panel complete (and W3 landed)
 
   // ------------------------------------------------------------------ layer 3
   if (P.W3) {
-    f32x4 o[2][2];
+    f32x4 o[2][TNO];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_slab<2>(panel, lds + A_BYTES, o, wave * 32, fr, fg);
-    mma_slab<2>(panel + PANEL_HALF, lds + STAGE + A_BYTES, o, wave * 32, fr, fg);
+      for (int j = 0; j < TNO; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_slab<TNO>(panel, lds + A_BYTES, o, wave * (16 * TNO), fr, fg);
+    mma_slab<TNO>(panel + PANEL_HALF, lds + STAGE + A_BYTES, o, wave * (16 * TNO), fr, fg);
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = wave * 32 + tn * 16 + fr;
+    for (int tn = 0; tn < TNO; ++tn) {
+      const int n = wave * (16 * TNO) + tn * 16 + fr;
       if (n >= P.out_dim) continue;
       const float bv = P.b3[n];
 #pragma unroll
@@ -200,8 +206,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
     }
   } else if (P.q) {
     // critic head: q[m] = h2[m, :] . w3 + b3   (8 rows per wave, lanes split the 256 columns)
-    for (int i = 0; i < 8; ++i) {
-      const int row = wave * 8 + i;
+    for (int i = 0; i < RW; ++i) {
+      const int row = wave * RW + i;
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -216,9 +222,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpBatch batch) {
   }
 }
 
+static int g_mlp_waves = 8;
+extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4) ? 4 : 8; }
+
 int mlp_init() {
-  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
-                         "mlp_fwd_kernel attr");
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                           "mlp_fwd_kernel<4> attr");
+  if (rc) return rc;
+  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                         "mlp_fwd_kernel<8> attr");
 }
 
 int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
@@ -231,6 +243,9 @@ int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
       if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b);
+  if (g_mlp_waves == 8)
+    hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3((rows + BM - 1) / BM, nprob), dim3(512), LDS_TOTAL, s, b);
+  else
+    hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b);
   return recnn_check_hip(hipGetLastError(), "mlp_fwd_kernel");
 }
