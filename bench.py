@@ -157,6 +157,8 @@ def main():
         L.load().recnn_tune_gemm_v0_threshold(int(os.environ["RECNN_V0_MIN_WG"]))
     if os.environ.get("RECNN_MLP_WAVES"):
         L.load().recnn_tune_mlp_waves(int(os.environ["RECNN_MLP_WAVES"]))
+    if os.environ.get("RECNN_GEMM_WAVES"):
+        L.load().recnn_tune_gemm_waves(int(os.environ["RECNN_GEMM_WAVES"]))
     if os.environ.get("RECNN_DMA_WAVES"):
         L.load().recnn_tune_gemm_dma_waves(int(os.environ["RECNN_DMA_WAVES"]))
     if os.environ.get("RECNN_DMA_DEEP"):

@@ -68,6 +68,8 @@ void recnn_tune_fused_mlp(int on);
 void recnn_tune_gemm_dma_depth(int deep);
 /* tuning knob: waves per workgroup of the LDS-DMA forward GEMM, 8 (default) or 4 (same 32x64 tile). */
 void recnn_tune_gemm_dma_waves(int waves);
+/* tuning knob: waves per workgroup of the register-staged dX / dW GEMM (same block tiles), 8 (default) or 4. */
+void recnn_tune_gemm_waves(int waves);
 /* tuning knob: waves per workgroup of the fused MLP forward kernel, 8 (default) or 4. */
 void recnn_tune_mlp_waves(int waves);
 /* 0 (default): a bf16 engine that samples its own batches (recnn_engine_bind_sampler) writes the batch rows in

@@ -95,6 +95,7 @@ SIGNATURES = {
     "recnn_tune_fused_mlp": (None, [_I]),
     "recnn_tune_gemm_dma_depth": (None, [_I]),
     "recnn_tune_gemm_dma_waves": (None, [_I]),
+    "recnn_tune_gemm_waves": (None, [_I]),
     "recnn_tune_mlp_waves": (None, [_I]),
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),

@@ -27,17 +27,17 @@ template <class TC, int KB> struct LdsCfg {
 };
 
 // ------------------------------------------------------------------ staging: k-contiguous
-template <class TC, bool MEM32, int R, int KB> struct KCLoader {
+template <class TC, bool MEM32, int R, int KB, int NT> struct KCLoader {
   static constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   static constexpr int CPR = BK / VEC;          // 16-byte LDS chunks per row (8)
-  static constexpr int NCH = R * CPR / 256;     // chunks per thread
+  static constexpr int NCH = R * CPR / NT;      // chunks per thread
   static constexpr bool CVT = MEM32 && (sizeof(TC) == 2);
   uint4 raw[NCH][CVT ? 2 : 1];
 
   __device__ inline void load(const void* base, int64_t ld, int row0, int row_max, int k0, int k_end, int tid) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      int c = tid + i * 256;
+      int c = tid + i * NT;
       int row = c / CPR, kc = c % CPR;
       int gr = min(row0 + row, row_max);  // clamp: rows past the end re-read the last valid row
       if (k0 + kc * VEC >= k_end) {       // k tail of the last stage: zeros
@@ -61,7 +61,7 @@ template <class TC, bool MEM32, int R, int KB> struct KCLoader {
   __device__ inline void store(TC* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      int c = tid + i * 256;
+      int c = tid + i * NT;
       int row = c / CPR, kc = c % CPR;
       uint4 v;
       if constexpr (CVT) {
@@ -81,20 +81,20 @@ template <class TC, bool MEM32, int R, int KB> struct KCLoader {
 // Source is [Kc, ld] with the tile dimension contiguous.  A unit = 4 consecutive k rows x one
 // 16-byte load along the tile dimension (NE elements); it is transposed in registers and written
 // as NE small vectors of 4 k values.
-template <class TC, bool MEM32, int R, int KB, bool TGF> struct KSLoader {
+template <class TC, bool MEM32, int R, int KB, bool TGF, int NT> struct KSLoader {
   static constexpr int VEC = LdsCfg<TC, KB>::VEC, BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   static constexpr bool SRC32 = MEM32 || (sizeof(TC) == 4);
   static constexpr int NE = SRC32 ? 4 : 8;      // tile elements per 16-byte load
   static constexpr int KG = BK / 4;             // k groups per stage
   static constexpr int UNITS = (R / NE) * KG;
-  static constexpr int UPT = (UNITS + 255) / 256;
+  static constexpr int UPT = (UNITS + NT - 1) / NT;
   uint4 raw[UPT][4];
 
   __device__ inline void load(const void* base, int64_t ld, int tile0, int k0, int k_end, int tid) {
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-      int u = tid + i * 256;
-      if (UNITS % 256 == 0 || u < UNITS) {
+      int u = tid + i * NT;
+      if (UNITS % NT == 0 || u < UNITS) {
         // TGF: consecutive lanes walk the (contiguous) tile dimension -> 256-byte runs per k row in global memory
         // (LDS writes then collide 4-way); otherwise consecutive lanes walk k (conflict-free LDS writes).
         int kg = TGF ? u / (R / NE) : u % KG, tg = TGF ? u % (R / NE) : u / KG;
@@ -114,8 +114,8 @@ template <class TC, bool MEM32, int R, int KB, bool TGF> struct KSLoader {
   __device__ inline void store(TC* lds, int tid) {
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-      int u = tid + i * 256;
-      if (UNITS % 256 == 0 || u < UNITS) {
+      int u = tid + i * NT;
+      if (UNITS % NT == 0 || u < UNITS) {
         int kg = TGF ? u / (R / NE) : u % KG, tg = TGF ? u % (R / NE) : u / KG;
         if constexpr (sizeof(TC) == 4) {
 #pragma unroll
@@ -220,9 +220,11 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
 }
 
 // ------------------------------------------------------------------ the kernel
-template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB, bool TGF>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB, bool TGF, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmBatch batch) {
+  // NW waves as 2 x (NW/2): wave tile (16 TM) x (16 TN), block tile (32 TM) x (16 TN NW/2)
+  constexpr int WC = NW / 2, NT = NW * 64;
+  constexpr int BM = 32 * TM, BN = 16 * TN * WC;
   constexpr int BK = LdsCfg<TC, KB>::BK, BKP = LdsCfg<TC, KB>::BKP;
   constexpr bool A_KS = (MODE == GEMM_DW);
   constexpr bool B_KS = (MODE != GEMM_FWD);
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   constexpr int STAGE = (BM + BN) * BKP;  // one LDS stage: A tile then B tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 16 * TM, wn0 = (wave & 1) * 16 * TN;
+  const int wm0 = (wave / WC) * 16 * TM, wn0 = (wave % WC) * 16 * TN;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
   }
   const int nt = nt0 + nt1;
 
-  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM, KB, TGF>, KCLoader<TC, A32, BM, KB>>::type;
-  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN, KB, TGF>, KCLoader<TC, B32, BN, KB>>::type;
+  using ALoader = typename std::conditional<A_KS, KSLoader<TC, A32, BM, KB, TGF, NT>, KCLoader<TC, A32, BM, KB, NT>>::type;
+  using BLoader = typename std::conditional<B_KS, KSLoader<TC, B32, BN, KB, TGF, NT>, KCLoader<TC, B32, BN, KB, NT>>::type;
   ALoader la;
   BLoader lb;
 
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch batch) {
         float v = cs[tn];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (fg == 0) red[(wave >> 1) * BN + wn0 + tn * 16 + fr] = v;
+        if (fg == 0) red[(wave / WC) * BN + wn0 + tn * 16 + fr] = v;
       }
       __syncthreads();
       // slab granularity is 32 rows whatever the block tile: a 64-row tile writes two slabs
@@ -507,11 +509,14 @@ extern "C" void recnn_tune_gemm_v0_threshold(int wg) { g_gemm_v0_min_wg = wg; }
 extern "C" void recnn_tune_gemm_variant(int v) { g_gemm_variant = v; }
 
 static int g_gemm_tgf = 0;
-extern "C" void recnn_tune_gemm_ks_layout(int tile_fastest) { g_gemm_tgf = tile_fastest; }
+extern "C" void recnn_tune_gemm_ks_layout(int tile_fastest) { g_gemm_tgf = tile_fastest; }  // measured: no effect; only the k-fastest mapping is built
 
-template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB>
+static int g_gemm_waves = 8;
+extern "C" void recnn_tune_gemm_waves(int w) { g_gemm_waves = (w == 4) ? 4 : 8; }
+
+template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB, int NW>
 static int launch_v(GemmLaunch* L, hipStream_t stream) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int BM = 32 * TM, BN = 16 * TN * (NW / 2);
   int maxwg = 0;
   for (int i = 0; i < L->nprob; ++i) {
     GemmProb& p = L->batch.p[i];
@@ -522,11 +527,8 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  dim3 grid(maxwg, L->nprob, 1), block(256, 1, 1);
-  if (MODE != GEMM_FWD && g_gemm_tgf)
-    hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB, (MODE != GEMM_FWD)>), grid, block, 0, stream, L->batch);
-  else
-    hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB, false>), grid, block, 0, stream, L->batch);
+  dim3 grid(maxwg, L->nprob, 1), block(NW * 64, 1, 1);
+  hipLaunchKernelGGL((gemm_kernel<TC, MODE, A32, B32, TM, TN, KB, false, NW>), grid, block, 0, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
 }
 
@@ -617,8 +619,14 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
     }
     v = wg >= g_gemm_v0_min_wg ? 0 : 1;
   }
-  if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 2, KB0>(L, stream);
-  return launch_v<TC, MODE, A32, B32, 1, 2, 2 * KB0>(L, stream);
+  // same block tiles with 4 waves (2x2) or 8 waves (2x4): more waves = more loads in flight per CU
+  // (measured: dX 7.5 -> 6.5 us with 8 waves, the dW launch 14 -> 19.5 us: its k-strided loads are spread too thin)
+  if (g_gemm_waves == 8 && MODE != GEMM_DW) {
+    if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 1, KB0, 8>(L, stream);
+    return launch_v<TC, MODE, A32, B32, 1, 1, 2 * KB0, 8>(L, stream);
+  }
+  if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 2, KB0, 4>(L, stream);
+  return launch_v<TC, MODE, A32, B32, 1, 2, 2 * KB0, 4>(L, stream);
 }
 
 template <class TC, int MODE> static int launch_m(GemmLaunch* L, hipStream_t s) {
