@@ -42,8 +42,7 @@ template <int NW>
 __device__ __forceinline__ void dma_rows(const void* base, int64_t ld, int row0, int row_max, int k0, int nrows,
                                          unsigned lds_dst, int wave, int lane) {
   const int q_row = lane >> 4, q_pos = lane & 15;
-  const int ninstr = nrows / (4 * NW);  // per wave
-  for (int j = 0; j < ninstr; ++j) {
+  for (int j = 0; (j * NW + wave) * 4 < nrows; ++j) {   // 4 rows per wave instruction, waves interleaved
     const int row = (j * NW + wave) * 4 + q_row;
     const int c = q_pos ^ (row & 15);
     const int gr = min(row0 + row, row_max);
@@ -108,7 +107,8 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const floa
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) {
   constexpr int TNH = HP / (16 * NW);   // 16-column MFMA tiles per wave in the hidden layers (4 waves: 4, 8 waves: 2)
-  constexpr int TNO = 128 / (16 * NW);  // same for the actor's 128 outputs
+  constexpr int OW = NW > 8 ? 8 : NW;   // waves that take part in the actor's 128-column output layer
+  constexpr int TNO = 128 / (16 * OW);  // 16-column tiles per participating wave there
   constexpr int RW = BM / NW;           // critic head rows per wave
   const MlpProb& P = batch.p[blockIdx.y];
   const int m0 = blockIdx.x * BM;
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 
   // ------------------------------------------------------------------ layer 3
   if (P.W3) {
+    if (wave < OW) {
     f32x4 o[2][TNO];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
           ((bf16_t*)P.out)[(int64_t)m * P.ldo + n] = f2bf(v);
         }
     }
+    }
   } else if (P.q) {
     // critic head: q[m] = h2[m, :] . w3 + b3   (8 rows per wave, lanes split the 256 columns)
     for (int i = 0; i < RW; ++i) {
@@ -222,15 +224,18 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
   }
 }
 
-static int g_mlp_waves = 8;
-extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4) ? 4 : 8; }
+static int g_mlp_waves = 16;
+extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4 || w == 16) ? w : 8; }
 
 int mlp_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
                            "mlp_fwd_kernel<4> attr");
   if (rc) return rc;
-  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
-                         "mlp_fwd_kernel<8> attr");
+  rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                       "mlp_fwd_kernel<8> attr");
+  if (rc) return rc;
+  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                         "mlp_fwd_kernel<16> attr");
 }
 
 int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
@@ -243,7 +248,9 @@ int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
       if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
-  if (g_mlp_waves == 8)
+  if (g_mlp_waves == 16)
+    hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b);
+  else if (g_mlp_waves == 8)
     hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3((rows + BM - 1) / BM, nprob), dim3(512), LDS_TOTAL, s, b);
   else
     hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b);
