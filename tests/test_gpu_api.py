@@ -320,3 +320,108 @@ def test_fused_run_equals_update_loop(recnn, cuda):
     for k in results[0][2]:
         assert torch.equal(results[0][2][k], results[1][2][k]), k
     assert results[0][3] == results[1][3] == n
+
+
+def test_optim_adam_matches_torch_adam(recnn, cuda):
+    """recnn_amd.optim.Adam (HIP kernel) against torch.optim.Adam on identical gradients, several steps, weight decay."""
+    torch.manual_seed(0)
+    w0 = torch.randn(300, 70, device=cuda)
+    grads = [torch.randn(300, 70, device=cuda) * 1e-2 for _ in range(5)]
+    pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    oa = recnn.optim.Adam([pa], lr=3e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2)
+    ob = torch.optim.Adam([pb], lr=3e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2)
+    for g in grads:
+        pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    assert rel_err(pa, pb) < 1e-6
+    assert rel_err(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]) < 1e-6 and oa.state[pa]["step"] == 5
+    assert recnn.optim.adam_config(oa)["beta2"] == 0.99 and recnn.optim.adam_config(torch.optim.SGD([pb], lr=0.1)) is None
+
+
+def test_soft_update_utility_matches_reference_formula(recnn, cuda):
+    a, b = recnn.nn.Actor(27, 8, 16).to(cuda), recnn.nn.Actor(27, 8, 16).to(cuda)
+    before = [p.detach().clone() for p in b.parameters()]
+    recnn.utils.soft_update(a, b, soft_tau=0.25)
+    for p, t0, t1 in zip(a.parameters(), before, b.parameters()):
+        assert torch.allclose(t1, t0 * (1.0 - 0.25) + p * 0.25, rtol=1e-6, atol=1e-7)      # utils/misc.py:3-5
+
+
+def test_value_update_function(recnn, cuda):
+    """recnn.nn.update.value_update: the critic half of the DDPG step, same signature as misc.py:10-20."""
+    from recnn_amd.nn import fused
+    fused.set_defaults(dtype="fp32", mask_mode="none")
+    ddpg = recnn.nn.DDPG(recnn.nn.Actor(1290, 128, 256, 6e-1), recnn.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+    batch = _ci_batch(cuda)
+    batch["done"] = (batch["done"] > 1).float()
+    ost = _oracle_state(ddpg.nets["policy_net"], ddpg.nets["value_net"], 1e-5, 1e-2, 1e-2)
+    before = ddpg.nets["value_net"].linear1.weight.detach().clone()
+    loss = recnn.nn.update.value_update(batch, ddpg.params, ddpg.nets, ddpg.optimizers, device=cuda, learn=True, step=0)
+    ref = O.ddpg_step(ost, {k: v.cpu() for k, v in batch.items()}, [], step=1, learn=True)      # step=1: no policy update
+    assert abs(float(loss) - ref["value"]) <= 1e-4 * ref["value"]
+    assert not torch.equal(before, ddpg.nets["value_net"].linear1.weight)
+    assert fro_err(ddpg.nets["value_net"].linear2.weight, ost.value["w2"]) < 1e-3
+    assert torch.equal(ddpg.nets["policy_net"].linear1.weight.cpu(), ost.policy["w1"])           # actor untouched
+
+
+@pytest.mark.parametrize("mode", ["fused", "generic"])
+def test_td3_api_matches_oracle(recnn, cuda, mode):
+    from recnn_amd.nn import fused
+    fused.set_defaults(dtype="fp32", mask_mode="hash", seed=3)
+    torch.manual_seed(4)
+    v1, v2 = recnn.nn.Critic(1290, 128, 256, 54e-2), recnn.nn.Critic(1290, 128, 256, 54e-2)
+    pol = recnn.nn.Actor(1290, 128, 256, 6e-1)
+    td3 = recnn.nn.TD3(pol, v1, v2)
+    ost = O.TD3State.create(O.params_from_module(pol), O.params_from_module(v1), O.params_from_module(v2),
+                            O.AdamState(lr=1e-3), O.AdamState(lr=1e-3), O.AdamState(lr=1e-3))
+    td3 = td3.to(cuda)
+    Opt = torch.optim.Adam if mode == "fused" else _PlainAdam
+    td3.optimizers = {"policy_optimizer": Opt(pol.parameters(), lr=1e-3), "value_optimizer1": Opt(v1.parameters(), lr=1e-3),
+                      "value_optimizer2": Opt(v2.parameters(), lr=1e-3)}
+    td3.params["policy_update"] = 2
+    ost.params["policy_update"] = 2
+    gen = torch.Generator().manual_seed(5)
+    B = 200
+    for t in range(4):
+        batch = {"state": torch.randn(B, 1290, generator=gen), "action": torch.randn(B, 128, generator=gen),
+                 "reward": torch.randn(B, generator=gen), "next_state": torch.randn(B, 1290, generator=gen),
+                 "done": (torch.rand(B, generator=gen) < 0.1).float()}
+        masks = [(torch.rand(B, 256, generator=gen) < 0.5).to(torch.uint8) for _ in range(8)]
+        noise = torch.randn(B, 128, generator=gen) * 0.5
+        ref = O.td3_step(ost, batch, noise, masks, step=t, learn=True)
+        with fused.external_randomness(td3.nets, masks=masks, noise=noise, algo="td3"):
+            lo = td3.update({k: v.to(cuda) for k, v in batch.items()}, learn=True)
+        td3.step()
+        for k in ("value1", "value2"):
+            assert abs(lo[k] - ref[k]) <= 1e-4 * ref[k], (t, k, lo, ref)
+        assert abs(lo["policy"] - ref["policy"]) <= 1e-4 * max(abs(ref["policy"]), 0.5), (t, lo, ref)
+    # td3.py:136-141: target policy never soft-updated; target critics are
+    assert torch.equal(td3.nets["target_policy_net"].linear1.weight.cpu(), ost.target_policy["w1"])
+    assert fro_err(td3.nets["target_value_net2"].linear1.weight, ost.target_value2["w1"]) < 1e-3
+    assert fro_err(pol.linear3.weight, ost.policy["w3"]) < 3e-3
+    # learn=False: losses only, debug tensors, nothing changes
+    w = v1.linear1.weight.detach().clone()
+    lo = td3.update({k: v.to(cuda) for k, v in batch.items()}, learn=False)
+    assert torch.equal(w, v1.linear1.weight) and td3.debug["next_action"].shape == (B, 128) and lo["value2"] > 0
+
+
+def test_frame_env_custom_embed_batch(recnn, cuda):
+    """A user-supplied embed_batch callable receives the windowed index batch, as in the reference (utils.py:181-187)."""
+    seen = {}
+
+    def my_embed(batch, item_embeddings_tensor, frame_size, *a, **k):
+        seen["items"] = batch["items"]
+        out = recnn.data.batch_tensor_embeddings(batch, item_embeddings_tensor, frame_size)
+        out["custom"] = True
+        return out
+    items, ratings, table = make_store(n_users=12, n_items=100, emb_dim=128, min_len=11, max_len=30, seed=6)
+    user_dict = {u: {"items": items[u], "ratings": ratings[u]} for u in range(12)}
+    env = recnn.data.env.FrameEnv.from_user_dict(torch.from_numpy(table), user_dict, list(range(10)), [10, 11], frame_size=10,
+                                                 batch_size=4, device=cuda, embed_batch=my_embed)
+    b = env.train_batch()
+    users = b["meta"]["users"].tolist()
+    ref = O.frame_batch([items[u] for u in users], [ratings[u] for u in users], table, 10)
+    assert b["custom"] and seen["items"].shape == (ref["state"].shape[0], 11)
+    assert np.array_equal(seen["items"].cpu().numpy(), ref["items"])
+    for k in ("state", "action", "reward", "next_state", "done"):
+        assert np.array_equal(b[k].cpu().numpy(), ref[k]), k
