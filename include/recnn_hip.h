@@ -347,6 +347,23 @@ int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream);
 const void* recnn_engine_buffer(recnn_engine* e, const char* name, int64_t* h_rows, int64_t* h_cols,
                                 int64_t* h_ld, int* h_is_f32);
 
+/* =====================================================================================
+ * 5. Batched exact top-K action scoring ("next" row)
+ *    replaces the retrieval step after the actor: faiss IndexFlatL2 / IndexFlatIP / IP on normalised rows
+ *    (examples/streamlit_demo.py:190-204), the per-item scipy loop `rank` (streamlit_demo.py:207-231) and
+ *    MilvusConnection.search (recnn/data/db_con.py:45-56).
+ *    metric: 0 = IP (q.t, descending), 1 = L2 (|q-t|^2, ascending), 2 = COS (q.t/|t|, descending).
+ *    Ties are broken towards the smaller item id.  emb_dim must be 128, k <= 64.
+ * ===================================================================================== */
+enum { RECNN_METRIC_IP = 0, RECNN_METRIC_L2 = 1, RECNN_METRIC_COS = 2 };
+/* per-item auxiliary array float[n_items] needed by L2 (|t|^2) and COS (1/|t|); build once per table */
+int recnn_topk_item_aux(const float* table, int n_items, int emb_dim, int metric, float* aux, void* stream);
+int recnn_topk_workspace_bytes(int n_queries, int k, int64_t* h_bytes);
+/* out_dist float[n_queries, k], out_ids int64[n_queries, k] (faiss / Milvus result layout) */
+int recnn_topk_search(const float* queries, int64_t ld_q, int n_queries, const float* table, int n_items, int emb_dim,
+                      int metric, const float* item_aux, int k, float* out_dist, int64_t* out_ids, void* workspace,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

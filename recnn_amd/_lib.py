@@ -135,6 +135,9 @@ SIGNATURES = {
     "recnn_engine_dp_graph_build": (_I, [_P, _I, _F, _I, _P]),
     "recnn_engine_dp_graph_launch": (_I, [_P, _I, _P]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),
+    "recnn_topk_item_aux": (_I, [_P, _I, _I, _I, _P, _P]),
+    "recnn_topk_workspace_bytes": (_I, [_I, _I, C.POINTER(_L)]),
+    "recnn_topk_search": (_I, [_P, _L, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "recnn_engine_buffer": (_P, [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
 }
 
