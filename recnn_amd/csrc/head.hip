@@ -9,29 +9,25 @@
 // and the first step of autograd's backward through linear3 of the critic.
 #include "head.h"
 
-// ---------------------------------------------------------------- row dot: one wave per row
-template <class TC> __device__ inline float row_dot(const TC* __restrict__ h, const float* __restrict__ w, int H, int lane) {
-  float s = 0.f;
-  for (int c = lane * 4; c < H; c += 256) {
-    float4 wv = *(const float4*)(w + c);
-    float x0, x1, x2, x3;
-    if constexpr (sizeof(TC) == 4) {
-      float4 hv = *(const float4*)(h + c);
-      x0 = hv.x; x1 = hv.y; x2 = hv.z; x3 = hv.w;
-    } else {
-      uint2 hv = *(const uint2*)(h + c);
-      x0 = bf2f((bf16_t)(hv.x & 0xFFFF)); x1 = bf2f((bf16_t)(hv.x >> 16));
-      x2 = bf2f((bf16_t)(hv.y & 0xFFFF)); x3 = bf2f((bf16_t)(hv.y >> 16));
-    }
-    s += x0 * wv.x + x1 * wv.y + x2 * wv.z + x3 * wv.w;
+// ---------------------------------------------------------------- row dots: one wave per row
+template <class TC> __device__ inline float dot4(const TC* __restrict__ h, const float4 wv) {
+  float x0, x1, x2, x3;
+  if constexpr (sizeof(TC) == 4) {
+    const float4 hv = *(const float4*)h;
+    x0 = hv.x; x1 = hv.y; x2 = hv.z; x3 = hv.w;
+  } else {
+    const uint2 hv = *(const uint2*)h;
+    x0 = bf2f((bf16_t)(hv.x & 0xFFFF)); x1 = bf2f((bf16_t)(hv.x >> 16));
+    x2 = bf2f((bf16_t)(hv.y & 0xFFFF)); x3 = bf2f((bf16_t)(hv.y >> 16));
   }
-  return wave_sum(s);
+  return x0 * wv.x + x1 * wv.y + x2 * wv.z + x3 * wv.w;
 }
 
-// 16 rows per block.  Phase 1: one wave per row (4 rows per wave, loads of all 4 rows issued together): TD target,
-// Q, dQ, loss partial.  Phase 2 (do_bwd): one thread per hidden column walks the block's 16 rows: dz2 and the
+// 16 rows per block.  Phase 1: one wave per row, 4 rows per wave; NT target heads and NC critic heads are compile-time
+// so the loads of all 4 x (NT + NC) row segments (and of reward / done / biases) are in flight together -- the kernel
+// is a chain of memory latencies, not bandwidth.  TD target, Q, dQ, loss partial.  Phase 2 (do_bwd): dz2 and the
 // partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
-template <class TC> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+template <class TC, int NT, int NC> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
   __shared__ float part[4][HEAD_MAX_CRITIC];
   __shared__ float sdelta[HEAD_MAX_CRITIC][HEAD_ROWS_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -39,27 +35,56 @@ template <class TC> __global__ __launch_bounds__(256) void head_kernel(const Hea
   float acc[HEAD_MAX_CRITIC];
 #pragma unroll
   for (int c = 0; c < HEAD_MAX_CRITIC; ++c) acc[c] = 0.f;
-  float tq[4], qv[HEAD_MAX_CRITIC][4];
+  float st[NT > 0 ? NT : 1][4], sc[NC][4], rew[4], dn[4];
+  int64_t roff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = min(r0 + wave * 4 + i, a.rows - 1);  // clamp: tail rows recompute the last row, results unused
+    roff[i] = (int64_t)r * a.ld_h;
+    rew[i] = NT > 0 ? a.reward[r] : 0.f;
+    dn[i] = NT > 0 ? a.done[r] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st[t][i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sc[c][i] = 0.f;
+  }
+  float tb[NT > 0 ? NT : 1], cb[NC];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tb[t] = a.tb3[t][0];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) cb[c] = a.cb3[c][0];
+  for (int k = lane * 4; k < a.H; k += 256) {
+    float4 wt[NT > 0 ? NT : 1], wc[NC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wt[t] = *(const float4*)(a.tw3[t] + k);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wc[c] = *(const float4*)(a.cw3[c] + k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) st[t][i] += dot4<TC>((const TC*)a.th2[t] + roff[i] + k, wt[t]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) sc[c][i] += dot4<TC>((const TC*)a.ch2[c] + roff[i] + k, wc[c]);
+    }
+  }
+  float tq[4], qv[HEAD_MAX_CRITIC][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
     tq[i] = 0.f;
-    if (a.n_target > 0) {
-      tq[i] = row_dot<TC>((const TC*)a.th2[0] + (int64_t)r * a.ld_h, a.tw3[0], a.H, lane) + a.tb3[0][0];
-      if (a.n_target > 1)
-        tq[i] = fminf(tq[i], row_dot<TC>((const TC*)a.th2[1] + (int64_t)r * a.ld_h, a.tw3[1], a.H, lane) + a.tb3[1][0]);
+    if constexpr (NT > 0) {
+      tq[i] = wave_sum(st[0][i]) + tb[0];
+      if constexpr (NT > 1) tq[i] = fminf(tq[i], wave_sum(st[1][i]) + tb[1]);
     }
 #pragma unroll
-    for (int c = 0; c < HEAD_MAX_CRITIC; ++c)
-      qv[c][i] = c < a.n_critic ? row_dot<TC>((const TC*)a.ch2[c] + (int64_t)r * a.ld_h, a.cw3[c], a.H, lane) + a.cb3[c][0] : 0.f;
+    for (int c = 0; c < HEAD_MAX_CRITIC; ++c) qv[c][i] = c < NC ? wave_sum(sc[c < NC ? c : 0][i]) + cb[c < NC ? c : 0] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + wave * 4 + i;
     const bool valid = r < a.rows;
     float y = 0.f;
-    if (a.n_target > 0 && valid) {
-      y = a.reward[r] + (1.0f - a.done[r]) * a.gamma * tq[i];
+    if (NT > 0 && valid) {
+      y = rew[i] + (1.0f - dn[i]) * a.gamma * tq[i];
       y = fminf(fmaxf(y, a.lo), a.hi);
       if (lane == 0) {
         if (a.expected) a.expected[r] = y;
@@ -67,8 +92,7 @@ template <class TC> __global__ __launch_bounds__(256) void head_kernel(const Hea
       }
     }
 #pragma unroll
-    for (int c = 0; c < HEAD_MAX_CRITIC; ++c) {
-      if (c >= a.n_critic) continue;
+    for (int c = 0; c < NC; ++c) {
       const float q = qv[c][i];
       float d;
       if (a.policy_mode) {
@@ -181,30 +205,47 @@ int head_launch(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   if (a.H % 8 || a.ld_h % 8) { recnn_set_error("head: hidden size and pitch must be multiples of 8"); return RECNN_E_INVALID; }
   dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK), block(256);
-  if (a.tc_bf16) hipLaunchKernelGGL(head_kernel<bf16_t>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(head_kernel<float>, grid, block, 0, s, a);
+  if (a.n_target < 0 || a.n_target > 2 || a.n_critic < 1 || a.n_critic > HEAD_MAX_CRITIC) {
+    recnn_set_error("head: n_target must be 0..2 and n_critic 1..2");
+    return RECNN_E_INVALID;
+  }
+#define HEAD_GO(TC, NT, NC) hipLaunchKernelGGL((head_kernel<TC, NT, NC>), grid, block, 0, s, a)
+#define HEAD_TC(NT, NC) do { if (a.tc_bf16) HEAD_GO(bf16_t, NT, NC); else HEAD_GO(float, NT, NC); } while (0)
+  switch (a.n_target * 2 + (a.n_critic - 1)) {
+    case 0: HEAD_TC(0, 1); break;
+    case 1: HEAD_TC(0, 2); break;
+    case 2: HEAD_TC(1, 1); break;
+    case 3: HEAD_TC(1, 2); break;
+    case 4: HEAD_TC(2, 1); break;
+    default: HEAD_TC(2, 2); break;
+  }
+#undef HEAD_TC
+#undef HEAD_GO
   return recnn_check_hip(hipGetLastError(), "head_kernel");
 }
 
 // ---------------------------------------------------------------- loss finalize (+ step tick)
 // losses[c] = scale[c] * sum(part[c][0..n)) ; then the device counters advance.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {
-  __shared__ float red[4];
-  for (int c = 0; c < a.n; ++c) {
+  // Wave w sums loss w; the counter updates ride on separate lanes of the last wave so that every global
+  // read-modify-write of this (single workgroup, latency-only) kernel is in flight at the same time.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = 255 - (int)threadIdx.x;  // 0..n_tick-1: tick counters, n_tick: sampler cursor
+  int32_t* cnt = nullptr;
+  int32_t cv = 0;
+  if (slot < a.n_tick) cnt = a.tick[slot];
+  else if (slot == a.n_tick) cnt = a.wrap_ptr;
+  if (cnt) cv = *cnt;
+  if (wave < a.n) {
     float s = 0.f;
-    for (int i = threadIdx.x; i < a.n_part[c]; i += 256) s += a.part[c][i];
+    for (int i = lane; i < a.n_part[wave]; i += 64) s += a.part[wave][i];
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) a.out[c] = ((red[0] + red[1]) + (red[2] + red[3])) * a.scale[c];
-    __syncthreads();
+    if (lane == 0) a.out[wave] = s * a.scale[wave];
   }
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < a.n_tick; ++i) *a.tick[i] += 1;
-    if (a.wrap_ptr) {
-      int c = *a.wrap_ptr + 1;
-      *a.wrap_ptr = c >= a.wrap_mod ? 0 : c;
-    }
+  if (cnt) {
+    cv += 1;
+    if (slot == a.n_tick && cv >= a.wrap_mod) cv = 0;
+    *cnt = cv;
   }
 }
 
