@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
   int* m_done = meta + 2 * R;
   int* m_valid = meta + 3 * R;
   long long* m_src = (long long*)(meta + 4 * R);   // CSR offset of the window start
-  int* s_off = (int*)(m_src + R);                  // inline plan: row prefix sums [n_users + 1]
-  int* s_sc = s_off + a.n_users + 1;               // inline plan: scan scratch [256]
+  long long* s_start = m_src + R;                  // inline plan: CSR offset of each batch user's history [n_users]
+  int* s_off = (int*)(s_start + (a.inline_plan ? a.n_users : 0));  // inline plan: row prefix sums [n_users + 1]
+  int* s_sc = s_off + a.n_users + 1;               // inline plan: per-wave totals [4]
 
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * R;
@@ -91,31 +92,38 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     const int n = a.n_users;
     const int per = (n + 255) / 256;
     int lens[4], sum = 0;
+    long long starts[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = tid * per + j;
       int v = 0;
+      long long o0 = 0;
       if (j < per && i < n) {
         const int su = users[i];
-        v = max((int)(a.user_off[su + 1] - a.user_off[su]) - F, 0);
+        o0 = a.user_off[su];
+        v = max((int)(a.user_off[su + 1] - o0) - F, 0);
       }
       lens[j] = v;
+      starts[j] = o0;
       sum += v;
     }
-    s_sc[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-      const int t = tid >= o ? s_sc[tid - o] : 0;
-      __syncthreads();
-      s_sc[tid] += t;
-      __syncthreads();
+    // block-wide exclusive scan: shuffles inside a wave, one barrier to combine the four wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
     }
-    int run = s_sc[tid] - sum;
+    if (lane == 63) s_sc[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_sc[w];
     if (tid == 0) s_off[0] = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = tid * per + j;
-      if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; }
+      if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; s_start[i] = starts[j]; }
     }
     __syncthreads();
     row_off = s_off;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
     const int r = row0 + tid;
     // rows past the planned total (fewer windows than requested) are left untouched
     int valid = r < a.rows && r < row_off[a.n_users];
-    int u = 0, t = 0, len = 0;
+    int u = 0, t = 0, last = 0;
     long long src = 0;
     if (valid) {
       // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
@@ -136,14 +144,12 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
       }
       u = lo;
       t = r - row_off[lo];
-      const int su = users[u];
-      const long long o0 = a.user_off[su];
-      len = (int)(a.user_off[su + 1] - o0);
-      src = o0 + t;
+      last = t == row_off[lo + 1] - row_off[lo] - 1;  // the user's final window: done = 1 (utils.py:70-71)
+      src = (a.inline_plan ? s_start[u] : a.user_off[users[u]]) + t;
     }
     m_valid[tid] = valid;
     m_src[tid] = src;
-    m_done[tid] = valid && (t == len - F - 1);
+    m_done[tid] = valid && last;
     // continuation of the previous row's window (same user => shifted by one)
     m_cont[tid] = 0;
     m_base[tid] = u;  // temporarily the user index
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
 template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_t s) {
   const int F1 = a.frame + 1;
   size_t lds = (size_t)R * F1 * a.emb * 4 + (size_t)R * F1 * 4 + 4 * R * 4 + R * 8 + 16;
-  if (a.inline_plan) lds += (size_t)(a.n_users + 1 + 256) * 4;
+  if (a.inline_plan) lds += (size_t)a.n_users * 8 + (size_t)(a.n_users + 1 + 4) * 4;
   if (lds > 160 * 1024) { recnn_set_error("frame_gather: tile does not fit LDS (%zu bytes)", lds); return RECNN_E_UNSUPPORTED; }
   dim3 grid((a.rows + R - 1) / R), block(256);
   hipError_t e = hipSuccess;
