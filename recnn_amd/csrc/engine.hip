@@ -170,7 +170,11 @@ void net_dims(recnn_engine* e, int ni) {
     tot += (int64_t)e->Ap * n.ld_w3;
   }
   n.shadow_elems = tot;
-  n.n_rows_blk = H + 1 + H + 1 + n.out_dim + 1;
+  {
+    const int64_t ne[6] = {(int64_t)H * n.in_dim, H, (int64_t)H * H, H, (int64_t)n.out_dim * H, n.out_dim};
+    n.n_rows_blk = 0;
+    for (int i = 0; i < 6; ++i) n.n_rows_blk += opt_blocks(ne[i]);
+  }
 }
 
 bool net_used(const recnn_engine* e, int ni) { return e->td3 || ni < RECNN_NET_VALUE2; }
@@ -399,7 +403,9 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
     t.col_rot = (i == W1 && n.critic) ? e->A : 0;
     t.gpart = n.gp[i];
     t.blk0 = blk;
-    blk += t.rows;
+    const int64_t ne = (int64_t)t.rows * t.cols;
+    blk += opt_blocks(ne);
+    t.small = opt_is_small(ne);
     t.nslab = 1;
     t.slab_stride = 0;
   }
@@ -419,6 +425,12 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
       L.t[B2].nslab = tiles_m; L.t[B2].slab_stride = H;
       L.t[B3].nslab = tiles_m; L.t[B3].slab_stride = e->A;
     }
+  }
+  for (int i = 0; i < 6; ++i) {
+    TensorSeg& t = L.t[i];
+    const int64_t ne = (int64_t)t.rows * t.cols;
+    t.vec4 = !t.small && ne % 4 == 0 && t.p_off % 4 == 0 && (t.nslab <= 1 || t.slab_stride % 4 == 0) &&
+             (((uintptr_t)t.gpart) & 15) == 0;
   }
   return L;
 }
@@ -912,30 +924,12 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
 
 }  // namespace
 
-// per-row |g| partial sums of the actor gradient (after any all-reduce), for the clip quirk
-__global__ __launch_bounds__(256) void l1_rows_kernel(const NetLayout L, const float* __restrict__ g, float* __restrict__ l1part) {
-  __shared__ float red[4];
-  const int b = blockIdx.x;
-  int ti = 0;
-  for (int i = 1; i < 6; ++i)
-    if (b >= L.t[i].blk0) ti = i;
-  const TensorSeg& T = L.t[ti];
-  const int row = b - T.blk0;
-  float s = 0.f;
-  for (int c = threadIdx.x; c < T.cols; c += 256) s += fabsf(g[T.p_off + (int64_t)row * T.cols + c]);
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) l1part[b] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 namespace {
 int ph_policy_l1(recnn_engine* e, hipStream_t s) {
   Net& pn = e->net[RECNN_NET_POLICY];
   NetLayout L = make_layout(e, RECNN_NET_POLICY, 0);
   return slot(e, "l1_norm_actor", 0, s, [&] {
-    hipLaunchKernelGGL(l1_rows_kernel, dim3(L.nblk), dim3(256), 0, s, L, pn.g, pn.l1part);
-    return recnn_check_hip(hipGetLastError(), "l1_rows_kernel");
+    return l1_blocks_launch(L, pn.g, pn.l1part, s);
   });
 }
 

@@ -12,13 +12,28 @@ struct TensorSeg {
   const float* gpart;   // gradient partial slabs (slab 0), NULL = none
   int nslab;
   int64_t slab_stride;
-  int blk0;             // first workgroup of this tensor (one workgroup per row)
+  int blk0;             // first workgroup of this tensor
+  int small;            // 1: OPT_SMALL_ELEMS elements per workgroup (slabs split over the 4 waves), 0: OPT_BLOCK_ELEMS
+  int vec4;             // offsets / sizes allow 16-byte accesses
 };
 struct NetLayout {
   TensorSeg t[6];
   int nblk;
   int64_t n_params;
 };
+
+// Workgroup -> element mapping of the optimizer kernels.  It depends on tensor shapes only, so every kernel that
+// produces or consumes the per-workgroup |g| partial sums (clip quirk) agrees on it.  A large tensor is cut into
+// flat chunks of OPT_BLOCK_ELEMS (4 consecutive elements per thread, one pass, everything in flight at once); a
+// small one (biases, the critic's last layer: few elements but up to rows/16 partial slabs each) into chunks of
+// OPT_SMALL_ELEMS whose slab range is split over the four waves.
+constexpr int OPT_BLOCK_ELEMS = 1024;
+constexpr int OPT_SMALL_ELEMS = 64;
+constexpr int OPT_SMALL_MAX = 1024;
+inline int opt_is_small(int64_t n) { return n <= OPT_SMALL_MAX; }
+inline int opt_blocks(int64_t n) {
+  return (int)(opt_is_small(n) ? (n + OPT_SMALL_ELEMS - 1) / OPT_SMALL_ELEMS : (n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS);
+}
 
 struct ApplyArgs {
   float* p;             // canonical parameters
@@ -44,3 +59,4 @@ struct ApplyArgs {
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);
 int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s);
 int scale_grads_launch(const NetLayout& L, float* gflat, const float* l1part, int n_l1, float grad_scale, hipStream_t s);
+int l1_blocks_launch(const NetLayout& L, const float* gflat, float* l1part, hipStream_t s);

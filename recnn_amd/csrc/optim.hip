@@ -5,7 +5,7 @@
 //                                                                  td3.py:97,101,134
 //   torch.nn.utils.clip_grad_norm_(policy.parameters(), -1, 1)     ddpg.py:92, td3.py:133
 //   recnn/utils/misc.py:1-5  soft_update   (target*(1-tau) + param*tau, that operand order)
-// One workgroup per parameter-matrix row over a flat fp32 arena; the same pass writes the compute-type
+// Flat chunks of each parameter tensor per workgroup (optim.h) over a flat fp32 arena; the same pass writes the compute-type
 // "shadow" copy of the weights (zero-padded, 16-byte aligned rows; critic W1 columns rotated to the
 // packed [action | state] batch layout) that the MFMA GEMMs read, and optionally the soft-updated target.
 #include "optim.h"
@@ -26,46 +26,127 @@ __device__ inline float block_sum256(float v, float* red /*[4]*/) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// fixed summation order (deterministic); 8 independent loads in flight per thread
-__device__ inline float sum_slabs(const TensorSeg& T, int64_t e) {
-  float g = 0.f;
+// ---- which elements of tensor T this thread owns (see optim.h for the mapping) -------------------------------
+struct Own {
+  int64_t e;   // first element (index inside the tensor)
+  int cnt;     // 0..4 consecutive elements
+  bool vec;    // 16-byte accesses allowed
+};
+__device__ inline Own own_elems(const TensorSeg& T, int bt) {
+  const int64_t n = (int64_t)T.rows * T.cols;
+  Own o;
+  if (T.small) {
+    o.e = (int64_t)bt * OPT_SMALL_ELEMS + (threadIdx.x & 63);
+    o.cnt = (threadIdx.x < 64 && o.e < n) ? 1 : 0;
+    o.vec = false;
+  } else {
+    o.e = (int64_t)bt * OPT_BLOCK_ELEMS + threadIdx.x * 4;
+    const int64_t left = n - o.e;
+    o.cnt = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+    o.vec = T.vec4 && o.cnt == 4;
+  }
+  return o;
+}
+__device__ inline void load_own(const float* __restrict__ src, const Own& o, float out[4]) {
+  if (o.vec) {
+    const float4 x = *(const float4*)src;
+    out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = j < o.cnt ? src[j] : 0.f;
+  }
+}
+__device__ inline void store_own(float* __restrict__ dst, const Own& o, const float v[4]) {
+  if (o.vec) {
+    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < o.cnt) dst[j] = v[j];
+  }
+}
+
+// Sum of the gradient partial slabs for the thread's elements; fixed order (deterministic).  All threads of the
+// workgroup must call it (the small-tensor path meets at a barrier).
+__device__ inline void slab_grads(const TensorSeg& T, int bt, const Own& o, float g[4], float (*sp)[OPT_SMALL_ELEMS]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = 0.f;
+  if (T.small) {
+    // wave w sums slabs [w*q, (w+1)*q) of element (lane); up to 32 loads in flight per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = (int64_t)bt * OPT_SMALL_ELEMS + lane;
+    const bool in = e < (int64_t)T.rows * T.cols;
+    const int q = (T.nslab + 3) >> 2;
+    int s = wave * q;
+    const int s_end = min(s + q, T.nslab);
+    float acc = 0.f;
+    if (in) {
+      for (; s + 32 <= s_end; s += 32) {
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+#pragma unroll
+        for (int w = 16; w > 0; w >>= 1)
+#pragma unroll
+          for (int j = 0; j < w; ++j) v[j] += v[j + w];
+        acc += v[0];
+      }
+      for (; s + 8 <= s_end; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (; s < s_end; ++s) acc += T.gpart[(int64_t)s * T.slab_stride + e];
+    }
+    sp[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) g[0] = (sp[0][lane] + sp[1][lane]) + (sp[2][lane] + sp[3][lane]);
+    return;
+  }
+  if (o.cnt == 0) return;
+  const float* base = T.gpart + o.e;
   int s = 0;
-  for (; s + 32 <= T.nslab; s += 32) {  // many small slabs (head / column-sum partials): 32 loads in flight
-    float v[32];
+  if (o.vec) {
+    for (; s + 8 <= T.nslab; s += 8) {
+      float4 v[8];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+      for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(base + (int64_t)(s + j) * T.slab_stride);
+      g[0] += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+      g[1] += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+      g[2] += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+      g[3] += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+    }
+    for (; s < T.nslab; ++s) {
+      const float4 v = *(const float4*)(base + (int64_t)s * T.slab_stride);
+      g[0] += v.x; g[1] += v.y; g[2] += v.z; g[3] += v.w;
+    }
+  } else {
+    for (; s < T.nslab; ++s)
 #pragma unroll
-    for (int w = 16; w > 0; w >>= 1)
-#pragma unroll
-      for (int j = 0; j < w; ++j) v[j] += v[j + w];
-    g += v[0];
+      for (int j = 0; j < 4; ++j)
+        if (j < o.cnt) g[j] += base[(int64_t)s * T.slab_stride + j];
   }
-  for (; s + 8 <= T.nslab; s += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
-    g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  }
-  for (; s < T.nslab; ++s) g += T.gpart[(int64_t)s * T.slab_stride + e];
-  return g;
 }
 
 // g_flat = sum of partial slabs (split-K slabs of the dW GEMMs, row-tile column sums for biases)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const NetLayout L, float* __restrict__ gflat,
                                                           float* __restrict__ l1part) {
   __shared__ float red[4];
+  __shared__ float sp[4][OPT_SMALL_ELEMS];
   const int b = blockIdx.x;
   const TensorSeg& T = L.t[find_tensor(L, b)];
-  const int row = b - T.blk0;
-  float l1 = 0.f;
-  for (int c = threadIdx.x; c < T.cols; c += 256) {
-    const int64_t e = (int64_t)row * T.cols + c;
-    const float g = sum_slabs(T, e);
-    gflat[T.p_off + e] = g;
-    l1 += fabsf(g);
-  }
+  const int bt = b - T.blk0;
+  const Own o = own_elems(T, bt);
+  float g[4];
+  slab_grads(T, bt, o, g, sp);
+  if (o.cnt) store_own(gflat + T.p_off + o.e, o, g);
   if (l1part) {
-    float tot = block_sum256(l1, red);
+    float l1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < o.cnt) l1 += fabsf(g[j]);
+    const float tot = block_sum256(l1, red);
     if (threadIdx.x == 0) l1part[b] = tot;
   }
 }
@@ -73,6 +154,27 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const NetLayout L, flo
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s) {
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(L.nblk), dim3(256), 0, s, L, gflat, l1part);
   return recnn_check_hip(hipGetLastError(), "grad_reduce_kernel");
+}
+
+// per-workgroup |g| partial sums of a flat gradient (after any all-reduce), same mapping as grad_reduce_kernel
+__global__ __launch_bounds__(256) void l1_blocks_kernel(const NetLayout L, const float* __restrict__ gflat,
+                                                        float* __restrict__ l1part) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const TensorSeg& T = L.t[find_tensor(L, b)];
+  const Own o = own_elems(T, b - T.blk0);
+  float g[4], l1 = 0.f;
+  load_own(gflat + T.p_off + o.e, o, g);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < o.cnt) l1 += fabsf(g[j]);
+  const float tot = block_sum256(l1, red);
+  if (threadIdx.x == 0) l1part[b] = tot;
+}
+
+int l1_blocks_launch(const NetLayout& L, const float* gflat, float* l1part, hipStream_t s) {
+  hipLaunchKernelGGL(l1_blocks_kernel, dim3(L.nblk), dim3(256), 0, s, L, gflat, l1part);
+  return recnn_check_hip(hipGetLastError(), "l1_blocks_kernel");
 }
 
 __device__ inline float clip_coef(const float* l1part, int n, float grad_scale, float* red) {
@@ -83,65 +185,84 @@ __device__ inline float clip_coef(const float* l1part, int n, float grad_scale, 
   return fminf(-1.0f / (total + 1e-6f), 1.0f);
 }
 
+// Adam (+ clip quirk) + shadow refresh + soft target update: one pass, each element touched by exactly one thread,
+// every load of the thread issued before the first use.
 __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const ApplyArgs a) {
   __shared__ float red[4];
+  __shared__ float sp[4][OPT_SMALL_ELEMS];
   const int b = blockIdx.x;
   const TensorSeg& T = L.t[find_tensor(L, b)];
-  const int row = b - T.blk0;
+  const int bt = b - T.blk0;
+  const Own o = own_elems(T, bt);
+  const int64_t e = T.p_off + o.e;
 
+  float p[4], m[4], v[4], tp[4], g[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = m[j] = v[j] = tp[j] = g[j] = 0.f;
+  if (o.cnt) {
+    load_own(a.p + e, o, p);
+    if (a.do_adam) { load_own(a.m + e, o, m); load_own(a.v + e, o, v); }
+    if (a.tgt_p) load_own(a.tgt_p + e, o, tp);
+  }
+  int t = 0;
+  if (a.do_adam) {
+    t = *a.t_ptr + 1;
+    if (a.from_slabs) {
+      slab_grads(T, bt, o, g, sp);
+      if (o.cnt && a.g_out) store_own(a.g_out + e, o, g);
+    } else if (o.cnt) {
+      load_own(a.g + e, o, g);
+    }
+  }
   float gs = a.grad_scale;
   if (a.n_l1 > 0) {
     const float coef = clip_coef(a.l1part, a.n_l1, a.grad_scale, red);
     if (a.coef_out && b == 0 && threadIdx.x == 0) a.coef_out[0] = coef;
     gs *= coef;
   }
-  float step_size = 0.f, bc2_sqrt = 1.f;
+  if (o.cnt == 0) return;
   if (a.do_adam) {
-    const int t = *a.t_ptr + 1;
     const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
     const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
-    step_size = (float)((double)a.lr / bc1);
-    bc2_sqrt = (float)sqrt(bc2);
+    const float step_size = (float)((double)a.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = g[j] * gs;
+      if (a.weight_decay != 0.f) gj += a.weight_decay * p[j];
+      m[j] += (1.0f - a.beta1) * (gj - m[j]);
+      v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+      const float denom = sqrtf(v[j]) / bc2_sqrt + a.eps;
+      p[j] -= step_size * (m[j] / denom);
+    }
+    store_own(a.m + e, o, m);
+    store_own(a.v + e, o, v);
+    store_own(a.p + e, o, p);
   }
-  for (int c = threadIdx.x; c < T.cols; c += 256) {
-    const int64_t e = T.p_off + (int64_t)row * T.cols + c;
-    float p = a.p[e];
-    if (a.do_adam) {
-      float graw;
-      if (a.from_slabs) {
-        graw = sum_slabs(T, (int64_t)row * T.cols + c);
-        if (a.g_out) a.g_out[e] = graw;
-      } else {
-        graw = a.g[e];
+  if (a.tgt_p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tp[j] = tp[j] * (1.0f - a.tau) + p[j] * a.tau;  // utils/misc.py:3-5 operand order
+    store_own(a.tgt_p + e, o, tp);
+  }
+  if (T.sh_off >= 0 && (a.shadow || (a.tgt_p && a.tgt_shadow))) {
+    int row = (int)(o.e / T.cols);
+    int col = (int)(o.e - (int64_t)row * T.cols);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < o.cnt) {
+        int cc = col + T.col_rot;
+        if (cc >= T.cols) cc -= T.cols;
+        const int64_t se = T.sh_off + (int64_t)row * T.sh_ld + cc;
+        if (a.shadow) {
+          if (a.tc_bf16) ((bf16_t*)a.shadow)[se] = f2bf(p[j]);
+          else ((float*)a.shadow)[se] = p[j];
+        }
+        if (a.tgt_p && a.tgt_shadow) {
+          if (a.tc_bf16) ((bf16_t*)a.tgt_shadow)[se] = f2bf(tp[j]);
+          else ((float*)a.tgt_shadow)[se] = tp[j];
+        }
       }
-      float g = graw * gs;
-      if (a.weight_decay != 0.f) g += a.weight_decay * p;
-      float m = a.m[e], v = a.v[e];
-      m += (1.0f - a.beta1) * (g - m);
-      v = a.beta2 * v + (1.0f - a.beta2) * g * g;
-      const float denom = sqrtf(v) / bc2_sqrt + a.eps;
-      p -= step_size * (m / denom);
-      a.m[e] = m;
-      a.v[e] = v;
-      a.p[e] = p;
-    }
-    int64_t se = -1;
-    if (T.sh_off >= 0) {
-      int cc = c + T.col_rot;
-      if (cc >= T.cols) cc -= T.cols;
-      se = T.sh_off + (int64_t)row * T.sh_ld + cc;
-      if (a.shadow) {
-        if (a.tc_bf16) ((bf16_t*)a.shadow)[se] = f2bf(p);
-        else ((float*)a.shadow)[se] = p;
-      }
-    }
-    if (a.tgt_p) {
-      const float tp = a.tgt_p[e] * (1.0f - a.tau) + p * a.tau;  // utils/misc.py:3-5 operand order
-      a.tgt_p[e] = tp;
-      if (se >= 0 && a.tgt_shadow) {
-        if (a.tc_bf16) ((bf16_t*)a.tgt_shadow)[se] = f2bf(tp);
-        else ((float*)a.tgt_shadow)[se] = tp;
-      }
+      if (++col == T.cols) { col = 0; ++row; }
     }
   }
 }
@@ -159,8 +280,13 @@ __global__ __launch_bounds__(256) void scale_grads_kernel(const NetLayout L, flo
   if (n_l1 > 0) gs *= clip_coef(l1part, n_l1, grad_scale, red);
   const int b = blockIdx.x;
   const TensorSeg& T = L.t[find_tensor(L, b)];
-  const int row = b - T.blk0;
-  for (int c = threadIdx.x; c < T.cols; c += 256) g[T.p_off + (int64_t)row * T.cols + c] *= gs;
+  const Own o = own_elems(T, b - T.blk0);
+  if (o.cnt == 0) return;
+  float x[4];
+  load_own(g + T.p_off + o.e, o, x);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] *= gs;
+  store_own(g + T.p_off + o.e, o, x);
 }
 
 int scale_grads_launch(const NetLayout& L, float* gflat, const float* l1part, int n_l1, float grad_scale, hipStream_t s) {
