@@ -77,6 +77,9 @@ void recnn_tune_mlp_waves(int waves);
 void recnn_tune_sampler_f32_rows(int on);
 /* tuning knob: number of batch splits (gradient slabs) of the layer-1 dW GEMM, 1..8. */
 void recnn_tune_dw_splits(int splits);
+/* tuning knob: 1 (default) = bf16 dW GEMMs copy their operands global -> LDS by DMA and read the MFMA fragments with
+ * the LDS transpose read; 0 = register-staged transposing loader. */
+void recnn_tune_dw_dma(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

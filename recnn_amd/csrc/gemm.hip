@@ -493,6 +493,182 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
   epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane);
 }
 
+// ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
+// dW[m][n] = sum_b dZ[b][m] * X[b][n]: BOTH operands are k-strided (k = batch row), i.e. stored with the tile
+// dimension contiguous.  The register-staged kernel above transposes them with 16-bit shuffles and 8-byte LDS
+// writes; here the rows go global -> LDS untouched (`global_load_lds_dwordx4`) and the MFMA fragments are read
+// with gfx950's `ds_read_b64_tr_b16`, which hands lane i of a 16-lane group column i of a [4 k][16 cols] block.
+// Tile 64 (m) x 64 (n); a k stage = 128 batch rows x 128 bytes per operand (32 KB for both); two stages, both in
+// flight before the first MFMA (a workgroup's whole k range when rows/splits <= 256).
+// LDS image of a stage: row b of an operand is 8 chunks of 16 bytes; chunk pair p of row b sits at pair position
+// p ^ f(b), f(b) = ((b>>1)&1) | (((b>>3)&1)<<1), so the 8 rows x 32 bytes one half-wave transpose read touches
+// (rows {0..3} and {8..11} of a k step, same 16 columns) fall on 8 different 32-byte bank groups.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+constexpr int DWT_SUB = 128;                       // batch rows per stage
+constexpr int DWT_OP_BYTES = DWT_SUB * 128;        // one operand of a stage
+constexpr int DWT_STAGE_BYTES = 2 * DWT_OP_BYTES;
+constexpr int DWT_LDS = 2 * DWT_STAGE_BYTES;
+
+__global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch) {
+  const GemmProb& P = batch.p[blockIdx.y];
+  const int nwg = P.tiles_m * P.tiles_n * P.dw_splits;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % P.tiles_n;
+  const int tile_m = (lid / P.tiles_n) % P.tiles_m;
+  const int split = lid / (P.tiles_n * P.tiles_m);
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+  const unsigned lds0 = (unsigned)(size_t)dsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const GemmSeg& G = P.seg[0];
+  const int Kc = G.K;
+  const int chunk = (((Kc + P.dw_splits - 1) / P.dw_splits) + 63) / 64 * 64;
+  const int kbeg = split * chunk;
+  const int kend = min(Kc, kbeg + chunk);
+  const int nt = kend > kbeg ? (kend - kbeg + DWT_SUB - 1) / DWT_SUB : 0;
+
+  // DMA geometry: wave instruction g = wave*8 + i covers rows 8*(g&15) .. +7 of operand g>>4 (64 lanes x 16 bytes)
+  const int d_row = lane >> 3, d_slot = lane & 7;
+  auto issue = [&](int t, int stage) {
+    const int k0 = kbeg + t * DWT_SUB;
+    const unsigned sbase = lds0 + stage * DWT_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int g = wave * 8 + i;
+      const int op = g >> 4, rg = g & 15;
+      const int f = ((d_row >> 1) & 1) | ((rg & 1) << 1);
+      const int c = (((d_slot >> 1) ^ f) << 1) | (d_slot & 1);
+      const int row = min(k0 + rg * 8 + d_row, kend - 1);  // clamped rows are masked out of the A fragments below
+      const char* src = op == 0 ? (const char*)G.A + ((int64_t)row * G.lda + m0) * 2 + c * 16
+                                : (const char*)G.B + ((int64_t)row * G.ldb + n0) * 2 + c * 16;
+      dma16(src, sbase + op * DWT_OP_BYTES + rg * 1024);
+    }
+  };
+
+  if (nt > 0) issue(0, 0);
+  if (nt > 1) issue(1, 1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sa = dsmem + (t & 1) * DWT_STAGE_BYTES;
+    const unsigned char* sb = sa + DWT_OP_BYTES;
+    const int k0 = kbeg + t * DWT_SUB;
+    const bool tail = k0 + DWT_SUB > kend;
+#pragma unroll
+    for (int ks = 0; ks < DWT_SUB / 32; ++ks) {
+      v4s16 a[2][2], b[2][2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = ks * 32 + fg * 8 + half * 4 + (fr >> 2);
+        const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+        const int rbyte = row * 128 + (fr & 1) * 8;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          const int c = ((wm0 + tm * 16) >> 3) + ((fr & 3) >> 1);  // 16-byte chunk holding the lane's 4 columns
+          const int slot = (((c >> 1) ^ f) << 1) | (c & 1);
+          a[tm][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s16*)(sa + rbyte + slot * 16));
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int c = ((wn0 + tn * 16) >> 3) + ((fr & 3) >> 1);
+          const int slot = (((c >> 1) ^ f) << 1) | (c & 1);
+          b[tn][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s16*)(sb + rbyte + slot * 16));
+        }
+      }
+      if (tail) {  // batch rows past the end of this split: zero the A side (the B side holds finite, clamped rows)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kk = k0 + ks * 32 + fg * 8 + half * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kk + j >= kend) { a[0][half][j] = 0; a[1][half][j] = 0; }
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          struct { v4s16 lo, hi; } av = {a[tm][0], a[tm][1]}, bv = {b[tn][0], b[tn][1]};
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (t + 2 < nt) {
+      __builtin_amdgcn_s_barrier();  // every wave is done reading this stage's slot
+      issue(t + 2, t & 1);
+    }
+  }
+
+  float* Cs = (float*)P.C + (int64_t)split * P.dw_slab_stride;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = n0 + wn0 + tn * 16 + fr;
+      const int mb = m0 + wm0 + tm * 16 + fg * 4;
+      if (n < P.dw_valid_cols) {
+        int cc = n + P.dw_col_rot;
+        if (cc >= P.dw_valid_cols) cc -= P.dw_valid_cols;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mb + r;
+          if (m < P.M) Cs[(int64_t)m * P.ldc + cc] = acc[tm][tn][r];
+        }
+      }
+    }
+}
+
+static int g_dw_dma = 1;
+extern "C" void recnn_tune_dw_dma(int on) { g_dw_dma = on; }
+
+// both operands bf16 in memory, 64-column tiles readable inside the row pitch (padding columns may hold anything:
+// they only reach outputs that are never written)
+static bool dw_dma_eligible(const GemmLaunch* L) {
+  if (!g_dw_dma || L->mode != GEMM_DW || L->dtype != RECNN_BF16 || L->a_f32 || L->b_f32) return false;
+  for (int i = 0; i < L->nprob; ++i) {
+    const GemmProb& p = L->batch.p[i];
+    if (p.nseg != 1 || p.seg[0].K <= 0) return false;
+    if (p.seg[0].lda < (p.M + 63) / 64 * 64 || p.seg[0].ldb < (p.N + 63) / 64 * 64) return false;
+  }
+  return true;
+}
+
+static int launch_dw_dma(GemmLaunch* L, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_dw_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DWT_LDS),
+                             "gemm dw dma attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.N + 63) / 64;
+    const int nwg = p.tiles_m * p.tiles_n * p.dw_splits;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL(gemm_dw_dma_kernel, dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), DWT_LDS, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_dw_dma_kernel launch");
+}
+
 // ------------------------------------------------------------------ host side
 void gemm_prob_init(GemmProb* p) {
   memset(p, 0, sizeof(*p));
@@ -594,6 +770,9 @@ int gemm_init() {
   GemmLaunch L;
   memset(&L, 0, sizeof(L));
   int rc;
+  L.mode = GEMM_DW;
+  if ((rc = launch_dw_dma(&L, nullptr))) return rc;
+  L.mode = GEMM_FWD;
   if ((rc = launch_dma_nw<float, 3, 4>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 5, 4>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 3, 4>(&L, nullptr))) return rc;
@@ -609,6 +788,9 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
   constexpr int KB0 = TcTraits<TC>::BK;
   if constexpr (MODE == GEMM_FWD && !A32 && !B32) {
     if (dma_eligible<TC>(L)) return launch_dma<TC>(L, stream);
+  }
+  if constexpr (MODE == GEMM_DW && sizeof(TC) == 2 && !A32 && !B32) {
+    if (dw_dma_eligible(L)) return launch_dw_dma(L, stream);
   }
   int v = g_gemm_variant;
   if (v < 0) {  // enough 64x64 tiles to give every CU a few workgroups?  else take the small-tile variant
