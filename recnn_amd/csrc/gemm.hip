@@ -504,12 +504,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 // p ^ f(b), f(b) = ((b>>1)&1) | (((b>>3)&1)<<1), so the 8 rows x 32 bytes one half-wave transpose read touches
 // (rows {0..3} and {8..11} of a k step, same 16 columns) fall on 8 different 32-byte bank groups.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
-constexpr int DWT_SUB = 128;                       // batch rows per stage
-constexpr int DWT_OP_BYTES = DWT_SUB * 128;        // one operand of a stage
-constexpr int DWT_STAGE_BYTES = 2 * DWT_OP_BYTES;
-constexpr int DWT_LDS = 2 * DWT_STAGE_BYTES;
-
-__global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch) {
+// SUB = batch rows per stage, NS = ring slots (all filled before the first MFMA).
+template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch) {
+  constexpr int DWT_SUB = SUB;
+  constexpr int DWT_OP_BYTES = DWT_SUB * 128;        // one operand of a stage
+  constexpr int DWT_STAGE_BYTES = 2 * DWT_OP_BYTES;
+  constexpr int NI = SUB / 16;                       // DMA instructions per wave and stage
+  constexpr int RG = SUB / 8;                        // 8-row groups per operand and stage
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n * P.dw_splits;
   if ((int)blockIdx.x >= nwg) return;
@@ -545,9 +546,9 @@ __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch)
     const int k0 = kbeg + t * DWT_SUB;
     const unsigned sbase = lds0 + stage * DWT_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int g = wave * 8 + i;
-      const int op = g >> 4, rg = g & 15;
+    for (int i = 0; i < NI; ++i) {
+      const int g = wave * NI + i;
+      const int op = g / RG, rg = g % RG;
       const int f = ((d_row >> 1) & 1) | ((rg & 1) << 1);
       const int c = (((d_slot >> 1) ^ f) << 1) | (d_slot & 1);
       const int row = min(k0 + rg * 8 + d_row, kend - 1);  // clamped rows are masked out of the A fragments below
@@ -557,13 +558,19 @@ __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch)
     }
   };
 
-  if (nt > 0) issue(0, 0);
-  if (nt > 1) issue(1, 1);
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    if (i < nt) issue(i, i);
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // stages issued so far: the NS of the prologue plus one per iteration 1..t-1
+    const int younger = min(nt - 1, NS - 1 + max(t - 1, 0)) - t;
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const unsigned char* sa = dsmem + (t & 1) * DWT_STAGE_BYTES;
+    __builtin_amdgcn_s_barrier();  // stage t is in LDS; every wave is done reading stage t-1
+    if (t >= 1 && t - 1 + NS < nt) issue(t - 1 + NS, (t - 1) % NS);
+    const unsigned char* sa = dsmem + (t % NS) * DWT_STAGE_BYTES;
     const unsigned char* sb = sa + DWT_OP_BYTES;
     const int k0 = kbeg + t * DWT_SUB;
     const bool tail = k0 + DWT_SUB > kend;
@@ -608,10 +615,6 @@ __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch)
                                                                 acc[tm][tn], 0, 0, 0);
         }
     }
-    if (t + 2 < nt) {
-      __builtin_amdgcn_s_barrier();  // every wave is done reading this stage's slot
-      issue(t + 2, t & 1);
-    }
   }
 
   float* Cs = (float*)P.C + (int64_t)split * P.dw_slab_stride;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch)
     }
 }
 
-static int g_dw_dma = 1;
+static int g_dw_dma = 2;  // 0 = off; 1..6 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4)
 extern "C" void recnn_tune_dw_dma(int on) { g_dw_dma = on; }
 
 // both operands bf16 in memory, 64-column tiles readable inside the row pitch (padding columns may hold anything:
@@ -648,10 +651,11 @@ static bool dw_dma_eligible(const GemmLaunch* L) {
   return true;
 }
 
-static int launch_dw_dma(GemmLaunch* L, hipStream_t stream) {
+template <int SUB, int NS> static int launch_dw_dma_v(GemmLaunch* L, hipStream_t stream) {
+  constexpr int LDS = NS * SUB * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_dw_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DWT_LDS),
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_dw_dma_kernel<SUB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS),
                              "gemm dw dma attr");
     if (rc) return rc;
     attr_done = true;
@@ -665,8 +669,19 @@ static int launch_dw_dma(GemmLaunch* L, hipStream_t stream) {
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL(gemm_dw_dma_kernel, dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), DWT_LDS, stream, L->batch);
+  hipLaunchKernelGGL((gemm_dw_dma_kernel<SUB, NS>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_dw_dma_kernel launch");
+}
+static int launch_dw_dma(GemmLaunch* L, hipStream_t stream, int variant = 0) {
+  switch (variant ? variant : g_dw_dma) {
+    case 2: return launch_dw_dma_v<64, 2>(L, stream);
+    case 3: return launch_dw_dma_v<64, 3>(L, stream);
+    case 4: return launch_dw_dma_v<64, 4>(L, stream);
+    case 5: return launch_dw_dma_v<32, 2>(L, stream);
+    case 6: return launch_dw_dma_v<32, 4>(L, stream);
+    case 1: return launch_dw_dma_v<128, 2>(L, stream);
+    default: return launch_dw_dma_v<64, 2>(L, stream);
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -771,7 +786,8 @@ int gemm_init() {
   memset(&L, 0, sizeof(L));
   int rc;
   L.mode = GEMM_DW;
-  if ((rc = launch_dw_dma(&L, nullptr))) return rc;
+  for (int v = 1; v <= 6; ++v)
+    if ((rc = launch_dw_dma(&L, nullptr, v))) return rc;
   L.mode = GEMM_FWD;
   if ((rc = launch_dma_nw<float, 3, 4>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 5, 4>(&L, nullptr))) return rc;

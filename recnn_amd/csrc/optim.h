@@ -54,6 +54,7 @@ struct ApplyArgs {
   float* coef_out;      // optional: the clip coefficient (debug)
   int from_slabs;       // gradient = sum of the layout's partial slabs (fused slab reduction); g_out receives it
   float* g_out;
+  double log_beta1, log_beta2;  // filled by apply_launch
 };
 
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
   }
   if (o.cnt == 0) return;
   if (a.do_adam) {
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    // bias corrections 1 - beta^t = -expm1(t ln beta) in double (torch computes them in Python floats)
+    const double bc1 = -expm1((double)t * a.log_beta1);
+    const double bc2 = -expm1((double)t * a.log_beta2);
     const float step_size = (float)((double)a.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
 #pragma unroll
@@ -247,6 +248,20 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
   if (T.sh_off >= 0 && (a.shadow || (a.tgt_p && a.tgt_shadow))) {
     int row = (int)(o.e / T.cols);
     int col = (int)(o.e - (int64_t)row * T.cols);
+    const bool pairs = a.tc_bf16 && o.vec && !((T.cols | T.col_rot | T.sh_ld) & 1) && !(T.sh_off & 1);
+    if (pairs) {  // two 4-byte stores instead of four 2-byte ones: a pair never straddles a row end or the rotation wrap
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        int cc = col + T.col_rot;
+        if (cc >= T.cols) cc -= T.cols;
+        const int64_t se = T.sh_off + (int64_t)row * T.sh_ld + cc;
+        if (a.shadow) *(uint32_t*)((bf16_t*)a.shadow + se) = pack_bf2(p[j], p[j + 1]);
+        if (a.tgt_p && a.tgt_shadow) *(uint32_t*)((bf16_t*)a.tgt_shadow + se) = pack_bf2(tp[j], tp[j + 1]);
+        col += 2;
+        if (col == T.cols) { col = 0; ++row; }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < o.cnt) {
@@ -267,7 +282,10 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
   }
 }
 
-int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s) {
+int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s) {
+  ApplyArgs a = a0;
+  a.log_beta1 = log((double)a.beta1);
+  a.log_beta2 = log((double)a.beta2);
   hipLaunchKernelGGL(apply_kernel, dim3(L.nblk), dim3(256), 0, s, L, a);
   return recnn_check_hip(hipGetLastError(), "apply_kernel");
 }
