@@ -80,6 +80,10 @@ void recnn_tune_dw_splits(int splits);
 /* tuning knob: 1 (default) = bf16 dW GEMMs copy their operands global -> LDS by DMA and read the MFMA fragments with
  * the LDS transpose read; 0 = register-staged transposing loader. */
 void recnn_tune_dw_dma(int on);
+/* tuning knob: 1 (default) = the target critic(s) run inside the fused MLP launch: a producer workgroup computes the
+ * next_state part of layer 1 while the target actor's workgroup of the same 32 rows runs, which then adds the
+ * next_action part and finishes the critic on chip (flag hand-off); 0 = separate launches after it. */
+void recnn_tune_chain_target_critic(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

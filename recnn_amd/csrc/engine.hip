@@ -89,6 +89,9 @@ struct recnn_engine {
   char* gen_action;                        // tc [Bc, Ap]
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
+  float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
+  int32_t* tc_flag[2];                     // ... their per-panel completion flags
+  float* tqv[2];                           // ... their outputs, fp32 [Bc]
   float *loss_part[3];                     // value1, value2, policy  (per head block)
   float* losses;                           // device float[4]
   float* coef_out;                         // device float[1]
@@ -213,6 +216,11 @@ int64_t carve(recnn_engine* e, char* base) {
   e->expected = (float*)c.take(Bc * 4);
   e->target_q = (float*)c.take(Bc * 4);
   e->qpi = (float*)c.take(Bc * 4);
+  for (int i = 0; i < e->n_critic; ++i) {
+    e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
+    e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
+    e->tqv[i] = (float*)c.take(Bc * 4);
+  }
   const int64_t nblk_head = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int64_t nblk_hb = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int64_t tiles_m = (Bc + 31) / 32;  // dX column-sum slabs (32 rows each)
@@ -294,6 +302,10 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = mlp_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
+  for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
+    rc = recnn_check_hip(hipMemset(e->tc_flag[i], 0, (size_t)(e->Bc / 32 + 1) * 4), "engine_create: flag reset");
+    if (rc) { delete e; return rc; }
+  }
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->net[ni].t_ptr = nullptr;
   e->net[RECNN_NET_POLICY].t_ptr = e->counters + 1;
   e->net[RECNN_NET_VALUE1].t_ptr = e->counters + 2;
@@ -588,6 +600,9 @@ extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 
 // g_fused_mlp: 0 = never, 1 = groups of >= 3 networks (a single network only occupies 64 CUs and streams its
 // whole W1 per workgroup: the tiled kernels are faster there), 2 = every forward
+int g_chain_target_critic = 1;
+extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic = on; }
+
 bool fused_mlp_ok(const recnn_engine* e, int nprob) {
   return g_fused_mlp && e->bf16 && e->Hp == 256 && e->Ap == 128 && (nprob >= 3 || g_fused_mlp >= 2);
 }
@@ -640,7 +655,10 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
-  const int n_first = (value_side ? 1 + nc : 0) + (actor_side ? 1 : 0);
+  bool chained = false;  // target critics computed inside the first fused launch
+  // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
+  const bool can_chain = value_side && g_chain_target_critic && e->A == e->Ap;
+  const int n_first = (value_side ? 1 + nc : 0) + (actor_side ? 1 : 0) + (can_chain ? nc : 0);
   if (fused_mlp_ok(e, n_first)) {
     // whole networks per launch: {target actor, critic(s), actor}
     if (value_side && e->td3 && !e->ext_noise) {
@@ -651,11 +669,37 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       MlpBatch mb;
       int np = 0;
       double fl = 0;
+      chained = can_chain;
+      if (chained) {
+        // producers first (launch order = dispatch order): state part of each target critic's layer 1
+        for (int c = 0; c < nc; ++c) {
+          MlpSpec fp{TVAL[c], e->xcn + aoff, e->ldx, e->K1a, A};
+          MlpProb* p = &mb.p[np++];
+          fill_mlp(e, fp, rows, p);
+          p->W2 = nullptr; p->W3 = nullptr; p->q = nullptr;
+          p->part_out = e->tc_part[c]; p->part_flag = e->tc_flag[c];
+          fl += 2.0 * rows * (double)e->H * e->S;
+        }
+      }
       if (value_side) {
         MlpSpec f{TPOL, e->xcn + aoff, e->ldx, e->K1a, 0};
         f.out = e->xcn; f.ldo = e->ldx;
         if (e->td3) { f.addend = e->ext_noise ? e->ext_noise : e->noise_buf; f.ld_add = A; f.add_clip = e->hy.noise_clip; }
+        MlpProb* pt = &mb.p[np];
         fl += fill_mlp(e, f, rows, &mb.p[np++]);
+        if (chained) {
+          pt->n_tail = nc;
+          for (int c = 0; c < nc; ++c) {
+            const Net& t = e->net[TVAL[c]];
+            MlpTail& T = pt->tail[c];
+            T.part = e->tc_part[c]; T.flag = e->tc_flag[c];
+            T.W1a = sh_ptr(e, TVAL[c], W1); T.ldw1 = t.ld_w1;
+            T.W2 = sh_ptr(e, TVAL[c], W2); T.ldw2 = t.ld_w2;
+            T.b1 = t.p + t.off[B1]; T.b2 = t.p + t.off[B2]; T.b3 = t.p + t.off[B3]; T.w3row = t.p + t.off[W3];
+            T.q = e->tqv[c];
+            fl += 2.0 * rows * ((double)e->H * A + (double)e->H * e->H + e->H);
+          }
+        }
         for (int c = 0; c < nc; ++c) {
           MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
           fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
@@ -731,7 +775,9 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
   }
   }  // first group
-  if (value_side && fused_mlp_ok(e, nc)) {
+  if (chained) {
+    // nothing left to launch for the target critics
+  } else if (value_side && fused_mlp_ok(e, nc)) {
     {
       MlpBatch mb;
       double fl = 0;
@@ -771,6 +817,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     for (int c = 0; c < nc; ++c) {
       const Net& t = e->net[TVAL[c]];
       h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
+      if (chained) h.tq_in[c] = e->tqv[c];
       const Net& v = e->net[VAL[c]];
       h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
       h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];

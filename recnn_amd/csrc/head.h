@@ -13,6 +13,7 @@ struct HeadArgs {
   const void* th2[2];
   const float* tw3[2];
   const float* tb3[2];
+  const float* tq_in[2];  // non-NULL: target critic values already computed (chained inside the MLP launch); th2/tw3/tb3 unused
   const float* reward;
   const float* done;
   float gamma, lo, hi;

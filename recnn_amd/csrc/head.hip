@@ -27,7 +27,7 @@ template <class TC> __device__ inline float dot4(const TC* __restrict__ h, const
 // so the loads of all 4 x (NT + NC) row segments (and of reward / done / biases) are in flight together -- the kernel
 // is a chain of memory latencies, not bandwidth.  TD target, Q, dQ, loss partial.  Phase 2 (do_bwd): dz2 and the
 // partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
-template <class TC, int NT, int NC> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
   __shared__ float part[4][HEAD_MAX_CRITIC];
   __shared__ float sdelta[HEAD_MAX_CRITIC][HEAD_ROWS_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,6 +35,7 @@ template <class TC, int NT, int NC> __global__ __launch_bounds__(256) void head_
   float acc[HEAD_MAX_CRITIC];
 #pragma unroll
   for (int c = 0; c < HEAD_MAX_CRITIC; ++c) acc[c] = 0.f;
+  constexpr int ND = PRE ? 0 : NT;  // target heads that still need their row dot
   float st[NT > 0 ? NT : 1][4], sc[NC][4], rew[4], dn[4];
   int64_t roff[4];
 #pragma unroll
@@ -44,25 +45,25 @@ template <class TC, int NT, int NC> __global__ __launch_bounds__(256) void head_
     rew[i] = NT > 0 ? a.reward[r] : 0.f;
     dn[i] = NT > 0 ? a.done[r] : 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) st[t][i] = 0.f;
+    for (int t = 0; t < NT; ++t) st[t][i] = PRE ? a.tq_in[t][r] : 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) sc[c][i] = 0.f;
   }
   float tb[NT > 0 ? NT : 1], cb[NC];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) tb[t] = a.tb3[t][0];
+  for (int t = 0; t < NT; ++t) tb[t] = PRE ? 0.f : a.tb3[t][0];
 #pragma unroll
   for (int c = 0; c < NC; ++c) cb[c] = a.cb3[c][0];
   for (int k = lane * 4; k < a.H; k += 256) {
     float4 wt[NT > 0 ? NT : 1], wc[NC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wt[t] = *(const float4*)(a.tw3[t] + k);
+    for (int t = 0; t < ND; ++t) wt[t] = *(const float4*)(a.tw3[t] + k);
 #pragma unroll
     for (int c = 0; c < NC; ++c) wc[c] = *(const float4*)(a.cw3[c] + k);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) st[t][i] += dot4<TC>((const TC*)a.th2[t] + roff[i] + k, wt[t]);
+      for (int t = 0; t < ND; ++t) st[t][i] += dot4<TC>((const TC*)a.th2[t] + roff[i] + k, wt[t]);
 #pragma unroll
       for (int c = 0; c < NC; ++c) sc[c][i] += dot4<TC>((const TC*)a.ch2[c] + roff[i] + k, wc[c]);
     }
@@ -72,8 +73,8 @@ template <class TC, int NT, int NC> __global__ __launch_bounds__(256) void head_
   for (int i = 0; i < 4; ++i) {
     tq[i] = 0.f;
     if constexpr (NT > 0) {
-      tq[i] = wave_sum(st[0][i]) + tb[0];
-      if constexpr (NT > 1) tq[i] = fminf(tq[i], wave_sum(st[1][i]) + tb[1]);
+      tq[i] = PRE ? st[0][i] : wave_sum(st[0][i]) + tb[0];
+      if constexpr (NT > 1) tq[i] = fminf(tq[i], PRE ? st[1][i] : wave_sum(st[1][i]) + tb[1]);
     }
 #pragma unroll
     for (int c = 0; c < HEAD_MAX_CRITIC; ++c) qv[c][i] = c < NC ? wave_sum(sc[c < NC ? c : 0][i]) + cb[c < NC ? c : 0] : 0.f;
@@ -209,7 +210,10 @@ int head_launch(const HeadArgs& a, hipStream_t s) {
     recnn_set_error("head: n_target must be 0..2 and n_critic 1..2");
     return RECNN_E_INVALID;
   }
-#define HEAD_GO(TC, NT, NC) hipLaunchKernelGGL((head_kernel<TC, NT, NC>), grid, block, 0, s, a)
+  const bool pre = a.n_target > 0 && a.tq_in[0] != nullptr;
+  if (pre && a.n_target > 1 && !a.tq_in[1]) { recnn_set_error("head: tq_in[1] missing"); return RECNN_E_INVALID; }
+#define HEAD_GO(TC, NT, NC) do { if (pre) hipLaunchKernelGGL((head_kernel<TC, NT, NC, true>), grid, block, 0, s, a); \
+                                 else hipLaunchKernelGGL((head_kernel<TC, NT, NC, false>), grid, block, 0, s, a); } while (0)
 #define HEAD_TC(NT, NC) do { if (a.tc_bf16) HEAD_GO(bf16_t, NT, NC); else HEAD_GO(float, NT, NC); } while (0)
   switch (a.n_target * 2 + (a.n_critic - 1)) {
     case 0: HEAD_TC(0, 1); break;

@@ -2,7 +2,25 @@
 #pragma once
 #include "common.h"
 
-constexpr int MLP_MAX_GROUP = 4;
+constexpr int MLP_MAX_GROUP = 6;
+constexpr int MLP_MAX_TAIL = 2;
+
+// A critic chained behind an actor panel inside the same launch (target critic on [next_action | next_state]):
+// the state part of its layer-1 pre-activation does not depend on the actor, so another workgroup of the launch
+// (a `part_out` problem) computes it while the actor panel runs; the actor's workgroup then adds the action part
+// and finishes layers 2 and 3 on chip.  `flag[panel]` goes 0 -> 1 when the part is complete (release) and back to
+// 0 when consumed, so the buffers need no per-launch reset.  Producers must precede consumers in the launch order.
+struct MlpTail {
+  const float* part;               // fp32 [rows, 256]
+  int32_t* flag;                   // [panels]
+  const void* W1a; int64_t ldw1;   // action columns of the critic's W1 shadow: bf16 [256 rows, 128 k]
+  const void* W2; int64_t ldw2;
+  const float* b1;
+  const float* b2;
+  const float* b3;
+  const float* w3row;
+  float* q;                        // out: fp32 [rows]
+};
 
 struct MlpProb {
   // layer-1 input: up to two k-contiguous bf16 segments accumulated into the same pre-activation
@@ -31,6 +49,12 @@ struct MlpProb {
   void* out; int64_t ldo;                // actor output, bf16 [rows, ldo]
   float* q;                              // critic output, fp32 [rows]
   const float* addend; int64_t ld_add; float add_clip;
+  // producer mode (layer 1 only, W2 unused): raw fp32 pre-activation part [rows, 256] + completion flags
+  float* part_out;
+  int32_t* part_flag;
+  // consumer side: critics chained behind this actor's output
+  int n_tail;
+  MlpTail tail[MLP_MAX_TAIL];
 };
 
 struct MlpBatch {
