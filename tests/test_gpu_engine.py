@@ -342,3 +342,47 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
         for k in O.PARAM_ORDER:
             assert torch.equal(outs[0][1][k], other[1][k]), k
             assert torch.equal(outs[0][2][k], other[2][k]), k
+
+
+@pytest.mark.parametrize("algo,B", [("ddpg", 2048), ("td3", 4096), ("ddpg", 77)])
+def test_chained_target_critic_equals_separate_launches(cuda, algo, B):
+    """bf16: the target critic finished inside the fused MLP launch (producer workgroup + flag hand-off, mlp.hip)
+    against the same critic run as separate launches.  Same arithmetic up to the fp32 summation order of layer 1
+    (state part and action part are accumulated separately), so TD targets agree to bf16 round-off of h1.
+    B=4096 TD3 is 768 workgroups of 160 KB LDS: producers and consumers are NOT all resident at once."""
+    from recnn_amd import _lib as L
+    S, A, H = 1290, 128, 256
+    td3 = algo == "td3"
+    actor, critics = _init_nets(5, S, A, H, 2 if td3 else 1)
+    gen = torch.Generator().manual_seed(11)
+    batch = _rand_batch(B, S, A, gen)
+    out = {}
+    try:
+        for chain in (1, 0, 1):
+            L.load().recnn_tune_chain_target_critic(chain)
+            eng = _engine(algo, S, A, H, B, "bf16", mask_mode="none")
+            nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
+            if td3:
+                nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
+            for ni, p in nets:
+                eng.load_params(ni, p)
+            eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3))
+            eng.set_counters()
+            eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+            if td3:
+                eng.set_external(noise=torch.randn(B, A, generator=torch.Generator().manual_seed(1)) * 0.5)
+            for _ in range(3):      # repeated launches: the hand-off flags must return to 0 every time
+                eng.step(B, False, 0)
+            torch.cuda.synchronize()
+            out.setdefault(chain, []).append((eng.buffer("expected")[:B].float().cpu().clone(), eng.losses()))
+    finally:
+        L.load().recnn_tune_chain_target_critic(1)
+    y1, l1 = out[1][0]
+    y0, l0 = out[0][0]
+    y1b, _ = out[1][1]
+    assert torch.equal(y1, y1b)                       # deterministic
+    assert torch.isfinite(y1).all()
+    scale = y0.abs().max().item() + 1e-6
+    assert (y1 - y0).abs().max().item() <= 2e-3 * scale, ((y1 - y0).abs().max().item(), scale)
+    for k in l0:
+        assert abs(l1[k] - l0[k]) <= 2e-3 * max(abs(l0[k]), 0.5), (k, l1, l0)
