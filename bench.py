@@ -163,6 +163,8 @@ def main():
         L.load().recnn_tune_gemm_dma_waves(int(os.environ["RECNN_DMA_WAVES"]))
     if os.environ.get("RECNN_DMA_DEEP"):
         L.load().recnn_tune_gemm_dma_depth(int(os.environ["RECNN_DMA_DEEP"]))
+    if os.environ.get("RECNN_BWD_PANEL"):
+        L.load().recnn_tune_bwd_panel(int(os.environ["RECNN_BWD_PANEL"]))
     if os.environ.get("RECNN_CHAIN_TC"):
         L.load().recnn_tune_chain_target_critic(int(os.environ["RECNN_CHAIN_TC"]))
     if os.environ.get("RECNN_DW_DMA"):

@@ -84,6 +84,9 @@ void recnn_tune_dw_dma(int on);
  * next_state part of layer 1 while the target actor's workgroup of the same 32 rows runs, which then adds the
  * next_action part and finishes the critic on chip (flag hand-off); 0 = separate launches after it. */
 void recnn_tune_chain_target_critic(int on);
+/* tuning knob: 1 (default) = on the chained bf16 path the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the
+ * first backward GEMM (dz1, db1 partial) run as one row-panel launch; 0 = head kernel + dX GEMM launch. */
+void recnn_tune_bwd_panel(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

@@ -79,10 +79,24 @@ __host__ __device__ inline uint32_t mask_word(uint32_t key, uint32_t row4, uint3
 __host__ __device__ inline bool mask_keep(uint32_t word, int r) { return (word >> (7 + 8 * r)) & 1u; }
 
 // ---------------------------------------------------------------- wave / block reductions
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums with DPP row operations (one VALU op per step) instead of ds_bpermute shuffles (LDS crossbar).
+template <int CTRL, int ROW_MASK = 0xF> __device__ inline float dpp_take(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each 32-lane half of the wave; valid in lanes 16..31 (lower half) and 48..63 (upper half)
+__device__ inline float half_sum32(float v) {
+  v += dpp_take<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_take<0x141>(v);       // row_half_mirror
+  v += dpp_take<0x140>(v);       // row_mirror: every lane of a 16-lane row holds the row total
+  v += dpp_take<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
   return v;
+}
+// sum over the wave, returned in every lane
+__device__ inline float wave_sum(float v) {
+  v = half_sum32(v);
+  v += dpp_take<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on one XCD

@@ -30,6 +30,7 @@
 #include "gemm.h"
 #include "head.h"
 #include "mlp.h"
+#include "bwd.h"
 #include "optim.h"
 
 int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s);
@@ -89,6 +90,7 @@ struct recnn_engine {
   char* gen_action;                        // tc [Bc, Ap]
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
+  bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
   float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
   int32_t* tc_flag[2];                     // ... their per-panel completion flags
   float* tqv[2];                           // ... their outputs, fp32 [Bc]
@@ -300,6 +302,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if (rc) { delete e; return rc; }
   if ((rc = gemm_init())) { delete e; return rc; }
   if ((rc = mlp_init())) { delete e; return rc; }
+  if ((rc = bwd_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
@@ -395,6 +398,8 @@ extern "C" int recnn_engine_set_counters(recnn_engine* e, int policy_t, int valu
 // ------------------------------------------------------------------------------------ layouts
 namespace {
 
+bool value_panel_ok(const recnn_engine* e);
+
 NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
   const Net& n = e->net[ni];
   NetLayout L;
@@ -429,9 +434,10 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
     L.t[W2].nslab = sp(SP_W2); L.t[W2].slab_stride = (int64_t)H * H;
     L.t[B1].nslab = tiles_m; L.t[B1].slab_stride = H;
     if (n.critic) {
-      L.t[W3].nslab = nblk_hb; L.t[W3].slab_stride = H;
-      L.t[B2].nslab = nblk_hb; L.t[B2].slab_stride = H;
-      L.t[B3].nslab = nblk_hb; L.t[B3].slab_stride = 1;
+      const int nhead = value_panel_ok(e) ? tiles_m : nblk_hb;  // bwd.hip emits one partial per 32 rows, head.hip per 16
+      L.t[W3].nslab = nhead; L.t[W3].slab_stride = H;
+      L.t[B2].nslab = nhead; L.t[B2].slab_stride = H;
+      L.t[B3].nslab = nhead; L.t[B3].slab_stride = 1;
     } else {
       L.t[W3].nslab = sp(SP_W3); L.t[W3].slab_stride = (int64_t)e->A * H;
       L.t[B2].nslab = tiles_m; L.t[B2].slab_stride = H;
@@ -603,6 +609,16 @@ extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 int g_chain_target_critic = 1;
 extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic = on; }
 
+int g_bwd_panel = 1;
+extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
+
+// bf16 value side on the fully fused path: target critics chained inside the forward launch (Q and Q' arrive as
+// per-row scalars), critic head + first backward GEMM in one row-panel launch (bwd.hip)
+bool value_chain_ok(const recnn_engine* e) {
+  return g_fused_mlp && g_chain_target_critic && e->bf16 && e->Hp == 256 && e->Ap == 128 && e->A == e->Ap;
+}
+bool value_panel_ok(const recnn_engine* e) { return value_chain_ok(e) && g_bwd_panel; }
+
 bool fused_mlp_ok(const recnn_engine* e, int nprob) {
   return g_fused_mlp && e->bf16 && e->Hp == 256 && e->Ap == 128 && (nprob >= 3 || g_fused_mlp >= 2);
 }
@@ -613,6 +629,7 @@ struct MlpSpec {
   const void* A1 = nullptr; int64_t lda1 = 0; int K1 = 0; int col1 = 0;
   void* h1 = nullptr; void* h2 = nullptr;
   void* out = nullptr; int64_t ldo = 0;
+  float* q = nullptr;  // critic: Q per row
   int mask_idx = -1;   // external mask index of the first hidden layer (second = +1); -1 = eval mode
   const float* addend = nullptr; int64_t ld_add = 0; float add_clip = 0.f;
 };
@@ -643,6 +660,7 @@ double fill_mlp(const recnn_engine* e, const MlpSpec& f, int rows, MlpProb* p) {
   }
   p->h1 = f.h1; p->h2 = f.h2; p->ldh = e->Hp;
   p->out = f.out; p->ldo = f.ldo;
+  p->q = f.q;
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
   return 2.0 * rows * ((double)e->H * n.in_dim + (double)e->H * e->H + (double)n.out_dim * e->H);
 }
@@ -657,7 +675,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   int rc;
   bool chained = false;  // target critics computed inside the first fused launch
   // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
-  const bool can_chain = value_side && g_chain_target_critic && e->A == e->Ap;
+  const bool can_chain = value_side && value_chain_ok(e);
   const int n_first = (value_side ? 1 + nc : 0) + (actor_side ? 1 : 0) + (can_chain ? nc : 0);
   if (fused_mlp_ok(e, n_first)) {
     // whole networks per launch: {target actor, critic(s), actor}
@@ -703,6 +721,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         for (int c = 0; c < nc; ++c) {
           MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
           fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
+          fc.q = e->q[c];
           fl += fill_mlp(e, fc, rows, &mb.p[np++]);
         }
       }
@@ -808,7 +827,37 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       if ((rc = g.run(s, "fwd_l2_target_critic"))) return rc;
     }
   }
-  if (value_side) {
+  e->panel_bwd_done = false;
+  if (value_side && chained && g_bwd_panel) {
+    // critic head + dz2 + dz1 in one row-panel launch (bwd.hip); Q comes from the forward launch, Q' from its tails
+    BwdPanelBatch bb;
+    memset(&bb, 0, sizeof(bb));
+    const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
+    double fl = 0;
+    for (int c = 0; c < nc; ++c) {
+      BwdPanelProb& b = bb.p[c];
+      Net& v = e->net[VAL[c]];
+      b.rows = rows; b.H = e->H; b.mode = 0;
+      b.q = e->q[c]; b.n_target = nc;
+      for (int t = 0; t < nc; ++t) b.tq[t] = e->tqv[t];
+      b.reward = e->reward; b.done = e->done; b.gamma = e->hy.gamma;
+      b.lo = e->td3 ? -INFINITY : e->hy.min_value;
+      b.hi = e->td3 ? INFINITY : e->hy.max_value;
+      if (c == 0) { b.expected = e->expected; b.target_q = e->target_q; }
+      b.delta_out = e->delta[c]; b.loss_part = e->loss_part[c];
+      b.h2 = e->cv[c].h2; b.ldh = Hp; b.w3 = v.p + v.off[W3]; b.scale = train ? 2.0f : 1.0f;
+      b.dz2 = e->dzc2[c];
+      b.W2 = sh_ptr(e, VAL[c], W2); b.ldw2 = v.ld_w2;
+      b.h1 = e->cv[c].h1; b.dz1 = e->dzc1[c];
+      if (value_bwd) {
+        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+        b.dw3_part = v.gp[W3]; b.db2_part = v.gp[B2]; b.db3_part = v.gp[B3]; b.colsum = v.gp[B1];
+      }
+      fl += 2.0 * rows * (double)e->H * e->H;
+    }
+    if ((rc = slot(e, "head_dx_critic", fl, s, [&] { return bwd_panel_launch(bb, nc, s); }))) return rc;
+    e->panel_bwd_done = true;
+  } else if (value_side) {
     // heads: TD target, Q, dQ, loss partials
     HeadArgs h;
     memset(&h, 0, sizeof(h));
@@ -848,7 +897,7 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   int rc;
-  {
+  if (!e->panel_bwd_done) {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
       g.flops += fill_dx(e, g.add(), rows, e->dzc2[c], Hp, Hp, VAL[c], W2, 0, H, e->dzc1[c], Hp, e->cv[c].h1, Hp, e->net[VAL[c]].gp[B1]);
@@ -955,7 +1004,8 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   memset(&a, 0, sizeof(a));
   const int nblk = (rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int nc = e->n_critic;
-  for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nblk; a.scale[c] = 1.0f / (float)rows; }
+  const int nval = value_panel_ok(e) ? (rows + BWD_ROWS - 1) / BWD_ROWS : nblk;
+  for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nval; a.scale[c] = 1.0f / (float)rows; }
   a.part[nc] = e->loss_part[2]; a.n_part[nc] = nblk; a.scale[nc] = -1.0f / (float)rows;
   a.n = nc + 1;
   a.out = e->losses;
