@@ -93,7 +93,9 @@ struct recnn_engine {
   bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
   float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
   int32_t* tc_flag[2];                     // ... their per-panel completion flags
-  float* tqv[2];                           // ... their outputs, fp32 [Bc]
+  float* tqv[2];
+  float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
+  int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
   float *loss_part[3];                     // value1, value2, policy  (per head block)
   float* losses;                           // device float[4]
   float* coef_out;                         // device float[1]
@@ -218,6 +220,8 @@ int64_t carve(recnn_engine* e, char* base) {
   e->expected = (float*)c.take(Bc * 4);
   e->target_q = (float*)c.take(Bc * 4);
   e->qpi = (float*)c.take(Bc * 4);
+  e->pl_cap = (int)(2 * Bc);
+  e->pl_part = (float*)c.take((int64_t)e->pl_cap * 4);
   for (int i = 0; i < e->n_critic; ++i) {
     e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
     e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
@@ -499,6 +503,7 @@ struct FwdSpec {
   int relu;
   int mask_idx;         // -1 = none
   const float* addend = nullptr; int64_t ld_add = 0; float add_clip = 0.f;
+  const float* dot_w = nullptr; float* dot_part = nullptr;
 };
 
 double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) {
@@ -534,6 +539,7 @@ double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) 
     }
   }
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
+  p->dot_w = f.dot_w; p->dot_part = f.dot_part;
   const double kreal = f.layer == 1 ? n.in_dim : e->H;
   return 2.0 * rows * p->N * kreal;
 }
@@ -922,12 +928,16 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
 }
 
 // Policy loss through the (updated) critic 1; optionally the gradient chain back into the actor.
-int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s) {
+// need_rows: per-row Q(s, pi(s)) wanted (debug / learn=False logging) -> head kernel; otherwise, on the fused bf16 path,
+// the loss is summed in the layer-2 GEMM's epilogue and the backward seed comes from the row-panel kernel (bwd.hip).
+int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s, bool need_rows = true) {
   const int A = e->A, Hp = e->Hp, H = e->H, Ap = e->Ap;
   const int POL = RECNN_NET_POLICY, V1 = RECNN_NET_VALUE1;
   const int m0 = e->td3 ? 6 : 4;
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
+  const bool use_dot = !need_rows && value_panel_ok(e) && !fused_mlp_ok(e, 1);
+  e->pl_dot_parts = 0;
   if (fused_mlp_ok(e, 1)) {
     // critic on [gen_action | state] with the UPDATED weights: one launch, two layer-1 contraction segments
     MlpBatch mb;
@@ -952,11 +962,27 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     Group g(e, GEMM_FWD, 0, 0);
     FwdSpec f{V1, 2, e->pc.h1, Hp, 0, Hp};
     f.C = e->pc.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0 + 1;
+    if (use_dot) { f.dot_w = e->net[V1].p + e->net[V1].off[W3]; f.dot_part = e->pl_part; }
     g.flops += fill_fwd(e, f, rows, g.add());
     if ((rc = g.run(s, "fwd_l2_pcritic"))) return rc;
+    if (use_dot) {
+      e->pl_dot_parts = g.L.batch.p[0].dot_parts;
+      RECNN_REQUIRE(e->pl_dot_parts > 0 && e->pl_dot_parts <= e->pl_cap, "policy loss: %d partial sums do not fit %d", e->pl_dot_parts, e->pl_cap);
+    }
   }
   }
-  {
+  if (use_dot) {
+    if (!backward) return 0;
+    // backward seed d = -1/B for every row: dz_e2 and dz_e1 in one row-panel launch, no critic parameter gradients
+    BwdPanelBatch bb;
+    memset(&bb, 0, sizeof(bb));
+    BwdPanelProb& b = bb.p[0];
+    const Net& v = e->net[V1];
+    b.rows = rows; b.H = H; b.mode = 1; b.delta_const = -1.0f / (float)rows;
+    b.h2 = e->pc.h2; b.ldh = Hp; b.w3 = v.p + v.off[W3]; b.scale = train ? 2.0f : 1.0f;
+    b.dz2 = e->dze2; b.W2 = sh_ptr(e, V1, W2); b.ldw2 = v.ld_w2; b.h1 = e->pc.h1; b.dz1 = e->dze1;
+    if ((rc = slot(e, "head_dx_pcritic", 2.0 * rows * (double)H * H, s, [&] { return bwd_panel_launch(bb, 1, s); }))) return rc;
+  } else {
     HeadArgs h;
     memset(&h, 0, sizeof(h));
     const Net& v = e->net[V1];
@@ -980,7 +1006,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     return g.run(s, nm);
   };
   // critic: dz_e1 = (dz_e2 W2) * 2[e1>0];   dact = dz_e1 * W1[:, action columns]  (shadow columns 0..A-1)
-  if ((rc = dx1("dx_pcritic_l2", e->dze2, Hp, Hp, V1, W2, H, e->dze1, Hp, e->pc.h1, nullptr))) return rc;
+  if (!use_dot && (rc = dx1("dx_pcritic_l2", e->dze2, Hp, Hp, V1, W2, H, e->dze1, Hp, e->pc.h1, nullptr))) return rc;
   if ((rc = dx1("dx_pcritic_action", e->dze1, Hp, Hp, V1, W1, A, e->dag, Ap, nullptr, pn.gp[B3]))) return rc;
   // actor: dz_p2 = (dact W3) * 2[p2>0];  dz_p1 = (dz_p2 W2) * 2[p1>0]
   if ((rc = dx1("dx_actor_l3", e->dag, Ap, Ap, POL, W3, H, e->dzp2, Hp, e->pa.h2, pn.gp[B2]))) return rc;
@@ -1007,6 +1033,11 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   const int nval = value_panel_ok(e) ? (rows + BWD_ROWS - 1) / BWD_ROWS : nblk;
   for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nval; a.scale[c] = 1.0f / (float)rows; }
   a.part[nc] = e->loss_part[2]; a.n_part[nc] = nblk; a.scale[nc] = -1.0f / (float)rows;
+  if (e->pl_dot_parts > 0) {  // policy loss = -(sum of the layer-2 epilogue's partial dots / B + b3)
+    const Net& v = e->net[RECNN_NET_VALUE1];
+    a.part[nc] = e->pl_part; a.n_part[nc] = e->pl_dot_parts;
+    a.add_ptr[nc] = v.p + v.off[B3]; a.add_scale[nc] = -1.0f;
+  }
   a.n = nc + 1;
   a.out = e->losses;
   a.tick[a.n_tick++] = e->counters;  // mask-key step
@@ -1102,7 +1133,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     if ((rc = value_apply(e, policy_step, 1.0f, s, rows))) return rc;
   }
   const bool pol = learn && policy_step;
-  if ((rc = ph_policy(e, rows, pol, true, s))) return rc;
+  if ((rc = ph_policy(e, rows, pol, true, s, !learn))) return rc;
   if (pol && (rc = policy_apply(e, true, 1.0f, s, true))) return rc;
   return ph_finish(e, rows, learn, pol, s);
 }
@@ -1139,7 +1170,7 @@ extern "C" int recnn_engine_policy_grads(recnn_engine* e, int rows, int backward
   int rc = check_ready(e, rows);
   if (rc) return rc;
   if ((rc = ph_forward(e, rows, false, true, false, (hipStream_t)stream))) return rc;
-  return ph_policy(e, rows, backward != 0, false, (hipStream_t)stream);
+  return ph_policy(e, rows, backward != 0, false, (hipStream_t)stream, false);
 }
 
 extern "C" int recnn_engine_policy_apply(recnn_engine* e, int soft, float grad_scale, void* stream) {
@@ -1270,9 +1301,9 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
     } else if (v == 4) {
       rc = ph_forward(e, rows, false, true, false, s);
     } else if (v == 1) {
-      if (!(rc = value_apply(e, false, grad_scale, s)) && !(rc = ph_policy(e, rows, false, false, s))) rc = ph_finish(e, rows, true, false, s);
+      if (!(rc = value_apply(e, false, grad_scale, s)) && !(rc = ph_policy(e, rows, false, false, s, false))) rc = ph_finish(e, rows, true, false, s);
     } else if (v == 2) {
-      if (!(rc = value_apply(e, true, grad_scale, s))) rc = ph_policy(e, rows, true, false, s);
+      if (!(rc = value_apply(e, true, grad_scale, s))) rc = ph_policy(e, rows, true, false, s, false);
     } else {
       if (!(rc = policy_apply(e, true, grad_scale, s))) rc = ph_finish(e, rows, true, true, s);
     }

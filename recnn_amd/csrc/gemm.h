@@ -31,6 +31,11 @@ struct GemmProb {
   const float* addend;
   int64_t ld_add;
   float add_clip;
+  // forward epilogue, optional: partial sums of sum_{m,n} C[m][n] * dot_w[n] (C as stored, i.e. rounded to the output
+  // type), one per wave: dot_part[workgroup * waves + wave]; the launcher sets dot_parts to their number
+  const float* dot_w;
+  float* dot_part;
+  int dot_parts;
   // dX epilogue
   const void* yref;
   int64_t ldy;

@@ -183,8 +183,10 @@ __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN
 
 // ------------------------------------------------------------------ forward epilogue (shared by both fwd kernels)
 template <class TC, int TM, int TN>
-__device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane) {
+__device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
+                                    int part_idx) {
   const int fr = lane & 15, fg = lane >> 4;
+  float sdot = 0.f;
   {
     uint32_t key = 0;
     if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, P.step_ptr ? *P.step_ptr : 0, P.stream_id);
@@ -196,6 +198,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
         const int mb = m0 + wm0 + tm * 16 + fg * 4;
         if (n < P.N) {
           const float bv = P.bias ? P.bias[n] : 0.f;
+          const float dw = P.dot_w ? P.dot_w[n] : 0.f;
           uint32_t word = 0;
           if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)n);
 #pragma unroll
@@ -210,12 +213,22 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
               if (P.relu) v = fmaxf(v, 0.f);
               if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
               else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
-              if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
-              else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, v);
+              if (P.c_f32) {
+                ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
+              } else {
+                TC* dst = (TC*)P.C + (int64_t)m * P.ldc + n;
+                tc_store(dst, v);
+                if constexpr (sizeof(TC) == 2) v = bf2f(f2bf(v));  // the value a consumer of C would read
+              }
+              sdot += v * dw;
             }
           }
         }
       }
+  }
+  if (P.dot_part) {  // uniform
+    sdot = wave_sum(sdot);
+    if (lane == 0) P.dot_part[part_idx] = sdot;
   }
 }
 
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const GemmBatch batch) {
   // ------------------------------------------------------------------ epilogue
   const int fr = lane & 15, fg = lane >> 4;
   if constexpr (MODE == GEMM_FWD) {
-    epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane);
+    epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
   } else if constexpr (MODE == GEMM_DX) {
     float cs[TN];
 #pragma unroll
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
       }
     }
   }
-  epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane);
+  epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
@@ -715,6 +728,7 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
     p.tiles_n = (p.N + BN - 1) / BN;
     int splits = (MODE == GEMM_DW) ? p.dw_splits : 1;
     int nwg = p.tiles_m * p.tiles_n * splits;
+    p.dot_parts = nwg * NW;
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
@@ -748,6 +762,7 @@ template <class TC, int NS, int NW> static int launch_dma_nw(GemmLaunch* L, hipS
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nwg = p.tiles_m * p.tiles_n;
+    p.dot_parts = nwg * NW;
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;

@@ -44,6 +44,8 @@ struct LossFinalizeArgs {
   const float* part[4];
   int n_part[4];
   float scale[4];
+  const float* add_ptr[4];  // optional: out[c] += add_scale[c] * (*add_ptr[c])
+  float add_scale[4];
   float* out;  // [4]
   int n_tick;
   int32_t* tick[6];

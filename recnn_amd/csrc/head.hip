@@ -231,8 +231,10 @@ int head_launch(const HeadArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------- loss finalize (+ step tick)
 // losses[c] = scale[c] * sum(part[c][0..n)) ; then the device counters advance.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {
-  // Wave w sums loss w; the counter updates ride on separate lanes of the last wave so that every global
-  // read-modify-write of this (single workgroup, latency-only) kernel is in flight at the same time.
+  // All 256 threads stride over every loss's partial sums (loads of all losses issued before the first reduction);
+  // the counter updates ride on separate lanes of the last wave so that every global read-modify-write of this
+  // single-workgroup, latency-only kernel is in flight at the same time.
+  __shared__ float red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = 255 - (int)threadIdx.x;  // 0..n_tick-1: tick counters, n_tick: sampler cursor
   int32_t* cnt = nullptr;
@@ -240,16 +242,38 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
   if (slot < a.n_tick) cnt = a.tick[slot];
   else if (slot == a.n_tick) cnt = a.wrap_ptr;
   if (cnt) cv = *cnt;
-  if (wave < a.n) {
-    float s = 0.f;
-    for (int i = lane; i < a.n_part[wave]; i += 64) s += a.part[wave][i];
-    s = wave_sum(s);
-    if (lane == 0) a.out[wave] = s * a.scale[wave];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < a.n) {
+      const float* __restrict__ part = a.part[c];
+      const int n = a.n_part[c];
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int i = threadIdx.x;
+      for (; i + 768 < n; i += 1024) {
+        s0 += part[i]; s1 += part[i + 256]; s2 += part[i + 512]; s3 += part[i + 768];
+      }
+      for (; i < n; i += 256) s0 += part[i];
+      acc[c] = (s0 + s1) + (s2 + s3);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < a.n) {
+      const float t = wave_sum(acc[c]);
+      if (lane == 0) red[c][wave] = t;
+    }
   }
   if (cnt) {
     cv += 1;
     if (slot == a.n_tick && cv >= a.wrap_mod) cv = 0;
     *cnt = cv;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.n) {
+    const int c = threadIdx.x;
+    const float s = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    a.out[c] = s * a.scale[c] + (a.add_ptr[c] ? a.add_scale[c] * a.add_ptr[c][0] : 0.f);
   }
 }
 
