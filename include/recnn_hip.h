@@ -87,6 +87,10 @@ void recnn_tune_chain_target_critic(int on);
 /* tuning knob: 1 (default) = on the chained bf16 path the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the
  * first backward GEMM (dz1, db1 partial) run as one row-panel launch; 0 = head kernel + dX GEMM launch. */
 void recnn_tune_bwd_panel(int on);
+/* tuning knob (before recnn_engine_graph_build): steps per "run" graph. -1 (default) = as many whole policy cycles
+ * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of
+ * 16 ordinary steps; 0 = single-step graphs only. */
+void recnn_tune_graph_run(int steps);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

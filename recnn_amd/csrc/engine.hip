@@ -115,7 +115,9 @@ struct recnn_engine {
   int prof_reps[PROF_MAX];
   bool prof_ready = false;
   // graphs
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};  // one ordinary step, one policy step, a run of steps
+  int grun_len = 0;          // steps in gexec[2]
+  bool grun_policy_first = false;  // gexec[2] = whole policy cycles (policy step + policy_every-1 ordinary steps, repeated)
   hipGraphExec_t gdp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
   int graph_rows = 0;
   bool hyper_set = false;
@@ -323,8 +325,9 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
 }
 
 static void drop_graphs(recnn_engine* e) {
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
+  e->grun_len = 0;
   for (int i = 0; i < 5; ++i)
     if (e->gdp[i]) { (void)hipGraphExecDestroy(e->gdp[i]); e->gdp[i] = nullptr; }
 }
@@ -1247,16 +1250,38 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
 }
 
 // ------------------------------------------------------------------------------------ graphs
+static int g_graph_run_len = -1;  // -1: whole policy cycles, up to 64 steps (policy_every > 32: 16 ordinary steps); 0/1: off
+extern "C" void recnn_tune_graph_run(int steps) { g_graph_run_len = steps; }
+
+// Three executable graphs: one ordinary step, one policy step, and a RUN of consecutive steps -- between two graph
+// launches the GPU idles for ~8 us (rocprofv3 kernel trace), inside a graph the kernels are back to back, so replaying
+// a whole policy cycle (1 policy step + policy_every-1 ordinary ones) per launch removes 90 % of those gaps.
 extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
-  for (int v = 0; v < 2; ++v) {
+  const int pe = e->hy.policy_every;
+  int run_len = g_graph_run_len;
+  bool pol_first = false;
+  if (run_len < 0) {
+    if (pe <= 32) { run_len = (64 / pe) * pe; pol_first = true; }  // as many whole cycles as fit 64 steps
+    else run_len = 16;
+  } else if (run_len >= 2) {
+    if (run_len > 64) run_len = 64;
+    if (run_len >= pe) { run_len = (run_len / pe) * pe; pol_first = true; }
+  }
+  if (run_len < 2) run_len = 0;
+  for (int v = 0; v < 3; ++v) {
     if (e->gexec[v]) { (void)hipGraphExecDestroy(e->gexec[v]); e->gexec[v] = nullptr; }
+    if (v == 2 && run_len == 0) continue;
     hipGraph_t graph = nullptr;
     RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = step_impl(e, rows, true, v == 1, s);
+    if (v < 2) {
+      rc = step_impl(e, rows, true, v == 1, s);
+    } else {
+      for (int i = 0; i < run_len && !rc; ++i) rc = step_impl(e, rows, true, pol_first && (i % pe) == 0, s);
+    }
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     RECNN_HIP(ce);
@@ -1264,15 +1289,31 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
     (void)hipGraphDestroy(graph);
     RECNN_HIP(ie);
   }
+  e->grun_len = run_len;
+  e->grun_policy_first = pol_first;
   e->graph_rows = rows;
   return 0;
 }
 
 extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream) {
   RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_run: graphs not built");
-  for (int i = 0; i < n_steps; ++i) {
-    const bool pol = ((first_step + i) % e->hy.policy_every) == 0;
+  const int pe = e->hy.policy_every, rl = e->gexec[2] ? e->grun_len : 0;
+  int i = 0;
+  while (i < n_steps) {
+    const int step = first_step + i;
+    const bool pol = (step % pe) == 0;
+    if (rl && n_steps - i >= rl) {
+      // the run graph fits if its step kinds line up: a whole cycle starts on a policy step, a run of ordinary
+      // steps must end before the next policy step
+      const bool fits = e->grun_policy_first ? pol : (!pol && pe - (step % pe) >= rl);
+      if (fits) {
+        RECNN_HIP(hipGraphLaunch(e->gexec[2], (hipStream_t)stream));
+        i += rl;
+        continue;
+      }
+    }
     RECNN_HIP(hipGraphLaunch(e->gexec[pol ? 1 : 0], (hipStream_t)stream));
+    ++i;
   }
   return 0;
 }

@@ -174,6 +174,7 @@ class FusedContext:
         if key != self.hyper_key:
             self.engine.set_hyper(policy_opt=pol_cfg, value_opt=val_cfg, **kw)
             self.hyper_key = key
+            self.graph_rows = None          # the engine dropped its graphs (they freeze the hyper-parameters)
 
     def apply_external(self, rows):
         """Parity runs: dropout masks / TD3 noise supplied by the caller for exactly one update."""

@@ -268,8 +268,11 @@ def test_td3_vs_oracle_b4096(cuda, dtype):
         _params_close(eng, ni, refp, ptol, tag, metric=fro_err)
 
 
-def test_graph_replay_equals_eager(cuda):
-    """hipGraph replay of the step (hash masks, device-side counters) == eager launches, bit for bit."""
+@pytest.mark.parametrize("first", [0, 1])
+def test_graph_replay_equals_eager(cuda, first):
+    """hipGraph replay of the step (hash masks, device-side counters) == eager launches, bit for bit.  With
+    policy_every=3 the replay uses the run graph (21 whole policy cycles = 63 steps per launch) where it lines up and
+    single-step graphs elsewhere (first=1 starts mid-cycle)."""
     from recnn_amd import _lib as L
     S, A, H, B = 1290, 128, 256, 512
     actor, (critic,) = _init_nets(4, S, A, H, 1)
@@ -284,13 +287,13 @@ def test_graph_replay_equals_eager(cuda):
         eng.set_counters()
         eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
         if mode == "eager":
-            for t in range(7):
+            for t in range(first, first + 70):
                 eng.step(B, True, t)
         else:
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):
                 eng.graph_build(B)
-                eng.graph_run(0, 7)
+                eng.graph_run(first, 70)
             side.synchronize()
         torch.cuda.synchronize()
         outs.append((eng.losses(), {k: v.clone() for k, v in eng.param_views(L.NET_POLICY).items()},
