@@ -91,6 +91,10 @@ void recnn_tune_bwd_panel(int on);
  * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of
  * 16 ordinary steps; 0 = single-step graphs only. */
 void recnn_tune_graph_run(int steps);
+/* tuning knob (before recnn_engine_graph_build): 1 (default) = inside a run graph the replay sampler + gather of step
+ * t+1 runs as extra workgroups of step t's critic optimizer launch, into a second batch buffer set (bf16 engines that
+ * sample their own batches); 0 = every step starts with its own gather launch. */
+void recnn_tune_pregather(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

@@ -87,6 +87,13 @@ struct recnn_engine {
   char *dze2, *dze1, *dag, *dzp2, *dzp1;   // policy backward chain
   char *xcs = nullptr, *xcn = nullptr;     // packed rows in the compute type: the bound fp32 rows, or bf16 twins
   char *xsh = nullptr, *xnh = nullptr;     // bf16 twins (workspace, bf16 mode only)
+  // second batch buffer set (bf16 sampler mode): inside a run graph the gather of step t+1 rides on the optimizer
+  // launch of step t and fills the set step t is not reading
+  char *xsh2 = nullptr, *xnh2 = nullptr;
+  float *reward2 = nullptr, *done2 = nullptr;
+  float *reward0 = nullptr, *done0 = nullptr;  // the bound reward / done arrays (set 0)
+  int cur_set = 0;
+  const GatherArgs* pregather = nullptr;   // set while the critic's optimizer launch should carry the next gather
   char* gen_action;                        // tc [Bc, Ap]
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
@@ -117,6 +124,7 @@ struct recnn_engine {
   // graphs
   hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};  // one ordinary step, one policy step, a run of steps
   int grun_len = 0;          // steps in gexec[2]
+  int grun_last_set = 0;     // batch buffer set its last step leaves the batch in
   bool grun_policy_first = false;  // gexec[2] = whole policy cycles (policy step + policy_every-1 ordinary steps, repeated)
   hipGraphExec_t gdp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
   int graph_rows = 0;
@@ -217,6 +225,10 @@ int64_t carve(recnn_engine* e, char* base) {
   if (e->bf16) {
     e->xsh = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh = c.take(Bc * (int64_t)e->ldx * 2);
+    e->xsh2 = c.take(Bc * (int64_t)e->ldx * 2);
+    e->xnh2 = c.take(Bc * (int64_t)e->ldx * 2);
+    e->reward2 = (float*)c.take(Bc * 4);
+    e->done2 = (float*)c.take(Bc * 4);
   }
   e->noise_buf = (float*)c.take(Bc * A * 4);
   e->expected = (float*)c.take(Bc * 4);
@@ -352,8 +364,10 @@ extern "C" int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, fl
   RECNN_REQUIRE(e && xs && xn && reward && done, "bind_batch: null pointer");
   RECNN_REQUIRE((((uintptr_t)xs | (uintptr_t)xn) & 15) == 0, "bind_batch: packed rows must be 16-byte aligned");
   e->xs = xs; e->xn = xn; e->reward = reward; e->done = done;
+  e->reward0 = reward; e->done0 = done;
   e->xcs = e->bf16 ? e->xsh : (char*)xs;
   e->xcn = e->bf16 ? e->xnh : (char*)xn;
+  e->cur_set = 0;
   drop_graphs(e);
   return 0;
 }
@@ -492,7 +506,9 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
     a.tgt_shadow = e->net[target_ni].shadow;
     a.tau = tau;
   }
-  return slot(e, do_adam ? (n.critic ? "adam_critic" : "adam_actor") : "shadow_refresh", 0, s, [&] { return apply_launch(L, a, s); }, !do_adam && target_ni < 0);
+  const GatherArgs* pg = (do_adam && ni == RECNN_NET_VALUE1) ? e->pregather : nullptr;
+  return slot(e, do_adam ? (n.critic ? (pg ? "adam_critic+gather" : "adam_critic") : "adam_actor") : "shadow_refresh", 0, s,
+              [&] { return apply_launch(L, a, s, pg); }, !do_adam && target_ni < 0);
 }
 
 // ---- GEMM problem builders ---------------------------------------------------------------
@@ -608,6 +624,8 @@ int check_ready(recnn_engine* e, int rows) {
 
 // ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
 static int g_fused_mlp = 1;
+static int g_pregather = 1;
+extern "C" void recnn_tune_pregather(int on) { g_pregather = on; }
 static int g_sampler_f32_rows = 0;
 extern "C" void recnn_tune_sampler_f32_rows(int on) { g_sampler_f32_rows = on; }
 extern "C" void recnn_tune_dw_splits(int s) { SP_W1 = s < 1 ? 1 : (s > SP_W1_MAX ? SP_W1_MAX : s); }
@@ -1082,36 +1100,59 @@ int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bo
   return apply_net(e, RECNN_NET_POLICY, 0, true, 0, grad_scale, true, tgt, e->hy.soft_tau, s);
 }
 
-int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
+// batch buffer set k (0: the bound / first set, 1: the look-ahead set of bf16 sampler mode)
+void use_set(recnn_engine* e, int k) {
+  e->cur_set = k;
+  if (k == 0) {
+    e->xcs = e->bf16 ? e->xsh : (char*)e->xs;
+    e->xcn = e->bf16 ? e->xnh : (char*)e->xn;
+    e->reward = e->reward0; e->done = e->done0;
+  } else {
+    e->xcs = e->xsh2; e->xcn = e->xnh2; e->reward = e->reward2; e->done = e->done2;
+  }
+}
+bool lookahead_ok(const recnn_engine* e) {
+  return e->has_sampler && e->bf16 && !g_sampler_f32_rows && e->smp.users_per_batch <= 1024 && g_pregather;
+}
+
+// gather of the batch `cursor_add` steps ahead of the device cursor into buffer set `set`
+GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add) {
   const recnn_sampler& m = e->smp;
   const bool inl = m.users_per_batch <= 1024;   // the gather plans its rows itself: one launch less
+  GatherArgs g;
+  memset(&g, 0, sizeof(g));
+  g.items = m.items; g.ratings = m.ratings; g.user_off = m.user_off; g.users = m.perm;
+  g.row_off = inl ? nullptr : m.row_off;
+  g.n_users = m.users_per_batch; g.rows = rows; g.frame = m.frame; g.emb = m.emb_dim; g.table = m.table;
+  g.state = e->xs + e->A; g.ld_state = e->ldx;
+  g.next_state = e->xn + e->A; g.ld_next = e->ldx;
+  g.action = e->xs; g.ld_action = e->ldx;
+  g.reward = set ? e->reward2 : e->reward0; g.done = set ? e->done2 : e->done0;
+  g.cursor = m.cursor; g.cursor_stride = m.users_per_batch;
+  g.cursor_add = cursor_add; g.cursor_mod = m.n_batches;
+  g.inline_plan = inl;
+  if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
+    char* hs = set ? e->xsh2 : e->xsh;
+    char* hn = set ? e->xnh2 : e->xnh;
+    g.state_h = (bf16_t*)hs + e->A; g.next_h = (bf16_t*)hn + e->A; g.action_h = (bf16_t*)hs;
+    g.ld_h = e->ldx;
+    // Nothing reads the fp32 rows when the engine samples its own batches in bf16: materialise the batch in
+    // the compute type only (recnn_tune_sampler_f32_rows(1) restores the fp32 copies, e.g. for inspection).
+    if (!g_sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
+  }
+  return g;
+}
+
+int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
+  const recnn_sampler& m = e->smp;
+  const bool inl = m.users_per_batch <= 1024;
   if (!inl) {
     int rc = slot(e, "frame_plan", 0, s, [&] {
       return recnn_frame_plan(m.user_off, m.perm, m.users_per_batch, m.frame, m.row_off, m.cursor, m.users_per_batch, s);
     });
     if (rc) return rc;
   }
-  return slot(e, "frame_gather", 0, s, [&] {
-    GatherArgs g;
-    memset(&g, 0, sizeof(g));
-    g.items = m.items; g.ratings = m.ratings; g.user_off = m.user_off; g.users = m.perm;
-    g.row_off = inl ? nullptr : m.row_off;
-    g.n_users = m.users_per_batch; g.rows = rows; g.frame = m.frame; g.emb = m.emb_dim; g.table = m.table;
-    g.state = e->xs + e->A; g.ld_state = e->ldx;
-    g.next_state = e->xn + e->A; g.ld_next = e->ldx;
-    g.action = e->xs; g.ld_action = e->ldx;
-    g.reward = e->reward; g.done = e->done;
-    g.cursor = m.cursor; g.cursor_stride = m.users_per_batch;
-    g.inline_plan = inl;
-    if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
-      g.state_h = (bf16_t*)e->xsh + e->A; g.next_h = (bf16_t*)e->xnh + e->A; g.action_h = (bf16_t*)e->xsh;
-      g.ld_h = e->ldx;
-      // Nothing reads the fp32 rows when the engine samples its own batches in bf16: materialise the batch in
-      // the compute type only (recnn_tune_sampler_f32_rows(1) restores the fp32 copies, e.g. for inspection).
-      if (!g_sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
-    }
-    return frame_gather_launch(g, s);
-  });
+  return slot(e, "frame_gather", 0, s, [&] { return frame_gather_launch(gather_args(e, rows, e->cur_set, 0), s); });
 }
 
 // Make the step's batch available in the compute type: built by the sampler, or converted from the bound fp32 rows.
@@ -1125,15 +1166,22 @@ int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
 }
 
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
-int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s) {
+// pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
+// optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
+int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered = false,
+              bool gather_next = false) {
   int rc;
-  if ((rc = stage_batch(e, rows, s))) return rc;
+  if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
     if ((rc = ph_value_backward(e, rows, false, s))) return rc;
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
     // next step, so on policy steps it is fused into the critic's Adam pass (ddpg.py:95-97).
-    if ((rc = value_apply(e, policy_step, 1.0f, s, rows))) return rc;
+    GatherArgs ga;
+    if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, 1); e->pregather = &ga; }
+    rc = value_apply(e, policy_step, 1.0f, s, rows);
+    e->pregather = nullptr;
+    if (rc) return rc;
   }
   const bool pol = learn && policy_step;
   if ((rc = ph_policy(e, rows, pol, true, s, !learn))) return rc;
@@ -1261,6 +1309,7 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
+  use_set(e, 0);
   const int pe = e->hy.policy_every;
   int run_len = g_graph_run_len;
   bool pol_first = false;
@@ -1280,7 +1329,13 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
     if (v < 2) {
       rc = step_impl(e, rows, true, v == 1, s);
     } else {
-      for (int i = 0; i < run_len && !rc; ++i) rc = step_impl(e, rows, true, pol_first && (i % pe) == 0, s);
+      const bool look = lookahead_ok(e);
+      for (int i = 0; i < run_len && !rc; ++i) {
+        if (look) use_set(e, i & 1);
+        rc = step_impl(e, rows, true, pol_first && (i % pe) == 0, s, look && i > 0, look && i + 1 < run_len);
+      }
+      e->grun_last_set = look ? ((run_len - 1) & 1) : 0;
+      use_set(e, 0);
     }
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1308,11 +1363,13 @@ extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_ste
       const bool fits = e->grun_policy_first ? pol : (!pol && pe - (step % pe) >= rl);
       if (fits) {
         RECNN_HIP(hipGraphLaunch(e->gexec[2], (hipStream_t)stream));
+        use_set(e, e->grun_last_set);  // where the debug views find the last batch
         i += rl;
         continue;
       }
     }
     RECNN_HIP(hipGraphLaunch(e->gexec[pol ? 1 : 0], (hipStream_t)stream));
+    use_set(e, 0);
     ++i;
   }
   return 0;
@@ -1330,6 +1387,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "dp_graph_build: capture needs a non-null stream");
+  use_set(e, 0);
   for (int v = 0; v < 5; ++v) {
     if (e->gdp[v]) { (void)hipGraphExecDestroy(e->gdp[v]); e->gdp[v] = nullptr; }
     if (v == 4 && !overlap_actor) continue;

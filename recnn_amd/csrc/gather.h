@@ -17,6 +17,7 @@ struct GatherArgs {
   float* done;
   const int32_t* cursor;
   int cursor_stride;
+  int cursor_add, cursor_mod;  // batch index = (*cursor + cursor_add) mod cursor_mod (cursor_mod 0: no wrap)
   int inline_plan;  // row_off == NULL: every workgroup scans the batch's history lengths itself (n_users <= 1024)
   // optional bf16 twins of the packed rows (engine, bf16 compute mode): same columns, row stride ld_h (elements)
   bf16_t* state_h;
@@ -27,3 +28,4 @@ struct GatherArgs {
 
 
 int frame_gather_launch(GatherArgs a, hipStream_t s);
+size_t frame_gather_lds_bytes(const GatherArgs& a, int rows_per_wg);

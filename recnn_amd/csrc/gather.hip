@@ -12,7 +12,7 @@
 // row share all of them, so each distinct (row, slot) embedding line is fetched ONCE into LDS
 // ((R+F)..R*(F+1) lines of E floats) with 16-byte coalesced loads and then streamed out to the
 // three outputs with the widest store the output alignment allows.
-#include "gather.h"
+#include "gather_dev.h"
 
 // ------------------------------------------------------------------ plan: row prefix sums
 __global__ __launch_bounds__(1024) void frame_plan_kernel(const int64_t* __restrict__ user_off,
@@ -57,188 +57,21 @@ extern "C" int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_us
 }
 
 // ------------------------------------------------------------------ gather
-template <int W> struct VecT;
-template <> struct VecT<4> { using type = float4; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<1> { using type = float; };
-
-// R rows per workgroup; W = floats per output store (4/2/1 by output alignment).
 template <int R, int W>
 __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
-  using V = typename VecT<W>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int F = a.frame, E = a.emb, F1 = F + 1;
-  float* lines = (float*)smem_raw;                 // [R*F1][E]
-  float* rat = lines + (size_t)R * F1 * E;         // [R*F1]
-  int* meta = (int*)(rat + R * F1);                // per row: base line, cont flag, done flag; + src offset (2 ints)
-  int* m_base = meta;
-  int* m_cont = meta + R;
-  int* m_done = meta + 2 * R;
-  int* m_valid = meta + 3 * R;
-  long long* m_src = (long long*)(meta + 4 * R);   // CSR offset of the window start
-  long long* s_start = m_src + R;                  // inline plan: CSR offset of each batch user's history [n_users]
-  int* s_off = (int*)(s_start + (a.inline_plan ? a.n_users : 0));  // inline plan: row prefix sums [n_users + 1]
-  int* s_sc = s_off + a.n_users + 1;               // inline plan: per-wave totals [4]
-
-  const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * R;
-  const int32_t* users = a.users;
-  if (a.cursor) users += (int64_t)(*a.cursor) * a.cursor_stride;
-
-  const int* row_off = a.row_off;
-  if (a.inline_plan) {
-    // exclusive prefix sum of max(L_u - F, 0) over the batch's users, recomputed per workgroup (a few hundred
-    // L2-resident loads) instead of a separate single-workgroup plan launch ahead of the gather
-    const int n = a.n_users;
-    const int per = (n + 255) / 256;
-    int lens[4], sum = 0;
-    long long starts[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid * per + j;
-      int v = 0;
-      long long o0 = 0;
-      if (j < per && i < n) {
-        const int su = users[i];
-        o0 = a.user_off[su];
-        v = max((int)(a.user_off[su + 1] - o0) - F, 0);
-      }
-      lens[j] = v;
-      starts[j] = o0;
-      sum += v;
-    }
-    // block-wide exclusive scan: shuffles inside a wave, one barrier to combine the four wave totals
-    const int lane = tid & 63, wave = tid >> 6;
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_sc[wave] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += s_sc[w];
-    if (tid == 0) s_off[0] = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid * per + j;
-      if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; s_start[i] = starts[j]; }
-    }
-    __syncthreads();
-    row_off = s_off;
-  }
-
-  if (tid < R) {
-    const int r = row0 + tid;
-    // rows past the planned total (fewer windows than requested) are left untouched
-    int valid = r < a.rows && r < row_off[a.n_users];
-    int u = 0, t = 0, last = 0;
-    long long src = 0;
-    if (valid) {
-      // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
-      int lo = 0, hi = a.n_users;
-      while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (row_off[mid] <= r) lo = mid; else hi = mid;
-      }
-      u = lo;
-      t = r - row_off[lo];
-      last = t == row_off[lo + 1] - row_off[lo] - 1;  // the user's final window: done = 1 (utils.py:70-71)
-      src = (a.inline_plan ? s_start[u] : a.user_off[users[u]]) + t;
-    }
-    m_valid[tid] = valid;
-    m_src[tid] = src;
-    m_done[tid] = valid && last;
-    // continuation of the previous row's window (same user => shifted by one)
-    m_cont[tid] = 0;
-    m_base[tid] = u;  // temporarily the user index
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int base = 0, prev_u = -1, prev_valid = 0;
-    for (int r = 0; r < R; ++r) {
-      int u = m_base[r];
-      int cont = r > 0 && prev_valid && m_valid[r] && u == prev_u;
-      if (r > 0) base += cont ? 1 : F1;
-      m_cont[r] = cont;
-      prev_u = u;
-      prev_valid = m_valid[r];
-      m_base[r] = base;
-    }
-  }
-  __syncthreads();
-
-  // ---- stage the distinct embedding lines + ratings into LDS
-  const int E4 = E >> 2;
-  for (int idx = tid; idx < R * F1 * E4; idx += 256) {
-    const int pair = idx / E4, e4 = idx - pair * E4;
-    const int r = pair / F1, j = pair - r * F1;
-    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
-    const int item = a.items[m_src[r] + j];
-    const float4 v = *(const float4*)(a.table + (int64_t)item * E + e4 * 4);
-    *(float4*)(lines + (size_t)(m_base[r] + j) * E + e4 * 4) = v;
-  }
-  for (int pair = tid; pair < R * F1; pair += 256) {
-    const int r = pair / F1, j = pair - r * F1;
-    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
-    rat[m_base[r] + j] = a.ratings[m_src[r] + j];
-  }
-  __syncthreads();
-
-  // ---- stream out: state / next_state embedding parts and the action
-  const int FE = F * E;
-  const int per_row = FE / W;
-  for (int idx = tid; idx < R * per_row; idx += 256) {
-    const int r = idx / per_row, q = idx - r * per_row;
-    if (!m_valid[r]) continue;
-    const float* src = lines + (size_t)m_base[r] * E + q * W;
-    if (a.state) {
-      *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
-      *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
-    }
-    if constexpr (W == 4) {
-      if (a.state_h) {
-        *(uint2*)(a.state_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
-        *(uint2*)(a.next_h + (int64_t)(row0 + r) * a.ld_h + q * 4) =
-            make_uint2(pack_bf2(src[E], src[E + 1]), pack_bf2(src[E + 2], src[E + 3]));
-      }
-    }
-  }
-  const int per_act = E / W;
-  for (int idx = tid; idx < R * per_act; idx += 256) {
-    const int r = idx / per_act, q = idx - r * per_act;
-    if (!m_valid[r]) continue;
-    const float* src = lines + (size_t)(m_base[r] + F) * E + q * W;
-    if (a.action) *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)src;
-    if constexpr (W == 4) {
-      if (a.action_h)
-        *(uint2*)(a.action_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
-    }
-  }
-  // ---- ratings tails, reward, done
-  for (int idx = tid; idx < R * F; idx += 256) {
-    const int r = idx / F, j = idx - r * F;
-    if (!m_valid[r]) continue;
-    if (a.state) {
-      a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
-      a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
-    }
-    if (a.state_h) {
-      a.state_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + j]);
-      a.next_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + 1 + j]);
-    }
-  }
-  if (tid < R && m_valid[tid]) {
-    a.reward[row0 + tid] = rat[m_base[tid] + F];
-    a.done[row0 + tid] = m_done[tid] ? 1.f : 0.f;
-  }
+  frame_gather_body<R, W>(a, blockIdx.x, smem_raw);
 }
 
-template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_t s) {
+size_t frame_gather_lds_bytes(const GatherArgs& a, int R) {
   const int F1 = a.frame + 1;
   size_t lds = (size_t)R * F1 * a.emb * 4 + (size_t)R * F1 * 4 + 4 * R * 4 + R * 8 + 16;
   if (a.inline_plan) lds += (size_t)a.n_users * 8 + (size_t)(a.n_users + 1 + 4) * 4;
+  return lds;
+}
+
+template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_t s) {
+  const size_t lds = frame_gather_lds_bytes(a, R);
   if (lds > 160 * 1024) { recnn_set_error("frame_gather: tile does not fit LDS (%zu bytes)", lds); return RECNN_E_UNSUPPORTED; }
   dim3 grid((a.rows + R - 1) / R), block(256);
   hipError_t e = hipSuccess;

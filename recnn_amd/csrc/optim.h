@@ -58,6 +58,8 @@ struct ApplyArgs {
 };
 
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);
-int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s);
+struct GatherArgs;
+// pregather != NULL: the sampler + gather of the NEXT step runs as extra workgroups of this launch
+int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s, const GatherArgs* pregather = nullptr);
 int scale_grads_launch(const NetLayout& L, float* gflat, const float* l1part, int n_l1, float grad_scale, hipStream_t s);
 int l1_blocks_launch(const NetLayout& L, const float* gflat, float* l1part, hipStream_t s);

@@ -9,6 +9,7 @@
 // "shadow" copy of the weights (zero-padded, 16-byte aligned rows; critic W1 columns rotated to the
 // packed [action | state] batch layout) that the MFMA GEMMs read, and optionally the soft-updated target.
 #include "optim.h"
+#include "gather_dev.h"
 
 __device__ inline int find_tensor(const NetLayout& L, int b) {
   int ti = 0;
@@ -187,10 +188,8 @@ __device__ inline float clip_coef(const float* l1part, int n, float grad_scale, 
 
 // Adam (+ clip quirk) + shadow refresh + soft target update: one pass, each element touched by exactly one thread,
 // every load of the thread issued before the first use.
-__global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const ApplyArgs a) {
-  __shared__ float red[4];
-  __shared__ float sp[4][OPT_SMALL_ELEMS];
-  const int b = blockIdx.x;
+__device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& a, const int b, float* red,
+                                           float (*sp)[OPT_SMALL_ELEMS]) {
   const TensorSeg& T = L.t[find_tensor(L, b)];
   const int bt = b - T.blk0;
   const Own o = own_elems(T, bt);
@@ -282,10 +281,41 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
   }
 }
 
-int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s) {
+__global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const ApplyArgs a) {
+  __shared__ float red[4];
+  __shared__ float sp[4][OPT_SMALL_ELEMS];
+  apply_body(L, a, blockIdx.x, red, sp);
+}
+
+// The optimizer pass of step t with the replay sampler + embedding gather of step t+1 as extra workgroups of the
+// same launch: the gather is a chain of dependent memory latencies with almost no bandwidth or ALU demand, the
+// optimizer pass streams -- run together, the gather's ~11 us disappear from the step's critical path.  The two
+// roles touch disjoint memory (the gather fills the OTHER batch buffer set, engine.hip).
+// The gather workgroups come first in the launch order: their latency chain starts at once and the optimizer
+// workgroups stream underneath it.
+__global__ __launch_bounds__(256) void apply_gather_kernel(const NetLayout L, const ApplyArgs a, const GatherArgs g, const int n_gather) {
+  __shared__ float red[4];
+  __shared__ float sp[4][OPT_SMALL_ELEMS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x < n_gather) frame_gather_body<4, 4>(g, blockIdx.x, smem_raw);
+  else apply_body(L, a, (int)blockIdx.x - n_gather, red, sp);
+}
+
+int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s, const GatherArgs* pregather) {
   ApplyArgs a = a0;
   a.log_beta1 = log((double)a.beta1);
   a.log_beta2 = log((double)a.beta2);
+  if (pregather) {
+    const GatherArgs& g = *pregather;
+    const size_t lds = frame_gather_lds_bytes(g, 4);
+    if (lds > 48 * 1024 || !g.state_h || g.state || (g.emb % 4) || g.rows <= 0) {
+      recnn_set_error("apply+gather: needs the bf16-only gather with a tile that fits 48 KB of LDS");
+      return RECNN_E_UNSUPPORTED;
+    }
+    const int ng = (g.rows + 3) / 4;
+    hipLaunchKernelGGL(apply_gather_kernel, dim3(L.nblk + ng), dim3(256), lds, s, L, a, g, ng);
+    return recnn_check_hip(hipGetLastError(), "apply_gather_kernel");
+  }
   hipLaunchKernelGGL(apply_kernel, dim3(L.nblk), dim3(256), 0, s, L, a);
   return recnn_check_hip(hipGetLastError(), "apply_kernel");
 }

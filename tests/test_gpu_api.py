@@ -282,19 +282,23 @@ def test_install_as_recnn(recnn, cuda):
     assert alias is recnn and alias_nn.DDPG is recnn.nn.DDPG and FrameEnv is recnn.data.env.FrameEnv
 
 
-def test_fused_run_equals_update_loop(recnn, cuda):
+@pytest.mark.parametrize("n_users,policy_step", [(60, 2), (900, 3)])
+def test_fused_run_equals_update_loop(recnn, cuda, n_users, policy_step):
     """algo.attach_env(env, rows).run(n) == n x (update(batch); step()) on the same batches, bit for bit.
+
+    900 users = 70+ batches per epoch: the replay then goes through the multi-step run graph (whole policy cycles per
+    graph launch, the gather of step t+1 riding on step t's optimizer launch into the second batch buffer set).
 
     The reference loop is driven with the batches the fused sampler would build: same epoch permutation (taken from the
     fused context), same fixed row count, hash dropout masks keyed by the same device step counter."""
     from recnn_amd.nn import fused
     fused.set_defaults(dtype="bf16", mask_mode="hash", seed=21)
-    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=60, seed=8)
+    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=n_users, seed=8)
     results = []
     for mode in ("fused", "loop"):
         torch.manual_seed(12)
         ddpg = recnn.nn.DDPG(recnn.nn.Actor(1290, 128, 256, 6e-1), recnn.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
-        ddpg.params["policy_step"] = 2
+        ddpg.params["policy_step"] = policy_step
         torch.manual_seed(99)                       # the epoch permutation is drawn from the CPU generator
         ddpg.attach_env(env, rows_per_batch=96, users_per_batch=12)
         ctx = ddpg._fused_ctx
