@@ -33,7 +33,7 @@
 #include "bwd.h"
 #include "optim.h"
 
-int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s);
+int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s);
 int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s);
 
 static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -94,6 +94,12 @@ struct recnn_engine {
   float *reward0 = nullptr, *done0 = nullptr;  // the bound reward / done arrays (set 0)
   int cur_set = 0;
   const GatherArgs* pregather = nullptr;   // set while the critic's optimizer launch should carry the next gather
+  // run graphs: the device counters (mask-key step, Adam steps, sampler cursor) are ticked ONCE, by the finalize of
+  // the run's last step; step i of the run is captured with these offsets on top of them
+  int run_off = 0;                         // steps of the run before this one
+  int run_t_off[RECNN_NET_COUNT] = {0};    // optimizer steps of each network earlier in the run
+  bool run_skip_finish = false;            // not the last step of a run: no finalize launch
+  int run_tick[3] = {1, 1, 1};             // increments applied by the finalize: steps, critic steps, actor steps
   char* gen_action;                        // tc [Bc, Ap]
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
@@ -490,6 +496,7 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
   a.tc_bf16 = e->bf16;
   a.do_adam = do_adam;
   a.t_ptr = n.t_ptr;
+  a.t_add = e->run_t_off[ni];
   if (do_adam) {
     RECNN_REQUIRE(n.g && n.m && n.v && n.t_ptr, "apply: network %d has no optimizer state bound", ni);
     a.lr = e->hy.lr[opt_idx]; a.beta1 = e->hy.beta1[opt_idx]; a.beta2 = e->hy.beta2[opt_idx];
@@ -554,7 +561,7 @@ double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) 
     } else {
       p->seed = e->cfg.seed;
       p->stream_id = (uint32_t)f.mask_idx;
-      p->step_ptr = e->counters;
+      p->step_ptr = e->counters; p->step_add = e->run_off;
     }
   }
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
@@ -682,7 +689,7 @@ double fill_mlp(const recnn_engine* e, const MlpSpec& f, int rows, MlpProb* p) {
       p->ld_mask = e->H;
     } else {
       p->seed = e->cfg.seed; p->stream1 = (uint32_t)f.mask_idx; p->stream2 = (uint32_t)f.mask_idx + 1;
-      p->step_ptr = e->counters;
+      p->step_ptr = e->counters; p->step_add = e->run_off;
     }
   }
   p->h1 = f.h1; p->h2 = f.h2; p->ldh = e->Hp;
@@ -707,7 +714,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   if (fused_mlp_ok(e, n_first)) {
     // whole networks per launch: {target actor, critic(s), actor}
     if (value_side && e->td3 && !e->ext_noise) {
-      if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s); }))) return rc;
+      if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
     }
     const int64_t aoff = (int64_t)A * e->esz;
     {
@@ -799,7 +806,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     if ((rc = g.run(s, "fwd_l2"))) return rc;
   }
   if (value_side && e->td3 && !e->ext_noise) {
-    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, s); }))) return rc;
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
   }
   {  // layer 3 of the actors: next_action into the action slot of the packed next rows, gen_action
     Group g(e, GEMM_FWD, 0, 0);
@@ -1047,6 +1054,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
 
 int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, hipStream_t s) {
+  if (e->run_skip_finish) return 0;  // inside a run graph: the last step's finalize ticks the counters for the whole run
   LossFinalizeArgs a;
   memset(&a, 0, sizeof(a));
   const int nblk = (rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
@@ -1061,13 +1069,15 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   }
   a.n = nc + 1;
   a.out = e->losses;
-  a.tick[a.n_tick++] = e->counters;  // mask-key step
+  // run_tick = {1, 1, 1} outside run graphs; the last step of a run adds the whole run's counts
+  a.tick_inc[a.n_tick] = e->run_tick[0]; a.tick[a.n_tick++] = e->counters;  // mask-key step
   if (ticked_value) {
-    a.tick[a.n_tick++] = e->net[RECNN_NET_VALUE1].t_ptr;
-    if (e->td3) a.tick[a.n_tick++] = e->net[RECNN_NET_VALUE2].t_ptr;
+    a.tick_inc[a.n_tick] = e->run_tick[1]; a.tick[a.n_tick++] = e->net[RECNN_NET_VALUE1].t_ptr;
+    if (e->td3) { a.tick_inc[a.n_tick] = e->run_tick[1]; a.tick[a.n_tick++] = e->net[RECNN_NET_VALUE2].t_ptr; }
   }
-  if (ticked_policy) a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr;
-  if (e->has_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; }
+  const bool run_final = e->run_tick[0] > 1;  // last step of a run graph: the actor took run_tick[2] steps during the run
+  if (run_final ? e->run_tick[2] > 0 : ticked_policy) { a.tick_inc[a.n_tick] = e->run_tick[2]; a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr; }
+  if (e->has_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; a.wrap_inc = e->run_tick[0]; }
   return slot(e, "loss_finalize", 0, s, [&] { return loss_finalize_launch(a, s); }, false);
 }
 
@@ -1152,7 +1162,7 @@ int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
     });
     if (rc) return rc;
   }
-  return slot(e, "frame_gather", 0, s, [&] { return frame_gather_launch(gather_args(e, rows, e->cur_set, 0), s); });
+  return slot(e, "frame_gather", 0, s, [&] { return frame_gather_launch(gather_args(e, rows, e->cur_set, e->run_off), s); });
 }
 
 // Make the step's batch available in the compute type: built by the sampler, or converted from the bound fp32 rows.
@@ -1178,7 +1188,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
     // next step, so on policy steps it is fused into the critic's Adam pass (ddpg.py:95-97).
     GatherArgs ga;
-    if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, 1); e->pregather = &ga; }
+    if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1); e->pregather = &ga; }
     rc = value_apply(e, policy_step, 1.0f, s, rows);
     e->pregather = nullptr;
     if (rc) return rc;
@@ -1330,10 +1340,22 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
       rc = step_impl(e, rows, true, v == 1, s);
     } else {
       const bool look = lookahead_ok(e);
+      int n_pol = 0;
       for (int i = 0; i < run_len && !rc; ++i) {
+        const bool pol = pol_first && (i % pe) == 0;
         if (look) use_set(e, i & 1);
-        rc = step_impl(e, rows, true, pol_first && (i % pe) == 0, s, look && i > 0, look && i + 1 < run_len);
+        // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
+        e->run_off = i;
+        for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
+        e->run_skip_finish = i + 1 < run_len;
+        if (pol) ++n_pol;
+        e->run_tick[0] = run_len; e->run_tick[1] = run_len; e->run_tick[2] = n_pol;
+        rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len);
       }
+      e->run_off = 0;
+      for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
+      e->run_skip_finish = false;
+      e->run_tick[0] = e->run_tick[1] = e->run_tick[2] = 1;
       e->grun_last_set = look ? ((run_len - 1) & 1) : 0;
       use_set(e, 0);
     }

@@ -28,6 +28,7 @@ struct GemmProb {
   int64_t ld_mask;
   uint32_t seed, stream_id;
   const int32_t* step_ptr;
+  int step_add;            // mask key step = *step_ptr + step_add (steps captured ahead of the device counter)
   const float* addend;
   int64_t ld_add;
   float add_clip;

@@ -189,7 +189,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
   float sdot = 0.f;
   {
     uint32_t key = 0;
-    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, P.step_ptr ? *P.step_ptr : 0, P.stream_id);
+    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -49,8 +49,9 @@ struct LossFinalizeArgs {
   float* out;  // [4]
   int n_tick;
   int32_t* tick[6];
-  int32_t* wrap_ptr;  // sampler cursor: *wrap_ptr = (*wrap_ptr + 1) % wrap_mod
-  int wrap_mod;
+  int tick_inc[6];     // *tick[i] += tick_inc[i]
+  int32_t* wrap_ptr;  // sampler cursor: *wrap_ptr = (*wrap_ptr + wrap_inc) % wrap_mod
+  int wrap_mod, wrap_inc;
 };
 
 int head_launch(const HeadArgs& a, hipStream_t s);

@@ -265,8 +265,12 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
     }
   }
   if (cnt) {
-    cv += 1;
-    if (slot == a.n_tick && cv >= a.wrap_mod) cv = 0;
+    if (slot == a.n_tick) {
+      cv += a.wrap_inc;
+      if (cv >= a.wrap_mod) cv -= a.wrap_mod;  // wrap_inc <= wrap_mod
+    } else {
+      cv += a.tick_inc[slot];
+    }
     *cnt = cv;
   }
   __syncthreads();
@@ -286,8 +290,8 @@ int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s) {
 // out[i] ~ N(0, stddev^2), counter-based (Box-Muller over two hashed uniforms), keyed by (seed, step).
 // The parity tests bypass it with the reference's own CPU draw (td3.py:74).
 __global__ __launch_bounds__(256) void noise_fill_kernel(float* __restrict__ out, int64_t n, float stddev, uint32_t seed,
-                                                         const int32_t* __restrict__ step_ptr) {
-  const uint32_t key = mask_key(seed, step_ptr ? *step_ptr : 0, 0xA511CEu);
+                                                         const int32_t* __restrict__ step_ptr, int step_add) {
+  const uint32_t key = mask_key(seed, (step_ptr ? *step_ptr : 0) + step_add, 0xA511CEu);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t a = mix32((uint32_t)i * 0x9E3779B1u + key);
     const uint32_t b = mix32(a ^ 0x68E31DA4u ^ (uint32_t)(i >> 32));
@@ -296,10 +300,10 @@ __global__ __launch_bounds__(256) void noise_fill_kernel(float* __restrict__ out
     out[i] = stddev * sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
   }
 }
-int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, hipStream_t s) {
+int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s) {
   if (n <= 0) return 0;
   int grid = (int)((n + 255) / 256);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(noise_fill_kernel, dim3(grid), dim3(256), 0, s, out, n, stddev, seed, step_ptr);
+  hipLaunchKernelGGL(noise_fill_kernel, dim3(grid), dim3(256), 0, s, out, n, stddev, seed, step_ptr, step_add);
   return recnn_check_hip(hipGetLastError(), "noise_fill_kernel");
 }

@@ -44,6 +44,7 @@ struct MlpProb {
   int64_t ld_mask;
   uint32_t seed, stream1, stream2;
   const int32_t* step_ptr;
+  int step_add;      // mask key step = *step_ptr + step_add
   // outputs
   void* h1; void* h2; int64_t ldh;      // bf16 [rows, ldh]; either may be NULL
   void* out; int64_t ldo;                // actor output, bf16 [rows, ldo]

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 
   uint32_t key1 = 0, key2 = 0;
   if (P.mask_mode == RECNN_MASK_HASH) {
-    const int32_t st = P.step_ptr ? *P.step_ptr : 0;
+    const int32_t st = (P.step_ptr ? *P.step_ptr : 0) + P.step_add;
     key1 = mask_key(P.seed, st, P.stream1);
     key2 = mask_key(P.seed, st, P.stream2);
   }

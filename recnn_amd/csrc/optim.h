@@ -43,7 +43,8 @@ struct ApplyArgs {
   void* shadow;         // tc shadow arena of this net (may be NULL)
   int tc_bf16;
   int do_adam;
-  const int32_t* t_ptr; // device: number of optimizer steps already taken
+  const int32_t* t_ptr; // device: number of optimizer steps already taken ...
+  int t_add;            // ... plus this many captured ahead of the counter (run graphs tick once, at their end)
   float lr, beta1, beta2, eps, weight_decay;
   float grad_scale;
   const float* l1part;  // clip quirk: per-workgroup |g| partial sums, n_l1 of them (0 = no clip)

@@ -205,7 +205,7 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
   }
   int t = 0;
   if (a.do_adam) {
-    t = *a.t_ptr + 1;
+    t = *a.t_ptr + 1 + a.t_add;
     if (a.from_slabs) {
       slab_grads(T, bt, o, g, sp);
       if (o.cnt && a.g_out) store_own(a.g_out + e, o, g);
