@@ -84,8 +84,10 @@ void recnn_tune_dw_dma(int on);
  * next_state part of layer 1 while the target actor's workgroup of the same 32 rows runs, which then adds the
  * next_action part and finishes the critic on chip (flag hand-off); 0 = separate launches after it. */
 void recnn_tune_chain_target_critic(int on);
-/* tuning knob: 1 (default) = on the chained bf16 path the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the
- * first backward GEMM (dz1, db1 partial) run as one row-panel launch; 0 = head kernel + dX GEMM launch. */
+/* tuning knob for the chained bf16 path: where the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the first
+ * backward GEMM (dz1, db1 partial) run.  2 (default) = inside the critic's forward workgroup of the fused MLP launch
+ * (Q' arrives from the chained target critic through per-row hand-off slots); 1 = one row-panel launch (bwd.hip);
+ * 0 = head kernel + dX GEMM launch. */
 void recnn_tune_bwd_panel(int on);
 /* tuning knob (before recnn_engine_graph_build): steps per "run" graph. -1 (default) = as many whole policy cycles
  * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of

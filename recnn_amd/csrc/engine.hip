@@ -107,6 +107,7 @@ struct recnn_engine {
   float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
   int32_t* tc_flag[2];                     // ... their per-panel completion flags
   float* tqv[2];
+  float* tq_ready[2][2];                   // [tail][consumer critic]: Q' hand-off slots for the in-forward critic backward
   float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
   int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
   float *loss_part[3];                     // value1, value2, policy  (per head block)
@@ -246,6 +247,7 @@ int64_t carve(recnn_engine* e, char* base) {
     e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
     e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
     e->tqv[i] = (float*)c.take(Bc * 4);
+    for (int j = 0; j < e->n_critic; ++j) e->tq_ready[i][j] = (float*)c.take(Bc * 4);
   }
   const int64_t nblk_head = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int64_t nblk_hb = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
@@ -331,6 +333,8 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
     rc = recnn_check_hip(hipMemset(e->tc_flag[i], 0, (size_t)(e->Bc / 32 + 1) * 4), "engine_create: flag reset");
+    for (int j = 0; j < e->n_critic && !rc; ++j)
+      rc = recnn_check_hip(hipMemsetD32((hipDeviceptr_t)e->tq_ready[i][j], (int)MLP_TQ_EMPTY, (size_t)e->Bc), "engine_create: slot reset");
     if (rc) { delete e; return rc; }
   }
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->net[ni].t_ptr = nullptr;
@@ -643,7 +647,7 @@ extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 int g_chain_target_critic = 1;
 extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic = on; }
 
-int g_bwd_panel = 1;
+int g_bwd_panel = 2;  // 0: head + dX launches, 1: row-panel launch (bwd.hip), 2: inside the critic's forward workgroup (mlp.hip)
 extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
 
 // bf16 value side on the fully fused path: target critics chained inside the forward launch (Q and Q' arrive as
@@ -708,6 +712,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
   bool chained = false;  // target critics computed inside the first fused launch
+  bool fwd_did_bwd = false;  // ... and the critics' head + layer-2 backward too
   // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
   const bool can_chain = value_side && value_chain_ok(e);
   const int n_first = (value_side ? 1 + nc : 0) + (actor_side ? 1 : 0) + (can_chain ? nc : 0);
@@ -722,6 +727,8 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       int np = 0;
       double fl = 0;
       chained = can_chain;
+      const bool in_fwd_bwd = chained && g_bwd_panel >= 2 && mlp_waves() == 16;
+      fwd_did_bwd = in_fwd_bwd;
       if (chained) {
         // producers first (launch order = dispatch order): state part of each target critic's layer 1
         for (int c = 0; c < nc; ++c) {
@@ -749,6 +756,10 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
             T.W2 = sh_ptr(e, TVAL[c], W2); T.ldw2 = t.ld_w2;
             T.b1 = t.p + t.off[B1]; T.b2 = t.p + t.off[B2]; T.b3 = t.p + t.off[B3]; T.w3row = t.p + t.off[W3];
             T.q = e->tqv[c];
+            if (in_fwd_bwd) {
+              T.n_ready = nc;
+              for (int k = 0; k < nc; ++k) T.ready_slot[k] = e->tq_ready[c][k];
+            }
             fl += 2.0 * rows * ((double)e->H * A + (double)e->H * e->H + e->H);
           }
         }
@@ -756,7 +767,26 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
           MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
           fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
           fc.q = e->q[c];
+          MlpProb* pc = &mb.p[np];
           fl += fill_mlp(e, fc, rows, &mb.p[np++]);
+          if (in_fwd_bwd) {
+            MlpCriticBwd& B = pc->cbwd;
+            Net& v = e->net[VAL[c]];
+            B.enabled = 1; B.n_target = nc;
+            for (int t = 0; t < nc; ++t) B.tq_slot[t] = e->tq_ready[t][c];
+            B.reward = e->reward; B.done = e->done; B.gamma = e->hy.gamma;
+            B.lo = e->td3 ? -INFINITY : e->hy.min_value;
+            B.hi = e->td3 ? INFINITY : e->hy.max_value;
+            if (c == 0) { B.expected = e->expected; B.target_q = e->target_q; }
+            B.delta_out = e->delta[c]; B.loss_part = e->loss_part[c];
+            B.scale = e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f;
+            B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];
+            if (value_bwd) {
+              RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+              B.dw3_part = v.gp[W3]; B.db2_part = v.gp[B2]; B.db3_part = v.gp[B3]; B.colsum = v.gp[B1];
+            }
+            fl += 2.0 * rows * (double)e->H * e->H;
+          }
         }
       }
       if (actor_side) {
@@ -862,7 +892,9 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     }
   }
   e->panel_bwd_done = false;
-  if (value_side && chained && g_bwd_panel) {
+  if (value_side && fwd_did_bwd) {
+    e->panel_bwd_done = true;   // nothing left to launch: losses, dz2, dz1 and the partials came out of the forward launch
+  } else if (value_side && chained && g_bwd_panel) {
     // critic head + dz2 + dz1 in one row-panel launch (bwd.hip); Q comes from the forward launch, Q' from its tails
     BwdPanelBatch bb;
     memset(&bb, 0, sizeof(bb));

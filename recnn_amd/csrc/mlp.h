@@ -4,6 +4,10 @@
 
 constexpr int MLP_MAX_GROUP = 6;
 constexpr int MLP_MAX_TAIL = 2;
+// Q' travels from a tail to the critic workgroups of the same rows through per-row slots accessed with relaxed
+// agent-scope atomics: the VALUE is the flag (slots rest at this NaN pattern), so the hand-off on the step's critical
+// path needs no L2 write-back / invalidate (a release-acquire pair there cost ~8 us).
+constexpr uint32_t MLP_TQ_EMPTY = 0x7FC0DEADu;
 
 // A critic chained behind an actor panel inside the same launch (target critic on [next_action | next_state]):
 // the state part of its layer-1 pre-activation does not depend on the actor, so another workgroup of the launch
@@ -20,6 +24,32 @@ struct MlpTail {
   const float* b3;
   const float* w3row;
   float* q;                        // out: fp32 [rows]
+  int n_ready;                     // consumers (critics with MlpCriticBwd) that take q through a hand-off slot
+  float* ready_slot[2];            // [rows] each
+};
+
+// Backward seed and layer-2 backward of a learning critic appended to its forward workgroup (learn steps): once the
+// chained target critic(s) of the same rows have delivered Q' (`tq_flag`), the workgroup -- which still holds h2, both
+// W2 k-slabs and its layer-1 relu/dropout gate bits on chip -- computes the TD error, dz2, the dW3/db2/db3 partials,
+// dz1 = (dz2 W2) * gate and the db1 partial.  Same outputs as bwd.hip's kernel, without its launch.
+struct MlpCriticBwd {
+  int enabled;
+  int n_target;
+  float* tq_slot[MLP_MAX_TAIL];     // [rows] hand-off slots of THIS consumer: hold MLP_TQ_EMPTY until the tail stores Q'
+  const float* reward;
+  const float* done;
+  float gamma, lo, hi;
+  float* expected;
+  float* target_q;
+  float* delta_out;
+  float* loss_part;                 // [panels]
+  float scale;                      // 2 when dropout is active
+  void* dz2;                        // bf16 [rows, ldh]
+  void* dz1;
+  float* dw3_part;                  // [panels][H] (NULL: no parameter gradients wanted)
+  float* db2_part;
+  float* db3_part;                  // [panels]
+  float* colsum;                    // db1 partial [panels][H]
 };
 
 struct MlpProb {
@@ -56,6 +86,7 @@ struct MlpProb {
   // consumer side: critics chained behind this actor's output
   int n_tail;
   MlpTail tail[MLP_MAX_TAIL];
+  MlpCriticBwd cbwd;
 };
 
 struct MlpBatch {
@@ -64,3 +95,4 @@ struct MlpBatch {
 
 int mlp_init();
 int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s);
+int mlp_waves();  // waves per workgroup of the variant mlp_launch will use (MlpCriticBwd needs 16)
