@@ -85,9 +85,10 @@ void recnn_tune_dw_dma(int on);
  * next_action part and finishes the critic on chip (flag hand-off); 0 = separate launches after it. */
 void recnn_tune_chain_target_critic(int on);
 /* tuning knob for the chained bf16 path: where the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the first
- * backward GEMM (dz1, db1 partial) run.  2 (default) = inside the critic's forward workgroup of the fused MLP launch
- * (Q' arrives from the chained target critic through per-row hand-off slots); 1 = one row-panel launch (bwd.hip);
- * 0 = head kernel + dX GEMM launch. */
+ * backward GEMM (dz1, db1 partial) run.  2 (default) = inside the fused MLP launch: the critic's forward workgroup emits
+ * UNIT backward tensors (dz / d), the target actor's workgroup evaluates the head (Q(s,a) reaches it through per-row
+ * hand-off slots), and the dW launch applies the per-row seed d and adds the bias / last-layer partial sums;
+ * 1 = one row-panel launch (bwd.hip); 0 = head kernel + dX GEMM launch. */
 void recnn_tune_bwd_panel(int on);
 /* tuning knob (before recnn_engine_graph_build): steps per "run" graph. -1 (default) = as many whole policy cycles
  * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of
@@ -362,6 +363,9 @@ int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
  * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */
 int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream);
 
+/* 1 if the last step left UNIT backward tensors in the debug views "critic1_dz2" / "critic1_dz1" (dz / d: the per-row
+ * loss seed "delta1" is applied by the consumers inside the dW launch), 0 if they hold dz itself. */
+int recnn_engine_unit_backward(recnn_engine* e);
 /* Debug / test access to intermediate device buffers by name
  * ("next_action", "expected", "q1", "gen_action", ...).  Returns NULL if unknown. */
 const void* recnn_engine_buffer(recnn_engine* e, const char* name, int64_t* h_rows, int64_t* h_cols,

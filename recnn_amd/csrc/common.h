@@ -30,16 +30,27 @@ int recnn_check_hip(hipError_t e, const char* what);
   } while (0)
 
 // ---------------------------------------------------------------- bf16 <-> f32
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline uint32_t cvt_pk_bf16(float lo, float hi) {
+  const hw_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
+}
 __host__ __device__ inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (bf16_t)(cvt_pk_bf16(f, 0.f) & 0xFFFFu);
+#else
   uint32_t u = __builtin_bit_cast(uint32_t, f);
   u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite)
   return (bf16_t)(u >> 16);
+#endif
 }
 __host__ __device__ inline float bf2f(bf16_t h) {
   uint32_t u = ((uint32_t)h) << 16;
   return __builtin_bit_cast(float, u);
 }
-__device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ inline uint32_t pack_bf2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 
 template <class T> struct TcTraits;
 template <> struct TcTraits<float> {

@@ -107,7 +107,8 @@ struct recnn_engine {
   float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
   int32_t* tc_flag[2];                     // ... their per-panel completion flags
   float* tqv[2];
-  float* tq_ready[2][2];                   // [tail][consumer critic]: Q' hand-off slots for the in-forward critic backward
+  float* q_slot[2];                        // Q(s, a) hand-off slots (critic workgroup -> head in the target actor's workgroup)
+  bool unit_bwd = false;                   // this step's dzc2 / dzc1 hold UNIT backward tensors (to be scaled by delta)
   float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
   int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
   float *loss_part[3];                     // value1, value2, policy  (per head block)
@@ -247,7 +248,7 @@ int64_t carve(recnn_engine* e, char* base) {
     e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
     e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
     e->tqv[i] = (float*)c.take(Bc * 4);
-    for (int j = 0; j < e->n_critic; ++j) e->tq_ready[i][j] = (float*)c.take(Bc * 4);
+    e->q_slot[i] = (float*)c.take(Bc * 4);
   }
   const int64_t nblk_head = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int64_t nblk_hb = (Bc + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
@@ -333,8 +334,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
     rc = recnn_check_hip(hipMemset(e->tc_flag[i], 0, (size_t)(e->Bc / 32 + 1) * 4), "engine_create: flag reset");
-    for (int j = 0; j < e->n_critic && !rc; ++j)
-      rc = recnn_check_hip(hipMemsetD32((hipDeviceptr_t)e->tq_ready[i][j], (int)MLP_TQ_EMPTY, (size_t)e->Bc), "engine_create: slot reset");
+    if (!rc) rc = recnn_check_hip(hipMemsetD32((hipDeviceptr_t)e->q_slot[i], (int)MLP_TQ_EMPTY, (size_t)e->Bc), "engine_create: slot reset");
     if (rc) { delete e; return rc; }
   }
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->net[ni].t_ptr = nullptr;
@@ -746,6 +746,19 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         if (e->td3) { f.addend = e->ext_noise ? e->ext_noise : e->noise_buf; f.ld_add = A; f.add_clip = e->hy.noise_clip; }
         MlpProb* pt = &mb.p[np];
         fl += fill_mlp(e, f, rows, &mb.p[np++]);
+        if (chained && in_fwd_bwd) {
+          MlpHead& Hd = pt->head;
+          Hd.n_critic = nc;
+          for (int c = 0; c < nc; ++c) {
+            Hd.q_slot[c] = e->q_slot[c];
+            Hd.delta_out[c] = e->delta[c]; Hd.loss_part[c] = e->loss_part[c];
+            Hd.db3_part[c] = value_bwd ? e->net[VAL[c]].gp[B3] : nullptr;
+          }
+          Hd.reward = e->reward; Hd.done = e->done; Hd.gamma = e->hy.gamma;
+          Hd.lo = e->td3 ? -INFINITY : e->hy.min_value;
+          Hd.hi = e->td3 ? INFINITY : e->hy.max_value;
+          Hd.expected = e->expected; Hd.target_q = e->target_q;
+        }
         if (chained) {
           pt->n_tail = nc;
           for (int c = 0; c < nc; ++c) {
@@ -756,10 +769,6 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
             T.W2 = sh_ptr(e, TVAL[c], W2); T.ldw2 = t.ld_w2;
             T.b1 = t.p + t.off[B1]; T.b2 = t.p + t.off[B2]; T.b3 = t.p + t.off[B3]; T.w3row = t.p + t.off[W3];
             T.q = e->tqv[c];
-            if (in_fwd_bwd) {
-              T.n_ready = nc;
-              for (int k = 0; k < nc; ++k) T.ready_slot[k] = e->tq_ready[c][k];
-            }
             fl += 2.0 * rows * ((double)e->H * A + (double)e->H * e->H + e->H);
           }
         }
@@ -771,20 +780,11 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
           fl += fill_mlp(e, fc, rows, &mb.p[np++]);
           if (in_fwd_bwd) {
             MlpCriticBwd& B = pc->cbwd;
-            Net& v = e->net[VAL[c]];
-            B.enabled = 1; B.n_target = nc;
-            for (int t = 0; t < nc; ++t) B.tq_slot[t] = e->tq_ready[t][c];
-            B.reward = e->reward; B.done = e->done; B.gamma = e->hy.gamma;
-            B.lo = e->td3 ? -INFINITY : e->hy.min_value;
-            B.hi = e->td3 ? INFINITY : e->hy.max_value;
-            if (c == 0) { B.expected = e->expected; B.target_q = e->target_q; }
-            B.delta_out = e->delta[c]; B.loss_part = e->loss_part[c];
+            B.enabled = 1;
+            B.q_slot = e->q_slot[c];
             B.scale = e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f;
-            B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];
-            if (value_bwd) {
-              RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
-              B.dw3_part = v.gp[W3]; B.db2_part = v.gp[B2]; B.db3_part = v.gp[B3]; B.colsum = v.gp[B1];
-            }
+            B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];   // UNIT tensors: the dW launch applies the per-row seed e->delta[c]
+            if (value_bwd) RECNN_REQUIRE(e->net[VAL[c]].g, "value backward: network %d has no gradient arena bound", VAL[c]);
             fl += 2.0 * rows * (double)e->H * e->H;
           }
         }
@@ -892,8 +892,12 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     }
   }
   e->panel_bwd_done = false;
+  e->unit_bwd = false;
   if (value_side && fwd_did_bwd) {
-    e->panel_bwd_done = true;   // nothing left to launch: losses, dz2, dz1 and the partials came out of the forward launch
+    // nothing left to launch here: losses, the per-row seed and the UNIT dz2 / dz1 came out of the forward launch; the dW
+    // launch scales them and adds the bias / last-layer partial sums
+    e->panel_bwd_done = true;
+    e->unit_bwd = true;
   } else if (value_side && chained && g_bwd_panel) {
     // critic head + dz2 + dz1 in one row-panel launch (bwd.hip); Q comes from the forward launch, Q' from its tails
     BwdPanelBatch bb;
@@ -972,12 +976,30 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   NetLayout L0 = make_layout(e, VAL[0], rows);
   {
     Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1 and dW1 = dz1^T [a|s], split over the batch into slabs
-    for (int c = 0; c < nc; ++c)
-      g.flops += fill_dw(e, g.add(), rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab,
+    DwVec vec;
+    memset(&vec, 0, sizeof(vec));
+    for (int c = 0; c < nc; ++c) {
+      GemmProb* p = g.add();
+      g.flops += fill_dw(e, p, rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab,
                          L0.t[W2].slab_stride);
-    for (int c = 0; c < nc; ++c)
-      g.flops += fill_dw(e, g.add(), rows, e->dzc1[c], Hp, H, e->xcs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1],
+      if (e->unit_bwd) p->a_row_scale = e->delta[c];
+    }
+    for (int c = 0; c < nc; ++c) {
+      GemmProb* p = g.add();
+      g.flops += fill_dw(e, p, rows, e->dzc1[c], Hp, H, e->xcs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1],
                          L0.t[W1].nslab, L0.t[W1].slab_stride);
+      if (e->unit_bwd) p->a_row_scale = e->delta[c];
+    }
+    if (e->unit_bwd) {  // dW3 / db2 / db1 partial sums per 32-row panel ride on this launch
+      vec.n = nc;
+      for (int c = 0; c < nc; ++c) {
+        Net& v = e->net[VAL[c]];
+        DwVecProb& q = vec.p[c];
+        q.rows = rows; q.H = H; q.delta = e->delta[c]; q.h2 = e->cv[c].h2; q.u2 = e->dzc2[c]; q.U = e->dzc1[c]; q.ldh = Hp;
+        q.dw3_part = v.gp[W3]; q.db2_part = v.gp[B2]; q.colsum = v.gp[B1];
+      }
+      g.L.vec = &vec;
+    }
     if ((rc = g.run(s, "dw_critic"))) return rc;
   }
   for (int c = 0; c < nc && reduce; ++c) {
@@ -1477,6 +1499,8 @@ extern "C" int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* st
 }
 
 // ------------------------------------------------------------------------------------ debug buffers
+extern "C" int recnn_engine_unit_backward(recnn_engine* e) { return e && e->unit_bwd ? 1 : 0; }
+
 extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, int64_t* rows, int64_t* cols, int64_t* ld,
                                            int* is_f32) {
   if (!e || !name) return nullptr;

@@ -42,6 +42,9 @@ struct GemmProb {
   int64_t ldy;
   float dx_scale;
   float* colsum;
+  // dW: optional per-row (= per batch row = k) scale of the A operand: A[k][m] *= a_row_scale[k]  (unit backward
+  // tensors times the per-row loss seed, mlp.h MlpCriticBwd)
+  const float* a_row_scale;
   // dW epilogue
   int dw_splits;
   int64_t dw_slab_stride;
@@ -56,10 +59,29 @@ struct GemmBatch {
   GemmProb p[GEMM_MAX_GROUP];
 };
 
+// Row-vector partial sums that ride on a dW launch as extra workgroups (one per 32-row panel and critic):
+//   dw3_part[panel][k] = sum_r d_r h2[r][k],  db2_part[panel][k] = sum_r d_r u2[r][k],  colsum[panel][k] = sum_r d_r U[r][k]
+struct DwVecProb {
+  int rows, H;
+  const float* delta;       // d_r, fp32 [rows]
+  const void* h2;           // bf16 [rows, ldh]
+  const void* u2;           // bf16 unit dz2
+  const void* U;            // bf16 unit dz1
+  int64_t ldh;
+  float* dw3_part;          // [panels][H]
+  float* db2_part;
+  float* colsum;
+};
+struct DwVec {
+  int n;
+  DwVecProb p[2];
+};
+
 // All problems of one launch share (dtype, mode, a_f32, b_f32).
 struct GemmLaunch {
   int dtype, mode, a_f32, b_f32, nprob;
   GemmBatch batch;
+  const DwVec* vec;   // dW launches only (bf16 DMA kernel), may be NULL
 };
 
 void gemm_prob_init(GemmProb* p);

@@ -517,14 +517,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 // p ^ f(b), f(b) = ((b>>1)&1) | (((b>>3)&1)<<1), so the 8 rows x 32 bytes one half-wave transpose read touches
 // (rows {0..3} and {8..11} of a k step, same 16 columns) fall on 8 different 32-byte bank groups.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
+constexpr int DW_SCALE_ROWS = 512;    // per-row scales of a workgroup's k range are staged in LDS up to this many rows
 // SUB = batch rows per stage, NS = ring slots (all filled before the first MFMA).
-template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch) {
+// one 32-row panel of one critic: per-column sums over the rows of d_r * {h2, u2, U}; thread = column
+__device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
+  const int m0 = panel * 32;
+  if (m0 >= V.rows) return;
+  for (int k = threadIdx.x; k < V.H; k += 256) {
+    float s3 = 0.f, s2 = 0.f, s1 = 0.f;
+#pragma unroll 8   // 24 loads in flight; more would raise the kernel's VGPR count and cost the GEMM tiles occupancy
+    for (int r = 0; r < 32; ++r) {
+      const int m = min(m0 + r, V.rows - 1);
+      const float d = m0 + r < V.rows ? V.delta[m] : 0.f;
+      const int64_t off = (int64_t)m * V.ldh + k;
+      s3 += d * bf2f(((const bf16_t*)V.h2)[off]);
+      s2 += d * bf2f(((const bf16_t*)V.u2)[off]);
+      s1 += d * bf2f(((const bf16_t*)V.U)[off]);
+    }
+    V.dw3_part[(int64_t)panel * V.H + k] = s3;
+    V.db2_part[(int64_t)panel * V.H + k] = s2;
+    V.colsum[(int64_t)panel * V.H + k] = s1;
+  }
+}
+
+template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch, const DwVec vec, const int nprob) {
+  // extra workgroups, first in the launch order (their chain of row loads is the longest single-workgroup path):
+  // row-vector partial sums for the bias / last-layer gradients
+  const int y0 = vec.n > 0 ? 1 : 0;
+  if (y0 && blockIdx.y == 0) {
+    const int vb = blockIdx.x;
+    if (vb < vec.n * ((vec.p[0].rows + 31) / 32)) dw_vec_role(vec.p[vb % vec.n], vb / vec.n);
+    return;
+  }
+  (void)nprob;
+  const GemmProb& P = batch.p[(int)blockIdx.y - y0];
   constexpr int DWT_SUB = SUB;
   constexpr int DWT_OP_BYTES = DWT_SUB * 128;        // one operand of a stage
   constexpr int DWT_STAGE_BYTES = 2 * DWT_OP_BYTES;
   constexpr int NI = SUB / 16;                       // DMA instructions per wave and stage
   constexpr int RG = SUB / 8;                        // 8-row groups per operand and stage
-  const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n * P.dw_splits;
   if ((int)blockIdx.x >= nwg) return;
   const int lid = xcd_remap(blockIdx.x, nwg);
@@ -574,6 +605,15 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
 #pragma unroll
   for (int i = 0; i < NS; ++i)
     if (i < nt) issue(i, i);
+  // per-row scales of this workgroup's k range -> LDS (read back in the k loop; a global load there would stall every
+  // k step for a memory latency)
+  float* sds = (float*)(dsmem + NS * DWT_STAGE_BYTES);
+  const bool lds_scale = P.a_row_scale && (kend - kbeg) <= DW_SCALE_ROWS;
+  if (lds_scale) {
+    for (int i = tid; i < kend - kbeg; i += 256) sds[i] = P.a_row_scale[kbeg + i];
+    for (int i = kend - kbeg + tid; i < ((kend - kbeg + 63) & ~63); i += 256) sds[i] = 0.f;
+    __syncthreads();
+  }
   for (int t = 0; t < nt; ++t) {
     // stages issued so far: the NS of the prologue plus one per iteration 1..t-1
     const int younger = min(nt - 1, NS - 1 + max(t - 1, 0)) - t;
@@ -617,6 +657,30 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (kk + j >= kend) { a[0][half][j] = 0; a[1][half][j] = 0; }
+        }
+      }
+      if (P.a_row_scale) {  // uniform: A rows are unit backward tensors, multiply batch row k by its loss seed d_k
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int kk = k0 + ks * 32 + fg * 8 + half * 4;
+          float dv[4];
+          if (lds_scale) {
+            const float4 d4 = *(const float4*)(sds + (kk - kbeg));
+            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+          } else if (kk + 3 < Kc) {   // kk is a multiple of 4 and the scale array is 16-byte aligned
+            const float4 d4 = *(const float4*)(P.a_row_scale + kk);
+            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dv[j] = P.a_row_scale[min(kk + j, Kc - 1)];
+          }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const uint2 raw = __builtin_bit_cast(uint2, a[tm][half]);
+            const uint2 sc = make_uint2(pack_bf2(bf2f((bf16_t)(raw.x & 0xFFFF)) * dv[0], bf2f((bf16_t)(raw.x >> 16)) * dv[1]),
+                                        pack_bf2(bf2f((bf16_t)(raw.y & 0xFFFF)) * dv[2], bf2f((bf16_t)(raw.y >> 16)) * dv[3]));
+            a[tm][half] = __builtin_bit_cast(v4s16, sc);
+          }
         }
       }
 #pragma unroll
@@ -665,7 +729,7 @@ static bool dw_dma_eligible(const GemmLaunch* L) {
 }
 
 template <int SUB, int NS> static int launch_dw_dma_v(GemmLaunch* L, hipStream_t stream) {
-  constexpr int LDS = NS * SUB * 256;
+  constexpr int LDS = NS * SUB * 256 + DW_SCALE_ROWS * 4;
   static bool attr_done = false;
   if (!attr_done) {
     int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_dw_dma_kernel<SUB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS),
@@ -682,7 +746,16 @@ template <int SUB, int NS> static int launch_dw_dma_v(GemmLaunch* L, hipStream_t
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((gemm_dw_dma_kernel<SUB, NS>), dim3(maxwg, L->nprob, 1), dim3(256, 1, 1), LDS, stream, L->batch);
+  DwVec vec;
+  memset(&vec, 0, sizeof(vec));
+  int extra = 0;
+  if (L->vec && L->vec->n > 0) {
+    vec = *L->vec;
+    extra = 1;
+    const int vb = vec.n * ((vec.p[0].rows + 31) / 32);
+    if (vb > maxwg) maxwg = vb;
+  }
+  hipLaunchKernelGGL((gemm_dw_dma_kernel<SUB, NS>), dim3(maxwg, L->nprob + extra, 1), dim3(256, 1, 1), LDS, stream, L->batch, vec, L->nprob);
   return recnn_check_hip(hipGetLastError(), "gemm_dw_dma_kernel launch");
 }
 static int launch_dw_dma(GemmLaunch* L, hipStream_t stream, int variant = 0) {
@@ -822,6 +895,11 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
   }
   if constexpr (MODE == GEMM_DW && sizeof(TC) == 2 && !A32 && !B32) {
     if (dw_dma_eligible(L)) return launch_dw_dma(L, stream);
+  }
+  if constexpr (MODE == GEMM_DW) {
+    bool scaled = L->vec != nullptr;
+    for (int i = 0; i < L->nprob; ++i) scaled = scaled || L->batch.p[i].a_row_scale != nullptr;
+    if (scaled) { recnn_set_error("gemm dw: row scaling / vector partials need the bf16 DMA kernel"); return RECNN_E_UNSUPPORTED; }
   }
   int v = g_gemm_variant;
   if (v < 0) {  // enough 64x64 tiles to give every CU a few workgroups?  else take the small-tile variant

@@ -4,9 +4,8 @@
 
 constexpr int MLP_MAX_GROUP = 6;
 constexpr int MLP_MAX_TAIL = 2;
-// Q' travels from a tail to the critic workgroups of the same rows through per-row slots accessed with relaxed
-// agent-scope atomics: the VALUE is the flag (slots rest at this NaN pattern), so the hand-off on the step's critical
-// path needs no L2 write-back / invalidate (a release-acquire pair there cost ~8 us).
+// Per-row scalars travel between workgroups of one launch through slots accessed with relaxed agent-scope atomics:
+// the VALUE is the flag (slots rest at this NaN pattern), so the hand-off needs no L2 write-back / invalidate.
 constexpr uint32_t MLP_TQ_EMPTY = 0x7FC0DEADu;
 
 // A critic chained behind an actor panel inside the same launch (target critic on [next_action | next_state]):
@@ -24,32 +23,38 @@ struct MlpTail {
   const float* b3;
   const float* w3row;
   float* q;                        // out: fp32 [rows]
-  int n_ready;                     // consumers (critics with MlpCriticBwd) that take q through a hand-off slot
-  float* ready_slot[2];            // [rows] each
 };
 
-// Backward seed and layer-2 backward of a learning critic appended to its forward workgroup (learn steps): once the
-// chained target critic(s) of the same rows have delivered Q' (`tq_flag`), the workgroup -- which still holds h2, both
-// W2 k-slabs and its layer-1 relu/dropout gate bits on chip -- computes the TD error, dz2, the dW3/db2/db3 partials,
-// dz1 = (dz2 W2) * gate and the db1 partial.  Same outputs as bwd.hip's kernel, without its launch.
+// Layer-2 backward of a learning critic appended to its forward workgroup (learn steps), in UNIT form: the workgroup
+// still holds h2, both W2 k-slabs and its layer-1 relu/dropout gate bits on chip, so it emits
+//     u2 = w3 * scale * [h2 > 0]                 (= dz2 / d)
+//     U  = (u2 W2) * scale * [h1 > 0]            (= dz1 / d)
+// where d = dLoss/dQ is a per-row scalar that depends on the target critic (another workgroup).  Nothing here waits
+// for it: the consumers of dz2 / dz1 (the dW GEMM and the bias / last-layer partial sums riding on its launch,
+// gemm.hip) multiply the rows by d.  Q(s, a) itself goes to the workgroup that evaluates the head through a
+// value-as-flag hand-off slot.
 struct MlpCriticBwd {
   int enabled;
-  int n_target;
-  float* tq_slot[MLP_MAX_TAIL];     // [rows] hand-off slots of THIS consumer: hold MLP_TQ_EMPTY until the tail stores Q'
+  float* q_slot;     // [rows] hand-off slot for Q(s, a) (rests at MLP_TQ_EMPTY) or NULL
+  float scale;       // 2 when dropout is active
+  void* dz2;         // out bf16 [rows, ldh]: u2
+  void* dz1;         // out bf16 [rows, ldh]: U
+};
+
+// TD target, TD error and loss of the learning critic(s), evaluated by the target actor's workgroup right after its
+// chained target critics (it owns Q' of the rows; Q(s, a) arrives through the critics' hand-off slots, which were
+// filled ~8 us earlier): recnn/nn/update/misc.py:6-7,33-39, td3.py:83-93.
+struct MlpHead {
+  int n_critic;              // 0: no head here
+  float* q_slot[2];          // per critic, [rows]
   const float* reward;
   const float* done;
   float gamma, lo, hi;
-  float* expected;
-  float* target_q;
-  float* delta_out;
-  float* loss_part;                 // [panels]
-  float scale;                      // 2 when dropout is active
-  void* dz2;                        // bf16 [rows, ldh]
-  void* dz1;
-  float* dw3_part;                  // [panels][H] (NULL: no parameter gradients wanted)
-  float* db2_part;
-  float* db3_part;                  // [panels]
-  float* colsum;                    // db1 partial [panels][H]
+  float* expected;           // y [rows]
+  float* target_q;           // min_t Q'_t [rows]
+  float* delta_out[2];       // d = 2 (q - y) / rows, per critic
+  float* loss_part[2];       // [panels] sum (q - y)^2
+  float* db3_part[2];        // [panels] sum d  (NULL: not wanted)
 };
 
 struct MlpProb {
@@ -87,6 +92,7 @@ struct MlpProb {
   int n_tail;
   MlpTail tail[MLP_MAX_TAIL];
   MlpCriticBwd cbwd;
+  MlpHead head;      // on the problem that carries the tails
 };
 
 struct MlpBatch {

@@ -306,13 +306,55 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
           sdot += n < P.H ? bf2f(hv) * T.w3row[n] : 0.f;
         }
         sdot = wave_sum(sdot);
-        if (lane == 0 && m0 + row < P.rows) {
+        if (lane == 0) {
           const float qv = sdot + T.b3[0];
-          T.q[m0 + row] = qv;
-          // hand Q' to the critic workgroups that finish their backward on chip (value = flag, see MLP_TQ_EMPTY)
-          for (int k = 0; k < T.n_ready; ++k)
-            __hip_atomic_store((uint32_t*)T.ready_slot[k] + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+          if (m0 + row < P.rows) T.q[m0 + row] = qv;
+          ((float*)(lds + STAGE))[ti * BM + row] = qv;   // for the head below (A slot of ring stage 1 is idle)
+        }
+      }
+    }
+    // ---------------------------------------------------------------- head of the learning critic(s)
+    if (P.head.n_critic > 0 && P.n_tail > 0) {
+      const MlpHead& Hd = P.head;
+      __syncthreads();   // Q' of all 32 rows (every tail) is in LDS
+      if (wave == 0) {
+        const float* stq = (const float*)(lds + STAGE);
+        const int r = lane & 31, m = m0 + r, mc = min(m, P.rows - 1);
+        const bool valid = lane < 32 && m < P.rows;
+        const float rew = Hd.reward[mc], dn = Hd.done[mc];
+        float tqv = stq[r];
+        if (P.n_tail > 1) tqv = fminf(tqv, stq[BM + r]);
+        float y = rew + (1.0f - dn) * Hd.gamma * tqv;
+        y = fminf(fmaxf(y, Hd.lo), Hd.hi);
+        if (valid) {
+          if (Hd.expected) Hd.expected[m] = y;
+          if (Hd.target_q) Hd.target_q[m] = tqv;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (c < Hd.n_critic) {
+            // Q(s, a) from the critic workgroup of the same rows: it finished its forward long ago; bounded spin
+            // (~0.2 s) on the value-as-flag slot, then put the slot back to rest
+            float q = 0.f;
+            if (valid) {
+              uint32_t* slot = (uint32_t*)Hd.q_slot[c] + m;
+              uint32_t bits = MLP_TQ_EMPTY;
+              int spins = 0;
+              while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MLP_TQ_EMPTY && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(1);
+              __hip_atomic_store(slot, MLP_TQ_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              q = __builtin_bit_cast(float, bits);
+            }
+            const float e = valid ? q - y : 0.f;
+            const float d = e * (2.0f / (float)P.rows);
+            if (valid && Hd.delta_out[c]) Hd.delta_out[c][m] = d;
+            const float tot = wave_sum(e * e);
+            const float dsum = wave_sum(d);
+            if (lane == 0) {
+              if (Hd.loss_part[c]) Hd.loss_part[c][blockIdx.x] = tot;
+              if (Hd.db3_part[c]) Hd.db3_part[c][blockIdx.x] = dsum;
+            }
+          }
         }
       }
     }
@@ -329,100 +371,41 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
         s += n < P.H ? bf2f(hv) * P.w3row[n] : 0.f;
       }
       s = wave_sum(s);
-      if (lane == 0 && m0 + row < P.rows) P.q[m0 + row] = s + P.b3[0];
-      if constexpr (NW == 16) {
-        if (P.cbwd.enabled && lane == 0) ((float*)lds)[row] = s + P.b3[0];  // q of the panel's rows: A slot of ring stage 0 is idle
+      if (lane == 0 && m0 + row < P.rows) {
+        const float qv = s + P.b3[0];
+        P.q[m0 + row] = qv;
+        if (P.cbwd.enabled && P.cbwd.q_slot)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
+          __hip_atomic_store((uint32_t*)P.cbwd.q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if constexpr (NW == 16) {
       if (P.cbwd.enabled) {
         const MlpCriticBwd& B = P.cbwd;
-        float* sq = (float*)lds;         // [32] q
-        float* sd = sq + 32;             // [32] d = dLoss/dQ
-        // everything that does not depend on Q' is requested before the wait for it
-        const int brow = lane & 31, bm = m0 + brow, bmc = min(bm, P.rows - 1);
-        const float rew = B.reward[bmc], dn = B.done[bmc];
-        const int n8 = (2 * wave + (lane >> 5)) * 8;
-        const int nb = min(n8, P.H - 8);
-        const float4 w3a = *(const float4*)(P.w3row + nb), w3b = *(const float4*)(P.w3row + nb + 4);
-        __syncthreads();   // sq complete
-        if (wave == 0) {
-          const int r = brow, m = bm;
-          const bool valid = lane < 32 && m < P.rows;
-          // ---- Q' of this row from the chained target critics: spin on the hand-off slot (bounded, ~0.2 s), then
-          // put the slot back to rest.  The tails belong to workgroups with lower ids: they were dispatched earlier.
-          float tqs[MLP_MAX_TAIL];
-#pragma unroll
-          for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
-            tqs[ti] = 0.f;
-            if (ti < B.n_target && valid) {
-              uint32_t* slot = (uint32_t*)B.tq_slot[ti] + m;
-              uint32_t bits = MLP_TQ_EMPTY;
-              int spins = 0;
-              while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MLP_TQ_EMPTY && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(1);
-              __hip_atomic_store(slot, MLP_TQ_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              tqs[ti] = __builtin_bit_cast(float, bits);
-            }
-          }
-          const float tqv = B.n_target > 1 ? fminf(tqs[0], tqs[1]) : tqs[0];
-          float y = rew + (1.0f - dn) * B.gamma * tqv;
-          y = fminf(fmaxf(y, B.lo), B.hi);
-          const float e = sq[r] - y;
-          const float d = valid ? e * (2.0f / (float)P.rows) : 0.f;
-          if (valid) {
-            if (B.expected) B.expected[m] = y;
-            if (B.target_q) B.target_q[m] = tqv;
-            if (B.delta_out) B.delta_out[m] = d;
-          }
-          if (lane < 32) sd[r] = d;
-          const float tot = wave_sum(valid ? e * e : 0.f);
-          const float dsum = wave_sum(d);
-          if (lane == 0) {
-            if (B.loss_part) B.loss_part[blockIdx.x] = tot;
-            if (B.db3_part) B.db3_part[blockIdx.x] = dsum;
-          }
-        }
-        __syncthreads();
-        // ---- dz2 = d * w3 * scale * [h2 > 0], in place in the panel; partial sums over the 32 rows by DPP
+        // ---- u2 = w3 * scale * [h2 > 0], in place in the panel (it becomes the A operand) and to global
         {
-          const int row = brow, m = bm;
+          const int row = lane & 31, m = m0 + row;
+          const int n8 = (2 * wave + (lane >> 5)) * 8;
+          const int nb = min(n8, P.H - 8);
+          const float4 w3a = *(const float4*)(P.w3row + nb), w3b = *(const float4*)(P.w3row + nb + 4);
           const float wsc = n8 < P.H ? B.scale : 0.f;
           const float w3v[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
+          __builtin_amdgcn_s_barrier();   // every wave is done reading h2 rows for its q dots
           unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16);
           const uint4 raw = *(const uint4*)cell;
           const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-          const float d = sd[row];
-          float dz[8], sw[8], sb[8];
+          float uz[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
-            dz[j] = hv > 0.f ? d * w3v[j] : 0.f;
-            sw[j] = d * hv;
-            sb[j] = dz[j];
+            uz[j] = hv > 0.f ? w3v[j] : 0.f;
           }
-          const uint4 packed = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+          const uint4 packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
           *(uint4*)cell = packed;
           if (m < P.rows) *(uint4*)((bf16_t*)B.dz2 + (int64_t)m * P.ldh + n8) = packed;
-          if (B.dw3_part) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              sw[j] = half_sum32(sw[j]);
-              sb[j] = half_sum32(sb[j]);
-            }
-            if (row == 31) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if (n8 + j < P.H) {
-                  B.dw3_part[(int64_t)blockIdx.x * P.H + n8 + j] = sw[j];
-                  B.db2_part[(int64_t)blockIdx.x * P.H + n8 + j] = sb[j];
-                }
-            }
-          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // dz2 panel complete
-        // ---- dz1 = (dz2 W2) * scale * gate(h1): W2 k-slabs are still in the two W slots (rows = out index = k here,
+        __builtin_amdgcn_s_barrier();   // u2 panel complete
+        // ---- U = (u2 W2) * scale * gate(h1): W2 k-slabs are still in the two W slots (rows = out index = k here,
         // 128 in-columns per slab, chunk c of row r at c ^ (r & 15)); B fragments by transpose reads
         f32x4 dacc[2];
         dacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -449,7 +432,6 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
             dacc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]), __builtin_bit_cast(bf16x8, bv), dacc[tm], 0, 0, 0);
         }
         const int n = wave * 16 + fr;
-        float cs = 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -457,15 +439,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
             const int mm = m0 + tm * 16 + fg * 4 + r;
             if (mm < P.rows && n < P.H) {
               const float v = ((gate1 >> (tm * 4 + r)) & 1u) ? dacc[tm][r] * B.scale : 0.f;
-              cs += v;
               ((bf16_t*)B.dz1)[(int64_t)mm * P.ldh + n] = f2bf(v);
             }
           }
-        if (B.colsum) {
-          cs += __shfl_xor(cs, 16, 64);
-          cs += __shfl_xor(cs, 32, 64);
-          if (fg == 0 && n < P.H) B.colsum[(int64_t)blockIdx.x * P.H + n] = cs;
-        }
       }
     }
   }
@@ -493,7 +469,7 @@ int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
     const MlpProb& p = b.p[i];
     if (p.rows > rows) rows = p.rows;
     if (p.H > HP || p.out_dim > 128) { recnn_set_error("mlp_fwd: hidden > 256 or out_dim > 128"); return RECNN_E_UNSUPPORTED; }
-    if (p.cbwd.enabled && (g_mlp_waves != 16 || p.W3 || !p.q || !p.cbwd.tq_slot[0] || !p.cbwd.dz2 || !p.cbwd.dz1)) {
+    if (p.cbwd.enabled && (g_mlp_waves != 16 || p.W3 || !p.q || !p.cbwd.dz2 || !p.cbwd.dz1)) {
       recnn_set_error("mlp_fwd: critic backward tail needs the 16-wave variant, a critic problem and its buffers");
       return RECNN_E_INVALID;
     }

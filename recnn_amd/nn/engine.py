@@ -279,4 +279,8 @@ class StepEngine:
             raise KeyError(name)
         dt = torch.float32 if esz == 4 else torch.bfloat16
         t = raw.view(dt).view(rows, ld.value)[:, :c.value]
-        return t.float().clone()
+        t = t.float().clone()
+        if name in ("critic1_dz2", "critic1_dz1") and self.lib.recnn_engine_unit_backward(self.handle):
+            # the fused bf16 path stores dz / d (unit backward tensors); the per-row seed d is applied inside the dW launch
+            t *= self.buffer("delta1", rows).reshape(rows, 1)
+        return t
