@@ -213,8 +213,7 @@ def main():
             dp = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=args.overlap)
 
         def run(first, n):
-            for t in range(first, first + n):
-                dp.step(t)
+            dp.run(first, n)
 
     def barrier():
         torch.cuda.synchronize(dev)

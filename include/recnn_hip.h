@@ -355,9 +355,17 @@ int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_step
  *   3: policy step: L1 clip + actor Adam (+soft update), finish
  *   4: (overlap_actor = 1 only) the actor forward alone; graph 0 then omits it, and the caller launches graph 4
  *      right after starting the critic all-reduce so that the collective's latency hides behind it
+ *   5: graph 1 of step t followed by graph 0 of step t+1 in ONE graph (one graph launch per step instead of two)
+ *   6: graph 3 of step t followed by graph 0 of step t+1
+ * `which` = kind + 8 * set, set = batch buffer set holding step t's batch: recnn_engine_dp_sets() returns 2 when
+ * consecutive steps alternate between two sets (then the sampler + gather of step t+1 rides on step t's critic
+ * optimizer launch inside graph 5), else 1 (always pass set 0).  A run of n steps:
+ *   launch 0;  per step: all-reduce critic arena(s); ordinary step: launch 5 (1 on the last step);
+ *   policy step: launch 2, all-reduce actor arena, launch 6 (3 on the last step);  set ^= 1 after 5 / 6 if 2 sets.
  * grad_scale (1/world_size) is baked into the graphs. */
 int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int overlap_actor, void* stream);
 int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
+int recnn_engine_dp_sets(recnn_engine* e);
 
 /* Host copy of the last step's losses (synchronises `stream`):
  * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */

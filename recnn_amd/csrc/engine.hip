@@ -22,6 +22,7 @@
 //   [policy step]  H4 head bwd, D2..D5 dX chain back to the actor, W2/W3 actor dW, R2, L1-norm, A2
 //   F   loss finalize + device step counters
 #include <math.h>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -134,7 +135,8 @@ struct recnn_engine {
   int grun_len = 0;          // steps in gexec[2]
   int grun_last_set = 0;     // batch buffer set its last step leaves the batch in
   bool grun_policy_first = false;  // gexec[2] = whole policy cycles (policy step + policy_every-1 ordinary steps, repeated)
-  hipGraphExec_t gdp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // data-parallel phase graphs
+  hipGraphExec_t gdp[7][2] = {};           // data-parallel phase graphs [kind][batch buffer set]
+  int dp_sets = 1;                         // 2: merged tail+head graphs alternate the batch buffer sets (look-ahead gather)
   int graph_rows = 0;
   bool hyper_set = false;
 };
@@ -350,8 +352,9 @@ static void drop_graphs(recnn_engine* e) {
   for (int i = 0; i < 3; ++i)
     if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
   e->grun_len = 0;
-  for (int i = 0; i < 5; ++i)
-    if (e->gdp[i]) { (void)hipGraphExecDestroy(e->gdp[i]); e->gdp[i] = nullptr; }
+  for (int i = 0; i < 7; ++i)
+    for (int k = 0; k < 2; ++k)
+      if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
 }
 
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
@@ -1452,49 +1455,104 @@ extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_ste
 }
 
 // Data-parallel phase graphs (see recnn_amd/parallel.py): the gradient all-reduces run between them.
-//   0  batch + all forwards + critic backward + slab reduction            -> all-reduce critic grads
-//   1  [non-policy step] critic Adam, policy loss, finish
-//   2  [policy step]     critic Adam (+soft), policy loss + actor backward -> all-reduce actor grads
-//   3  [policy step]     L1 clip + actor Adam (+soft), finish
-//   4  (overlap mode)    actor forward alone: runs while the critic all-reduce is in flight; graph 0 then
-//                        leaves the actor out of its first group
+//   kind 0 H    batch + all forwards + critic backward + slab reduction            -> all-reduce critic grads
+//   kind 1 T1   [ordinary step] critic Adam, policy loss, finish
+//   kind 2 T2   [policy step]   critic Adam (+soft), policy loss + actor backward    -> all-reduce actor grads
+//   kind 3 T3   [policy step]   L1 clip + actor Adam (+soft), finish
+//   kind 4      (overlap mode)  actor forward alone: runs while the critic all-reduce is in flight; graph 0 then
+//                               leaves the actor out of its first group
+//   kind 5 T1H  T1 of step t followed by H of step t+1 in ONE graph (one graph launch per step instead of two: the GPU
+//               idles ~8 us between graph launches); with two batch buffer sets the sampler + gather of step t+1 rides
+//               on step t's critic optimizer launch, as in the single-GPU run graphs
+//   kind 6 T3H  T3 followed by H of the next step
+// `which` of recnn_engine_dp_graph_launch = kind + 8 * set (the buffer set step t's batch is in).
+static int dp_capture(recnn_engine* e, hipStream_t s, hipGraphExec_t* out, const std::function<int()>& body) {
+  if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
+  hipGraph_t graph = nullptr;
+  RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  RECNN_HIP(ce);
+  hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  RECNN_HIP(ie);
+  (void)e;
+  return 0;
+}
+
 extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int overlap_actor, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "dp_graph_build: capture needs a non-null stream");
+  for (int i = 0; i < 7; ++i)
+    for (int k = 0; k < 2; ++k)
+      if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
+  const bool look = !overlap_actor && lookahead_ok(e);
+  e->dp_sets = look ? 2 : 1;
+  auto head = [&](bool pregathered) -> int {
+    int r = pregathered ? 0 : stage_batch(e, rows, s);
+    if (!r && !(r = ph_forward(e, rows, true, !overlap_actor, true, s))) r = ph_value_backward(e, rows, true, s);
+    return r;
+  };
   use_set(e, 0);
-  for (int v = 0; v < 5; ++v) {
-    if (e->gdp[v]) { (void)hipGraphExecDestroy(e->gdp[v]); e->gdp[v] = nullptr; }
-    if (v == 4 && !overlap_actor) continue;
-    hipGraph_t graph = nullptr;
-    RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = 0;
-    if (v == 0) {
-      if (!(rc = stage_batch(e, rows, s)) && !(rc = ph_forward(e, rows, true, !overlap_actor, true, s)))
-        rc = ph_value_backward(e, rows, true, s);
-    } else if (v == 4) {
-      rc = ph_forward(e, rows, false, true, false, s);
-    } else if (v == 1) {
-      if (!(rc = value_apply(e, false, grad_scale, s)) && !(rc = ph_policy(e, rows, false, false, s, false))) rc = ph_finish(e, rows, true, false, s);
-    } else if (v == 2) {
-      if (!(rc = value_apply(e, true, grad_scale, s))) rc = ph_policy(e, rows, true, false, s, false);
-    } else {
-      if (!(rc = policy_apply(e, true, grad_scale, s))) rc = ph_finish(e, rows, true, true, s);
-    }
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    RECNN_HIP(ce);
-    hipError_t ie = hipGraphInstantiate(&e->gdp[v], graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    RECNN_HIP(ie);
+  if ((rc = dp_capture(e, s, &e->gdp[0][0], [&] { return head(false); }))) return rc;
+  if (overlap_actor && (rc = dp_capture(e, s, &e->gdp[4][0], [&] { return ph_forward(e, rows, false, true, false, s); }))) return rc;
+  for (int set = 0; set < e->dp_sets && !rc; ++set) {
+    use_set(e, set);
+    rc = dp_capture(e, s, &e->gdp[1][set], [&] {
+      int r;
+      if (!(r = value_apply(e, false, grad_scale, s)) && !(r = ph_policy(e, rows, false, false, s, false))) r = ph_finish(e, rows, true, false, s);
+      return r;
+    });
+    if (!rc) rc = dp_capture(e, s, &e->gdp[2][set], [&] {
+      int r;
+      if (!(r = value_apply(e, true, grad_scale, s))) r = ph_policy(e, rows, true, false, s, false);
+      return r;
+    });
+    if (!rc) rc = dp_capture(e, s, &e->gdp[3][set], [&] {
+      int r;
+      if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
+      return r;
+    });
+    if (overlap_actor) continue;   // the overlap variant keeps one graph per phase
+    if (!rc) rc = dp_capture(e, s, &e->gdp[5][set], [&] {
+      GatherArgs ga;
+      if (look) { ga = gather_args(e, rows, set ^ 1, 1); e->pregather = &ga; }
+      int r = value_apply(e, false, grad_scale, s);
+      e->pregather = nullptr;
+      if (!r && !(r = ph_policy(e, rows, false, false, s, false))) r = ph_finish(e, rows, true, false, s);
+      if (!r) {
+        if (look) use_set(e, set ^ 1);
+        r = head(look);
+        use_set(e, set);
+      }
+      return r;
+    });
+    if (!rc) rc = dp_capture(e, s, &e->gdp[6][set], [&] {
+      int r;
+      if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
+      if (!r) {
+        if (look) use_set(e, set ^ 1);
+        r = head(false);   // the policy step's tail does not look ahead: its own gather, after the cursor tick
+        use_set(e, set);
+      }
+      return r;
+    });
   }
-  return 0;
+  use_set(e, 0);
+  return rc;
 }
 
+extern "C" int recnn_engine_dp_sets(recnn_engine* e) { return e ? e->dp_sets : 1; }
+
 extern "C" int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream) {
-  RECNN_REQUIRE(e && which >= 0 && which < 5 && e->gdp[which], "dp_graph_launch: graph %d not built", which);
-  RECNN_HIP(hipGraphLaunch(e->gdp[which], (hipStream_t)stream));
+  const int kind = which & 7, set = which >> 3;
+  RECNN_REQUIRE(e && which >= 0 && kind < 7 && set < 2 && e->gdp[kind][set], "dp_graph_launch: graph %d not built", which);
+  RECNN_HIP(hipGraphLaunch(e->gdp[kind][set], (hipStream_t)stream));
+  // where the debug views find the batch afterwards: merged graphs (kinds 5, 6) end in the other set's head
+  use_set(e, (kind >= 5 && e->dp_sets == 2) ? (set ^ 1) : set);
   return 0;
 }
 

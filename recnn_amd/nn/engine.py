@@ -243,6 +243,9 @@ class StepEngine:
         L.call("recnn_engine_dp_graph_build", self.handle, rows, float(grad_scale), int(overlap_actor), self._stream())
         self._dp_graphs = True
 
+    def dp_sets(self) -> int:
+        return int(self.lib.recnn_engine_dp_sets(self.handle))
+
     def dp_graph_launch(self, which: int):
         L.call("recnn_engine_dp_graph_launch", self.handle, which, self._stream())
 

@@ -85,6 +85,33 @@ class DataParallelStepper:
             e.policy_apply(True, self.scale)
         e.finish(self.rows, learn, policy)
 
+    def run(self, first: int, n: int, learn: bool = True):
+        """`n` consecutive steps.  With phase graphs (and no overlap mode) the tail of step t and the head of step t+1
+        replay as ONE graph -- one graph launch per step instead of two -- and, when the engine samples its own
+        bf16 batches, the gather of step t+1 rides on step t's critic optimizer launch (two batch buffer sets)."""
+        e = self.engine
+        if n <= 0:
+            return
+        if not (self.graphs and learn) or self.overlap:
+            for t in range(first, first + n):
+                self.step(t, learn)
+            return
+        two = e.dp_sets() == 2
+        s = 0
+        e.dp_graph_launch(0)
+        for i in range(n):
+            t, last = first + i, i == n - 1
+            for ni in e.value_nets():
+                self._allreduce(e.grad_arena(ni))
+            if t % e.policy_every != 0:
+                e.dp_graph_launch((1 if last else 5) + 8 * s)
+            else:
+                e.dp_graph_launch(2 + 8 * s)
+                self._allreduce(e.grad_arena(L.NET_POLICY))
+                e.dp_graph_launch((3 if last else 6) + 8 * s)
+            if two and not last:
+                s ^= 1
+
     def check_replicas(self, tensors) -> float:
         """max |x - mean over ranks| over the given parameter tensors (0 when replicas agree bit for bit)."""
         worst = 0.0

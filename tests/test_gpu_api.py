@@ -140,11 +140,11 @@ def test_module_forward_backward_matches_torch(recnn, cuda):
     assert torch.equal(act(s), act(s))
 
 
-def _env(recnn, cuda, rows_per_batch=None, contiguous=False, n_users=40, seed=2):
+def _env(recnn, cuda, rows_per_batch=None, contiguous=False, n_users=40, seed=2, n_train=32):
     items, ratings, table = make_store(n_users=n_users, n_items=500, emb_dim=128, min_len=11, max_len=90, seed=seed)
     user_dict = {100 + 3 * u: {"items": items[u], "ratings": ratings[u]} for u in range(n_users)}
     ids = list(user_dict.keys())
-    env = recnn.data.env.FrameEnv.from_user_dict(torch.from_numpy(table), user_dict, ids[:32], ids[32:], frame_size=10,
+    env = recnn.data.env.FrameEnv.from_user_dict(torch.from_numpy(table), user_dict, ids[:n_train], ids[n_train:], frame_size=10,
                                                  batch_size=5, device=cuda, rows_per_batch=rows_per_batch,
                                                  contiguous=contiguous)
     return env, user_dict, table
@@ -293,7 +293,7 @@ def test_fused_run_equals_update_loop(recnn, cuda, n_users, policy_step):
     fused context), same fixed row count, hash dropout masks keyed by the same device step counter."""
     from recnn_amd.nn import fused
     fused.set_defaults(dtype="bf16", mask_mode="hash", seed=21)
-    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=n_users, seed=8)
+    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=n_users, seed=8, n_train=32 if n_users == 60 else 864)
     results = []
     for mode in ("fused", "loop"):
         torch.manual_seed(12)
@@ -324,6 +324,48 @@ def test_fused_run_equals_update_loop(recnn, cuda, n_users, policy_step):
     for k in results[0][2]:
         assert torch.equal(results[0][2][k], results[1][2][k]), k
     assert results[0][3] == results[1][3] == n
+
+
+def test_dp_run_with_sampler_equals_fused_run(recnn, cuda):
+    """DataParallelStepper.run (one rank, gloo): merged tail+head phase graphs, two batch buffer sets with the gather of
+    step t+1 riding on step t's optimizer launch == the single-GPU run graphs, bit for bit."""
+    import os
+    import torch.distributed as dist
+    from recnn_amd.nn import fused
+    from recnn_amd.parallel import DataParallelStepper
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29578")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    fused.set_defaults(dtype="bf16", mask_mode="hash", seed=33)
+    env, user_dict, table = _env(recnn, cuda, rows_per_batch=96, n_users=900, seed=8, n_train=864)
+    results = []
+    n = 40
+    for mode in ("fused", "dp"):
+        torch.manual_seed(12)
+        ddpg = recnn.nn.DDPG(recnn.nn.Actor(1290, 128, 256, 6e-1), recnn.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+        ddpg.params["policy_step"] = 3
+        torch.manual_seed(99)
+        ddpg.attach_env(env, rows_per_batch=96, users_per_batch=12)
+        ctx = ddpg._fused_ctx
+        assert ctx.sampler["n_batches"] > n
+        if mode == "fused":
+            ddpg.run(n)
+        else:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                dp = DataParallelStepper(ctx.engine, 96)
+                assert ctx.engine.dp_sets() == 2
+                dp.run(0, n)
+            side.synchronize()
+        torch.cuda.synchronize()
+        lo = ctx.engine.losses()
+        results.append((lo, {k: v.detach().clone() for k, v in ddpg.nets["policy_net"].state_dict().items()},
+                        {k: v.detach().clone() for k, v in ddpg.nets["value_net"].state_dict().items()}))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    for j in (1, 2):
+        for k in results[0][j]:
+            assert torch.equal(results[0][j][k], results[1][j][k]), k
 
 
 def test_optim_adam_matches_torch_adam(recnn, cuda):

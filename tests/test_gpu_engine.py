@@ -319,7 +319,7 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
     gen = torch.Generator().manual_seed(7)
     batch = _rand_batch(B, S, A, gen)
     outs = []
-    for mode in ("fused", "dp_graphs", "dp_graphs_overlap", "dp_eager"):
+    for mode in ("fused", "dp_graphs", "dp_graphs_overlap", "dp_eager", "dp_run"):
         eng = _engine("ddpg", S, A, H, B, "bf16", mask_mode="hash", seed=5)
         eng.load_params(L.NET_POLICY, actor); eng.load_params(L.NET_TARGET_POLICY, actor)
         eng.load_params(L.NET_VALUE1, critic); eng.load_params(L.NET_TARGET_VALUE1, critic)
@@ -332,10 +332,13 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
                 for t in range(5):
                     eng.step(B, True, t)
             else:
-                dp = DataParallelStepper(eng, B, use_graphs=mode.startswith("dp_graphs"),
+                dp = DataParallelStepper(eng, B, use_graphs=mode.startswith("dp_graphs") or mode == "dp_run",
                                          always_reduce=(mode == "dp_graphs_overlap"), overlap=(mode == "dp_graphs_overlap"))
-                for t in range(5):
-                    dp.step(t)
+                if mode == "dp_run":        # tail of step t + head of step t+1 in one graph
+                    dp.run(0, 5)
+                else:
+                    for t in range(5):
+                        dp.step(t)
         side.synchronize()
         torch.cuda.synchronize()
         outs.append((eng.losses(), {k: v.clone() for k, v in eng.param_views(L.NET_POLICY).items()},
