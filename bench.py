@@ -163,6 +163,8 @@ def main():
         L.load().recnn_tune_gemm_dma_waves(int(os.environ["RECNN_DMA_WAVES"]))
     if os.environ.get("RECNN_DMA_DEEP"):
         L.load().recnn_tune_gemm_dma_depth(int(os.environ["RECNN_DMA_DEEP"]))
+    if os.environ.get("RECNN_DEFER_PC"):
+        L.load().recnn_tune_defer_policy_fwd(int(os.environ["RECNN_DEFER_PC"]))
     if os.environ.get("RECNN_PREGATHER"):
         L.load().recnn_tune_pregather(int(os.environ["RECNN_PREGATHER"]))
     if os.environ.get("RECNN_GRAPH_RUN"):

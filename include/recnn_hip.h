@@ -98,6 +98,11 @@ void recnn_tune_graph_run(int steps);
  * t+1 runs as extra workgroups of step t's critic optimizer launch, into a second batch buffer set (bf16 engines that
  * sample their own batches); 0 = every step starts with its own gather launch. */
 void recnn_tune_pregather(int on);
+/* tuning knob (before recnn_engine_graph_build): 1 (default) = inside a run graph the policy-loss forward of an ordinary
+ * step (critic on [pi(s) | s] with the just-updated weights; nothing later depends on it) rides as an extra problem on
+ * the NEXT step's fused forward launch instead of two GEMM launches of its own (DDPG, bf16 sampler engines);
+ * policy steps and the last step of a run keep it in order. */
+void recnn_tune_defer_policy_fwd(int on);
 /* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
  * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
 void recnn_tune_gemm_ks_layout(int tile_fastest);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "recnn_tune_bwd_panel": (None, [_I]),
     "recnn_tune_graph_run": (None, [_I]),
     "recnn_tune_pregather": (None, [_I]),
+    "recnn_tune_defer_policy_fwd": (None, [_I]),
     "recnn_engine_unit_backward": (_I, [_P]),
     "recnn_engine_dp_sets": (_I, [_P]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),

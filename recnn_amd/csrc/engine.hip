@@ -101,7 +101,9 @@ struct recnn_engine {
   int run_t_off[RECNN_NET_COUNT] = {0};    // optimizer steps of each network earlier in the run
   bool run_skip_finish = false;            // not the last step of a run: no finalize launch
   int run_tick[3] = {1, 1, 1};             // increments applied by the finalize: steps, critic steps, actor steps
-  char* gen_action;                        // tc [Bc, Ap]
+  char* gen_action;                        // tc [Bc, Ap] of the current batch buffer set
+  char *gen_action0 = nullptr, *gen_action2 = nullptr;
+  struct PendingPc { bool on = false; int set = 0; int run_off = 0; } pending_pc;  // deferred policy-loss forward (run graphs)
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
   bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
@@ -231,7 +233,9 @@ int64_t carve(recnn_engine* e, char* base) {
   e->dag = c.take(Bc * Ap * es);
   e->dzp2 = c.take(Bc * Hp * es);
   e->dzp1 = c.take(Bc * Hp * es);
-  e->gen_action = c.take(Bc * Ap * es);
+  e->gen_action0 = c.take(Bc * Ap * es);
+  e->gen_action2 = c.take(Bc * Ap * es);
+  e->gen_action = e->gen_action0;
   if (e->bf16) {
     e->xsh = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh = c.take(Bc * (int64_t)e->ldx * 2);
@@ -638,6 +642,8 @@ int check_ready(recnn_engine* e, int rows) {
 
 // ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
 static int g_fused_mlp = 1;
+static int g_defer_policy_fwd = 1;
+extern "C" void recnn_tune_defer_policy_fwd(int on) { g_defer_policy_fwd = on; }
 static int g_pregather = 1;
 extern "C" void recnn_tune_pregather(int on) { g_pregather = on; }
 static int g_sampler_f32_rows = 0;
@@ -796,6 +802,21 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         MlpSpec f{POL, e->xcs + aoff, e->ldx, e->K1a, 0};
         f.h1 = e->pa.h1; f.h2 = e->pa.h2; f.out = e->gen_action; f.ldo = e->Ap; f.mask_idx = actor_m1;
         fl += fill_mlp(e, f, rows, &mb.p[np++]);
+      }
+      if (e->pending_pc.on && np < MLP_MAX_GROUP) {
+        // the policy-loss forward of the PREVIOUS step of this run (critic on [gen_action | state] of that step's
+        // batch, weights as that step's optimizer left them = the current ones) rides here as one more problem: nothing
+        // of this or later steps depends on it, and the launch has idle CUs once its short workgroups are done
+        const auto& pp = e->pending_pc;
+        const char* xs_prev = pp.set ? e->xsh2 : e->xsh;
+        MlpSpec f{RECNN_NET_VALUE1, pp.set ? e->gen_action2 : e->gen_action0, e->Ap, e->Ap, 0};
+        f.A1 = xs_prev + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
+        f.q = e->qpi;
+        f.mask_idx = e->td3 ? 6 : 4;
+        MlpProb* pd = &mb.p[np++];
+        fl += fill_mlp(e, f, rows, pd);
+        pd->step_add = pp.run_off;
+        e->pending_pc.on = false;
       }
       if ((rc = slot(e, "mlp_fwd_nets", fl, s, [&] { return mlp_launch(mb, np, s); }))) return rc;
     }
@@ -1174,8 +1195,10 @@ void use_set(recnn_engine* e, int k) {
     e->xcs = e->bf16 ? e->xsh : (char*)e->xs;
     e->xcn = e->bf16 ? e->xnh : (char*)e->xn;
     e->reward = e->reward0; e->done = e->done0;
+    e->gen_action = e->gen_action0;
   } else {
     e->xcs = e->xsh2; e->xcn = e->xnh2; e->reward = e->reward2; e->done = e->done2;
+    e->gen_action = e->gen_action2;
   }
 }
 bool lookahead_ok(const recnn_engine* e) {
@@ -1236,7 +1259,7 @@ int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
 // pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
 // optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered = false,
-              bool gather_next = false) {
+              bool gather_next = false, bool defer_policy_fwd = false) {
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
@@ -1251,7 +1274,12 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     if (rc) return rc;
   }
   const bool pol = learn && policy_step;
-  if ((rc = ph_policy(e, rows, pol, true, s, !learn))) return rc;
+  if (defer_policy_fwd && !pol && learn) {
+    // run graphs: the next step's forward launch carries this step's policy-loss forward (see ph_forward)
+    e->pending_pc.on = true; e->pending_pc.set = e->cur_set; e->pending_pc.run_off = e->run_off;
+  } else if ((rc = ph_policy(e, rows, pol, true, s, !learn))) {
+    return rc;
+  }
   if (pol && (rc = policy_apply(e, true, 1.0f, s, true))) return rc;
   return ph_finish(e, rows, learn, pol, s);
 }
@@ -1407,9 +1435,13 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
         e->run_skip_finish = i + 1 < run_len;
         if (pol) ++n_pol;
         e->run_tick[0] = run_len; e->run_tick[1] = run_len; e->run_tick[2] = n_pol;
-        rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len);
+        // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
+        // buffer set and room for a 5th problem: DDPG)
+        const bool defer = look && g_defer_policy_fwd && !e->td3 && value_chain_ok(e) && i + 1 < run_len;
+        rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len, defer);
       }
       e->run_off = 0;
+      e->pending_pc.on = false;
       for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
       e->run_skip_finish = false;
       e->run_tick[0] = e->run_tick[1] = e->run_tick[2] = 1;
