@@ -372,6 +372,11 @@ int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int
 int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
 int recnn_engine_dp_sets(recnn_engine* e);
 
+/* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
+ * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
+ * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every
+ * step replayed inside a run graph, whose per-step partial sums are kept and reduced at the end of the run. */
+int recnn_engine_read_counters(recnn_engine* e, int32_t* h_out4, void* stream);
 /* Host copy of the last step's losses (synchronises `stream`):
  * DDPG: {value, policy}; TD3: {value1, value2, policy}.  h_out has room for 4 floats. */
 int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream);

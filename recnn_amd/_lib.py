@@ -106,6 +106,7 @@ SIGNATURES = {
     "recnn_tune_defer_policy_fwd": (None, [_I]),
     "recnn_engine_unit_backward": (_I, [_P]),
     "recnn_engine_dp_sets": (_I, [_P]),
+    "recnn_engine_read_counters": (_I, [_P, _P, _P]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),

@@ -34,6 +34,8 @@
 #include "bwd.h"
 #include "optim.h"
 
+constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
+
 int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s);
 int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s);
 
@@ -114,7 +116,13 @@ struct recnn_engine {
   bool unit_bwd = false;                   // this step's dzc2 / dzc1 hold UNIT backward tensors (to be scaled by delta)
   float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
   int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
-  float *loss_part[3];                     // value1, value2, policy  (per head block)
+  float *loss_part[3];                     // value1, value2, policy  (per head block): the CURRENT step's slot of ...
+  float *loss_part_base[3];                // ... LOSS_HIST_MAX per-step slots (run graphs keep every step's partial sums)
+  int64_t loss_part_stride = 0;
+  float* pl_part_base = nullptr;
+  float* loss_ring = nullptr;              // [LOSS_RING][4] losses of the last LOSS_RING steps, indexed by the device step counter
+  int hist_pol_count[LOSS_HIST_MAX];       // capture-time description of the run being captured
+  unsigned char hist_pol_add[LOSS_HIST_MAX];
   float* losses;                           // device float[4]
   float* coef_out;                         // device float[1]
   int32_t* counters;                       // device int32[8]: step, t_policy, t_value1, t_value2
@@ -249,7 +257,9 @@ int64_t carve(recnn_engine* e, char* base) {
   e->target_q = (float*)c.take(Bc * 4);
   e->qpi = (float*)c.take(Bc * 4);
   e->pl_cap = (int)(2 * Bc);
-  e->pl_part = (float*)c.take((int64_t)e->pl_cap * 4);
+  e->pl_part_base = (float*)c.take((int64_t)LOSS_HIST_MAX * e->pl_cap * 4);
+  e->pl_part = e->pl_part_base;
+  e->loss_ring = (float*)c.take((int64_t)LOSS_RING * 4 * 4);
   for (int i = 0; i < e->n_critic; ++i) {
     e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
     e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
@@ -263,7 +273,8 @@ int64_t carve(recnn_engine* e, char* base) {
     e->q[i] = (float*)c.take(Bc * 4);
     e->delta[i] = (float*)c.take(Bc * 4);
   }
-  for (int i = 0; i < 3; ++i) e->loss_part[i] = (float*)c.take(nblk_head * 4);
+  e->loss_part_stride = nblk_head;
+  for (int i = 0; i < 3; ++i) { e->loss_part_base[i] = (float*)c.take((int64_t)LOSS_HIST_MAX * nblk_head * 4); e->loss_part[i] = e->loss_part_base[i]; }
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) {
     if (!net_used(e, ni) || !net_learns(ni)) continue;
     Net& n = e->net[ni];
@@ -540,7 +551,7 @@ struct FwdSpec {
   int relu;
   int mask_idx;         // -1 = none
   const float* addend = nullptr; int64_t ld_add = 0; float add_clip = 0.f;
-  const float* dot_w = nullptr; float* dot_part = nullptr;
+  const float* dot_w = nullptr; const float* dot_bias = nullptr; float* dot_part = nullptr;
 };
 
 double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) {
@@ -576,7 +587,7 @@ double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) 
     }
   }
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
-  p->dot_w = f.dot_w; p->dot_part = f.dot_part;
+  p->dot_w = f.dot_w; p->dot_bias = f.dot_bias; p->dot_part = f.dot_part;
   const double kreal = f.layer == 1 ? n.in_dim : e->H;
   return 2.0 * rows * p->N * kreal;
 }
@@ -811,7 +822,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         const char* xs_prev = pp.set ? e->xsh2 : e->xsh;
         MlpSpec f{RECNN_NET_VALUE1, pp.set ? e->gen_action2 : e->gen_action0, e->Ap, e->Ap, 0};
         f.A1 = xs_prev + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
-        f.q = e->qpi;
+        f.q = e->pl_part_base + (int64_t)pp.run_off * e->pl_cap;   // that step's policy-loss slot: Q per row, b3 included
         f.mask_idx = e->td3 ? 6 : 4;
         MlpProb* pd = &mb.p[np++];
         fl += fill_mlp(e, f, rows, pd);
@@ -1068,12 +1079,13 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     Group g(e, GEMM_FWD, 0, 0);
     FwdSpec f{V1, 2, e->pc.h1, Hp, 0, Hp};
     f.C = e->pc.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0 + 1;
-    if (use_dot) { f.dot_w = e->net[V1].p + e->net[V1].off[W3]; f.dot_part = e->pl_part; }
+    if (use_dot) { f.dot_w = e->net[V1].p + e->net[V1].off[W3]; f.dot_bias = e->net[V1].p + e->net[V1].off[B3]; f.dot_part = e->pl_part; }
     g.flops += fill_fwd(e, f, rows, g.add());
     if ((rc = g.run(s, "fwd_l2_pcritic"))) return rc;
     if (use_dot) {
       e->pl_dot_parts = g.L.batch.p[0].dot_parts;
       RECNN_REQUIRE(e->pl_dot_parts > 0 && e->pl_dot_parts <= e->pl_cap, "policy loss: %d partial sums do not fit %d", e->pl_dot_parts, e->pl_cap);
+      if (e->run_off < LOSS_HIST_MAX) { e->hist_pol_count[e->run_off] = e->pl_dot_parts; e->hist_pol_add[e->run_off] = 0; }
     }
   }
   }
@@ -1140,10 +1152,8 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   const int nval = value_panel_ok(e) ? (rows + BWD_ROWS - 1) / BWD_ROWS : nblk;
   for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nval; a.scale[c] = 1.0f / (float)rows; }
   a.part[nc] = e->loss_part[2]; a.n_part[nc] = nblk; a.scale[nc] = -1.0f / (float)rows;
-  if (e->pl_dot_parts > 0) {  // policy loss = -(sum of the layer-2 epilogue's partial dots / B + b3)
-    const Net& v = e->net[RECNN_NET_VALUE1];
+  if (e->pl_dot_parts > 0) {  // policy loss = -(sum of the layer-2 epilogue's partial dots, b3 included) / B
     a.part[nc] = e->pl_part; a.n_part[nc] = e->pl_dot_parts;
-    a.add_ptr[nc] = v.p + v.off[B3]; a.add_scale[nc] = -1.0f;
   }
   a.n = nc + 1;
   a.out = e->losses;
@@ -1156,6 +1166,20 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   const bool run_final = e->run_tick[0] > 1;  // last step of a run graph: the actor took run_tick[2] steps during the run
   if (run_final ? e->run_tick[2] > 0 : ticked_policy) { a.tick_inc[a.n_tick] = e->run_tick[2]; a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr; }
   if (e->has_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; a.wrap_inc = e->run_tick[0]; }
+  a.ring = e->loss_ring; a.ring_mask = LOSS_RING - 1;
+  if (run_final && value_panel_ok(e) && e->run_off >= 1 && e->run_off < LOSS_HIST_MAX) {
+    // losses of the run's earlier steps from their kept partial sums (the step counter is not ticked yet)
+    LossHistoryArgs h;
+    memset(&h, 0, sizeof(h));
+    h.n_steps = e->run_off; h.n = nc + 1;
+    for (int c = 0; c < nc; ++c) { h.part[c] = e->loss_part_base[c]; h.stride[c] = e->loss_part_stride; h.n_part[c] = nval; h.scale[c] = 1.0f / (float)rows; }
+    h.part[nc] = e->pl_part_base; h.stride[nc] = e->pl_cap; h.scale[nc] = -1.0f / (float)rows;
+    for (int i = 0; i < e->run_off; ++i) { h.pol_count[i] = e->hist_pol_count[i]; h.pol_add[i] = e->hist_pol_add[i]; }
+    h.b3 = e->net[RECNN_NET_VALUE1].p + e->net[RECNN_NET_VALUE1].off[B3];
+    h.step_ctr = e->counters; h.ring = e->loss_ring; h.ring_mask = LOSS_RING - 1;
+    int hrc = slot(e, "loss_history", 0, s, [&] { return loss_history_launch(h, s); }, false);
+    if (hrc) return hrc;
+  }
   return slot(e, "loss_finalize", 0, s, [&] { return loss_finalize_launch(a, s); }, false);
 }
 
@@ -1186,6 +1210,12 @@ int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bo
   // TD3 never soft-updates the target policy (td3.py:136-141); DDPG does (ddpg.py:98-100).
   const int tgt = (soft && !e->td3) ? RECNN_NET_TARGET_POLICY : -1;
   return apply_net(e, RECNN_NET_POLICY, 0, true, 0, grad_scale, true, tgt, e->hy.soft_tau, s);
+}
+
+// per-step slot of the loss partial sums (run graphs: step i of the run; everything else: slot 0)
+void use_hist_slot(recnn_engine* e, int i) {
+  for (int c = 0; c < 3; ++c) e->loss_part[c] = e->loss_part_base[c] + (int64_t)i * e->loss_part_stride;
+  e->pl_part = e->pl_part_base + (int64_t)i * e->pl_cap;
 }
 
 // batch buffer set k (0: the bound / first set, 1: the look-ahead set of bf16 sampler mode)
@@ -1277,6 +1307,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   if (defer_policy_fwd && !pol && learn) {
     // run graphs: the next step's forward launch carries this step's policy-loss forward (see ph_forward)
     e->pending_pc.on = true; e->pending_pc.set = e->cur_set; e->pending_pc.run_off = e->run_off;
+    e->hist_pol_count[e->run_off] = rows; e->hist_pol_add[e->run_off] = 0;
   } else if ((rc = ph_policy(e, rows, pol, true, s, !learn))) {
     return rc;
   }
@@ -1342,6 +1373,13 @@ extern "C" int recnn_engine_soft_update(recnn_engine* e, int ni, int target_ni, 
 extern "C" int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy_stepped, void* stream) {
   RECNN_REQUIRE(e && rows > 0, "finish: bad arguments");
   return ph_finish(e, rows, value_stepped != 0, policy_stepped != 0, (hipStream_t)stream);
+}
+
+extern "C" int recnn_engine_read_counters(recnn_engine* e, int32_t* h_out, void* stream) {
+  RECNN_REQUIRE(e && h_out, "read_counters: null pointer");
+  RECNN_HIP(hipMemcpyAsync(h_out, e->counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
 }
 
 extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream) {
@@ -1431,6 +1469,8 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
         if (look) use_set(e, i & 1);
         // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
         e->run_off = i;
+        use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
+        e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
         for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
         e->run_skip_finish = i + 1 < run_len;
         if (pol) ++n_pol;
@@ -1441,6 +1481,7 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
         rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len, defer);
       }
       e->run_off = 0;
+      use_hist_slot(e, 0);
       e->pending_pc.on = false;
       for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
       e->run_skip_finish = false;
@@ -1602,7 +1643,7 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
       {"q1", e->q[0], 1, 1, 1},                    {"q2", e->q[1], 1, 1, 1},
       {"delta1", e->delta[0], 1, 1, 1},            {"delta2", e->delta[1], 1, 1, 1},
       {"q_pi", e->qpi, 1, 1, 1},                   {"losses", e->losses, 4, 4, 1},
-      {"clip_coef", e->coef_out, 1, 1, 1},
+      {"clip_coef", e->coef_out, 1, 1, 1},         {"loss_ring", e->loss_ring, 4, 4, 1},
       {"critic1_h1", e->cv[0].h1, e->H, Hp, 0},    {"critic1_h2", e->cv[0].h2, e->H, Hp, 0},
       {"actor_h1", e->pa.h1, e->H, Hp, 0},         {"actor_h2", e->pa.h2, e->H, Hp, 0},
       {"critic1_dz2", e->dzc2[0], e->H, Hp, 0},    {"critic1_dz1", e->dzc1[0], e->H, Hp, 0},
@@ -1613,7 +1654,7 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
   };
   for (const Ent& t : tab)
     if (!strcmp(t.n, name)) {
-      if (rows) *rows = (!strcmp(name, "losses") || !strcmp(name, "clip_coef")) ? 1 : e->cfg.max_rows;
+      if (rows) *rows = (!strcmp(name, "losses") || !strcmp(name, "clip_coef")) ? 1 : (!strcmp(name, "loss_ring") ? LOSS_RING : e->cfg.max_rows);
       if (cols) *cols = t.c;
       if (ld) *ld = t.l;
       if (is_f32) *is_f32 = t.f;

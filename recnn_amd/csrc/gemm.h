@@ -35,6 +35,7 @@ struct GemmProb {
   // forward epilogue, optional: partial sums of sum_{m,n} C[m][n] * dot_w[n] (C as stored, i.e. rounded to the output
   // type), one per wave: dot_part[workgroup * waves + wave]; the launcher sets dot_parts to their number
   const float* dot_w;
+  const float* dot_bias;   // optional scalar added once per output row (the N = 1 layer's bias, read at launch time)
   float* dot_part;
   int dot_parts;
   // dX epilogue

@@ -221,6 +221,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
                 if constexpr (sizeof(TC) == 2) v = bf2f(f2bf(v));  // the value a consumer of C would read
               }
               sdot += v * dw;
+              if (n == 0 && P.dot_bias) sdot += P.dot_bias[0];
             }
           }
         }

@@ -52,7 +52,28 @@ struct LossFinalizeArgs {
   int tick_inc[6];     // *tick[i] += tick_inc[i]
   int32_t* wrap_ptr;  // sampler cursor: *wrap_ptr = (*wrap_ptr + wrap_inc) % wrap_mod
   int wrap_mod, wrap_inc;
+  float* ring;        // optional loss history ring [ring_mask + 1][4]: entry (old *tick[0] + tick_inc[0] - 1) & ring_mask
+  int ring_mask;
 };
+
+// Losses of the earlier steps of a run graph (their partial sums were kept per step; the run's last step is
+// finalized by loss_finalize_kernel): one workgroup per step, written into the same history ring.
+constexpr int LOSS_HIST_MAX = 64;
+struct LossHistoryArgs {
+  int n_steps;                 // steps 0 .. n_steps-1 of the run
+  int n;                       // losses per step (<= 4); index n-1 is the policy loss
+  const float* part[4];        // step 0's partial sums
+  int64_t stride[4];           // floats between consecutive steps
+  int n_part[4];
+  float scale[4];
+  int pol_count[LOSS_HIST_MAX];          // per step: number of policy-loss partials ...
+  unsigned char pol_add[LOSS_HIST_MAX];  // ... and whether -b3 still has to be added (GEMM-epilogue partial dots)
+  const float* b3;
+  const int32_t* step_ctr;     // device step counter, not yet ticked for this run
+  float* ring;
+  int ring_mask;
+};
+int loss_history_launch(const LossHistoryArgs& a, hipStream_t s);
 
 int head_launch(const HeadArgs& a, hipStream_t s);
 int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s);

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
   // the counter updates ride on separate lanes of the last wave so that every global read-modify-write of this
   // single-workgroup, latency-only kernel is in flight at the same time.
   __shared__ float red[4][4];
+  __shared__ int s_old;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = 255 - (int)threadIdx.x;  // 0..n_tick-1: tick counters, n_tick: sampler cursor
   int32_t* cnt = nullptr;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
   if (slot < a.n_tick) cnt = a.tick[slot];
   else if (slot == a.n_tick) cnt = a.wrap_ptr;
   if (cnt) cv = *cnt;
+  if (slot == 0) s_old = cv;   // tick[0] is the step counter
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -277,8 +279,46 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
   if ((int)threadIdx.x < a.n) {
     const int c = threadIdx.x;
     const float s = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
-    a.out[c] = s * a.scale[c] + (a.add_ptr[c] ? a.add_scale[c] * a.add_ptr[c][0] : 0.f);
+    const float v = s * a.scale[c] + (a.add_ptr[c] ? a.add_scale[c] * a.add_ptr[c][0] : 0.f);
+    a.out[c] = v;
+    if (a.ring && a.n_tick > 0) a.ring[(int64_t)((s_old + a.tick_inc[0] - 1) & a.ring_mask) * 4 + c] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void loss_history_kernel(const LossHistoryArgs a) {
+  __shared__ float red[4][4];
+  const int j = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < a.n) {
+      const float* __restrict__ part = a.part[c] + (int64_t)j * a.stride[c];
+      const int n = c == a.n - 1 ? a.pol_count[j] : a.n_part[c];
+      float s0 = 0.f;
+      for (int i = threadIdx.x; i < n; i += 256) s0 += part[i];
+      acc[c] = s0;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < a.n) {
+      const float t = wave_sum(acc[c]);
+      if (lane == 0) red[c][wave] = t;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.n) {
+    const int c = threadIdx.x;
+    float v = ((red[c][0] + red[c][1]) + (red[c][2] + red[c][3])) * a.scale[c];
+    if (c == a.n - 1 && a.pol_add[j]) v -= a.b3[0];
+    a.ring[(int64_t)((*a.step_ctr + j) & a.ring_mask) * 4 + c] = v;
+  }
+}
+
+int loss_history_launch(const LossHistoryArgs& a, hipStream_t s) {
+  if (a.n_steps <= 0) return 0;
+  hipLaunchKernelGGL(loss_history_kernel, dim3(a.n_steps), dim3(256), 0, s, a);
+  return recnn_check_hip(hipGetLastError(), "loss_history_kernel");
 }
 
 int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s) {

@@ -80,8 +80,10 @@ class Algo:
         self._fused_ctx, self._fused_keys = ctx, keys
         return self
 
-    def run(self, n_steps: int):
-        """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync)."""
+    def run(self, n_steps: int, history: bool = False):
+        """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync).
+        history=True: returns (last losses, [losses of each of the n_steps steps]) -- what the reference's loop would
+        have collected from `update()` step by step (kept on the device, up to 1024 steps back)."""
         ctx = getattr(self, "_fused_ctx", None)
         if ctx is None:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
@@ -95,6 +97,11 @@ class Algo:
             ctx.bump(self.optimizers[k], ni, n_policy if ni == fused.L.NET_POLICY else n_steps)
         losses = ctx.engine.losses()
         losses["step"] = self._step - 1
+        if history:
+            hist = ctx.engine.loss_history(min(n_steps, 1024))
+            for i, h in enumerate(hist):
+                h["step"] = self._step - len(hist) + i
+            return losses, hist
         return losses
 
 

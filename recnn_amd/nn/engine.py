@@ -255,6 +255,22 @@ class StepEngine:
     def graph_run(self, first_step: int, n_steps: int):
         L.call("recnn_engine_graph_run", self.handle, first_step, n_steps, self._stream())
 
+    def counters(self):
+        """(steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps) as the device counts them."""
+        h = (C.c_int32 * 4)()
+        L.call("recnn_engine_read_counters", self.handle, h, self._stream())
+        return tuple(int(x) for x in h)
+
+    def loss_history(self, n_steps: int):
+        """Losses of the last `n_steps` (<= 1024) steps, oldest first -- also of steps replayed inside run graphs."""
+        end = self.counters()[0]
+        ring = self.buffer("loss_ring", 1024)
+        out = []
+        for st in range(end - n_steps, end):
+            v = ring[st % 1024].tolist()
+            out.append({"value1": v[0], "value2": v[1], "policy": v[2]} if self.td3 else {"value": v[0], "policy": v[1]})
+        return out
+
     def losses(self):
         """Synchronises the stream and returns the last step's losses as python floats."""
         L.call("recnn_engine_read_losses", self.handle, self._losses_host, self._stream())

@@ -305,9 +305,10 @@ def test_fused_run_equals_update_loop(recnn, cuda, n_users, policy_step):
         n = ctx.sampler["n_batches"]
         assert n == len(env.base.train_user_dataset.users) // 12
         if mode == "fused":
-            out = ddpg.run(n)
-            assert out["step"] == n - 1 and ddpg._step == n
+            out, hist = ddpg.run(n, history=True)
+            assert out["step"] == n - 1 and ddpg._step == n and len(hist) == n
         else:
+            hist = []
             perm = ctx.perm.cpu().numpy()
             ids = env.store.user_ids
             ctx.engine.unbind_sampler()
@@ -316,14 +317,23 @@ def test_fused_run_equals_update_loop(recnn, cuda, n_users, policy_step):
                 batch = env.collate_users(users)
                 assert batch["state"].shape[0] == 96
                 out = ddpg.update(batch, learn=True)
+                hist.append(dict(out))
                 ddpg.step()
         torch.cuda.synchronize()
+        histories = locals().get("histories", [])
+        histories.append(hist)
         results.append((out["value"], out["policy"], {k: v.detach().clone() for k, v in ddpg.nets["policy_net"].state_dict().items()},
                         int(ddpg.optimizers["value_optimizer"].state[ddpg.nets["value_net"].linear1.weight]["step"])))
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     for k in results[0][2]:
         assert torch.equal(results[0][2][k], results[1][2][k]), k
     assert results[0][3] == results[1][3] == n
+    # per-step losses kept on the device during the replay == what update() returned step by step (summation order of
+    # the final reductions differs: relative 1e-5)
+    for a, b in zip(histories[0], histories[1]):
+        assert a["step"] == b["step"]
+        for k in ("value", "policy"):
+            assert abs(a[k] - b[k]) <= 1e-5 * max(abs(b[k]), 1.0), (a, b)
 
 
 def test_dp_run_with_sampler_equals_fused_run(recnn, cuda):
