@@ -337,8 +337,12 @@ int recnn_engine_soft_update(recnn_engine* e, int net, int target_net, float tau
  * and advances the device step / optimizer counters. */
 int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy_stepped, void* stream);
 
-/* Capture `recnn_engine_step` for a fixed row count into two hipGraphs (policy / non-policy
- * step) and replay `n_steps` consecutive steps starting at `first_step`. */
+/* Capture `recnn_engine_step` for a fixed row count into hipGraphs -- one ordinary step, one policy step, and a RUN
+ * graph of whole policy cycles (up to 64 steps, see recnn_tune_graph_run) -- and replay `n_steps` consecutive steps
+ * starting at `first_step`, using the run graph wherever the step kinds line up.  Inside a run graph the device
+ * counters are ticked once at its end, the sampler + gather of step t+1 and the policy-loss forward of step t ride on
+ * other launches (recnn_tune_pregather, recnn_tune_defer_policy_fwd), and every step's losses land in the history ring
+ * (recnn_engine_read_counters). */
 int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
 int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream);
 
