@@ -166,7 +166,7 @@ def test_ddpg_full_b32_matches_reference_losses(cuda, golden_dir):
             assert abs(float(got[k].double().abs().sum()) - ref_sum) <= FP32_RTOL * ref_sum + 1e-6, (tag, k)
 
 
-@pytest.mark.parametrize("dtype,B", [("fp32", 2048), ("bf16", 2048), ("fp32", 333)])
+@pytest.mark.parametrize("dtype,B", [("fp32", 2048), ("bf16", 2048), ("fp32", 333), ("bf16", 333)])
 def test_ddpg_vs_oracle(cuda, dtype, B):
     """configs[1] shape: B=2048, S=1290, A=128, H=256; 12 steps (two policy steps) with identical masks."""
     from recnn_amd import _lib as L
