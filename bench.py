@@ -169,6 +169,8 @@ def main():
         L.load().recnn_tune_pregather(int(os.environ["RECNN_PREGATHER"]))
     if os.environ.get("RECNN_GRAPH_RUN"):
         L.load().recnn_tune_graph_run(int(os.environ["RECNN_GRAPH_RUN"]))
+    if os.environ.get("RECNN_POLICY_CHAIN"):
+        L.load().recnn_tune_policy_chain(int(os.environ["RECNN_POLICY_CHAIN"]))
     if os.environ.get("RECNN_BWD_PANEL"):
         L.load().recnn_tune_bwd_panel(int(os.environ["RECNN_BWD_PANEL"]))
     if os.environ.get("RECNN_CHAIN_TC"):

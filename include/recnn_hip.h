@@ -90,6 +90,10 @@ void recnn_tune_chain_target_critic(int on);
  * hand-off slots), and the dW launch applies the per-row seed d and adds the bias / last-layer partial sums;
  * 1 = one row-panel launch (bwd.hip); 0 = head kernel + dX GEMM launch. */
 void recnn_tune_bwd_panel(int on);
+/* tuning knob: 1 (default) = on policy steps of the fused bf16 path the gradient chain from the policy loss back into the
+ * actor (dz_e2 -> dz_e1 -> dact -> dz_p2 -> dz_p1 with their bias partial sums) runs as ONE row-panel launch; 0 = the
+ * row-panel launch for the first two links + one dX GEMM launch per remaining link. */
+void recnn_tune_policy_chain(int on);
 /* tuning knob (before recnn_engine_graph_build): steps per "run" graph. -1 (default) = as many whole policy cycles
  * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of
  * 16 ordinary steps; 0 = single-step graphs only. */

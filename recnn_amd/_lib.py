@@ -101,6 +101,7 @@ SIGNATURES = {
     "recnn_tune_dw_dma": (None, [_I]),
     "recnn_tune_chain_target_critic": (None, [_I]),
     "recnn_tune_bwd_panel": (None, [_I]),
+    "recnn_tune_policy_chain": (None, [_I]),
     "recnn_tune_graph_run": (None, [_I]),
     "recnn_tune_pregather": (None, [_I]),
     "recnn_tune_defer_policy_fwd": (None, [_I]),

@@ -41,5 +41,34 @@ struct BwdPanelBatch {
   BwdPanelProb p[BWD_MAX_GROUP];
 };
 
+// The whole gradient chain from the policy loss back into the actor for one 32-row panel (policy steps):
+//   dz_e2 = d * w3c * s * [e2 > 0]          d = -1/B           (critic layer 3, ddpg.py:79)
+//   dz_e1 = (dz_e2 W2c) * s * [e1 > 0]                          (critic layer 2)
+//   dact  =  dz_e1 W1c[:, action columns]        -> db3 partial (critic layer 1 into the action = actor layer 3 output)
+//   dz_p2 = (dact W3a) * s * [p2 > 0]            -> db2 partial (actor layer 3 -> 2)
+//   dz_p1 = (dz_p2 W2a) * s * [p1 > 0]           -> db1 partial (actor layer 2 -> 1)
+// dact, dz_p2, dz_p1 go to global memory (A operands of the actor's dW GEMMs); the critic's dz stay on chip.
+struct BwdChainArgs {
+  int rows, H, A;
+  float delta_const, scale;
+  int64_t ldh;              // pitch of the [rows, 256] bf16 activation / dz buffers
+  const void* e2;           // policy-critic h2, h1 (bf16)
+  const void* e1;
+  const float* w3c;         // critic last layer, fp32 [H]
+  const void* W2c; int64_t ldw2c;     // bf16 shadows, rows = out index
+  const void* W1c; int64_t ldw1c;     // action columns are columns 0 .. A-1
+  const void* W3a; int64_t ldw3a;     // [A rows, ld]
+  const void* W2a; int64_t ldw2a;
+  const void* p2;           // actor h2, h1
+  const void* p1;
+  void* dact; int64_t ldact;          // bf16 [rows, ldact]
+  void* dzp2;
+  void* dzp1;
+  float* db3_part;          // [panels][A]
+  float* db2_part;          // [panels][H]
+  float* db1_part;          // [panels][H]
+};
+int bwd_chain_launch(const BwdChainArgs& a, hipStream_t s);
+
 int bwd_init();
 int bwd_panel_launch(const BwdPanelBatch& b, int nprob, hipStream_t s);

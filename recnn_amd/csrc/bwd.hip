@@ -207,9 +207,196 @@ __global__ __launch_bounds__(NW * 64) void bwd_panel_kernel(const BwdPanelBatch 
   }
 }
 
+// ------------------------------------------------------------------ policy-gradient chain (policy steps)
+// Seven weight k-slabs (<= 64 KB each) stream through two LDS slots while four GEMMs run back to back on a 32-row
+// panel that never leaves the CU.  Slab s of a B operand with n columns holds 128 k rows x n bf16; 32-byte segment q of
+// row k sits at segment position q ^ g(k) (g as above), so transpose reads are conflict free for n = 256 and n = 128.
+namespace {
+constexpr int CH_SLOT = 64 * 1024;
+constexpr int CH_PANEL = 2 * CH_SLOT;           // two ping-pong panels of 32 x 256 bf16 (16 KB each)
+constexpr int CH_PANEL_BYTES = 2 * PANEL_HALF;
+constexpr int CH_LDS = CH_PANEL + 2 * CH_PANEL_BYTES;   // 160 KB
+
+struct ChSlab { const void* W; int64_t ld; int k0; int krows; int ncols; int col0; };
+
+// k rows [k0, k0 + krows) x ncols columns (from column col0) -> LDS slab; one wave instruction = 1024 bytes
+__device__ __forceinline__ void ch_dma_slab(const ChSlab& S, int k_max, unsigned lds_dst, int wave, int lane) {
+  const int rpi = S.ncols == 256 ? 2 : 4;            // rows per wave instruction
+  const int cpr = S.ncols / 8;                        // 16-byte chunks per row (32 or 16)
+  const int r_in = lane / cpr, slot = lane % cpr;
+  const int n_instr = S.krows / rpi;
+  for (int j = wave; j < n_instr; j += NW) {
+    const int row = j * rpi + r_in;
+    const int g = (row & 3) | (((row >> 3) & 1) << 2);
+    const int c = (((slot >> 1) ^ g) << 1) | (slot & 1);
+    const int gk = min(S.k0 + row, k_max);
+    dma16((const char*)S.W + ((int64_t)gk * S.ld + S.col0) * 2 + c * 16, lds_dst + j * 1024);
+  }
+}
+
+// acc += panel(32 x 128 k, half `half` of the panel) x slab (128 k rows x ncols); wave owns columns [16 wave, +16)
+__device__ __forceinline__ void ch_mma(const unsigned char* panel, int half, const unsigned char* slab, int row_bytes, int krows,
+                                       f32x4 (&acc)[2], int wave, int fr, int fg) {
+  const unsigned char* sa = panel + half * PANEL_HALF;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks * 32 >= krows) break;
+    const int pos = ((ks * 4 + fg) ^ fr) * 16;
+    uint4 a[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + pos);
+    v4s16 b[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int k = ks * 32 + fg * 8 + hh * 4 + (fr >> 2);
+      const int g = (k & 3) | (((k >> 3) & 1) << 2);
+      b[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) v4s16*)(slab + k * row_bytes + ((wave ^ g) * 32) + (fr & 3) * 8));
+    }
+    struct { v4s16 lo, hi; } bv = {b[0], b[1]};
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+      acc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]), __builtin_bit_cast(bf16x8, bv), acc[tm], 0, 0, 0);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(NW * 64) void bwd_chain_kernel(const BwdChainArgs P) {
+  const int m0 = blockIdx.x * BWD_ROWS;
+  if (m0 >= P.rows) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // the seven slabs in consumption order
+  const ChSlab slabs[7] = {
+      {P.W2c, P.ldw2c, 0, 128, 256, 0}, {P.W2c, P.ldw2c, 128, 128, 256, 0},   // stage 1: K = 256 (out of critic L2), N = 256
+      {P.W1c, P.ldw1c, 0, 128, 128, 0}, {P.W1c, P.ldw1c, 128, 128, 128, 0},   // stage 2: K = 256 (out of critic L1), N = 128 action columns
+      {P.W3a, P.ldw3a, 0, 128, 256, 0},                                         // stage 3: K = 128 (actor outputs), N = 256
+      {P.W2a, P.ldw2a, 0, 128, 256, 0}, {P.W2a, P.ldw2a, 128, 128, 256, 0}};  // stage 4
+  const int kmax[7] = {HP - 1, HP - 1, HP - 1, HP - 1, 127, HP - 1, HP - 1};
+  ch_dma_slab(slabs[0], kmax[0], lds0, wave, lane);
+  ch_dma_slab(slabs[1], kmax[1], lds0 + CH_SLOT, wave, lane);
+
+  // gates of the three gated stages for this lane's accumulator elements (column 16 wave + fr, rows tm*16 + fg*4 + r)
+  const int n = wave * 16 + fr;
+  const int ncl = min(n, P.H - 1);
+  uint32_t gate_e1 = 0, gate_p2 = 0, gate_p1 = 0;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mm = min(m0 + tm * 16 + fg * 4 + r, P.rows - 1);
+      const int64_t off = (int64_t)mm * P.ldh + ncl;
+      if (bf2f(((const bf16_t*)P.e1)[off]) > 0.f) gate_e1 |= 1u << (tm * 4 + r);
+      if (bf2f(((const bf16_t*)P.p2)[off]) > 0.f) gate_p2 |= 1u << (tm * 4 + r);
+      if (bf2f(((const bf16_t*)P.p1)[off]) > 0.f) gate_p1 |= 1u << (tm * 4 + r);
+    }
+
+  // ---- stage 0: dz_e2 panel from e2 (thread: row lane & 31, 8 columns)
+  unsigned char* panel[2] = {lds + CH_PANEL, lds + CH_PANEL + CH_PANEL_BYTES};
+  {
+    const int row = lane & 31, m = m0 + row, mc = min(m, P.rows - 1);
+    const int n8 = (2 * wave + (lane >> 5)) * 8;
+    const int nb = min(n8, P.H - 8);
+    uint4 raw = *(const uint4*)((const bf16_t*)P.e2 + (int64_t)mc * P.ldh + n8);
+    if (m >= P.rows) raw = make_uint4(0, 0, 0, 0);
+    const float4 w3a = *(const float4*)(P.w3c + nb), w3b = *(const float4*)(P.w3c + nb + 4);
+    const float wsc = n8 < P.H ? P.scale * P.delta_const : 0.f;
+    const float w3v[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    float dz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
+      dz[j] = hv > 0.f ? w3v[j] : 0.f;
+    }
+    *(uint4*)(panel[0] + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16)) =
+        make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+  }
+
+  f32x4 acc[2];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // stage of each slab, whether it is the stage's last slab, which half of the A panel it multiplies
+  const int st_of[7] = {1, 1, 2, 2, 3, 4, 4};
+  const int last_of[7] = {0, 1, 0, 1, 1, 0, 1};
+  const int half_of[7] = {0, 1, 0, 1, 0, 0, 1};
+  int cur = 0;   // panel holding the current stage's A operand
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    // slab i has landed once only the (at most one) younger slab's DMAs are outstanding
+    if (i + 1 < 7) {
+      // instructions per wave of the younger slab: krows / rows-per-instr / NW
+      const int ni_next = (slabs[i + 1].krows / (slabs[i + 1].ncols == 256 ? 2 : 4)) / NW;
+      if (ni_next == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const int stage = st_of[i];
+    const int ncols = slabs[i].ncols;
+    if (wave * 16 < ncols)
+      ch_mma(panel[cur], half_of[i], lds + (i & 1) * CH_SLOT, ncols * 2, slabs[i].krows, acc, wave, fr, fg);
+    if (last_of[i]) {
+      // ---- stage epilogue: gate, column sums, global store, next panel
+      const uint32_t gate = stage == 1 ? gate_e1 : (stage == 3 ? gate_p2 : (stage == 4 ? gate_p1 : 0xFFu));
+      const float sc = stage == 2 ? 1.0f : P.scale;
+      const int nvalid = stage == 2 ? P.A : P.H;
+      bf16_t* gout = stage == 2 ? (bf16_t*)P.dact : (stage == 3 ? (bf16_t*)P.dzp2 : (stage == 4 ? (bf16_t*)P.dzp1 : nullptr));
+      const int64_t ldg = stage == 2 ? P.ldact : P.ldh;
+      float* cpart = stage == 2 ? P.db3_part : (stage == 3 ? P.db2_part : (stage == 4 ? P.db1_part : nullptr));
+      unsigned char* nxt = panel[cur ^ 1];
+      float cs = 0.f;
+      if (wave * 16 < ncols) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tm * 16 + fg * 4 + r, mm = m0 + row;
+            float v = ((gate >> (tm * 4 + r)) & 1u) ? acc[tm][r] * sc : 0.f;
+            if (mm >= P.rows || n >= nvalid) v = 0.f;
+            cs += v;
+            const bf16_t hv = f2bf(v);
+            if (gout && mm < P.rows && n < nvalid) gout[(int64_t)mm * ldg + n] = hv;
+            if (stage < 4) *(bf16_t*)(nxt + (n >> 7) * PANEL_HALF + row * 256 + ((((n & 127) >> 3) ^ (row & 15)) * 16) + (n & 7) * 2) = hv;
+          }
+        if (cpart) {
+          cs += __shfl_xor(cs, 16, 64);
+          cs += __shfl_xor(cs, 32, 64);
+          if (fg == 0 && n < nvalid) cpart[(int64_t)blockIdx.x * nvalid + n] = cs;
+        }
+      }
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      cur ^= 1;
+    }
+    if (i + 2 < 7) {
+      __builtin_amdgcn_s_barrier();   // every wave is done reading slot i & 1
+      ch_dma_slab(slabs[i + 2], kmax[i + 2], lds0 + (i & 1) * CH_SLOT, wave, lane);
+    }
+  }
+}
+
+int bwd_chain_launch(const BwdChainArgs& a, hipStream_t s) {
+  if (a.rows <= 0) return 0;
+  if (a.H > HP || a.A > 128 || (a.H % 8) || (a.A % 8) || a.ldh < HP || (a.ldh % 8) || a.ldact < 128 || (a.ldact % 8)) {
+    recnn_set_error("bwd_chain: needs hidden <= 256, action_dim <= 128 (multiples of 8) and padded pitches");
+    return RECNN_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(bwd_chain_kernel, dim3((a.rows + BWD_ROWS - 1) / BWD_ROWS), dim3(NW * 64), CH_LDS, s, a);
+  return recnn_check_hip(hipGetLastError(), "bwd_chain_kernel");
+}
+
 int bwd_init() {
-  return recnn_check_hip(hipFuncSetAttribute((const void*)bwd_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
-                         "bwd_panel_kernel attr");
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)bwd_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+                           "bwd_panel_kernel attr");
+  if (rc) return rc;
+  return recnn_check_hip(hipFuncSetAttribute((const void*)bwd_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS),
+                         "bwd_chain_kernel attr");
 }
 
 int bwd_panel_launch(const BwdPanelBatch& b, int nprob, hipStream_t s) {

@@ -667,6 +667,8 @@ extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
 int g_chain_target_critic = 1;
 extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic = on; }
 
+int g_policy_chain = 1;
+extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
 int g_bwd_panel = 2;  // 0: head + dX launches, 1: row-panel launch (bwd.hip), 2: inside the critic's forward workgroup (mlp.hip)
 extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
 
@@ -1054,6 +1056,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
   const bool use_dot = !need_rows && value_panel_ok(e) && !fused_mlp_ok(e, 1);
+  bool chain_done = false;
   e->pl_dot_parts = 0;
   if (fused_mlp_ok(e, 1)) {
     // critic on [gen_action | state] with the UPDATED weights: one launch, two layer-1 contraction segments
@@ -1091,6 +1094,26 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   }
   if (use_dot) {
     if (!backward) return 0;
+    Net& pn0 = e->net[POL];
+    RECNN_REQUIRE(pn0.g, "policy backward: the actor has no gradient arena bound");
+    if (g_policy_chain) {
+      // the whole chain dz_e2 -> dz_e1 -> dact -> dz_p2 -> dz_p1 on a row panel that never leaves the CU (bwd.hip)
+      BwdChainArgs c;
+      memset(&c, 0, sizeof(c));
+      const Net& v = e->net[V1];
+      c.rows = rows; c.H = H; c.A = A; c.delta_const = -1.0f / (float)rows; c.scale = train ? 2.0f : 1.0f; c.ldh = Hp;
+      c.e2 = e->pc.h2; c.e1 = e->pc.h1; c.w3c = v.p + v.off[W3];
+      c.W2c = sh_ptr(e, V1, W2); c.ldw2c = v.ld_w2;
+      c.W1c = sh_ptr(e, V1, W1); c.ldw1c = v.ld_w1;
+      c.W3a = sh_ptr(e, POL, W3); c.ldw3a = pn0.ld_w3;
+      c.W2a = sh_ptr(e, POL, W2); c.ldw2a = pn0.ld_w2;
+      c.p2 = e->pa.h2; c.p1 = e->pa.h1;
+      c.dact = e->dag; c.ldact = Ap; c.dzp2 = e->dzp2; c.dzp1 = e->dzp1;
+      c.db3_part = pn0.gp[B3]; c.db2_part = pn0.gp[B2]; c.db1_part = pn0.gp[B1];
+      const double fl = 2.0 * rows * ((double)H * H + (double)H * A + (double)A * H + (double)H * H);
+      if ((rc = slot(e, "bwd_chain_policy", fl, s, [&] { return bwd_chain_launch(c, s); }))) return rc;
+      chain_done = true;
+    } else {
     // backward seed d = -1/B for every row: dz_e2 and dz_e1 in one row-panel launch, no critic parameter gradients
     BwdPanelBatch bb;
     memset(&bb, 0, sizeof(bb));
@@ -1100,6 +1123,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     b.h2 = e->pc.h2; b.ldh = Hp; b.w3 = v.p + v.off[W3]; b.scale = train ? 2.0f : 1.0f;
     b.dz2 = e->dze2; b.W2 = sh_ptr(e, V1, W2); b.ldw2 = v.ld_w2; b.h1 = e->pc.h1; b.dz1 = e->dze1;
     if ((rc = slot(e, "head_dx_pcritic", 2.0 * rows * (double)H * H, s, [&] { return bwd_panel_launch(bb, 1, s); }))) return rc;
+    }
   } else {
     HeadArgs h;
     memset(&h, 0, sizeof(h));
@@ -1124,11 +1148,13 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     return g.run(s, nm);
   };
   // critic: dz_e1 = (dz_e2 W2) * 2[e1>0];   dact = dz_e1 * W1[:, action columns]  (shadow columns 0..A-1)
+  if (!chain_done) {
   if (!use_dot && (rc = dx1("dx_pcritic_l2", e->dze2, Hp, Hp, V1, W2, H, e->dze1, Hp, e->pc.h1, nullptr))) return rc;
   if ((rc = dx1("dx_pcritic_action", e->dze1, Hp, Hp, V1, W1, A, e->dag, Ap, nullptr, pn.gp[B3]))) return rc;
   // actor: dz_p2 = (dact W3) * 2[p2>0];  dz_p1 = (dz_p2 W2) * 2[p1>0]
   if ((rc = dx1("dx_actor_l3", e->dag, Ap, Ap, POL, W3, H, e->dzp2, Hp, e->pa.h2, pn.gp[B2]))) return rc;
   if ((rc = dx1("dx_actor_l2", e->dzp2, Hp, Hp, POL, W2, H, e->dzp1, Hp, e->pa.h1, pn.gp[B1]))) return rc;
+  }
   NetLayout L = make_layout(e, POL, rows);
   {
     Group g(e, GEMM_DW, 0, 0);
