@@ -105,7 +105,7 @@ struct recnn_engine {
   int run_tick[3] = {1, 1, 1};             // increments applied by the finalize: steps, critic steps, actor steps
   char* gen_action;                        // tc [Bc, Ap] of the current batch buffer set
   char *gen_action0 = nullptr, *gen_action2 = nullptr;
-  struct PendingPc { bool on = false; int set = 0; int run_off = 0; } pending_pc;  // deferred policy-loss forward (run graphs)
+  struct PendingPc { bool on = false; int set = 0; int run_off = 0; int slot = 0; } pending_pc;  // deferred policy-loss forward
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
   bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
@@ -824,7 +824,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         const char* xs_prev = pp.set ? e->xsh2 : e->xsh;
         MlpSpec f{RECNN_NET_VALUE1, pp.set ? e->gen_action2 : e->gen_action0, e->Ap, e->Ap, 0};
         f.A1 = xs_prev + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
-        f.q = e->pl_part_base + (int64_t)pp.run_off * e->pl_cap;   // that step's policy-loss slot: Q per row, b3 included
+        f.q = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;   // that step's policy-loss slot: Q per row, b3 included
         f.mask_idx = e->td3 ? 6 : 4;
         MlpProb* pd = &mb.p[np++];
         fl += fill_mlp(e, f, rows, pd);
@@ -1332,7 +1332,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   const bool pol = learn && policy_step;
   if (defer_policy_fwd && !pol && learn) {
     // run graphs: the next step's forward launch carries this step's policy-loss forward (see ph_forward)
-    e->pending_pc.on = true; e->pending_pc.set = e->cur_set; e->pending_pc.run_off = e->run_off;
+    e->pending_pc.on = true; e->pending_pc.set = e->cur_set; e->pending_pc.run_off = e->run_off; e->pending_pc.slot = e->run_off;
     e->hist_pol_count[e->run_off] = rows; e->hist_pol_add[e->run_off] = 0;
   } else if ((rc = ph_policy(e, rows, pol, true, s, !learn))) {
     return rc;
@@ -1600,6 +1600,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
   if (overlap_actor && (rc = dp_capture(e, s, &e->gdp[4][0], [&] { return ph_forward(e, rows, false, true, false, s); }))) return rc;
   for (int set = 0; set < e->dp_sets && !rc; ++set) {
     use_set(e, set);
+    use_hist_slot(e, set);   // loss partial sums of a step live in the slot of its batch buffer set
     rc = dp_capture(e, s, &e->gdp[1][set], [&] {
       int r;
       if (!(r = value_apply(e, false, grad_scale, s)) && !(r = ph_policy(e, rows, false, false, s, false))) r = ph_finish(e, rows, true, false, s);
@@ -1610,8 +1611,10 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       if (!(r = value_apply(e, true, grad_scale, s))) r = ph_policy(e, rows, true, false, s, false);
       return r;
     });
+    const int pol_dots = e->pl_dot_parts;   // how the policy step's loss partials were produced (by graph 2's ph_policy)
     if (!rc) rc = dp_capture(e, s, &e->gdp[3][set], [&] {
       int r;
+      e->pl_dot_parts = pol_dots;
       if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
       return r;
     });
@@ -1621,26 +1624,48 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       if (look) { ga = gather_args(e, rows, set ^ 1, 1); e->pregather = &ga; }
       int r = value_apply(e, false, grad_scale, s);
       e->pregather = nullptr;
-      if (!r && !(r = ph_policy(e, rows, false, false, s, false))) r = ph_finish(e, rows, true, false, s);
+      // With two buffer sets the policy-loss forward of step t rides on step t+1's forward launch (as in the run
+      // graphs); step t's finalize then closes the graph: the head of step t+1 is captured one step ahead of the
+      // device counters and writes its loss partial sums into the other per-step slot.
+      const bool defer = look && g_defer_policy_fwd && !e->td3 && value_chain_ok(e);
+      if (!r) {
+        if (defer) {
+          e->pending_pc.on = true; e->pending_pc.set = set; e->pending_pc.run_off = 0; e->pending_pc.slot = set;
+        } else if (!(r = ph_policy(e, rows, false, false, s, false))) {
+          r = ph_finish(e, rows, true, false, s);
+        }
+      }
       if (!r) {
         if (look) use_set(e, set ^ 1);
+        if (defer) { e->run_off = 1; use_hist_slot(e, set ^ 1); }
         r = head(look);
+        if (defer) {
+          e->run_off = 0;
+          use_hist_slot(e, set);
+          e->pl_dot_parts = rows;   // Q per row (b3 included) in this step's policy slot
+          if (!r) r = ph_finish(e, rows, true, false, s);
+          e->pl_dot_parts = 0;
+        }
+        e->pending_pc.on = false;
         use_set(e, set);
       }
       return r;
     });
     if (!rc) rc = dp_capture(e, s, &e->gdp[6][set], [&] {
       int r;
+      e->pl_dot_parts = pol_dots;
       if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
       if (!r) {
-        if (look) use_set(e, set ^ 1);
+        if (look) { use_set(e, set ^ 1); use_hist_slot(e, set ^ 1); }
         r = head(false);   // the policy step's tail does not look ahead: its own gather, after the cursor tick
         use_set(e, set);
+        use_hist_slot(e, set);
       }
       return r;
     });
   }
   use_set(e, 0);
+  use_hist_slot(e, 0);
   return rc;
 }
 

@@ -371,8 +371,12 @@ def test_dp_run_with_sampler_equals_fused_run(recnn, cuda):
         torch.cuda.synchronize()
         lo = ctx.engine.losses()
         results.append((lo, {k: v.detach().clone() for k, v in ddpg.nets["policy_net"].state_dict().items()},
-                        {k: v.detach().clone() for k, v in ddpg.nets["value_net"].state_dict().items()}))
+                        {k: v.detach().clone() for k, v in ddpg.nets["value_net"].state_dict().items()},
+                        ctx.engine.loss_history(n)))
     assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    for a, b in zip(results[0][3], results[1][3]):       # every step's losses, not only the last one's
+        for k in ("value", "policy"):
+            assert abs(a[k] - b[k]) <= 1e-5 * max(abs(b[k]), 1.0), (a, b)
     for j in (1, 2):
         for k in results[0][j]:
             assert torch.equal(results[0][j][k], results[1][j][k]), k
