@@ -84,3 +84,31 @@ def test_rolling_window_and_get_base_batch_shapes():
     out = recnn_amd.data.get_base_batch(b, device=torch.device("cpu"))
     assert [tuple(t.shape) for t in out] == [(4, 6), (4, 2), (4, 1), (4, 6), (4, 1)]
     assert len(recnn_amd.data.get_base_batch(b, device=torch.device("cpu"), done=False)) == 4
+
+
+def test_vectorised_etl_matches_reference_fixture_including_timestamp_ties(golden_dir):
+    """csr_from_ratings / prepare_dataset against the REAL reference's prepare_dataset output
+    (tests/golden/etl_ties.npz, oracle/make_golden_etl.py): same users, same per-user item and rating sequences,
+    bit for bit -- also for rows with equal timestamps, whose order pandas' unstable sort decides."""
+    import pandas
+    from recnn_amd.data import dataset_functions as F
+    g = np.load(os.path.join(golden_dir, "etl_ties.npz"))
+    key_to_id = {int(k): i for i, k in enumerate(g["keys"])}
+    dense = np.asarray([key_to_id[int(k)] for k in g["in_movieId"]], dtype=np.int64)
+    users, off, items, ratings = F.csr_from_ratings(g["in_userId"], dense, 2.0 * (g["in_rating"] - 2.5), g["in_timestamp"])
+    assert np.array_equal(users, g["uids"]) and np.array_equal(off, g["user_off"])
+    assert np.array_equal(items, g["items"]) and np.array_equal(ratings, g["ratings"])
+
+    class Base:
+        pass
+    base = Base()
+    base.key_to_id = key_to_id
+    df = pandas.DataFrame({"userId": g["in_userId"], "movieId": g["in_movieId"], "rating": g["in_rating"],
+                           "timestamp": g["in_timestamp"]})
+    args = F.DataFuncArgsMut(df=df, base=base, users=None, user_dict=None)
+    args, _ = F.prepare_dataset(args, F.DataFuncKwargs(frame_size=10))
+    assert list(args.users) == list(g["users_filtered"])            # > frame_size ratings, longest history first
+    for i, u in enumerate(g["uids"]):
+        a, b = g["user_off"][i], g["user_off"][i + 1]
+        assert np.array_equal(args.user_dict[int(u)]["items"], g["items"][a:b])
+        assert np.array_equal(args.user_dict[int(u)]["ratings"], g["ratings"][a:b])
