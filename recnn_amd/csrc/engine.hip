@@ -721,6 +721,7 @@ double fill_mlp(const recnn_engine* e, const MlpSpec& f, int rows, MlpProb* p) {
   p->h1 = f.h1; p->h2 = f.h2; p->ldh = e->Hp;
   p->out = f.out; p->ldo = f.ldo;
   p->q = f.q;
+  p->cbwd_idx = -1;
   p->addend = f.addend; p->ld_add = f.ld_add; p->add_clip = f.add_clip;
   return 2.0 * rows * ((double)e->H * n.in_dim + (double)e->H * e->H + (double)n.out_dim * e->H);
 }
@@ -746,6 +747,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     const int64_t aoff = (int64_t)A * e->esz;
     {
       MlpBatch mb;
+      memset(&mb, 0, sizeof(mb));
       int np = 0;
       double fl = 0;
       chained = can_chain;
@@ -769,7 +771,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         MlpProb* pt = &mb.p[np];
         fl += fill_mlp(e, f, rows, &mb.p[np++]);
         if (chained && in_fwd_bwd) {
-          MlpHead& Hd = pt->head;
+          MlpHead& Hd = mb.head;
           Hd.n_critic = nc;
           for (int c = 0; c < nc; ++c) {
             Hd.q_slot[c] = e->q_slot[c];
@@ -785,7 +787,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
           pt->n_tail = nc;
           for (int c = 0; c < nc; ++c) {
             const Net& t = e->net[TVAL[c]];
-            MlpTail& T = pt->tail[c];
+            MlpTail& T = mb.tail[c];
             T.part = e->tc_part[c]; T.flag = e->tc_flag[c];
             T.W1a = sh_ptr(e, TVAL[c], W1); T.ldw1 = t.ld_w1;
             T.W2 = sh_ptr(e, TVAL[c], W2); T.ldw2 = t.ld_w2;
@@ -801,7 +803,8 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
           MlpProb* pc = &mb.p[np];
           fl += fill_mlp(e, fc, rows, &mb.p[np++]);
           if (in_fwd_bwd) {
-            MlpCriticBwd& B = pc->cbwd;
+            MlpCriticBwd& B = mb.cbwd[c];
+            pc->cbwd_idx = c;
             B.enabled = 1;
             B.q_slot = e->q_slot[c];
             B.scale = e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f;
@@ -900,6 +903,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   } else if (value_side && fused_mlp_ok(e, nc)) {
     {
       MlpBatch mb;
+      memset(&mb, 0, sizeof(mb));
       double fl = 0;
       for (int c = 0; c < nc; ++c) {
         MlpSpec f{TVAL[c], e->xcn, e->ldx, e->K1c, 0};
@@ -1061,6 +1065,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   if (fused_mlp_ok(e, 1)) {
     // critic on [gen_action | state] with the UPDATED weights: one launch, two layer-1 contraction segments
     MlpBatch mb;
+    memset(&mb, 0, sizeof(mb));
     MlpSpec f{V1, e->gen_action, Ap, Ap, 0};
     f.A1 = e->xcs + (int64_t)A * e->esz; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
     f.h1 = e->pc.h1; f.h2 = e->pc.h2; f.mask_idx = m0;
@@ -1502,8 +1507,8 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
         if (pol) ++n_pol;
         e->run_tick[0] = run_len; e->run_tick[1] = run_len; e->run_tick[2] = n_pol;
         // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
-        // buffer set and room for a 5th problem: DDPG)
-        const bool defer = look && g_defer_policy_fwd && !e->td3 && value_chain_ok(e) && i + 1 < run_len;
+        // buffer set)
+        const bool defer = look && g_defer_policy_fwd && value_chain_ok(e) && i + 1 < run_len;
         rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len, defer);
       }
       e->run_off = 0;
@@ -1627,7 +1632,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       // With two buffer sets the policy-loss forward of step t rides on step t+1's forward launch (as in the run
       // graphs); step t's finalize then closes the graph: the head of step t+1 is captured one step ahead of the
       // device counters and writes its loss partial sums into the other per-step slot.
-      const bool defer = look && g_defer_policy_fwd && !e->td3 && value_chain_ok(e);
+      const bool defer = look && g_defer_policy_fwd && value_chain_ok(e);
       if (!r) {
         if (defer) {
           e->pending_pc.on = true; e->pending_pc.set = set; e->pending_pc.run_off = 0; e->pending_pc.slot = set;

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-constexpr int MLP_MAX_GROUP = 6;
+constexpr int MLP_MAX_GROUP = 8;
 constexpr int MLP_MAX_TAIL = 2;
 // Per-row scalars travel between workgroups of one launch through slots accessed with relaxed agent-scope atomics:
 // the VALUE is the flag (slots rest at this NaN pattern), so the hand-off needs no L2 write-back / invalidate.
@@ -89,14 +89,17 @@ struct MlpProb {
   float* part_out;
   int32_t* part_flag;
   // consumer side: critics chained behind this actor's output
-  int n_tail;
-  MlpTail tail[MLP_MAX_TAIL];
-  MlpCriticBwd cbwd;
-  MlpHead head;      // on the problem that carries the tails
+  int n_tail;        // > 0: this (target actor) problem carries MlpBatch::tail[0 .. n_tail) and MlpBatch::head
+  int cbwd_idx;      // >= 0: this critic problem carries MlpBatch::cbwd[cbwd_idx]; -1: none
 };
 
+// Kernel argument (by value, < 4 KB): the problems plus ONE copy of the chained-critic / head / critic-backward
+// descriptions (a launch has at most one problem that carries tails).
 struct MlpBatch {
   MlpProb p[MLP_MAX_GROUP];
+  MlpTail tail[MLP_MAX_TAIL];
+  MlpHead head;
+  MlpCriticBwd cbwd[2];
 };
 
 int mlp_init();

@@ -198,16 +198,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
     dma_rows<NW>(P.W3, P.ldw3, 0, 127, 0, 128, lds0 + A_BYTES, wave, lane);
     dma_rows<NW>(P.W3, P.ldw3, 0, 127, KB, 128, lds0 + A_BYTES + 128 * 256, wave, lane);
     if (P.n_tail) {              // ... which leaves slot 1 for the first chained critic's action-column slab of W1
-      dma_rows<NW>(P.tail[0].W1a, P.tail[0].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
+      dma_rows<NW>(batch.tail[0].W1a, batch.tail[0].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
       if (tid == 0) {
         // bounded spin (~0.2 s): a producer has a lower workgroup id, so it was dispatched before this workgroup and
         // never waits itself (by now it normally finished long ago); the bound only turns a broken launch order into
         // wrong numbers instead of a hang
         for (int ti = 0; ti < P.n_tail; ++ti) {
           int spins = 0;
-          while (__hip_atomic_load(P.tail[ti].flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
+          while (__hip_atomic_load(batch.tail[ti].flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(2);
-          __hip_atomic_store(P.tail[ti].flag + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(batch.tail[ti].flag + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) pacc[ti][tm][tn][r] = P.tail[ti].part[(int64_t)(m0 + tm * 16 + fg * 4 + r) * HP + n];
+              for (int r = 0; r < 4; ++r) pacc[ti][tm][tn][r] = batch.tail[ti].part[(int64_t)(m0 + tm * 16 + fg * 4 + r) * HP + n];
           }
         }
     }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 #pragma unroll
     for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
       if (ti >= P.n_tail) break;
-      const MlpTail& T = P.tail[ti];
+      const MlpTail& T = batch.tail[ti];
       constexpr int NI = HP / (4 * NW);  // DMA instructions per wave for one 256-row slab
       // layer-3 MMAs (ti = 0) / the previous critic's head are done; action panel written; W1a and the parts landed
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       mma_slab<TNH>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);
       __builtin_amdgcn_s_barrier();  // everyone is done reading the h1 panel and both slots
       if (ti + 1 < P.n_tail)
-        dma_rows<NW>(P.tail[ti + 1].W1a, P.tail[ti + 1].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
+        dma_rows<NW>(batch.tail[ti + 1].W1a, batch.tail[ti + 1].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
       hidden_epilogue<TNH>(acc, T.b2, P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       }
     }
     // ---------------------------------------------------------------- head of the learning critic(s)
-    if (P.head.n_critic > 0 && P.n_tail > 0) {
-      const MlpHead& Hd = P.head;
+    if (batch.head.n_critic > 0 && P.n_tail > 0) {
+      const MlpHead& Hd = batch.head;
       __syncthreads();   // Q' of all 32 rows (every tail) is in LDS
       if (wave == 0) {
         const float* stq = (const float*)(lds + STAGE);
@@ -374,13 +374,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       if (lane == 0 && m0 + row < P.rows) {
         const float qv = s + P.b3[0];
         P.q[m0 + row] = qv;
-        if (P.cbwd.enabled && P.cbwd.q_slot)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
-          __hip_atomic_store((uint32_t*)P.cbwd.q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx].q_slot)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
+          __hip_atomic_store((uint32_t*)batch.cbwd[P.cbwd_idx].q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if constexpr (NW == 16) {
-      if (P.cbwd.enabled) {
-        const MlpCriticBwd& B = P.cbwd;
+      if (P.cbwd_idx >= 0) {
+        const MlpCriticBwd& B = batch.cbwd[P.cbwd_idx];
         // ---- u2 = w3 * scale * [h2 > 0], in place in the panel (it becomes the A operand) and to global
         {
           const int row = lane & 31, m = m0 + row;
@@ -469,7 +469,7 @@ int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
     const MlpProb& p = b.p[i];
     if (p.rows > rows) rows = p.rows;
     if (p.H > HP || p.out_dim > 128) { recnn_set_error("mlp_fwd: hidden > 256 or out_dim > 128"); return RECNN_E_UNSUPPORTED; }
-    if (p.cbwd.enabled && (g_mlp_waves != 16 || p.W3 || !p.q || !p.cbwd.dz2 || !p.cbwd.dz1)) {
+    if (p.cbwd_idx >= 2 || (p.cbwd_idx >= 0 && (g_mlp_waves != 16 || p.W3 || !p.q || !b.cbwd[p.cbwd_idx].dz2 || !b.cbwd[p.cbwd_idx].dz1))) {
       recnn_set_error("mlp_fwd: critic backward tail needs the 16-wave variant, a critic problem and its buffers");
       return RECNN_E_INVALID;
     }
