@@ -268,11 +268,12 @@ def test_td3_vs_oracle_b4096(cuda, dtype):
         _params_close(eng, ni, refp, ptol, tag, metric=fro_err)
 
 
-@pytest.mark.parametrize("first", [0, 1])
-def test_graph_replay_equals_eager(cuda, first):
+@pytest.mark.parametrize("first,pe", [(0, 3), (1, 3), (0, 40)])
+def test_graph_replay_equals_eager(cuda, first, pe):
     """hipGraph replay of the step (hash masks, device-side counters) == eager launches, bit for bit.  With
     policy_every=3 the replay uses the run graph (21 whole policy cycles = 63 steps per launch) where it lines up and
-    single-step graphs elsewhere (first=1 starts mid-cycle)."""
+    single-step graphs elsewhere (first=1 starts mid-cycle); with policy_every=40 the run graph is 16 ordinary steps
+    and has to stop before every policy step."""
     from recnn_amd import _lib as L
     S, A, H, B = 1290, 128, 256, 512
     actor, (critic,) = _init_nets(4, S, A, H, 1)
@@ -283,7 +284,7 @@ def test_graph_replay_equals_eager(cuda, first):
         eng = _engine("ddpg", S, A, H, B, "fp32", mask_mode="hash", seed=77)
         eng.load_params(L.NET_POLICY, actor); eng.load_params(L.NET_TARGET_POLICY, actor)
         eng.load_params(L.NET_VALUE1, critic); eng.load_params(L.NET_TARGET_VALUE1, critic)
-        eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3), policy_every=3)
+        eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3), policy_every=pe)
         eng.set_counters()
         eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
         if mode == "eager":
