@@ -714,7 +714,7 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
     }
 }
 
-static int g_dw_dma = 2;  // 0 = off; 1..6 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4)
+static int g_dw_dma = 2;  // 0 = off; 1..7 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3)
 extern "C" void recnn_tune_dw_dma(int on) { g_dw_dma = on; }
 
 // both operands bf16 in memory, 64-column tiles readable inside the row pitch (padding columns may hold anything:
@@ -766,6 +766,7 @@ static int launch_dw_dma(GemmLaunch* L, hipStream_t stream, int variant = 0) {
     case 4: return launch_dw_dma_v<64, 4>(L, stream);
     case 5: return launch_dw_dma_v<32, 2>(L, stream);
     case 6: return launch_dw_dma_v<32, 4>(L, stream);
+    case 7: return launch_dw_dma_v<32, 3>(L, stream);
     case 1: return launch_dw_dma_v<128, 2>(L, stream);
     default: return launch_dw_dma_v<64, 2>(L, stream);
   }
@@ -875,7 +876,7 @@ int gemm_init() {
   memset(&L, 0, sizeof(L));
   int rc;
   L.mode = GEMM_DW;
-  for (int v = 1; v <= 6; ++v)
+  for (int v = 1; v <= 7; ++v)
     if ((rc = launch_dw_dma(&L, nullptr, v))) return rc;
   L.mode = GEMM_FWD;
   if ((rc = launch_dma_nw<float, 3, 4>(&L, nullptr))) return rc;
