@@ -109,8 +109,8 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3"], help="td3 --rows 4096 = BASELINE.json configs[2]")
     ap.add_argument("--rows", type=int, default=B_ROWS, help="transition rows per step per GPU")
