@@ -765,6 +765,26 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         }
       }
       if (value_side) {
+        // launch order = dispatch order, and a workgroup may only wait for workgroups dispatched before it: the critics
+        // (whose Q(s, a) the head in the target actor's workgroup picks up) come BEFORE the target actor, like the
+        // target critics' layer-1 producers -- otherwise a batch with more panels than CUs would dead-lock (bounded)
+        for (int c = 0; c < nc; ++c) {
+          MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
+          fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
+          fc.q = e->q[c];
+          MlpProb* pc = &mb.p[np];
+          fl += fill_mlp(e, fc, rows, &mb.p[np++]);
+          if (in_fwd_bwd) {
+            MlpCriticBwd& B = mb.cbwd[c];
+            pc->cbwd_idx = c;
+            B.enabled = 1;
+            B.q_slot = e->q_slot[c];
+            B.scale = e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f;
+            B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];   // UNIT tensors: the dW launch applies the per-row seed e->delta[c]
+            if (value_bwd) RECNN_REQUIRE(e->net[VAL[c]].g, "value backward: network %d has no gradient arena bound", VAL[c]);
+            fl += 2.0 * rows * (double)e->H * e->H;
+          }
+        }
         MlpSpec f{TPOL, e->xcn + aoff, e->ldx, e->K1a, 0};
         f.out = e->xcn; f.ldo = e->ldx;
         if (e->td3) { f.addend = e->ext_noise ? e->ext_noise : e->noise_buf; f.ld_add = A; f.add_clip = e->hy.noise_clip; }
@@ -794,23 +814,6 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
             T.b1 = t.p + t.off[B1]; T.b2 = t.p + t.off[B2]; T.b3 = t.p + t.off[B3]; T.w3row = t.p + t.off[W3];
             T.q = e->tqv[c];
             fl += 2.0 * rows * ((double)e->H * A + (double)e->H * e->H + e->H);
-          }
-        }
-        for (int c = 0; c < nc; ++c) {
-          MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
-          fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
-          fc.q = e->q[c];
-          MlpProb* pc = &mb.p[np];
-          fl += fill_mlp(e, fc, rows, &mb.p[np++]);
-          if (in_fwd_bwd) {
-            MlpCriticBwd& B = mb.cbwd[c];
-            pc->cbwd_idx = c;
-            B.enabled = 1;
-            B.q_slot = e->q_slot[c];
-            B.scale = e->cfg.mask_mode != RECNN_MASK_NONE ? 2.0f : 1.0f;
-            B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];   // UNIT tensors: the dW launch applies the per-row seed e->delta[c]
-            if (value_bwd) RECNN_REQUIRE(e->net[VAL[c]].g, "value backward: network %d has no gradient arena bound", VAL[c]);
-            fl += 2.0 * rows * (double)e->H * e->H;
           }
         }
       }
