@@ -351,12 +351,14 @@ def test_data_parallel_stepper_world1_equals_fused_step(cuda):
             assert torch.equal(outs[0][2][k], other[2][k]), k
 
 
-@pytest.mark.parametrize("algo,B", [("ddpg", 2048), ("td3", 4096), ("ddpg", 77)])
+@pytest.mark.parametrize("algo,B", [("ddpg", 2048), ("td3", 4096), ("ddpg", 77), ("ddpg", 8192)])
 def test_chained_target_critic_equals_separate_launches(cuda, algo, B):
     """bf16: the target critic finished inside the fused MLP launch (producer workgroup + flag hand-off, mlp.hip)
     against the same critic run as separate launches.  Same arithmetic up to the fp32 summation order of layer 1
     (state part and action part are accumulated separately), so TD targets agree to bf16 round-off of h1.
-    B=4096 TD3 is 768 workgroups of 160 KB LDS: producers and consumers are NOT all resident at once."""
+    B=4096 TD3 is 768 workgroups of 160 KB LDS: producers and consumers are NOT all resident at once; B=8192 has as many
+    32-row panels as the GPU has CUs, so every hand-off must point from an earlier-dispatched workgroup to a later one
+    (the launch order is part of the contract: a wrong order shows up here as a 100x slower, wrong result)."""
     from recnn_amd import _lib as L
     S, A, H = 1290, 128, 256
     td3 = algo == "td3"
