@@ -112,3 +112,19 @@ def test_vectorised_etl_matches_reference_fixture_including_timestamp_ties(golde
         a, b = g["user_off"][i], g["user_off"][i + 1]
         assert np.array_equal(args.user_dict[int(u)]["items"], g["items"][a:b])
         assert np.array_equal(args.user_dict[int(u)]["ratings"], g["ratings"][a:b])
+
+
+def test_csr_from_ratings_edge_cases():
+    from recnn_amd.data import dataset_functions as F
+    e = np.zeros(0, dtype=np.int64)
+    users, off, items, ratings = F.csr_from_ratings(e, e, e.astype(np.float64), e)
+    assert len(users) == 0 and off.tolist() == [0] and len(items) == 0
+    # one user, already in time order; ids above 2^16 take the two-pass radix path
+    u = np.full(5, 70000, dtype=np.int64)
+    users, off, items, ratings = F.csr_from_ratings(u, np.arange(5), np.arange(5) * 0.5, np.arange(5))
+    assert users.tolist() == [70000] and off.tolist() == [0, 5] and items.tolist() == [0, 1, 2, 3, 4]
+    # interleaved users, reversed time
+    u = np.array([3, 1, 3, 1, 2], dtype=np.int64)
+    users, off, items, ratings = F.csr_from_ratings(u, np.array([10, 11, 12, 13, 14]), np.ones(5), np.array([5, 4, 3, 2, 1]))
+    assert users.tolist() == [1, 2, 3] and off.tolist() == [0, 2, 3, 5] and items.tolist() == [13, 11, 14, 12, 10]
+    assert F._stable_argsort_ids(np.array([-1, 5, 2])).tolist() == [0, 2, 1]          # negative ids: generic stable sort
