@@ -299,6 +299,11 @@ typedef struct recnn_sampler {
   int32_t* cursor;            /* device int32: next batch index */
 } recnn_sampler;
 int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* h_sampler);  /* NULL unbinds */
+/* Who draws from a bound sampler: graph replays (recnn_engine_graph_run), the data-parallel phase graphs and
+ * recnn_engine_profile always do.  Eager calls (recnn_engine_step / value_grads / finish) run on the BOUND batch --
+ * `algo.update(env.test_batch(), learn=False)` between two replays evaluates the batch it was given and leaves the
+ * sampler cursor alone -- unless on = 1 is set here (eager data-parallel phases). */
+int recnn_engine_sampler_eager(recnn_engine* e, int on);
 
 /* External inputs for parity runs: masks uint8[n_masks][max_rows][hidden] (6 DDPG, 8 TD3, in the
  * reference's consumption order), noise float[max_rows][action_dim] (TD3, unclipped). */
@@ -341,10 +346,11 @@ int recnn_engine_soft_update(recnn_engine* e, int net, int target_net, float tau
  * and advances the device step / optimizer counters. */
 int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy_stepped, void* stream);
 
-/* Capture `recnn_engine_step` for a fixed row count into hipGraphs -- one ordinary step, one policy step, and a RUN
- * graph of whole policy cycles (up to 64 steps, see recnn_tune_graph_run) -- and replay `n_steps` consecutive steps
- * starting at `first_step`, using the run graph wherever the step kinds line up.  Inside a run graph the device
- * counters are ticked once at its end, the sampler + gather of step t+1 and the policy-loss forward of step t ride on
+/* Capture `recnn_engine_step` for a fixed row count into hipGraphs -- one ordinary step, one policy step, and a family
+ * of RUN graphs (k ordinary steps; a policy step + k ordinary steps, k < policy_every; whole policy cycles up to 64
+ * steps, see recnn_tune_graph_run) -- and replay `n_steps` consecutive steps starting at `first_step`: ANY
+ * (first_step, n_steps) is covered with at most n_steps / policy_every + 2 graph launches (policy_every <= 17; longer
+ * cycles compose power-of-two stretches).  Inside a run graph the device counters are ticked once at its end, the sampler + gather of step t+1 and the policy-loss forward of step t ride on
  * other launches (recnn_tune_pregather, recnn_tune_defer_policy_fwd), and every step's losses land in the history ring
  * (recnn_engine_read_counters). */
 int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
@@ -380,6 +386,11 @@ int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int
 int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
 int recnn_engine_dp_sets(recnn_engine* e);
 
+/* In-launch hand-offs (the fused forward chains dependent networks through producer / consumer workgroups) wait with
+ * a bound; a wait that runs out sets a device error word and both readers below then return RECNN_E_STATE (and clear
+ * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
+ * on purpose (tests). */
+void recnn_tune_mlp_fault(int mode);
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

@@ -141,10 +141,20 @@ struct recnn_engine {
   int prof_reps[PROF_MAX];
   bool prof_ready = false;
   // graphs
-  hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};  // one ordinary step, one policy step, a run of steps
-  int grun_len = 0;          // steps in gexec[2]
-  int grun_last_set = 0;     // batch buffer set its last step leaves the batch in
-  bool grun_policy_first = false;  // gexec[2] = whole policy cycles (policy step + policy_every-1 ordinary steps, repeated)
+  // gexec[0] / gexec[1]: one ordinary step / one policy step.  Run graphs (several steps per graph launch):
+  //   grun_o[k]  k ordinary steps                      (k >= 2; k = 1 is gexec[0])
+  //   grun_p[k]  a policy step + k ordinary steps      (k >= 1; k = 0 is gexec[1]); k = policy_every-1 is a whole cycle
+  //   grun_multi whole policy cycles, grun_multi_len steps (starts on a policy step)
+  // graph_run() covers any (first_step, n_steps) with them: see recnn_engine_graph_run
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  static constexpr int RUN_MAX = 64;       // = LOSS_HIST_MAX: steps per run graph
+  hipGraphExec_t grun_o[RUN_MAX + 1] = {};
+  hipGraphExec_t grun_p[RUN_MAX + 1] = {};
+  hipGraphExec_t grun_multi = nullptr;
+  int grun_multi_len = 0;
+  bool grun_look = false;    // run graphs alternate the two batch buffer sets (look-ahead gather)
+  bool use_sampler = false;  // the step being issued / captured draws its batch from the bound sampler
+  bool sampler_eager = false;  // eager public calls (recnn_engine_step, value_grads) draw from the sampler too
   hipGraphExec_t gdp[7][2] = {};           // data-parallel phase graphs [kind][batch buffer set]
   int dp_sets = 1;                         // 2: merged tail+head graphs alternate the batch buffer sets (look-ahead gather)
   int graph_rows = 0;
@@ -292,7 +302,7 @@ int64_t carve(recnn_engine* e, char* base) {
     }
     n.l1part = (float*)c.take((int64_t)n.n_rows_blk * 4);
   }
-  e->losses = (float*)c.take(16);
+  e->losses = (float*)c.take(32);   // float[4] losses + int32 error word of the in-launch hand-offs (losses[4], see mlp.h)
   e->coef_out = (float*)c.take(16);
   e->counters = (int32_t*)c.take(64);
   e->l1_scratch = (float*)c.take(4096);
@@ -364,9 +374,15 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
 }
 
 static void drop_graphs(recnn_engine* e) {
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 2; ++i)
     if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
-  e->grun_len = 0;
+  for (int i = 0; i <= recnn_engine::RUN_MAX; ++i) {
+    if (e->grun_o[i]) { (void)hipGraphExecDestroy(e->grun_o[i]); e->grun_o[i] = nullptr; }
+    if (e->grun_p[i]) { (void)hipGraphExecDestroy(e->grun_p[i]); e->grun_p[i] = nullptr; }
+  }
+  if (e->grun_multi) { (void)hipGraphExecDestroy(e->grun_multi); e->grun_multi = nullptr; }
+  e->grun_multi_len = 0;
+  e->graph_rows = 0;
   for (int i = 0; i < 7; ++i)
     for (int k = 0; k < 2; ++k)
       if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
@@ -837,6 +853,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         pd->step_add = pp.run_off;
         e->pending_pc.on = false;
       }
+      mb.err = (int32_t*)(e->losses + 4);
       if ((rc = slot(e, "mlp_fwd_nets", fl, s, [&] { return mlp_launch(mb, np, s); }))) return rc;
     }
   } else {
@@ -1199,7 +1216,7 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   }
   const bool run_final = e->run_tick[0] > 1;  // last step of a run graph: the actor took run_tick[2] steps during the run
   if (run_final ? e->run_tick[2] > 0 : ticked_policy) { a.tick_inc[a.n_tick] = e->run_tick[2]; a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr; }
-  if (e->has_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; a.wrap_inc = e->run_tick[0]; }
+  if (e->has_sampler && e->use_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; a.wrap_inc = e->run_tick[0]; }
   a.ring = e->loss_ring; a.ring_mask = LOSS_RING - 1;
   if (run_final && value_panel_ok(e) && e->run_off >= 1 && e->run_off < LOSS_HIST_MAX) {
     // losses of the run's earlier steps from their kept partial sums (the step counter is not ticked yet)
@@ -1311,7 +1328,7 @@ int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
 
 // Make the step's batch available in the compute type: built by the sampler, or converted from the bound fp32 rows.
 int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
-  if (e->has_sampler) return frame_gather_packed(e, rows, s);
+  if (e->has_sampler && e->use_sampler) return frame_gather_packed(e, rows, s);
   if (e->bf16)
     return slot(e, "rows_to_bf16", 0, s, [&] {
       return rows_to_bf16_launch(e->xs, e->xn, (bf16_t*)e->xsh, (bf16_t*)e->xnh, rows, e->ldx, s);
@@ -1360,13 +1377,27 @@ extern "C" int recnn_engine_step(recnn_engine* e, int rows, int learn, int step,
   int rc = check_ready(e, rows);
   if (rc) return rc;
   const bool pol = (step % e->hy.policy_every) == 0;
-  return step_impl(e, rows, learn != 0, pol, (hipStream_t)stream);
+  use_set(e, 0);
+  e->use_sampler = e->has_sampler && e->sampler_eager;
+  rc = step_impl(e, rows, learn != 0, pol, (hipStream_t)stream);
+  e->use_sampler = false;
+  return rc;
+}
+
+extern "C" int recnn_engine_sampler_eager(recnn_engine* e, int on) {
+  RECNN_REQUIRE(e, "sampler_eager: null engine");
+  e->sampler_eager = on != 0;
+  return 0;
 }
 
 extern "C" int recnn_engine_value_grads(recnn_engine* e, int rows, int learn, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
-  if ((rc = stage_batch(e, rows, (hipStream_t)stream))) return rc;
+  use_set(e, 0);
+  e->use_sampler = e->has_sampler && e->sampler_eager;
+  rc = stage_batch(e, rows, (hipStream_t)stream);
+  e->use_sampler = false;
+  if (rc) return rc;
   if ((rc = ph_forward(e, rows, true, false, learn != 0, (hipStream_t)stream))) return rc;
   if (learn) return ph_value_backward(e, rows, true, (hipStream_t)stream);
   return 0;
@@ -1406,21 +1437,41 @@ extern "C" int recnn_engine_soft_update(recnn_engine* e, int ni, int target_ni, 
 
 extern "C" int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy_stepped, void* stream) {
   RECNN_REQUIRE(e && rows > 0, "finish: bad arguments");
-  return ph_finish(e, rows, value_stepped != 0, policy_stepped != 0, (hipStream_t)stream);
+  e->use_sampler = e->has_sampler && e->sampler_eager;   // the step's batch came from the sampler: advance its cursor
+  const int rc = ph_finish(e, rows, value_stepped != 0, policy_stepped != 0, (hipStream_t)stream);
+  e->use_sampler = false;
+  return rc;
+}
+
+// A non-zero error word means a cross-workgroup wait inside a launch ran out (mlp.h): the step's numbers are void.
+static int report_handoff_error(recnn_engine* e, int32_t word, hipStream_t s) {
+  if (!word) return 0;
+  (void)hipMemsetAsync(e->losses + 4, 0, sizeof(int32_t), s);
+  (void)hipStreamSynchronize(s);
+  recnn_set_error("engine: an in-launch hand-off timed out (error word 0x%x:%s%s) -- the launch order / residency contract of "
+                  "the fused forward was violated; the results of the steps since the last read are invalid", word,
+                  (word & MLP_ERR_PART_TIMEOUT) ? " target-critic layer-1 part" : "", (word & MLP_ERR_Q_TIMEOUT) ? " Q(s,a) slot" : "");
+  return RECNN_E_STATE;
 }
 
 extern "C" int recnn_engine_read_counters(recnn_engine* e, int32_t* h_out, void* stream) {
   RECNN_REQUIRE(e && h_out, "read_counters: null pointer");
+  int32_t word = 0;
   RECNN_HIP(hipMemcpyAsync(h_out, e->counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RECNN_HIP(hipMemcpyAsync(&word, e->losses + 4, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return 0;
+  return report_handoff_error(e, word, (hipStream_t)stream);
 }
 
 extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream) {
   RECNN_REQUIRE(e && h_out, "read_losses: null pointer");
-  RECNN_HIP(hipMemcpyAsync(h_out, e->losses, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  float h[5];
+  RECNN_HIP(hipMemcpyAsync(h, e->losses, 5 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return 0;
+  memcpy(h_out, h, 4 * sizeof(float));
+  int32_t word;
+  memcpy(&word, h + 4, sizeof(word));
+  return report_handoff_error(e, word, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ per-launch profile
@@ -1442,7 +1493,9 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
   for (int it = 0; it < n_steps; ++it) {
     e->prof_on = true;
     e->prof_n = 0;
+    e->use_sampler = e->has_sampler;
     rc = step_impl(e, rows, true, policy_steps != 0, s);
+    e->use_sampler = false;
     e->prof_on = false;
     if (rc) return rc;
     RECNN_HIP(hipStreamSynchronize(s));
@@ -1468,95 +1521,121 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
 static int g_graph_run_len = -1;  // -1: whole policy cycles, up to 64 steps (policy_every > 32: 16 ordinary steps); 0/1: off
 extern "C" void recnn_tune_graph_run(int steps) { g_graph_run_len = steps; }
 
-// Three executable graphs: one ordinary step, one policy step, and a RUN of consecutive steps -- between two graph
-// launches the GPU idles for ~8 us (rocprofv3 kernel trace), inside a graph the kernels are back to back, so replaying
-// a whole policy cycle (1 policy step + policy_every-1 ordinary ones) per launch removes 90 % of those gaps.
+// Executable graphs: one ordinary step, one policy step, and a family of RUN graphs (several consecutive steps per
+// graph launch) -- between two graph launches the GPU idles for ~8 us (rocprofv3 kernel trace), inside a graph the
+// kernels are back to back, the sampler + gather of step t+1 rides on step t's optimizer launch and the policy-loss
+// forward of step t on step t+1's forward launch.  Which steps of a run are policy steps is frozen at capture time, so
+// the family holds every shape graph_run() needs to cover ANY (first_step, n_steps):
+//   grun_o[k]   k ordinary steps                  -- the stretch up to the next policy step / the end of the request
+//   grun_p[k]   a policy step + k ordinary steps  -- k = policy_every-1 is a whole cycle, smaller k the request's tail
+//   grun_multi  as many whole cycles as fit 64 steps
+// (policy_every <= 17: every k; larger: k in {1, 2, 4, 8, 16, 32} and greedy composition.)
+namespace {
+// One run of `len` steps captured into *out; pol_first: its first step is a policy step (then every policy_every-th).
+int capture_run(recnn_engine* e, int rows, hipStream_t s, bool pol_first, int len, hipGraphExec_t* out) {
+  if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
+  const int pe = e->hy.policy_every;
+  const bool look = lookahead_ok(e) && len > 1;
+  hipGraph_t graph = nullptr;
+  int rc = 0;
+  RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  e->use_sampler = e->has_sampler;
+  int n_pol = 0;
+  for (int i = 0; i < len && !rc; ++i) {
+    const bool pol = pol_first && (i % pe) == 0;
+    use_set(e, look ? (i & 1) : 0);
+    // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
+    e->run_off = i;
+    use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
+    e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
+    for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
+    e->run_skip_finish = i + 1 < len;
+    if (pol) ++n_pol;
+    e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
+    // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
+    // buffer set)
+    const bool defer = look && g_defer_policy_fwd && value_chain_ok(e) && i + 1 < len;
+    rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
+  }
+  e->run_off = 0;
+  use_hist_slot(e, 0);
+  e->pending_pc.on = false;
+  for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
+  e->run_skip_finish = false;
+  e->run_tick[0] = e->run_tick[1] = e->run_tick[2] = 1;
+  e->use_sampler = false;
+  use_set(e, 0);
+  hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  RECNN_HIP(ce);
+  hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  RECNN_HIP(ie);
+  return 0;
+}
+// the run lengths kept for `limit` (largest useful length): every length when the family stays small, else powers of two
+bool run_len_kept(int k, int limit) { return k >= 1 && k <= limit && (limit <= 16 || (k & (k - 1)) == 0); }
+}  // namespace
+
 extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream) {
   int rc = check_ready(e, rows);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
-  use_set(e, 0);
+  drop_graphs(e);
   const int pe = e->hy.policy_every;
-  int run_len = g_graph_run_len;
-  bool pol_first = false;
-  if (run_len < 0) {
-    if (pe <= 32) { run_len = (64 / pe) * pe; pol_first = true; }  // as many whole cycles as fit 64 steps
-    else run_len = 16;
-  } else if (run_len >= 2) {
-    if (run_len > 64) run_len = 64;
-    if (run_len >= pe) { run_len = (run_len / pe) * pe; pol_first = true; }
-  }
-  if (run_len < 2) run_len = 0;
-  for (int v = 0; v < 3; ++v) {
-    if (e->gexec[v]) { (void)hipGraphExecDestroy(e->gexec[v]); e->gexec[v] = nullptr; }
-    if (v == 2 && run_len == 0) continue;
-    hipGraph_t graph = nullptr;
-    RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    if (v < 2) {
-      rc = step_impl(e, rows, true, v == 1, s);
-    } else {
-      const bool look = lookahead_ok(e);
-      int n_pol = 0;
-      for (int i = 0; i < run_len && !rc; ++i) {
-        const bool pol = pol_first && (i % pe) == 0;
-        if (look) use_set(e, i & 1);
-        // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
-        e->run_off = i;
-        use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
-        e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
-        for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
-        e->run_skip_finish = i + 1 < run_len;
-        if (pol) ++n_pol;
-        e->run_tick[0] = run_len; e->run_tick[1] = run_len; e->run_tick[2] = n_pol;
-        // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
-        // buffer set)
-        const bool defer = look && g_defer_policy_fwd && value_chain_ok(e) && i + 1 < run_len;
-        rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < run_len, defer);
-      }
-      e->run_off = 0;
-      use_hist_slot(e, 0);
-      e->pending_pc.on = false;
-      for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
-      e->run_skip_finish = false;
-      e->run_tick[0] = e->run_tick[1] = e->run_tick[2] = 1;
-      e->grun_last_set = look ? ((run_len - 1) & 1) : 0;
-      use_set(e, 0);
+  int cap = g_graph_run_len < 0 ? recnn_engine::RUN_MAX : g_graph_run_len;   // longest run graph wanted
+  if (cap > recnn_engine::RUN_MAX) cap = recnn_engine::RUN_MAX;
+  if ((rc = capture_run(e, rows, s, false, 1, &e->gexec[0]))) return rc;
+  if ((rc = capture_run(e, rows, s, true, 1, &e->gexec[1]))) return rc;
+  if (cap >= 2) {
+    const int o_max = pe - 1 < cap ? pe - 1 : cap;            // ordinary stretch: never across a policy step
+    for (int k = 2; k <= o_max; ++k)
+      if (run_len_kept(k, o_max) && (rc = capture_run(e, rows, s, false, k, &e->grun_o[k]))) return rc;
+    const int p_max = pe - 1 < cap - 1 ? pe - 1 : cap - 1;    // policy step + k ordinary ones
+    for (int k = 1; k <= p_max; ++k)
+      if (run_len_kept(k, p_max) && (rc = capture_run(e, rows, s, true, k + 1, &e->grun_p[k]))) return rc;
+    const int cycles = cap / pe;
+    if (cycles >= 2) {
+      if ((rc = capture_run(e, rows, s, true, cycles * pe, &e->grun_multi))) return rc;
+      e->grun_multi_len = cycles * pe;
     }
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    RECNN_HIP(ce);
-    hipError_t ie = hipGraphInstantiate(&e->gexec[v], graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    RECNN_HIP(ie);
   }
-  e->grun_len = run_len;
-  e->grun_policy_first = pol_first;
+  e->grun_look = lookahead_ok(e);
   e->graph_rows = rows;
   return 0;
 }
 
+// Replays n_steps consecutive steps starting at step number first_step with as few graph launches as the family allows:
+// [ordinary stretch up to the next policy step] [multi-cycle graphs] [whole cycles] [policy step + tail].
 extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream) {
   RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_run: graphs not built");
-  const int pe = e->hy.policy_every, rl = e->gexec[2] ? e->grun_len : 0;
+  const int pe = e->hy.policy_every;
+  hipStream_t s = (hipStream_t)stream;
   int i = 0;
   while (i < n_steps) {
-    const int step = first_step + i;
+    const int step = first_step + i, rem = n_steps - i;
     const bool pol = (step % pe) == 0;
-    if (rl && n_steps - i >= rl) {
-      // the run graph fits if its step kinds line up: a whole cycle starts on a policy step, a run of ordinary
-      // steps must end before the next policy step
-      const bool fits = e->grun_policy_first ? pol : (!pol && pe - (step % pe) >= rl);
-      if (fits) {
-        RECNN_HIP(hipGraphLaunch(e->gexec[2], (hipStream_t)stream));
-        use_set(e, e->grun_last_set);  // where the debug views find the last batch
-        i += rl;
-        continue;
+    hipGraphExec_t g = nullptr;
+    int len = 1;
+    if (pol) {
+      if (e->grun_multi && rem >= e->grun_multi_len) { g = e->grun_multi; len = e->grun_multi_len; }
+      else {
+        int k = (rem < pe ? rem : pe) - 1;                    // ordinary steps that may follow inside this cycle
+        if (k > recnn_engine::RUN_MAX) k = recnn_engine::RUN_MAX;
+        while (k >= 1 && !e->grun_p[k]) --k;
+        if (k >= 1) { g = e->grun_p[k]; len = k + 1; } else g = e->gexec[1];
       }
+    } else {
+      int k = pe - (step % pe);                               // ordinary steps before the next policy step
+      if (k > rem) k = rem;
+      if (k > recnn_engine::RUN_MAX) k = recnn_engine::RUN_MAX;
+      while (k >= 2 && !e->grun_o[k]) --k;
+      if (k >= 2) { g = e->grun_o[k]; len = k; } else g = e->gexec[0];
     }
-    RECNN_HIP(hipGraphLaunch(e->gexec[pol ? 1 : 0], (hipStream_t)stream));
-    use_set(e, 0);
-    ++i;
+    RECNN_HIP(hipGraphLaunch(g, s));
+    use_set(e, (e->grun_look && len > 1) ? ((len - 1) & 1) : 0);   // where the debug views find the last batch
+    i += len;
   }
   return 0;
 }
@@ -1598,6 +1677,8 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
   const bool look = !overlap_actor && lookahead_ok(e);
   e->dp_sets = look ? 2 : 1;
+  struct SamplerScope { recnn_engine* e; ~SamplerScope() { e->use_sampler = false; } } sampler_scope{e};
+  e->use_sampler = e->has_sampler;
   auto head = [&](bool pregathered) -> int {
     int r = pregathered ? 0 : stage_batch(e, rows, s);
     if (!r && !(r = ph_forward(e, rows, true, !overlap_actor, true, s))) r = ph_value_backward(e, rows, true, s);

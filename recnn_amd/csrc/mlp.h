@@ -100,7 +100,15 @@ struct MlpBatch {
   MlpTail tail[MLP_MAX_TAIL];
   MlpHead head;
   MlpCriticBwd cbwd[2];
+  // Cross-workgroup waits are bounded: a wait that runs out ORs its bit into *err (device word, may be NULL) before the
+  // workgroup carries on with whatever is in memory; the host side turns a non-zero word into RECNN_E_STATE when the
+  // step's losses / counters are read (recnn_engine_read_losses), so a broken hand-off never passes as a number.
+  int32_t* err;
+  int spin_limit;    // polls before giving up (0: the default, ~0.2 s)
+  int fault;         // test hook (recnn_tune_mlp_fault): 1 = producers do not raise their flag, 2 = critics do not fill the Q slot
 };
+constexpr int MLP_ERR_PART_TIMEOUT = 1;   // layer-1 part of a chained target critic never arrived
+constexpr int MLP_ERR_Q_TIMEOUT = 2;      // Q(s, a) hand-off slot never filled
 
 int mlp_init();
 int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s);

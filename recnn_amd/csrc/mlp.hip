@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
         for (int r = 0; r < 4; ++r) P.part_out[(int64_t)(m0 + tm * 16 + fg * 4 + r) * HP + n] = acc[tm][tn][r];
     }
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
-    if (tid == 0) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
+    if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
     return;
   }
   __builtin_amdgcn_s_barrier();  // ring free
@@ -201,12 +201,15 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       dma_rows<NW>(batch.tail[0].W1a, batch.tail[0].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
       if (tid == 0) {
         // bounded spin (~0.2 s): a producer has a lower workgroup id, so it was dispatched before this workgroup and
-        // never waits itself (by now it normally finished long ago); the bound only turns a broken launch order into
-        // wrong numbers instead of a hang
+        // never waits itself (by now it normally finished long ago); the bound turns a broken launch order into a
+        // REPORTED error (batch.err -> RECNN_E_STATE at the next loss / counter read) instead of a hang
+        const int limit = batch.spin_limit > 0 ? batch.spin_limit : (1 << 22);
         for (int ti = 0; ti < P.n_tail; ++ti) {
           int spins = 0;
-          while (__hip_atomic_load(batch.tail[ti].flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22))
+          bool ok;
+          while (!(ok = __hip_atomic_load(batch.tail[ti].flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) && ++spins < limit)
             __builtin_amdgcn_s_sleep(2);
+          if (!ok && batch.err) __hip_atomic_fetch_or(batch.err, MLP_ERR_PART_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(batch.tail[ti].flag + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -340,8 +343,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
               uint32_t* slot = (uint32_t*)Hd.q_slot[c] + m;
               uint32_t bits = MLP_TQ_EMPTY;
               int spins = 0;
-              while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MLP_TQ_EMPTY && ++spins < (1 << 22))
+              const int limit = batch.spin_limit > 0 ? batch.spin_limit : (1 << 22);
+              while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MLP_TQ_EMPTY && ++spins < limit)
                 __builtin_amdgcn_s_sleep(1);
+              if (bits == MLP_TQ_EMPTY && batch.err) __hip_atomic_fetch_or(batch.err, MLP_ERR_Q_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_store(slot, MLP_TQ_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               q = __builtin_bit_cast(float, bits);
             }
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       if (lane == 0 && m0 + row < P.rows) {
         const float qv = s + P.b3[0];
         P.q[m0 + row] = qv;
-        if (P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx].q_slot)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
+        if (P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx].q_slot && batch.fault != 2)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
           __hip_atomic_store((uint32_t*)batch.cbwd[P.cbwd_idx].q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -448,6 +453,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 }
 
 static int g_mlp_waves = 16;
+static int g_mlp_fault = 0;
+// test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
+// error path (tests/test_gpu_engine.py::test_broken_handoff_is_reported)
+extern "C" void recnn_tune_mlp_fault(int mode) { g_mlp_fault = mode; }
 extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4 || w == 16) ? w : 8; }
 
 int mlp_init() {
@@ -463,7 +472,10 @@ int mlp_init() {
 
 int mlp_waves() { return g_mlp_waves; }
 
-int mlp_launch(const MlpBatch& b, int nprob, hipStream_t s) {
+int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
+  MlpBatch b = b_in;
+  b.fault = g_mlp_fault;
+  if (g_mlp_fault) b.spin_limit = 1 << 12;
   int rows = 0;
   for (int i = 0; i < nprob; ++i) {
     const MlpProb& p = b.p[i];

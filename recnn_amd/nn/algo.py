@@ -57,20 +57,27 @@ class Algo:
         self._step += 1
 
     # ---- extension: fused training on a device-resident FrameEnv (no reference counterpart) --------------------
-    def attach_env(self, env, rows_per_batch: int, users_per_batch: int = None, shard=(0, 1)):
+    def attach_env(self, env, rows_per_batch: int, users_per_batch: int = None, shard=(0, 1), dtype: str = None):
         """Let the engine sample its own batches from `env`'s TRAIN users: `run(n)` then executes n update steps
         (sampler, gather, update, step()) as hipGraph replays with no Python or host work per step.  Equivalent to
         `for batch in env.train_dataloader: self.update(batch); self.step()` with fixed `rows_per_batch`-row batches.
         Needs Adam optimizers (recnn_amd.optim.Adam / torch.optim.Adam) in `self.optimizers`.
-        `shard=(rank, world)` restricts the sampler to this data-parallel rank's share of the train users."""
+        `shard=(rank, world)` restricts the sampler to this data-parallel rank's share of the train users.
+        `dtype`: 'fp32' | 'bf16' compute type of the engine (default: fused.DEFAULTS['dtype']); only honoured before the
+        networks' first update.
+
+        Batches are FIXED-SIZE: `users_per_batch` users are drawn per step and their windows are cut to the first
+        `rows_per_batch` rows, so with the default `users_per_batch` (sized so that even the shortest histories fill the
+        batch) most windows of long-history users are not visited in an epoch.  The equivalence with
+        `for batch in env.train_dataloader` therefore holds for such truncated batches (`env.collate_users(users)` with
+        `rows_per_batch` set), not for the reference's variable-size whole-user batches."""
         from . import fused
-        from ..optim import adam_config
         algo = "td3" if "value_net1" in self.nets else "ddpg"
         keys = ("policy_optimizer", "value_optimizer1", "value_optimizer2") if algo == "td3" else ("policy_optimizer", "value_optimizer")
-        cfgs = [adam_config(self.optimizers[k]) for k in keys]
-        if any(c is None for c in cfgs) or (algo == "td3" and cfgs[1] != cfgs[2]):
-            raise ValueError("attach_env needs plain Adam optimizers (recnn_amd.optim.Adam or torch.optim.Adam)")
+        cfgs = self._fused_adam_cfgs(keys)
         ctx = fused.context_for(algo, self.nets)
+        if dtype is not None and ctx.engine is None:
+            ctx.dtype = dtype
         ctx.ensure(self.nets, rows_per_batch)
         ctx.set_hyper(self.params, cfgs[0], cfgs[1])
         ctx.apply_external(rows_per_batch)
@@ -79,6 +86,13 @@ class Algo:
         ctx.attach_sampler(env, rows_per_batch, users_per_batch, shard)
         self._fused_ctx, self._fused_keys = ctx, keys
         return self
+
+    def _fused_adam_cfgs(self, keys):
+        from ..optim import adam_config
+        cfgs = [adam_config(self.optimizers[k]) for k in keys]
+        if any(c is None for c in cfgs) or (len(cfgs) == 3 and cfgs[1] != cfgs[2]):
+            raise ValueError("attach_env / run need plain Adam optimizers (recnn_amd.optim.Adam or torch.optim.Adam)")
+        return cfgs
 
     def run(self, n_steps: int, history: bool = False):
         """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync).
@@ -89,6 +103,12 @@ class Algo:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
         every = self.params["policy_update" if "value_net1" in self.nets else "policy_step"]
         first = self._step
+        # hyper-parameters and optimizer settings are frozen into the graphs: re-read them (lr schedules, edits of
+        # self.params) -- a change rebuilds the graphs
+        cfgs = self._fused_adam_cfgs(self._fused_keys)
+        ctx.ensure(self.nets, ctx.sampler["rows"])
+        ctx.set_hyper(self.params, cfgs[0], cfgs[1])
+        ctx.apply_external(ctx.sampler["rows"])
         ctx.run_steps(first, n_steps)
         self._step += n_steps
         n_policy = len(range(first + (-first) % every, first + n_steps, every))

@@ -76,6 +76,7 @@ class StepEngine:
                 L.call("recnn_engine_bind_net", h, ni, L.ptr(self.params[ni]), L.ptr(self.grads.get(ni)),
                        L.ptr(self.adam_m.get(ni)), L.ptr(self.adam_v.get(ni)))
             L.call("recnn_engine_bind_batch", h, L.ptr(self.xs), L.ptr(self.xn), L.ptr(self.reward), L.ptr(self.done))
+            self.has_sampler = False
             self.n_masks = 8 if self.td3 else 6
             self.ext_masks = None
             self.ext_noise = None
@@ -195,9 +196,16 @@ class StepEngine:
                       n_batches, frame, emb_dim, table.data_ptr(), self._row_off.data_ptr(), self.cursor.data_ptr())
         L.call("recnn_engine_bind_sampler", self.handle, C.byref(m))
         self.n_batches = n_batches
+        self.has_sampler = True
 
     def unbind_sampler(self):
         L.call("recnn_engine_bind_sampler", self.handle, None)
+        self.has_sampler = False
+
+    def sampler_eager(self, on: bool):
+        """Eager calls (step / value_grads / finish) normally run on the BOUND batch even while a sampler is attached
+        (only graph replays, the data-parallel phase graphs and profile() draw from it); on=True makes them sample too."""
+        L.call("recnn_engine_sampler_eager", self.handle, int(on))
 
     def profile(self, rows: int, policy: bool, n_steps: int = 20):
         """Per-launch average device time of an eager step: [(name, ms, flops)]."""

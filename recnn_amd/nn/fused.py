@@ -24,7 +24,10 @@ _MODULE_PARAMS = (("linear1", "weight"), ("linear1", "bias"), ("linear2", "weigh
                   ("linear3", "weight"), ("linear3", "bias"))
 
 # process-wide defaults for engines created by the update functions
-DEFAULTS = {"dtype": "bf16", "mask_mode": "hash", "seed": None, "min_capacity": 256}
+# dtype: the update functions are the reference's drop-in API, so they default to the reference's arithmetic (fp32,
+# exact-fp32 MFMA: matches the CPU reference within 1e-4).  bf16 compute (fp32 master weights and accumulation) is the
+# throughput mode: opt in with set_defaults(dtype="bf16") -- bench.py and Algo.attach_env(..., dtype="bf16") do.
+DEFAULTS = {"dtype": "fp32", "mask_mode": "hash", "seed": None, "min_capacity": 256}
 
 _contexts: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _by_module: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
@@ -83,6 +86,22 @@ class FusedContext:
             want_in = self.S + self.A if ni >= L.NET_VALUE1 else self.S
             if m.linear1.in_features != want_in or m.linear1.out_features != self.H or m.linear2.in_features != self.H:
                 raise L.RecnnHipError(f"network '{name}' does not have the Actor/Critic shape the engine was built for")
+        # Dropout as the engine implements it: Dropout(0.5) active on the learning nets, none on the targets -- what the
+        # reference's Algo classes set up (models.py:60,205: p=0.5; algo.py:76-77: targets .eval()).  Anything else is
+        # refused instead of silently computing something different from what the modules say.
+        learners = [nets[n] for n, ni in self.names.items() if ni in (L.NET_POLICY, L.NET_VALUE1, L.NET_VALUE2)]
+        targets = [nets[n] for n, ni in self.names.items() if ni not in (L.NET_POLICY, L.NET_VALUE1, L.NET_VALUE2)]
+        train = {bool(m.training) for m in learners}
+        if len(train) != 1 or any(t.training for t in targets):
+            raise L.RecnnHipError(f"{self.algo}_update: unsupported train/eval mix -- the learning nets must share one mode "
+                                  "and the target nets must be in eval mode (as recnn.nn.DDPG / TD3 construct them)")
+        self.nets_train = train.pop()
+        for m in learners:
+            dl = getattr(m, "drop_layer", None)
+            p_drop = float(getattr(dl, "p", 0.5)) if dl is not None else 0.0
+            if self.nets_train and self.mask_mode == "hash" and p_drop != 0.5:
+                raise L.RecnnHipError(f"{self.algo}_update: drop_layer.p = {p_drop}: the fused step implements Dropout(p=0.5) "
+                                      "(the reference's value) or none (put the nets in eval mode / set_defaults(mask_mode='none'))")
 
     def ensure(self, nets, rows: int):
         self._check_modules(nets)
@@ -151,14 +170,20 @@ class FusedContext:
             xs, xn, reward, done, rows, _ = packed
             eng.bind_batch(xs, xn, reward, done)
             self._bound_external_batch = True
+            self.graph_rows = None          # binding a batch drops the engine's graphs
             return rows
-        if getattr(self, "_bound_external_batch", None):
-            eng.bind_batch()
-            self._bound_external_batch = None
+        self._own_batch()
         for k in ("state", "action", "reward", "next_state", "done"):
             if k not in batch:
                 raise KeyError(f"batch has no '{k}'")
         return eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+
+    def _own_batch(self):
+        """Back to the engine's own packed-row buffers after a FrameEnv batch was bound in place."""
+        if getattr(self, "_bound_external_batch", None):
+            self.engine.bind_batch()
+            self._bound_external_batch = None
+            self.graph_rows = None
 
     def set_hyper(self, algo_params: dict, pol_cfg: Optional[dict], val_cfg: Optional[dict]):
         P = algo_params
@@ -180,10 +205,11 @@ class FusedContext:
         """Parity runs: dropout masks / TD3 noise supplied by the caller for exactly one update."""
         eng = self.engine
         if self.external is None:
-            want = L.MASK_HASH if self.mask_mode == "hash" else L.MASK_NONE
+            want = L.MASK_HASH if (self.mask_mode == "hash" and getattr(self, "nets_train", True)) else L.MASK_NONE
             if eng.mask_mode != want:
                 L.call("recnn_engine_set_mask_mode", eng.handle, want)
                 eng.mask_mode = want
+                self.graph_rows = None      # the engine dropped its graphs
             return
         masks, noise = self.external
         self.external = None
@@ -194,6 +220,7 @@ class FusedContext:
             if eng.mask_mode != L.MASK_EXTERNAL:
                 L.call("recnn_engine_set_mask_mode", eng.handle, L.MASK_EXTERNAL)
                 eng.mask_mode = L.MASK_EXTERNAL
+                self.graph_rows = None
         eng.set_external(masks=masks, noise=noise)
 
     # ------------------------------------------------------------------ fused training loop on a device-resident env
@@ -230,8 +257,9 @@ class FusedContext:
             self._side = torch.cuda.Stream(device=eng.device)
         cur = torch.cuda.current_stream(eng.device)
         self._side.wait_stream(cur)
+        self._own_batch()                    # the sampler writes the engine's own rows
         with torch.cuda.stream(self._side):
-            if self.graph_rows != sm["rows"]:
+            if getattr(self, "graph_rows", None) != sm["rows"]:
                 eng.graph_build(sm["rows"])
                 self.graph_rows = sm["rows"]
             done = 0

@@ -55,5 +55,9 @@ def value_update(batch, params, nets, optimizer, device=torch.device("cpu"), deb
             ctx._sync_versions()
     else:
         _log_value_debug(ctx, rows, debug, writer, step)
+    # close the step on the device: ticks the mask-key step counter and, for the fused optimizer, the critic's Adam
+    # step counter (apply_net reads t = *t_ptr + 1) -- without it repeated calls reuse the same dropout masks and
+    # apply the bias correction of step 1 forever
+    L.call("recnn_engine_finish", eng.handle, rows, int(bool(learn and cfg)), 0, s)
     q, y = eng.buffer("q1", rows), eng.buffer("expected", rows)
     return torch.pow(q - y, 2).mean()

@@ -48,6 +48,8 @@ class DataParallelStepper:
         self.overlap = bool(self.graphs and overlap and (self.world > 1 or always_reduce))
         if self.graphs:
             engine.dp_graph_build(rows, self.scale, self.overlap)
+        elif getattr(engine, "has_sampler", False):
+            engine.sampler_eager(True)      # eager phases: value_grads builds the step's batch from the sampler
 
     def _allreduce(self, t: torch.Tensor):
         if self.world > 1 or self.always_reduce:
