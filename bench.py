@@ -106,6 +106,53 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
             "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s"}
 
 
+# launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports
+KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlp_fwd_kernel", "mlp_l1_nets": "mlp_l1_kernel", "mlp_tail_nets": "mlp_tail_kernel",
+                  "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
+                  "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel"}
+
+
+def measure_traffic(argv_tail, kernel_substr, timeout_s=240):
+    """HBM bytes per launch of one kernel from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3
+    sections) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a child
+    run of this same benchmark, counter unit KB, FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B),
+    WRITE_SIZE as is.  Returns (bytes or None, note)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "already running under a profiler"
+    means = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"recnn_pmc_{ctr}_", dir="/tmp")
+        cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__)] + argv_tail
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
+                           env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            vals = []
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, f))):
+                            if kernel_substr in r["Kernel_Name"] and r.get("Counter_Name", ctr) == ctr:
+                                vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {ctr} rows for {kernel_substr}"
+            means[ctr] = sum(vals) / len(vals)
+        except Exception as ex:                                    # profiler unavailable on this box: report null
+            return None, f"{ctr} pass failed: {type(ex).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = means["FETCH_SIZE"] * 1024.0 * 2.0 + means["WRITE_SIZE"] * 1024.0
+    return total, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on a child run of this command, mean per "
+                   f"launch of {kernel_substr}: fetch 2 x {means['FETCH_SIZE'] * 1024:.0f} B + write {means['WRITE_SIZE'] * 1024:.0f} B")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +162,10 @@ def main():
     ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3"], help="td3 --rows 4096 = BASELINE.json configs[2]")
     ap.add_argument("--rows", type=int, default=B_ROWS, help="transition rows per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs behind roofline.traffic")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank steps on its own --rows rows (headline); strong: the GLOBAL batch is --rows rows, "
+                         "each rank takes rows/N of it")
     ap.add_argument("--overlap", action="store_true", help="data parallel: overlap the critic all-reduce with the actor forward")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     args = ap.parse_args()
@@ -129,6 +180,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rows = args.rows
+    if args.scaling == "strong":
+        if rows % world:
+            raise SystemExit(f"--scaling strong: {rows} rows do not split over {world} ranks")
+        rows //= world
     use_dp = world > 1 or args.force_dp
     if use_dp:
         import torch.distributed as dist
@@ -244,11 +299,16 @@ def main():
         out = {
             "metric": "DDPG update steps/sec (batch 2048, frame 10, emb 128)" if (args.algo, rows) == ("ddpg", B_ROWS)
                       else f"{args.algo.upper()} update steps/sec (batch {rows}, frame 10, emb 128)",
-            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            # weak scaling: every rank completes `steps` updates on its own `rows`-row batch -> N x steps batch-updates;
+            # strong scaling: the ranks share ONE `args.rows`-row batch per step -> `steps` updates in total
+            "value": (world if args.scaling == "weak" else 1) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": args.scaling,
+            # synchronised optimizer updates per second (one per step whatever N is) and transition rows consumed per second
+            "global_updates_per_s": args.steps / elapsed, "rows_per_s": world * rows * args.steps / elapsed,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("configs[1]: DDPG" if args.algo == "ddpg" else "configs[2]: TD3 (twin critics, delayed actor)")
-                                   + f", {rows} transition rows/step/GPU, frame_size 10, emb_dim 128, "
+                                   + f", {rows} transition rows/step/GPU ({args.scaling} scaling), frame_size 10, emb_dim 128, "
                                    "Actor/Critic hidden 256, Adam, policy+soft update every 10th step, synthetic ML20M-shaped "
                                    "replay store (138,493 users, 26,744 items, ~20M ratings)",
                        "rows_per_step_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single",
@@ -258,20 +318,22 @@ def main():
         with torch.cuda.stream(stream):
             prof = eng.profile(rows, policy=False, n_steps=50)
             prof_pol = eng.profile(rows, policy=True, n_steps=10)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(tpath):          # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be
-            traffic = json.load(open(tpath))   # collected from inside this process); absent -> null
         dom = max(prof, key=lambda r: r[1])
+        # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
+        traffic, traffic_note = None, "skipped"
+        if world == 1 and not args.no_traffic and not use_dp:
+            tail = ["--steps", "40", "--warmup", "20", "--no-cpu-baseline", "--no-traffic", "--dtype", args.dtype,
+                    "--algo", args.algo, "--rows", str(args.rows)]
+            traffic, traffic_note = measure_traffic(tail, KERNEL_OF_SLOT.get(dom[0], dom[0]))
         if dom[2] > 0:
             ach = dom[2] / (dom[1] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             out["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic.get(dom[0], {}).get("traffic_bytes"),
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
                                "avg_ms": dom[1], "flops_per_launch": dom[2]}
         else:
             out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": None, "traffic": None, "avg_ms": dom[1]}
+                               "frac": None, "traffic": traffic, "traffic_source": traffic_note, "avg_ms": dom[1]}
         g = [r for r in prof if r[0] == "frame_gather"]
         if g:
             f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
@@ -279,7 +341,7 @@ def main():
             gbs = per_row * rows / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                      "traffic": traffic.get("frame_gather", {}).get("traffic_bytes"), "avg_ms": g[0][1],
+                                      "traffic": None, "avg_ms": g[0][1],
                                       "bytes_per_launch": per_row * rows,
                                       "rows_dtype": "fp32+bf16" if (f32_rows and args.dtype == "bf16") else args.dtype}
         gemm_fl = sum(r[2] for r in prof)
