@@ -1218,14 +1218,20 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   if (run_final ? e->run_tick[2] > 0 : ticked_policy) { a.tick_inc[a.n_tick] = e->run_tick[2]; a.tick[a.n_tick++] = e->net[RECNN_NET_POLICY].t_ptr; }
   if (e->has_sampler && e->use_sampler) { a.wrap_ptr = e->smp.cursor; a.wrap_mod = e->smp.n_batches; a.wrap_inc = e->run_tick[0]; }
   a.ring = e->loss_ring; a.ring_mask = LOSS_RING - 1;
-  if (run_final && value_panel_ok(e) && e->run_off >= 1 && e->run_off < LOSS_HIST_MAX) {
+  if (run_final && e->run_off >= 1 && e->run_off < LOSS_HIST_MAX) {
     // losses of the run's earlier steps from their kept partial sums (the step counter is not ticked yet)
     LossHistoryArgs h;
     memset(&h, 0, sizeof(h));
     h.n_steps = e->run_off; h.n = nc + 1;
     for (int c = 0; c < nc; ++c) { h.part[c] = e->loss_part_base[c]; h.stride[c] = e->loss_part_stride; h.n_part[c] = nval; h.scale[c] = 1.0f / (float)rows; }
-    h.part[nc] = e->pl_part_base; h.stride[nc] = e->pl_cap; h.scale[nc] = -1.0f / (float)rows;
-    for (int i = 0; i < e->run_off; ++i) { h.pol_count[i] = e->hist_pol_count[i]; h.pol_add[i] = e->hist_pol_add[i]; }
+    h.scale[nc] = -1.0f / (float)rows;
+    if (value_panel_ok(e)) {   // policy loss from the layer-2 epilogue's partial dots / the deferred forward's per-row Q
+      h.part[nc] = e->pl_part_base; h.stride[nc] = e->pl_cap;
+      for (int i = 0; i < e->run_off; ++i) { h.pol_count[i] = e->hist_pol_count[i]; h.pol_add[i] = e->hist_pol_add[i]; }
+    } else {                   // ... from the head kernel's per-block partial sums (fp32 / generic path)
+      h.part[nc] = e->loss_part_base[2]; h.stride[nc] = e->loss_part_stride;
+      for (int i = 0; i < e->run_off; ++i) { h.pol_count[i] = nblk; h.pol_add[i] = 0; }
+    }
     h.b3 = e->net[RECNN_NET_VALUE1].p + e->net[RECNN_NET_VALUE1].off[B3];
     h.step_ctr = e->counters; h.ring = e->loss_ring; h.ring_mask = LOSS_RING - 1;
     int hrc = slot(e, "loss_history", 0, s, [&] { return loss_history_launch(h, s); }, false);
@@ -1571,6 +1577,8 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, bool pol_first, int le
   hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   RECNN_HIP(ie);
+  // pay the one-time device-side set-up of the executable graph now, not inside somebody's timed first replay
+  if (hipGraphUpload(*out, s) != hipSuccess) (void)hipGetLastError();
   return 0;
 }
 // the run lengths kept for `limit` (largest useful length): every length when the family stays small, else powers of two
