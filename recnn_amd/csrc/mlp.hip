@@ -452,6 +452,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
   }
 }
 
+int mlp64_init();
+int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
+static int g_mlp_panel = 64;   // rows per workgroup: 64 = mlp64.hip (default), 32 = the kernel in this file
+extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_panel = rows == 32 ? 32 : 64; }
 static int g_mlp_waves = 16;
 static int g_mlp_fault = 0;
 // test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
@@ -460,7 +464,9 @@ extern "C" void recnn_tune_mlp_fault(int mode) { g_mlp_fault = mode; }
 extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4 || w == 16) ? w : 8; }
 
 int mlp_init() {
-  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
+  int rc = mlp64_init();
+  if (rc) return rc;
+  rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
                            "mlp_fwd_kernel<4> attr");
   if (rc) return rc;
   rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
@@ -493,6 +499,7 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
       if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
+  if (g_mlp_panel == 64 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);
   if (g_mlp_waves == 16)
     hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b);
   else if (g_mlp_waves == 8)

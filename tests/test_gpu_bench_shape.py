@@ -180,7 +180,7 @@ def test_run_interleaved_with_test_updates(cuda):
     out = ddpg.run(12)                                               # graphs are rebuilt on the engine's own rows
     torch.cuda.synchronize()
     assert np.isfinite(out["value"]) and out["step"] == 24
-    assert ctx.engine.counters() == (27, 4, 25, 0) and int(ctx.engine.cursor.item()) == 25
+    assert ctx.engine.counters() == (27, 3, 25, 0) and int(ctx.engine.cursor.item()) == 25   # policy steps 0, 10, 20
     assert not torch.equal(w0, ddpg.nets["value_net"].linear1.weight)
 
 
