@@ -391,6 +391,10 @@ int recnn_engine_dp_sets(recnn_engine* e);
  * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
  * on purpose (tests). */
 void recnn_tune_mlp_fault(int mode);
+/* fused MLP forward: rows per workgroup (64 = csrc/mlp64.hip, the default; 32 = csrc/mlp.hip, bit-identical results) and
+ * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
+void recnn_tune_mlp_panel(int rows);
+void recnn_tune_mlp_map(int mode);
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

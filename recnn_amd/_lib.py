@@ -106,6 +106,8 @@ SIGNATURES = {
     "recnn_tune_pregather": (None, [_I]),
     "recnn_tune_defer_policy_fwd": (None, [_I]),
     "recnn_tune_mlp_fault": (None, [_I]),
+    "recnn_tune_mlp_panel": (None, [_I]),
+    "recnn_tune_mlp_map": (None, [_I]),
     "recnn_engine_sampler_eager": (_I, [_P, _I]),
     "recnn_engine_unit_backward": (_I, [_P]),
     "recnn_engine_dp_sets": (_I, [_P]),

@@ -35,7 +35,8 @@ constexpr int STAGE = A_BYTES + W_BYTES;      // 40 KB
 constexpr int NS = 3;
 constexpr int PANEL_OFF = NS * STAGE;         // 120 KB
 constexpr int PANEL_Q = BM * ROWB;            // 64 columns of the 64 x 256 activation panel, same image as an A slab
-constexpr int LDS_TOTAL = PANEL_OFF + 4 * PANEL_Q;   // 152 KB
+constexpr int BIAS_OFF = PANEL_OFF + 4 * PANEL_Q;    // fp32 biases: b1 | b2 | b3 | tail0 b1 | tail0 b2 | tail1 b1 | tail1 b2, 256 floats each
+constexpr int LDS_TOTAL = BIAS_OFF + 7 * 1024;        // 159 KB
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst_uniform))
       : "memory");
 }
 
@@ -92,13 +93,14 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
 }
 
 // hidden-layer epilogue: bias + relu + dropout -> bf16 into the LDS panel (the next layer's A operand)
-__device__ __forceinline__ uint32_t hidden_epilogue(f32x4 (&acc)[2][2], const float (&bv)[2], int H, int rows, int m0, int wm, int wn,
+__device__ __forceinline__ uint32_t hidden_epilogue(f32x4 (&acc)[2][2], const float* bias_lds, int H, int rows, int m0, int wm, int wn,
                                                     int fr, int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
                                                     unsigned char* panel) {
   uint32_t bits = 0;
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     const int n = wn * 32 + tn * 16 + fr;
+    const float bvn = bias_lds[n];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int rb = wm * 32 + tm * 16 + fg * 4;
@@ -107,7 +109,7 @@ __device__ __forceinline__ uint32_t hidden_epilogue(f32x4 (&acc)[2][2], const fl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rb + r, m = m0 + row;
-        float v = fmaxf(acc[tm][tn][r] + bv[tn], 0.f);
+        float v = fmaxf(acc[tm][tn][r] + bvn, 0.f);
         if (mask_mode == RECNN_MASK_EXTERNAL) v = (m < rows && n < H && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
         else if (mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
         if (n >= H) v = 0.f;
@@ -169,41 +171,34 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
   const bool do_cbwd = !has_w3 && P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx < 0 ? 0 : P.cbwd_idx].enabled;
   const int total = P.part_out ? n1 : n1 + 4 + (has_w3 ? 4 + 6 * P.n_tail : (do_cbwd ? 4 : 0));
 
-  // ---- everything the epilogues need from global memory, fetched and waited for BEFORE the first DMA
-  float b1v[2], b2v[2], b3v = 0.f;
-  float tb1[MLP_MAX_TAIL][2], tb2[MLP_MAX_TAIL][2];
+  // ---- biases -> LDS BEFORE the first DMA is issued: a compiler-visible global load that is waited for while DMAs are in
+  // flight drains the ring (the compiler's s_waitcnt cannot count them); the epilogues read them with ds_read
+  float* bias_lds = (float*)(lds + BIAS_OFF);
+  if (!P.part_out && tid < HP) {
+    const int n = tid;
+    bias_lds[n] = n < P.H ? P.b1[n] : 0.f;
+    bias_lds[HP + n] = n < P.H ? P.b2[n] : 0.f;
+    bias_lds[2 * HP + n] = (has_w3 && n < P.out_dim) ? P.b3[n] : 0.f;
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = wn * 32 + tn * 16 + fr;
-    b1v[tn] = (n < P.H && !P.part_out) ? P.b1[n] : 0.f;
-    b2v[tn] = (n < P.H && !P.part_out) ? P.b2[n] : 0.f;
-#pragma unroll
-    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
-      tb1[ti][tn] = (ti < P.n_tail && n < P.H) ? batch.tail[ti].b1[n] : 0.f;
-      tb2[ti][tn] = (ti < P.n_tail && n < P.H) ? batch.tail[ti].b2[n] : 0.f;
-    }
+    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti)
+      if (ti < P.n_tail) {
+        bias_lds[(3 + 2 * ti) * HP + n] = n < P.H ? batch.tail[ti].b1[n] : 0.f;
+        bias_lds[(4 + 2 * ti) * HP + n] = n < P.H ? batch.tail[ti].b2[n] : 0.f;
+      }
   }
-  if (has_w3) { const int n = wn * 16 + fr; b3v = n < P.out_dim ? P.b3[n] : 0.f; }
   uint32_t key1 = 0, key2 = 0;
   if (P.mask_mode == RECNN_MASK_HASH) {
     const int32_t st = (P.step_ptr ? *P.step_ptr : 0) + P.step_add;
     key1 = mask_key(P.seed, st, P.stream1);
     key2 = mask_key(P.seed, st, P.stream2);
   }
-  // the empty asm makes the compiler wait for these loads HERE (it cannot count the DMAs issued below)
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    asm volatile("" : "+v"(b1v[tn]), "+v"(b2v[tn]));
-#pragma unroll
-    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) asm volatile("" : "+v"(tb1[ti][tn]), "+v"(tb2[ti][tn]));
-  }
-  asm volatile("" : "+v"(b3v));
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the first slab's barrier publishes the bias area)
 
   // ---- the ring
   int head = 0, issued = 0, st_issue = 0, st_head = 0;
   auto issue = [&]() {
     const int i = issued;
-    const unsigned st = lds0 + st_issue * STAGE;
+    const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + st_issue * STAGE);
     const unsigned wimg = st + A_BYTES;
     if (i < n1) {
       const int sg = i < nt0 ? 0 : 1;
@@ -290,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + panel_idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  const uint32_t gate1 = hidden_epilogue(acc, b1v, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel);
+  const uint32_t gate1 = hidden_epilogue(acc, bias_lds, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel);
 
   // ------------------------------------------------------------------ layer 2
 #pragma unroll
@@ -304,8 +299,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     refill();
     mma_slab<2>(panel + j * PANEL_Q, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
   }
-  // chained critics: wait for the producers' layer-1 parts and fetch them (overlaps epilogue 2 and layer 3)
-  f32x4 pacc[MLP_MAX_TAIL][2][2];
+  // chained critics: wait for the producers' layer-1 parts (the fetch itself follows epilogue 2, straight into the dead accumulators)
   if (has_w3 && P.n_tail) {
     if (tid == 0) {
       // bounded spin: a producer has a lower logical workgroup id and never waits itself; a wait that runs out is
@@ -320,26 +314,22 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
         __hip_atomic_store(batch.tail[ti].flag + panel_idx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    __builtin_amdgcn_s_barrier();   // flags seen (tid 0's acquire dropped this CU's stale lines); also: everyone is done with the h1 panel
-#pragma unroll
-    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti)
-      if (ti < P.n_tail) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          const int n = wn * 32 + tn * 16 + fr;
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              pacc[ti][tm][tn][r] = batch.tail[ti].part[(int64_t)(m0 + wm * 32 + tm * 16 + fg * 4 + r) * HP + n];
-        }
-      }
-  } else {
-    __builtin_amdgcn_s_barrier();   // everyone is done with the h1 panel
   }
-  hidden_epilogue(acc, b2v, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel);
+  __builtin_amdgcn_s_barrier();   // everyone is done with the h1 panel; flags seen (tid 0's acquire dropped this CU's stale lines)
+  hidden_epilogue(acc, bias_lds + HP, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel);
 
+  auto load_part = [&](const float* part) {   // the accumulators start from the producer's fp32 layer-1 state part
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = wn * 32 + tn * 16 + fr;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tm][tn][r] = part[(int64_t)(m0 + wm * 32 + tm * 16 + fg * 4 + r) * HP + n];
+    }
+  };
   if (has_w3) {
+    if (P.n_tail) load_part(batch.tail[0].part);   // in flight under layer 3
     // ---------------------------------------------------------------- layer 3 (actor): 64 x 128 outputs
     f32x4 o[2][1];
     o[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -354,12 +344,13 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     {
       const int n = wn * 16 + fr;
       const bool ncol = n < P.out_dim;
+      const float b3n = bias_lds[2 * HP + n];
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * 32 + tm * 16 + fg * 4 + r, m = m0 + row;
-          float v = o[tm][0][r] + b3v;
+          float v = o[tm][0][r] + b3n;
           if (P.addend && ncol && m < P.rows) {
             const float z = P.addend[(int64_t)m * P.ld_add + n];
             v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
@@ -375,17 +366,14 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
       if (ti >= P.n_tail) break;
       const MlpTail& T = batch.tail[ti];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = pacc[ti][i][j];
+      if (ti > 0) load_part(T.part);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {        // + action panel x W1a (behind the first barrier: action panel written, panel reads done)
         const unsigned char* st = wait_slab();
         refill();
         mma_slab<2>(lds + j * STAGE, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
       }
-      hidden_epilogue(acc, tb1[ti], P.H, P.rows, m0, wm, wn, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
+      hidden_epilogue(acc, bias_lds + (3 + 2 * ti) * HP, P.H, P.rows, m0, wm, wn, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -397,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
         mma_slab<2>(panel + j * PANEL_Q, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
       }
       __builtin_amdgcn_s_barrier();  // everyone is done reading the h1 panel
-      hidden_epilogue(acc, tb2[ti], P.H, P.rows, m0, wm, wn, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
+      hidden_epilogue(acc, bias_lds + (4 + 2 * ti) * HP, P.H, P.rows, m0, wm, wn, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -459,11 +447,13 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
         }
       }
     }
-  } else if (P.q) {
-    // ---------------------------------------------------------------- critic head: q[m] = h2[m, :] . w3 + b3
+  } else {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // h2 panel complete
     if (P.h2) panel_to_global(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
+  }
+  if (!has_w3 && P.q) {
+    // ---------------------------------------------------------------- critic head: q[m] = h2[m, :] . w3 + b3
 #pragma unroll
     for (int i = 0; i < BM / NW; ++i) {
       const int row = wave * (BM / NW) + i;
