@@ -256,9 +256,18 @@ typedef struct recnn_hyper {
   float soft_tau;
   int policy_every;                    /* policy_step / policy_update */
   float noise_std, noise_clip;         /* TD3 */
-  /* Adam, [0] = policy optimizer, [1] = value optimizer(s) */
+  /* optimizer slots: [0] = policy optimizer, [1] = value optimizer(s) */
   float lr[2], beta1[2], beta2[2], eps[2], weight_decay[2];
+  /* opt_kind: RECNN_OPT_ADAM = torch.optim.Adam arithmetic (L2 weight decay folded into the gradient);
+   *           RECNN_OPT_RANGER = RAdam (variance-rectified Adam, decoupled lr*wd*p decay) + Lookahead(la_k, la_alpha):
+   *           the shape of the reference's default torch_optimizer.Ranger (recnn/nn/algo.py:84-89, 139-147); needs the
+   *           slow-weight arena bound with recnn_engine_bind_slow. */
+  int opt_kind[2];
+  float la_alpha[2];          /* Lookahead interpolation (Ranger default 0.5) */
+  int la_k[2];                /* Lookahead period in optimizer steps (Ranger default 6) */
+  float nsma_threshold[2];    /* rectification switch: adaptive step iff N_sma > threshold (Ranger default 5) */
 } recnn_hyper;
+enum { RECNN_OPT_ADAM = 0, RECNN_OPT_RANGER = 1 };
 
 /* Sizes (in bytes) of the buffers the caller must allocate for an engine. */
 typedef struct recnn_engine_sizes {
@@ -278,6 +287,13 @@ void recnn_engine_destroy(recnn_engine* e);
  * array laid out [w1 | b1 | w2 | b2 | w3 | b3] in torch's [out,in] row-major layout.
  * grads/m/v may be NULL for target networks. */
 int recnn_engine_bind_net(recnn_engine* e, int net, float* params, float* grads, float* adam_m, float* adam_v);
+/* Lookahead slow weights of a learning network (flat fp32 arena, canonical layout, initialised by the caller with the
+ * parameters as they were when the optimizer state was created); required for RECNN_OPT_RANGER. */
+int recnn_engine_bind_slow(recnn_engine* e, int net, float* slow);
+/* One optimizer step over a flat fp32 array, RAdam + Lookahead (RECNN_OPT_RANGER arithmetic; step_t = 1-based step). */
+int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold, int step_t,
+                      float grad_scale, void* stream);
 
 /* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
 int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);
@@ -395,6 +411,7 @@ void recnn_tune_mlp_fault(int mode);
  * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
 void recnn_tune_mlp_panel(int rows);
 void recnn_tune_mlp_map(int mode);
+void recnn_tune_mlp_probe(int bits);   /* timing experiments on the 64-row kernel's operand streams; results are garbage */
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RECNN_HIP_LIB") or os.path.join(_HERE, "csrc", "libre
 F32, BF16 = 0, 1
 MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
 ALGO_DDPG, ALGO_TD3 = 0, 1
+OPT_ADAM, OPT_RANGER = 0, 1
 NET_POLICY, NET_TARGET_POLICY, NET_VALUE1, NET_TARGET_VALUE1, NET_VALUE2, NET_TARGET_VALUE2 = range(6)
 
 
@@ -59,6 +60,7 @@ class Hyper(C.Structure):
         ("noise_std", C.c_float), ("noise_clip", C.c_float),
         ("lr", C.c_float * 2), ("beta1", C.c_float * 2), ("beta2", C.c_float * 2),
         ("eps", C.c_float * 2), ("weight_decay", C.c_float * 2),
+        ("opt_kind", C.c_int * 2), ("la_alpha", C.c_float * 2), ("la_k", C.c_int * 2), ("nsma_threshold", C.c_float * 2),
     ]
 
 
@@ -108,6 +110,7 @@ SIGNATURES = {
     "recnn_tune_mlp_fault": (None, [_I]),
     "recnn_tune_mlp_panel": (None, [_I]),
     "recnn_tune_mlp_map": (None, [_I]),
+    "recnn_tune_mlp_probe": (None, [_I]),
     "recnn_engine_sampler_eager": (_I, [_P, _I]),
     "recnn_engine_unit_backward": (_I, [_P]),
     "recnn_engine_dp_sets": (_I, [_P]),
@@ -129,6 +132,8 @@ SIGNATURES = {
     "recnn_engine_destroy": (None, [_P]),
     "recnn_engine_bind_net": (_I, [_P, _I, _P, _P, _P, _P]),
     "recnn_engine_bind_batch": (_I, [_P, _P, _P, _P, _P]),
+    "recnn_engine_bind_slow": (_I, [_P, _I, _P]),
+    "recnn_ranger_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),
     "recnn_engine_profile": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(_I)]),

@@ -50,6 +50,7 @@ constexpr int SP_W1_MAX = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the
 struct Net {
   bool critic = false, bound = false;
   float *p = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // canonical flat arenas (caller owned)
+  float* slow = nullptr;                                          // Lookahead slow weights (Ranger), caller owned
   int in_dim = 0, out_dim = 0;
   int64_t off[6] = {0, 0, 0, 0, 0, 0};
   int64_t n_params = 0;
@@ -404,6 +405,14 @@ extern "C" int recnn_engine_bind_net(recnn_engine* e, int ni, float* params, flo
   return 0;
 }
 
+extern "C" int recnn_engine_bind_slow(recnn_engine* e, int ni, float* slow) {
+  RECNN_REQUIRE(e && ni >= 0 && ni < RECNN_NET_COUNT && net_used(e, ni) && net_learns(ni), "bind_slow: not a learning network of this algorithm");
+  RECNN_REQUIRE(!slow || ((uintptr_t)slow & 15) == 0, "bind_slow: arena must be 16-byte aligned");
+  e->net[ni].slow = slow;
+  drop_graphs(e);
+  return 0;
+}
+
 extern "C" int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done) {
   RECNN_REQUIRE(e && xs && xn && reward && done, "bind_batch: null pointer");
   RECNN_REQUIRE((((uintptr_t)xs | (uintptr_t)xn) & 15) == 0, "bind_batch: packed rows must be 16-byte aligned");
@@ -440,6 +449,8 @@ extern "C" int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* m
 extern "C" int recnn_engine_set_hyper(recnn_engine* e, const recnn_hyper* h) {
   RECNN_REQUIRE(e && h, "set_hyper: null pointer");
   RECNN_REQUIRE(h->policy_every > 0, "set_hyper: policy_every must be positive");
+  for (int i = 0; i < 2; ++i)
+    RECNN_REQUIRE(h->opt_kind[i] == RECNN_OPT_ADAM || (h->opt_kind[i] == RECNN_OPT_RANGER && h->la_k[i] >= 0), "set_hyper: bad optimizer kind");
   e->hy = *h;
   e->hyper_set = true;
   drop_graphs(e);
@@ -539,6 +550,11 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
     RECNN_REQUIRE(n.g && n.m && n.v && n.t_ptr, "apply: network %d has no optimizer state bound", ni);
     a.lr = e->hy.lr[opt_idx]; a.beta1 = e->hy.beta1[opt_idx]; a.beta2 = e->hy.beta2[opt_idx];
     a.eps = e->hy.eps[opt_idx]; a.weight_decay = e->hy.weight_decay[opt_idx];
+    a.opt_kind = e->hy.opt_kind[opt_idx];
+    if (a.opt_kind == RECNN_OPT_RANGER) {
+      RECNN_REQUIRE(n.slow, "apply: network %d runs Ranger but has no Lookahead slow-weight arena bound (recnn_engine_bind_slow)", ni);
+      a.slow = n.slow; a.la_alpha = e->hy.la_alpha[opt_idx]; a.la_k = e->hy.la_k[opt_idx]; a.nsma_thr = e->hy.nsma_threshold[opt_idx];
+    }
   }
   a.grad_scale = grad_scale;
   a.from_slabs = from_slabs && do_adam && rows > 0;

@@ -148,7 +148,7 @@ __device__ __forceinline__ float row_dot(const unsigned char* panel, int row, in
 }
 }  // namespace
 
-__global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, int npanel, int map_mode) {
+__global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, int npanel, int map_mode, int probe) {
   int bid = blockIdx.x;
   if (map_mode == 2) bid = xcd_remap(bid, gridDim.x);
   const int prob = bid / npanel, panel_idx = bid - prob * npanel;
@@ -203,9 +203,17 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     if (i < n1) {
       const int sg = i < nt0 ? 0 : 1;
       const int k0 = (sg == 0 ? i : i - nt0) * KS;
-      if (wave < 8) dma_img8(P.A[sg], P.lda[sg], m0, row_max, k0, wave, st, lane);
-      dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave, wimg, lane);
-      dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave + 16, wimg, lane);
+      // probe (timing experiments only, results are garbage): 1 = every panel reads batch rows 0..63 (A operand L2-hot),
+      // 2 = no W DMA in layer 1, 4 = no A DMA in layer 1
+      if (wave < 8 && !(probe & 4)) dma_img8(P.A[sg], P.lda[sg], (probe & 1) ? 0 : m0, row_max, k0, wave, st, lane);
+      else if (wave < 8) dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave, st, lane);
+      if (!(probe & 2)) {
+        dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave, wimg, lane);
+        dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave + 16, wimg, lane);
+      } else {
+        dma_img8(P.W1, P.ldw1, 0, 15, P.w1_col[sg], wave & 1, wimg, lane);
+        dma_img8(P.W1, P.ldw1, 0, 15, P.w1_col[sg], wave & 1, wimg, lane);
+      }
     } else {
       int j = i - n1;
       if (j < 4) {
@@ -547,6 +555,8 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
 
 static int g_mlp_map = 0;
 extern "C" void recnn_tune_mlp_map(int mode) { g_mlp_map = mode == 2 ? 2 : 0; }
+static int g_mlp_probe = 0;
+extern "C" void recnn_tune_mlp_probe(int bits) { g_mlp_probe = bits; }   // timing experiments (see issue() in the kernel)
 
 int mlp64_init() {
   return recnn_check_hip(hipFuncSetAttribute((const void*)mlp64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
@@ -562,6 +572,6 @@ int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s) {
     if (p.ldh != HP && (p.h1 || p.h2 || p.cbwd_idx >= 0)) { recnn_set_error("mlp64: hidden activations must have pitch 256"); return RECNN_E_INVALID; }
   }
   const int npanel = (rows + BM - 1) / BM;
-  hipLaunchKernelGGL(mlp64_kernel, dim3(npanel * nprob), dim3(NW * 64), LDS_TOTAL, s, b, npanel, g_mlp_map);
+  hipLaunchKernelGGL(mlp64_kernel, dim3(npanel * nprob), dim3(NW * 64), LDS_TOTAL, s, b, npanel, g_mlp_map, g_mlp_probe);
   return recnn_check_hip(hipGetLastError(), "mlp64_kernel");
 }

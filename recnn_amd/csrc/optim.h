@@ -56,7 +56,25 @@ struct ApplyArgs {
   int from_slabs;       // gradient = sum of the layout's partial slabs (fused slab reduction); g_out receives it
   float* g_out;
   double log_beta1, log_beta2;  // filled by apply_launch
+  int opt_kind;         // RECNN_OPT_ADAM | RECNN_OPT_RANGER
+  float* slow;          // Ranger: Lookahead slow weights (canonical layout)
+  float la_alpha;
+  int la_k;
+  float nsma_thr;
 };
+
+// RAdam step scalars for step t (double, as the Python implementations compute them): rectified?, step size factor
+struct RadamScalars { int rect; float step; };
+__host__ __device__ inline RadamScalars radam_scalars(int t, double log_beta1, double log_beta2, double beta2, double nsma_thr) {
+  const double b2t = exp((double)t * log_beta2), b1t = exp((double)t * log_beta1);
+  const double n_max = 2.0 / (1.0 - beta2) - 1.0;
+  const double n_sma = n_max - 2.0 * (double)t * b2t / (1.0 - b2t);
+  RadamScalars r;
+  r.rect = n_sma > nsma_thr;
+  r.step = (float)((r.rect ? sqrt((1.0 - b2t) * (n_sma - 4.0) / (n_max - 4.0) * (n_sma - 2.0) / n_sma * n_max / (n_max - 2.0)) : 1.0)
+                   / (1.0 - b1t));
+  return r;
+}
 
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);
 struct GatherArgs;

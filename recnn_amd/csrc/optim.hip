@@ -195,17 +195,19 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
   const Own o = own_elems(T, bt);
   const int64_t e = T.p_off + o.e;
 
-  float p[4], m[4], v[4], tp[4], g[4];
+  float p[4], m[4], v[4], tp[4], g[4], sl[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) p[j] = m[j] = v[j] = tp[j] = g[j] = 0.f;
+  for (int j = 0; j < 4; ++j) p[j] = m[j] = v[j] = tp[j] = g[j] = sl[j] = 0.f;
+  const bool ranger = a.do_adam && a.opt_kind == RECNN_OPT_RANGER;
+  int t = a.do_adam ? *a.t_ptr + 1 + a.t_add : 0;
+  const bool la_sync = ranger && a.la_k > 0 && (t % a.la_k) == 0;   // Lookahead: slow += alpha (p - slow); p = slow
   if (o.cnt) {
     load_own(a.p + e, o, p);
     if (a.do_adam) { load_own(a.m + e, o, m); load_own(a.v + e, o, v); }
     if (a.tgt_p) load_own(a.tgt_p + e, o, tp);
+    if (la_sync) load_own(a.slow + e, o, sl);
   }
-  int t = 0;
   if (a.do_adam) {
-    t = *a.t_ptr + 1 + a.t_add;
     if (a.from_slabs) {
       slab_grads(T, bt, o, g, sp);
       if (o.cnt && a.g_out) store_own(a.g_out + e, o, g);
@@ -220,7 +222,29 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
     gs *= coef;
   }
   if (o.cnt == 0) return;
-  if (a.do_adam) {
+  if (ranger) {
+    // RAdam + Lookahead, the published torch_optimizer.Ranger algorithm (recnn/nn/algo.py:84-89 builds it; the package
+    // itself is absent and un-pinned: restated, see recnn_amd/optim.py):
+    //   v = b2 v + (1-b2) g^2;  m = b1 m + (1-b1) g;  N_sma = N_max - 2 t b2^t / (1 - b2^t)
+    //   p -= wd lr p;  N_sma > thr: p -= step lr m / (sqrt(v) + eps)  else  p -= step lr m
+    //   every k-th step: slow += alpha (p - slow); p = slow
+    const RadamScalars rs = radam_scalars(t, a.log_beta1, a.log_beta2, (double)a.beta2, (double)a.nsma_thr);
+    const float sl_lr = rs.step * a.lr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = g[j] * gs;
+      v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+      m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
+      if (a.weight_decay != 0.f) p[j] += (-a.weight_decay * a.lr) * p[j];
+      if (rs.rect) p[j] += -sl_lr * (m[j] / (sqrtf(v[j]) + a.eps));
+      else p[j] += -sl_lr * m[j];
+      if (la_sync) { sl[j] += a.la_alpha * (p[j] - sl[j]); p[j] = sl[j]; }
+    }
+    store_own(a.m + e, o, m);
+    store_own(a.v + e, o, v);
+    store_own(a.p + e, o, p);
+    if (la_sync) store_own(a.slow + e, o, sl);
+  } else if (a.do_adam) {
     // bias corrections 1 - beta^t = -expm1(t ln beta) in double (torch computes them in Python floats)
     const double bc1 = -expm1((double)t * a.log_beta1);
     const double bc2 = -expm1((double)t * a.log_beta2);
@@ -406,4 +430,39 @@ extern "C" int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, flo
   hipLaunchKernelGGL(l1_part_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
   hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, grid, out);
   return recnn_check_hip(hipGetLastError(), "l1_norm_flat");
+}
+
+__global__ __launch_bounds__(256) void ranger_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, float* __restrict__ slow, int64_t n, float lr,
+                                                          float beta1, float beta2, float eps, float wd, float la_alpha, int la_sync,
+                                                          int rect, float step, float gs) {
+  const float sl_lr = step * lr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    const float gi = g[i] * gs;
+    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+    mi = beta1 * mi + (1.0f - beta1) * gi;
+    if (wd != 0.f) pi += (-wd * lr) * pi;
+    if (rect) pi += -sl_lr * (mi / (sqrtf(vi) + eps));
+    else pi += -sl_lr * mi;
+    if (la_sync) {
+      float si = slow[i];
+      si += la_alpha * (pi - si);
+      pi = si;
+      slow[i] = si;
+    }
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+extern "C" int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold,
+                                 int step_t, float grad_scale, void* stream) {
+  RECNN_REQUIRE(p && g && m && v && slow && n >= 0 && step_t >= 1, "ranger_flat: bad arguments");
+  if (n == 0) return 0;
+  const RadamScalars rs = radam_scalars(step_t, log((double)beta1), log((double)beta2), (double)beta2, (double)nsma_threshold);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ranger_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
+                     weight_decay, la_alpha, (la_k > 0 && step_t % la_k == 0) ? 1 : 0, rs.rect, rs.step, grad_scale);
+  return recnn_check_hip(hipGetLastError(), "ranger_flat");
 }

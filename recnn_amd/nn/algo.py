@@ -4,11 +4,14 @@ Same public attributes (nets, optimizers, params, _step, debug, writer, device, 
 methods (update, to, step).  Targets are deep copies put in eval mode and hard-synced (soft_tau = 1.0) exactly
 as the reference does; the sync itself happens when the networks reach the GPU if they were built on the CPU.
 
-Default optimizers: the reference builds `torch_optimizer.Ranger(lr=1e-5, weight_decay=1e-2)` -- a third-party
-package that is neither vendored nor pinned by the reference.  Here the default is the fused
-`recnn_amd.optim.Adam(lr=1e-5, weight_decay=1e-2)` (the optimizer north_star names and the substitution the
-reference's own docs show, `algo.optimizers[...] = torch.optim.Adam(...)`).  `recnn_amd.optim.Ranger` is
-available as an explicitly unverified restatement; any torch optimizer can be assigned to `algo.optimizers[...]`.
+Default optimizers: like the reference (`torch_optimizer.Ranger(lr=1e-5, weight_decay=1e-2)`, algo.py:84-89,139-147)
+the facades build `recnn_amd.optim.Ranger(lr=1e-5, weight_decay=1e-2)` -- RAdam + Lookahead, executed by the fused HIP
+optimizer pass of the step engine.  `torch_optimizer` is a third-party package the reference neither vendors nor pins, so
+that arithmetic is restated from its published algorithm and flagged "parity unpinned" (recnn_amd/optim.py).
+The optimizer of record for parity and for bench.py is Adam (north_star; the substitution the reference's own docs
+show): `algo.optimizers[...] = recnn_amd.optim.Adam(...)` / `torch.optim.Adam(...)`, or
+`recnn_amd.nn.algo.set_default_optimizer("adam")` before constructing the facade.  Any other torch optimizer can be
+assigned too (it is then stepped by torch between the engine's gradient phases).
 """
 import copy
 
@@ -17,7 +20,22 @@ import torch
 from .. import optim, utils
 from . import update
 
-__all__ = ["Algo", "DDPG", "TD3"]
+__all__ = ["Algo", "DDPG", "TD3", "set_default_optimizer"]
+
+_DEFAULT_OPTIMIZER = "ranger"
+
+
+def set_default_optimizer(kind: str):
+    """'ranger' (the reference's default shape) or 'adam' (the optimizer of record for parity runs)."""
+    global _DEFAULT_OPTIMIZER
+    if kind not in ("ranger", "adam"):
+        raise ValueError(kind)
+    _DEFAULT_OPTIMIZER = kind
+
+
+def _default_opt(params, lr=1e-5, weight_decay=1e-2):
+    cls = optim.Ranger if _DEFAULT_OPTIMIZER == "ranger" else optim.Adam
+    return cls(params, lr=lr, weight_decay=weight_decay)
 
 
 def _hard_sync(net, target):
@@ -61,7 +79,7 @@ class Algo:
         """Let the engine sample its own batches from `env`'s TRAIN users: `run(n)` then executes n update steps
         (sampler, gather, update, step()) as hipGraph replays with no Python or host work per step.  Equivalent to
         `for batch in env.train_dataloader: self.update(batch); self.step()` with fixed `rows_per_batch`-row batches.
-        Needs Adam optimizers (recnn_amd.optim.Adam / torch.optim.Adam) in `self.optimizers`.
+        Needs optimizers the engine runs itself (recnn_amd.optim.Adam / Ranger, torch.optim.Adam) in `self.optimizers`.
         `shard=(rank, world)` restricts the sampler to this data-parallel rank's share of the train users.
         `dtype`: 'fp32' | 'bf16' compute type of the engine (default: fused.DEFAULTS['dtype']); only honoured before the
         networks' first update.
@@ -88,10 +106,11 @@ class Algo:
         return self
 
     def _fused_adam_cfgs(self, keys):
-        from ..optim import adam_config
-        cfgs = [adam_config(self.optimizers[k]) for k in keys]
+        from ..optim import fused_config
+        cfgs = [fused_config(self.optimizers[k]) for k in keys]
         if any(c is None for c in cfgs) or (len(cfgs) == 3 and cfgs[1] != cfgs[2]):
-            raise ValueError("attach_env / run need plain Adam optimizers (recnn_amd.optim.Adam or torch.optim.Adam)")
+            raise ValueError("attach_env / run need optimizers the engine runs itself: recnn_amd.optim.Adam / Ranger or "
+                             "torch.optim.Adam (both critics of TD3 with equal settings)")
         return cfgs
 
     def run(self, n_steps: int, history: bool = False):
@@ -135,8 +154,8 @@ class DDPG(Algo):
         target_value_net.eval()
         _hard_sync(value_net, target_value_net)
         _hard_sync(policy_net, target_policy_net)
-        value_optimizer = optim.Adam(value_net.parameters(), lr=1e-5, weight_decay=1e-2)
-        policy_optimizer = optim.Adam(policy_net.parameters(), lr=1e-5, weight_decay=1e-2)
+        value_optimizer = _default_opt(value_net.parameters())
+        policy_optimizer = _default_opt(policy_net.parameters())
         self.nets = {"value_net": value_net, "target_value_net": target_value_net, "policy_net": policy_net,
                      "target_policy_net": target_policy_net}
         self.optimizers = {"policy_optimizer": policy_optimizer, "value_optimizer": value_optimizer}
@@ -157,9 +176,9 @@ class TD3(Algo):
         _hard_sync(value_net1, target_value_net1)
         _hard_sync(value_net2, target_value_net2)
         _hard_sync(policy_net, target_policy_net)
-        value_optimizer1 = optim.Adam(value_net1.parameters(), lr=1e-5, weight_decay=1e-2)
-        value_optimizer2 = optim.Adam(value_net2.parameters(), lr=1e-5, weight_decay=1e-2)
-        policy_optimizer = optim.Adam(policy_net.parameters(), lr=1e-5, weight_decay=1e-2)
+        value_optimizer1 = _default_opt(value_net1.parameters())
+        value_optimizer2 = _default_opt(value_net2.parameters())
+        policy_optimizer = _default_opt(policy_net.parameters())
         self.nets = {"value_net1": value_net1, "target_value_net1": target_value_net1, "value_net2": value_net2,
                      "target_value_net2": target_value_net2, "policy_net": policy_net,
                      "target_policy_net": target_policy_net}

@@ -66,6 +66,7 @@ class StepEngine:
             self.grads: Dict[int, torch.Tensor] = {}
             self.adam_m: Dict[int, torch.Tensor] = {}
             self.adam_v: Dict[int, torch.Tensor] = {}
+            self.slow: Dict[int, torch.Tensor] = {}
             for ni in self.nets:
                 n = int(sz.master_floats_critic if ni >= L.NET_VALUE1 else sz.master_floats_actor)
                 self.params[ni] = torch.zeros(n, dtype=torch.float32, device=device)
@@ -133,7 +134,14 @@ class StepEngine:
     def set_hyper(self, gamma=0.99, min_value=-10.0, max_value=10.0, soft_tau=0.001, policy_every=10,
                   noise_std=0.5, noise_clip=3.0, policy_opt=None, value_opt=None):
         def opt(d):
-            return {**dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0), **(d or {})}
+            d = dict(d or {})
+            if d.get("kind", "adam") == "ranger":       # torch_optimizer.Ranger's defaults (recnn_amd/optim.py)
+                base = dict(kind="ranger", lr=1e-3, beta1=0.95, beta2=0.999, eps=1e-5, weight_decay=0.0, alpha=0.5, k=6,
+                            nsma_threshold=5.0)
+            else:
+                base = dict(kind="adam", lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, alpha=0.0, k=0,
+                            nsma_threshold=5.0)
+            return {**base, **d}
         po, vo = opt(policy_opt), opt(value_opt)
         h = L.Hyper()
         h.gamma, h.min_value, h.max_value = gamma, min_value, max_value
@@ -141,8 +149,23 @@ class StepEngine:
         h.noise_std, h.noise_clip = noise_std, noise_clip
         for i, o in enumerate((po, vo)):
             h.lr[i], h.beta1[i], h.beta2[i], h.eps[i], h.weight_decay[i] = o["lr"], o["beta1"], o["beta2"], o["eps"], o["weight_decay"]
+            h.opt_kind[i] = L.OPT_RANGER if o["kind"] == "ranger" else L.OPT_ADAM
+            h.la_alpha[i], h.la_k[i], h.nsma_threshold[i] = o["alpha"], int(o["k"]), o["nsma_threshold"]
+        nets = ((L.NET_POLICY,), self.value_nets())
+        for i, o in enumerate((po, vo)):
+            if o["kind"] == "ranger":
+                for ni in nets[i]:
+                    self.ensure_slow(ni)
         self.hyper = h
         L.call("recnn_engine_set_hyper", self.handle, C.byref(h))
+
+    def ensure_slow(self, ni: int) -> torch.Tensor:
+        """Lookahead slow-weight arena of a learning network (Ranger), created as a copy of the current parameters --
+        what torch_optimizer.Ranger does when it first sees a parameter."""
+        if ni not in self.slow:
+            self.slow[ni] = self.params[ni].detach().clone()
+            L.call("recnn_engine_bind_slow", self.handle, ni, L.ptr(self.slow[ni]))
+        return self.slow[ni]
 
     def set_counters(self, policy_t=0, value1_t=0, value2_t=0, step=0):
         L.call("recnn_engine_set_counters", self.handle, policy_t, value1_t, value2_t, step)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from ..optim import adam_config
+from ..optim import fused_config
 from .engine import NET_NAMES_DDPG, NET_NAMES_TD3, PARAM_NAMES, StepEngine
 
 _MODULE_PARAMS = (("linear1", "weight"), ("linear1", "bias"), ("linear2", "weight"), ("linear2", "bias"),
@@ -275,10 +275,17 @@ class FusedContext:
 
     # ------------------------------------------------------------------ optimizer state mirrors
     def mirror_optimizer_state(self, opt, ni):
-        """Expose the engine's Adam moments through `opt.state` (state_dict compatibility)."""
+        """Expose the engine's optimizer state (Adam / RAdam moments, Lookahead slow weights) through `opt.state`
+        (state_dict compatibility); state that existed before the adoption is carried over."""
         eng = self.engine
         mv = eng.param_views(ni, eng.adam_m[ni])
         vv = eng.param_views(ni, eng.adam_v[ni])
+        cfg = fused_config(opt)
+        ranger = cfg is not None and cfg["kind"] == "ranger"
+        sv = None
+        if ranger:
+            fresh = ni not in eng.slow
+            sv = eng.param_views(ni, eng.ensure_slow(ni))
         t = self.opt_t[ni]
         is_torch = type(opt) is torch.optim.Adam
         for p, k in zip(_module_params(self.modules[ni]), PARAM_NAMES):
@@ -288,6 +295,12 @@ class FusedContext:
                 vv[k].copy_(st["exp_avg_sq"])
                 t = max(t, int(st.get("step", 0)))
             st["exp_avg"], st["exp_avg_sq"] = mv[k], vv[k]
+            if ranger:
+                if st.get("slow_buffer") is not None and st["slow_buffer"].data_ptr() != sv[k].data_ptr():
+                    sv[k].copy_(st["slow_buffer"])
+                elif st.get("slow_buffer") is None and (fresh or self.opt_t[ni] == 0):
+                    sv[k].copy_(p.data)               # Lookahead starts from the parameters as they are at the first step
+                st["slow_buffer"] = sv[k]
             st["step"] = torch.tensor(float(t)) if is_torch else t
         if t != self.opt_t[ni]:
             self.opt_t[ni] = t
@@ -300,7 +313,10 @@ class FusedContext:
         for p in _module_params(self.modules[ni]):
             st = opt.state[p]
             if "exp_avg" in st:
-                st["step"] = torch.tensor(float(t)) if is_torch else t
+                if is_torch and isinstance(st.get("step"), torch.Tensor):
+                    st["step"].fill_(float(t))
+                else:
+                    st["step"] = torch.tensor(float(t)) if is_torch else t
 
 
 def context_for(algo: str, nets) -> FusedContext:
@@ -330,5 +346,6 @@ class external_randomness:
 
 
 def fused_adam_configs(optimizer: dict, keys):
-    cfgs = [adam_config(optimizer.get(k)) for k in keys]
+    """Per-optimizer configurations when ALL of them run inside the engine (Adam or Ranger arithmetic), else None."""
+    cfgs = [fused_config(optimizer.get(k)) for k in keys]
     return cfgs if all(c is not None for c in cfgs) else None

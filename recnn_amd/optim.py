@@ -4,9 +4,14 @@
            torch.optim.Adam: L2 weight decay, bias correction, eps outside the sqrt).  When both optimizers of
            an update are (this or torch's) plain Adam, `ddpg_update` / `td3_update` run Adam INSIDE the fused
            step engine (one launch per network, fused with the shadow refresh and the soft target update).
-`Ranger`-- RAdam + Lookahead in plain torch ops.  The reference's default `torch_optimizer.Ranger`
-           (recnn/nn/algo.py:84-89) is an absent, un-pinned third-party package; this restatement follows its
-           published algorithm from memory and is NOT verified against it ("parity unpinned").
+`Ranger`-- RAdam + Lookahead, the optimizer the reference builds by default (`torch_optimizer.Ranger(lr=1e-5,
+           weight_decay=1e-2)`, recnn/nn/algo.py:84-89,139-147).  step() is the fused HIP kernel `recnn_ranger_flat`; inside
+           `ddpg_update` / `td3_update` / `Algo.run` the same arithmetic runs in the engine's optimizer pass (fused with the
+           gradient slab reduction, the shadow refresh and the soft target update).  `torch_optimizer` is an absent,
+           un-pinned third-party package: the arithmetic follows its published algorithm from memory and is NOT verified
+           against it ("parity unpinned").  What IS pinned: with weight_decay = 0 the RAdam part equals
+           torch.optim.RAdam (same rectification term, same threshold, eps outside the sqrt), and Lookahead is three lines
+           (tests/test_gpu_optim.py); `Ranger.reference_step` is the same algorithm in plain torch ops.
 """
 import math
 
@@ -14,7 +19,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Adam", "Ranger", "adam_config"]
+__all__ = ["Adam", "Ranger", "adam_config", "fused_config"]
 
 
 class Adam(torch.optim.Optimizer):
@@ -73,12 +78,35 @@ def adam_config(opt):
                 weight_decay=float(g["weight_decay"]))
 
 
+def fused_config(opt):
+    """Hyper-parameters (with "kind": "adam" | "ranger") if the fused engine reproduces `opt` exactly, else None."""
+    cfg = adam_config(opt)
+    if cfg is not None:
+        return dict(cfg, kind="adam")
+    if type(opt) is Ranger and len(opt.param_groups) == 1:
+        g = opt.param_groups[0]
+        return dict(kind="ranger", lr=float(g["lr"]), beta1=float(g["betas"][0]), beta2=float(g["betas"][1]), eps=float(g["eps"]),
+                    weight_decay=float(g["weight_decay"]), alpha=float(g["alpha"]), k=int(g["k"]),
+                    nsma_threshold=float(g["N_sma_threshhold"]))
+    return None
+
+
 class Ranger(torch.optim.Optimizer):
-    """RAdam (variance rectified Adam) + Lookahead(k, alpha).  UNVERIFIED restatement, see module docstring."""
+    """RAdam (variance rectified Adam) + Lookahead(k, alpha); defaults of torch_optimizer.Ranger.  See the module docstring
+    for what is and is not verified."""
 
     def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5, weight_decay=0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or not (0 <= alpha <= 1) or k < 1:
+            raise ValueError("invalid Ranger hyper-parameter")
         super().__init__(params, dict(lr=lr, alpha=alpha, k=k, N_sma_threshhold=N_sma_threshhold, betas=betas, eps=eps,
                                       weight_decay=weight_decay))
+
+    @staticmethod
+    def _init_state(st, p):
+        st["step"] = 0
+        st["exp_avg"] = torch.zeros_like(p.data)
+        st["exp_avg_sq"] = torch.zeros_like(p.data)
+        st["slow_buffer"] = p.data.clone()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -86,6 +114,32 @@ class Ranger(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        stream = None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise L.RecnnHipError("recnn_amd.optim.Ranger: parameters must live on the GPU (no CPU fallback)")
+                if p.dtype != torch.float32 or not p.data.is_contiguous():
+                    raise L.RecnnHipError("recnn_amd.optim.Ranger: parameters must be contiguous float32")
+                st = self.state[p]
+                if not st:
+                    self._init_state(st, p)
+                st["step"] = int(st["step"]) + 1
+                g = p.grad.data if p.grad.data.is_contiguous() else p.grad.data.contiguous()
+                stream = stream or L.current_stream()
+                L.call("recnn_ranger_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                       L.ptr(st["slow_buffer"]), p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                       float(group["weight_decay"]), float(group["alpha"]), int(group["k"]), float(group["N_sma_threshhold"]),
+                       int(st["step"]), 1.0, stream)
+        return loss
+
+    @torch.no_grad()
+    def reference_step(self):
+        """The same step in plain torch ops (any device): the readable statement of the algorithm the kernel implements;
+        tests compare the two."""
         for group in self.param_groups:
             b1, b2 = group["betas"]
             n_max = 2.0 / (1.0 - b2) - 1.0
@@ -95,10 +149,7 @@ class Ranger(torch.optim.Optimizer):
                 g = p.grad.data.float()
                 st = self.state[p]
                 if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p.data)
-                    st["exp_avg_sq"] = torch.zeros_like(p.data)
-                    st["slow_buffer"] = p.data.clone()
+                    self._init_state(st, p)
                 st["step"] += 1
                 t = st["step"]
                 m, v = st["exp_avg"], st["exp_avg_sq"]
@@ -121,4 +172,3 @@ class Ranger(torch.optim.Optimizer):
                     slow = st["slow_buffer"]
                     slow.add_(p.data - slow, alpha=group["alpha"])
                     p.data.copy_(slow)
-        return loss

@@ -23,3 +23,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no GPU is visible")
     return torch.device("cuda")
+
+
+@pytest.fixture(autouse=True)
+def _adam_is_the_optimizer_of_record():
+    """The facades default to Ranger like the reference (recnn/nn/algo.py:84-89); the parity oracle and north_star's
+    optimizer is Adam, so tests construct DDPG / TD3 with Adam unless they ask for Ranger themselves."""
+    from recnn_amd.nn import algo
+    algo.set_default_optimizer("adam")
+    yield
+    algo.set_default_optimizer("ranger")
