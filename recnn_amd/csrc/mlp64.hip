@@ -194,57 +194,95 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the first slab's barrier publishes the bias area)
 
-  // ---- the ring
+  // ---- the ring.  Everything the per-slab path needs is hoisted into registers first: the DMA statements clobber "memory",
+  // so any P.* / batch.* field read after them would be re-fetched from the kernel-argument segment every slab.
+  const int ir8 = lane >> 3, p8 = lane & 7;
+  const int w_row = wave * 8 + ir8;                       // image row of this lane in DMA instruction `wave` (second one: +128)
+  const int w_chunk = (p8 ^ swz(w_row)) * 16;             // source chunk behind LDS position p8 (swz(row + 128) == swz(row))
+  const unsigned dst_a = wave * 1024, dst_w0 = A_BYTES + wave * 1024, dst_w1 = A_BYTES + (wave + 16) * 1024;
+  // per-lane source pointers of a [rows x 128 B] image of matrix `base` (pitch ld elements) at k offset k0
+  struct Src { const char* p0; const char* p1; };
+  auto w_src = [&](const void* base, int64_t ld, int k0) -> Src {
+    const char* q = (const char*)base + ((int64_t)w_row * ld + k0) * 2 + w_chunk;
+    return Src{q, q + ld * 256};                          // 128 rows further down
+  };
+  auto a_src = [&](const void* base, int64_t ld) -> const char* {
+    return (const char*)base + (int64_t)min(m0 + w_row, row_max) * ld * 2 + w_chunk;
+  };
+  const int nseg = P.nseg;
+  const char* a_ptr = a_src(P.A[0], P.lda[0]);
+  const char* a_ptr1 = nseg > 1 ? a_src(P.A[1], P.lda[1]) : nullptr;
+  Src w1 = w_src(P.W1, P.ldw1, P.w1_col[0]);
+  const Src w1b = nseg > 1 ? w_src(P.W1, P.ldw1, P.w1_col[1]) : w1;
+  if (probe & 1) a_ptr = (const char*)P.A[0] + (int64_t)min(w_row, row_max) * P.lda[0] * 2 + w_chunk;
+  const void* const W2p = P.W2; const int64_t ldw2 = P.ldw2;
+  const void* const W3p = P.W3; const int64_t ldw3 = P.ldw3;
+  Src cur = w1;                                           // pointer pair of the weight matrix being streamed after layer 1
+  const char* curT = nullptr;                             // ... of the transposed-use W2 image (unit backward)
   int head = 0, issued = 0, st_issue = 0, st_head = 0;
-  auto issue = [&]() {
-    const int i = issued;
+  auto stage_of_issue = [&]() -> unsigned {
     const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + st_issue * STAGE);
-    const unsigned wimg = st + A_BYTES;
-    if (i < n1) {
-      const int sg = i < nt0 ? 0 : 1;
-      const int k0 = (sg == 0 ? i : i - nt0) * KS;
-      // probe (timing experiments only, results are garbage): 1 = every panel reads batch rows 0..63 (A operand L2-hot),
-      // 2 = no W DMA in layer 1, 4 = no A DMA in layer 1
-      if (wave < 8 && !(probe & 4)) dma_img8(P.A[sg], P.lda[sg], (probe & 1) ? 0 : m0, row_max, k0, wave, st, lane);
-      else if (wave < 8) dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave, st, lane);
-      if (!(probe & 2)) {
-        dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave, wimg, lane);
-        dma_img8(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, wave + 16, wimg, lane);
+    st_issue = st_issue == NS - 1 ? 0 : st_issue + 1;
+    ++issued;
+    return st;
+  };
+  auto issue_l1 = [&]() {                                 // layer-1 slab `issued`: A panel + W1 k-slab
+    if (issued == nt0) { a_ptr = a_ptr1; w1 = w1b; }      // second contraction segment
+    const unsigned st = stage_of_issue();
+    if (wave < 8 && !(probe & 4)) dma16(a_ptr, st + dst_a);
+    if (!(probe & 2)) { dma16(w1.p0, st + dst_w0); dma16(w1.p1, st + dst_w1); }
+    else { dma16(w1.p0, st + dst_w0); }
+    a_ptr += ROWB; w1.p0 += ROWB; w1.p1 += ROWB;
+  };
+  auto issue_w = [&]() {                                  // a 256-row weight slab from `cur`
+    const unsigned st = stage_of_issue();
+    dma16(cur.p0, st + dst_w0);
+    dma16(cur.p1, st + dst_w1);
+    cur.p0 += ROWB; cur.p1 += ROWB;
+  };
+  auto issue_w3 = [&]() {                                 // a 128-row slab (actor output layer): one instruction per wave
+    const unsigned st = stage_of_issue();
+    dma16(cur.p0, st + dst_w0);
+    cur.p0 += ROWB;
+  };
+  auto issue_t = [&]() {                                  // transposed-use image of 64 W2 rows
+    const unsigned st = stage_of_issue();
+    dma16(curT, st + dst_w0);
+    dma16(curT + 256, st + dst_w1);                       // column half 1
+    curT += ldw2 * 2 * KS;
+  };
+  // slab `issued` of the post-layer-1 sequence: [W2 x4] then actor: [W3 x4] [tail: W1a x2, W2 x4]...; critic: [W2^T x4]
+  auto refill = [&]() {
+    if (issued >= total) return;
+    int j = issued - n1;
+    if (j < 0) { issue_l1(); return; }
+    if (j < 4) {
+      if (j == 0) cur = w_src(W2p, ldw2, 0);
+      issue_w();
+    } else if (has_w3) {
+      j -= 4;
+      if (j < 4) {
+        if (j == 0) cur = w_src(W3p, ldw3, 0);
+        issue_w3();
       } else {
-        dma_img8(P.W1, P.ldw1, 0, 15, P.w1_col[sg], wave & 1, wimg, lane);
-        dma_img8(P.W1, P.ldw1, 0, 15, P.w1_col[sg], wave & 1, wimg, lane);
+        j -= 4;
+        const int ti = j >= 6 ? 1 : 0, r = j - ti * 6;
+        if (r == 0) cur = w_src(batch.tail[ti].W1a, batch.tail[ti].ldw1, 0);
+        else if (r == 2) cur = w_src(batch.tail[ti].W2, batch.tail[ti].ldw2, 0);
+        issue_w();
       }
     } else {
-      int j = i - n1;
-      if (j < 4) {
-        dma_img8(P.W2, P.ldw2, 0, HP - 1, j * KS, wave, wimg, lane);
-        dma_img8(P.W2, P.ldw2, 0, HP - 1, j * KS, wave + 16, wimg, lane);
-      } else if (has_w3) {
-        j -= 4;
-        if (j < 4) {
-          dma_img8(P.W3, P.ldw3, 0, 127, j * KS, wave, wimg, lane);
-        } else {
-          j -= 4;
-          const int ti = j / 6, r = j - ti * 6;
-          const MlpTail& T = batch.tail[ti];
-          const void* wb = r < 2 ? T.W1a : T.W2;
-          const int64_t ld = r < 2 ? T.ldw1 : T.ldw2;
-          const int k0 = (r < 2 ? r : r - 2) * KS;
-          dma_img8(wb, ld, 0, HP - 1, k0, wave, wimg, lane);
-          dma_img8(wb, ld, 0, HP - 1, k0, wave + 16, wimg, lane);
-        }
-      } else {
-        j -= 4;
-        dma_imgT(P.W2, P.ldw2, j * KS, wave, wimg, lane);
-        dma_imgT(P.W2, P.ldw2, j * KS, wave + 16, wimg, lane);
+      j -= 4;
+      if (j == 0) {
+        const int krow = (wave & 15) * 4 + (lane >> 4);   // DMA instruction `wave`: column half 0, k rows 4 wave .. 4 wave + 3
+        curT = (const char*)W2p + (int64_t)krow * ldw2 * 2 + (((lane & 15) ^ (krow & 15)) * 16);
       }
+      issue_t();
     }
-    ++issued;
-    st_issue = st_issue == NS - 1 ? 0 : st_issue + 1;
   };
   // DMA instructions this wave issues for slab i
   auto dma_count = [&](int i) -> int {
-    if (i < n1) return wave < 8 ? 3 : 2;
+    if (i < n1) return (wave < 8 && !(probe & 4)) ? ((probe & 2) ? 2 : 3) : ((probe & 2) ? 1 : 2);
     if (has_w3 && i >= n1 + 4 && i < n1 + 8) return 1;
     return 2;
   };
@@ -263,9 +301,8 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     st_head = st_head == NS - 1 ? 0 : st_head + 1;
     return st;
   };
-  auto refill = [&]() { if (issued < total) issue(); };
-  issue();
-  if (total > 1) issue();
+  issue_l1();
+  issue_l1();
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -274,7 +311,13 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ------------------------------------------------------------------ layer 1
-  for (int t = 0; t < n1; ++t) {
+  for (int t = 0; t < n1 - 2; ++t) {   // steady state: slab t + 2 is another layer-1 slab
+    const unsigned char* st = wait_slab();
+    issue_l1();
+    mma_slab<2>(st, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {        // last two slabs: the refill is the next layer's first weight slabs (nothing for a producer)
     const unsigned char* st = wait_slab();
     refill();
     mma_slab<2>(st, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);

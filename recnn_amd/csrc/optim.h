@@ -56,12 +56,18 @@ struct ApplyArgs {
   int from_slabs;       // gradient = sum of the layout's partial slabs (fused slab reduction); g_out receives it
   float* g_out;
   double log_beta1, log_beta2;  // filled by apply_launch
+  float omb1, omb2;             // 1 - beta in the precision torch uses (Python double, then rounded to float): apply_launch
   int opt_kind;         // RECNN_OPT_ADAM | RECNN_OPT_RANGER
   float* slow;          // Ranger: Lookahead slow weights (canonical layout)
   float la_alpha;
   int la_k;
   float nsma_thr;
 };
+
+// The hyper-parameters cross the C ABI as floats; torch computes 1 - beta and beta^t from the Python double the user wrote
+// (0.999, not float(0.999) = 0.99900001287...: 1 - 0.999f is off by 1.3e-5 relative).  A float keeps 7 significant digits,
+// so printing it with 7 digits recovers the literal.
+double recnn_snap7(float x);
 
 // RAdam step scalars for step t (double, as the Python implementations compute them): rectified?, step size factor
 struct RadamScalars { int rect; float step; };

@@ -11,6 +11,12 @@
 #include "optim.h"
 #include "gather_dev.h"
 
+double recnn_snap7(float x) {
+  char buf[40];
+  snprintf(buf, sizeof(buf), "%.7g", (double)x);
+  return strtod(buf, nullptr);
+}
+
 __device__ inline int find_tensor(const NetLayout& L, int b) {
   int ti = 0;
 #pragma unroll
@@ -228,13 +234,13 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
     //   v = b2 v + (1-b2) g^2;  m = b1 m + (1-b1) g;  N_sma = N_max - 2 t b2^t / (1 - b2^t)
     //   p -= wd lr p;  N_sma > thr: p -= step lr m / (sqrt(v) + eps)  else  p -= step lr m
     //   every k-th step: slow += alpha (p - slow); p = slow
-    const RadamScalars rs = radam_scalars(t, a.log_beta1, a.log_beta2, (double)a.beta2, (double)a.nsma_thr);
+    const RadamScalars rs = radam_scalars(t, a.log_beta1, a.log_beta2, exp(a.log_beta2), (double)a.nsma_thr);
     const float sl_lr = rs.step * a.lr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gj = g[j] * gs;
-      v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
-      m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
+      v[j] = a.beta2 * v[j] + a.omb2 * gj * gj;
+      m[j] = a.beta1 * m[j] + a.omb1 * gj;
       if (a.weight_decay != 0.f) p[j] += (-a.weight_decay * a.lr) * p[j];
       if (rs.rect) p[j] += -sl_lr * (m[j] / (sqrtf(v[j]) + a.eps));
       else p[j] += -sl_lr * m[j];
@@ -254,8 +260,8 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
     for (int j = 0; j < 4; ++j) {
       float gj = g[j] * gs;
       if (a.weight_decay != 0.f) gj += a.weight_decay * p[j];
-      m[j] += (1.0f - a.beta1) * (gj - m[j]);
-      v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+      m[j] += a.omb1 * (gj - m[j]);
+      v[j] = a.beta2 * v[j] + a.omb2 * gj * gj;
       const float denom = sqrtf(v[j]) / bc2_sqrt + a.eps;
       p[j] -= step_size * (m[j] / denom);
     }
@@ -327,8 +333,10 @@ __global__ __launch_bounds__(256) void apply_gather_kernel(const NetLayout L, co
 
 int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s, const GatherArgs* pregather) {
   ApplyArgs a = a0;
-  a.log_beta1 = log((double)a.beta1);
-  a.log_beta2 = log((double)a.beta2);
+  a.log_beta1 = log(recnn_snap7(a.beta1));
+  a.log_beta2 = log(recnn_snap7(a.beta2));
+  a.omb1 = (float)(1.0 - recnn_snap7(a.beta1));
+  a.omb2 = (float)(1.0 - recnn_snap7(a.beta2));
   if (pregather) {
     const GatherArgs& g = *pregather;
     const size_t lds = frame_gather_lds_bytes(g, 4);
@@ -383,14 +391,15 @@ extern "C" int recnn_soft_update_flat(float* target, const float* net, int64_t n
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float lr, float beta1, float beta2,
-                                                        float eps, float wd, float step_size, float bc2_sqrt, float gs) {
+                                                        float eps, float wd, float step_size, float bc2_sqrt, float gs, float omb1,
+                                                        float omb2) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pi = p[i];
     float gi = g[i] * gs;
     if (wd != 0.f) gi += wd * pi;
     float mi = m[i], vi = v[i];
-    mi += (1.0f - beta1) * (gi - mi);
-    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+    mi += omb1 * (gi - mi);
+    vi = beta2 * vi + omb2 * gi * gi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
@@ -400,11 +409,12 @@ extern "C" int recnn_adam_flat(float* p, const float* g, float* m, float* v, int
                                float eps, float weight_decay, int step_t, float grad_scale, void* stream) {
   RECNN_REQUIRE(p && g && m && v && n >= 0 && step_t >= 1, "adam_flat: bad arguments");
   if (n == 0) return 0;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step_t), bc2 = 1.0 - pow((double)beta2, (double)step_t);
+  const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
+  const double bc1 = 1.0 - pow(b1, (double)step_t), bc2 = 1.0 - pow(b2, (double)step_t);
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
+                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2));
   return recnn_check_hip(hipGetLastError(), "adam_flat");
 }
 
@@ -435,13 +445,13 @@ extern "C" int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, flo
 __global__ __launch_bounds__(256) void ranger_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, float* __restrict__ slow, int64_t n, float lr,
                                                           float beta1, float beta2, float eps, float wd, float la_alpha, int la_sync,
-                                                          int rect, float step, float gs) {
+                                                          int rect, float step, float gs, float omb1, float omb2) {
   const float sl_lr = step * lr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pi = p[i], mi = m[i], vi = v[i];
     const float gi = g[i] * gs;
-    vi = beta2 * vi + (1.0f - beta2) * gi * gi;
-    mi = beta1 * mi + (1.0f - beta1) * gi;
+    vi = beta2 * vi + omb2 * gi * gi;
+    mi = beta1 * mi + omb1 * gi;
     if (wd != 0.f) pi += (-wd * lr) * pi;
     if (rect) pi += -sl_lr * (mi / (sqrtf(vi) + eps));
     else pi += -sl_lr * mi;
@@ -459,10 +469,12 @@ extern "C" int recnn_ranger_flat(float* p, const float* g, float* m, float* v, f
                                  int step_t, float grad_scale, void* stream) {
   RECNN_REQUIRE(p && g && m && v && slow && n >= 0 && step_t >= 1, "ranger_flat: bad arguments");
   if (n == 0) return 0;
-  const RadamScalars rs = radam_scalars(step_t, log((double)beta1), log((double)beta2), (double)beta2, (double)nsma_threshold);
+  const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
+  const RadamScalars rs = radam_scalars(step_t, log(b1), log(b2), b2, (double)nsma_threshold);
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(ranger_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
-                     weight_decay, la_alpha, (la_k > 0 && step_t % la_k == 0) ? 1 : 0, rs.rect, rs.step, grad_scale);
+                     weight_decay, la_alpha, (la_k > 0 && step_t % la_k == 0) ? 1 : 0, rs.rect, rs.step, grad_scale,
+                     (float)(1.0 - b1), (float)(1.0 - b2));
   return recnn_check_hip(hipGetLastError(), "ranger_flat");
 }
