@@ -411,7 +411,8 @@ void recnn_tune_mlp_fault(int mode);
  * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
 void recnn_tune_mlp_panel(int rows);
 void recnn_tune_mlp_map(int mode);
-void recnn_tune_mlp_probe(int bits);   /* timing experiments on the 64-row kernel's operand streams; results are garbage */
+void recnn_tune_mlp_probe(int bits);
+void recnn_tune_mlp_trace(void* device_u64_wg16);   /* shader-clock stamps of the kernel's phases, [workgroup][16] uint64, NULL = off */   /* timing experiments on the 64-row kernel's operand streams; results are garbage */
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

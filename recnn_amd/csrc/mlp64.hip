@@ -148,7 +148,10 @@ __device__ __forceinline__ float row_dot(const unsigned char* panel, int row, in
 }
 }  // namespace
 
-__global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, int npanel, int map_mode, int probe) {
+// trace (tools / bench.py RECNN_MLP_TRACE): when non-null, lane 0 of wave 0 of every workgroup stamps the shader clock at the
+// phase boundaries into trace[logical workgroup id][16]
+#define MLP64_STAMP(i) do { if (trace && tid == 0) trace[(int64_t)bid * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, int npanel, int map_mode, int probe, unsigned long long* trace) {
   int bid = blockIdx.x;
   if (map_mode == 2) bid = xcd_remap(bid, gridDim.x);
   const int prob = bid / npanel, panel_idx = bid - prob * npanel;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
   const int wm = wave >> 3, wn = wave & 7;
   const int row_max = P.rows - 1;
   unsigned char* panel = lds + PANEL_OFF;
+  MLP64_STAMP(0);
 
   // ---- slab schedule of this workgroup
   const int nt0 = P.K[0] / KS;
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     st_head = st_head == NS - 1 ? 0 : st_head + 1;
     return st;
   };
+  MLP64_STAMP(1);
   issue_l1();
   issue_l1();
 
@@ -312,7 +317,10 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
 
   // ------------------------------------------------------------------ layer 1
   for (int t = 0; t < n1 - 2; ++t) {   // steady state: slab t + 2 is another layer-1 slab
+    if (t == 2) MLP64_STAMP(10);
+    if (t == 12) MLP64_STAMP(11);
     const unsigned char* st = wait_slab();
+    if (t == 12) MLP64_STAMP(12);
     issue_l1();
     mma_slab<2>(st, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
   }
@@ -322,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     refill();
     mma_slab<2>(st, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
   }
+  MLP64_STAMP(2);
   if (P.part_out) {
     // producer of a chained critic: hand the raw pre-activation part to the consumer workgroup of this panel
 #pragma unroll
@@ -334,10 +343,12 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     }
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
     if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + panel_idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    MLP64_STAMP(9);
     return;
   }
   const uint32_t gate1 = hidden_epilogue(acc, bias_lds, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel);
 
+  MLP64_STAMP(3);
   // ------------------------------------------------------------------ layer 2
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     refill();
     mma_slab<2>(panel + j * PANEL_Q, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
   }
+  MLP64_STAMP(4);
   // chained critics: wait for the producers' layer-1 parts (the fetch itself follows epilogue 2, straight into the dead accumulators)
   if (has_w3 && P.n_tail) {
     if (tid == 0) {
@@ -369,6 +381,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
   __builtin_amdgcn_s_barrier();   // everyone is done with the h1 panel; flags seen (tid 0's acquire dropped this CU's stale lines)
   hidden_epilogue(acc, bias_lds + HP, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel);
 
+  MLP64_STAMP(5);
   auto load_part = [&](const float* part) {   // the accumulators start from the producer's fp32 layer-1 state part
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
           if (P.n_tail) *(bf16_t*)(lds + (n >> 6) * STAGE + row * ROWB + ((((n & 63) >> 3) ^ swz(row)) * 16) + (n & 7) * 2) = hv;
         }
     }
+    MLP64_STAMP(6);
     // ---------------------------------------------------------------- chained critics (target critic on the new action)
 #pragma unroll
     for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
@@ -450,6 +464,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
         }
       }
     }
+    MLP64_STAMP(7);
     // ---------------------------------------------------------------- head of the learning critic(s)
     if (batch.head.n_critic > 0 && P.n_tail > 0) {
       const MlpHead& Hd = batch.head;
@@ -516,6 +531,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
           __hip_atomic_store((uint32_t*)batch.cbwd[P.cbwd_idx].q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    MLP64_STAMP(6);
     if (do_cbwd) {
       const MlpCriticBwd& B = batch.cbwd[P.cbwd_idx];
       __builtin_amdgcn_s_barrier();   // every wave is done reading h2 rows for its q dots
@@ -594,10 +610,13 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
       }
     }
   }
+  MLP64_STAMP(9);
 }
 
 static int g_mlp_map = 0;
 extern "C" void recnn_tune_mlp_map(int mode) { g_mlp_map = mode == 2 ? 2 : 0; }
+static unsigned long long* g_mlp_trace = nullptr;
+extern "C" void recnn_tune_mlp_trace(void* device_u64_wg16) { g_mlp_trace = (unsigned long long*)device_u64_wg16; }
 static int g_mlp_probe = 0;
 extern "C" void recnn_tune_mlp_probe(int bits) { g_mlp_probe = bits; }   // timing experiments (see issue() in the kernel)
 
@@ -615,6 +634,6 @@ int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s) {
     if (p.ldh != HP && (p.h1 || p.h2 || p.cbwd_idx >= 0)) { recnn_set_error("mlp64: hidden activations must have pitch 256"); return RECNN_E_INVALID; }
   }
   const int npanel = (rows + BM - 1) / BM;
-  hipLaunchKernelGGL(mlp64_kernel, dim3(npanel * nprob), dim3(NW * 64), LDS_TOTAL, s, b, npanel, g_mlp_map, g_mlp_probe);
+  hipLaunchKernelGGL(mlp64_kernel, dim3(npanel * nprob), dim3(NW * 64), LDS_TOTAL, s, b, npanel, g_mlp_map, g_mlp_probe, g_mlp_trace);
   return recnn_check_hip(hipGetLastError(), "mlp64_kernel");
 }

@@ -51,6 +51,7 @@ class StepEngine:
         sz = L.EngineSizes()
         L.call("recnn_engine_query", C.byref(cfg), C.byref(sz))
         self.sizes = sz
+        self._view_cache = {}
         self.ld_x = int(sz.ld_x)
         with torch.cuda.device(device):
             self.workspace = torch.zeros(int(sz.workspace_bytes), dtype=torch.uint8, device=device)
@@ -85,6 +86,7 @@ class StepEngine:
                 self.ext_masks = torch.ones(self.n_masks, max_rows, hidden, dtype=torch.uint8, device=device)
             self._bind_external()
         self._losses_host = (C.c_float * 4)()
+        self._view_cache = {}
 
     # ------------------------------------------------------------------ plumbing
     def _bind_external(self):
@@ -110,6 +112,10 @@ class StepEngine:
     def param_views(self, ni: int, arena: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Views [out,in]/[out] into a flat canonical arena laid out [w1|b1|w2|b2|w3|b3]."""
         a = self.params[ni] if arena is None else arena
+        key = (ni, a.data_ptr())
+        hit = self._view_cache.get(key)
+        if hit is not None:
+            return hit
         H, i, o = self.H, self.in_dim(ni), self.out_dim(ni)
         shapes = [(H, i), (H,), (H, H), (H,), (o, H), (o,)]
         out, off = {}, 0
@@ -119,6 +125,7 @@ class StepEngine:
                 n *= d
             out[name] = a[off:off + n].view(*shp)
             off += n
+        self._view_cache[key] = out
         return out
 
     def load_params(self, ni: int, p: Dict[str, torch.Tensor]):

@@ -73,6 +73,7 @@ class FusedContext:
         self.mask_mode = DEFAULTS["mask_mode"]
         self.seed = DEFAULTS["seed"]
         self.sampler_env = None
+        self._view_ptrs, self._view_ptrs_engine = {}, None
 
     # ------------------------------------------------------------------ engine lifetime
     def _check_modules(self, nets):
@@ -127,8 +128,13 @@ class FusedContext:
         self._sync_versions()
 
     def _is_adopted(self, ni, m):
-        views = self.engine.param_views(ni)
-        return all(p.data.data_ptr() == views[k].data_ptr() for p, k in zip(_module_params(m), PARAM_NAMES))
+        ptrs = self._view_ptrs.get(ni)
+        if ptrs is None or self._view_ptrs_engine is not self.engine:
+            if self._view_ptrs_engine is not self.engine:
+                self._view_ptrs, self._view_ptrs_engine = {}, self.engine
+            views = self.engine.param_views(ni)
+            ptrs = self._view_ptrs[ni] = [views[k].data_ptr() for k in PARAM_NAMES]
+        return all(p.data.data_ptr() == q for p, q in zip(_module_params(m), ptrs))
 
     def _adopt(self, ni, m):
         eng = self.engine

@@ -1,0 +1,50 @@
+"""Phase timeline of the 64-row fused MLP forward (csrc/mlp64.hip) from in-kernel shader-clock stamps.
+usage: python tools/mlp_trace.py [probe_bits]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recnn_amd import _lib as L
+from recnn_amd.nn.engine import StepEngine
+
+probe = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+S, A, H, B = 1290, 128, 256, 2048
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+
+def mk(inp, out):
+    return {"w1": torch.randn(H, inp) * 0.03, "b1": torch.randn(H) * 0.1, "w2": torch.randn(H, H) * 0.06, "b2": torch.randn(H) * 0.1,
+            "w3": torch.randn(out, H) * 0.3, "b3": torch.randn(out) * 0.3}
+actor, critic = mk(S, A), mk(S + A, 1)
+eng = StepEngine("ddpg", S, A, H, B, dtype="bf16", mask_mode="hash", seed=1, device=dev)
+for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
+    eng.load_params(ni, p)
+eng.set_hyper(policy_opt=dict(lr=1e-5), value_opt=dict(lr=1e-5))
+eng.set_counters()
+eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
+trace = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
+L.load().recnn_tune_mlp_probe(probe)
+for t in range(5):
+    eng.step(B, True, 1)
+torch.cuda.synchronize()
+L.load().recnn_tune_mlp_trace(L.ptr(trace))
+eng.step(B, True, 1)
+torch.cuda.synchronize()
+L.load().recnn_tune_mlp_trace(None)
+tr = trace.cpu().numpy()
+npanel = B // 64
+names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
+t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
+t_end = tr[:npanel * 4, 9].max()
+print(f"probe {probe}: launch span {t_end - t_start} ticks (first workgroup start -> last workgroup end)")
+labels = {1: "setup done", 10: "L1 slab 2", 11: "L1 slab 12 (before wait)", 12: "L1 slab 12 (after wait+barrier)", 2: "L1 done", 3: "epilogue 1 done",
+          4: "L2 done", 5: "epilogue 2 done", 6: "L3 done / critic head done", 7: "tails done", 9: "end"}
+for pi, nm in enumerate(names):
+    rows = tr[pi * npanel:(pi + 1) * npanel]
+    print(f"== {nm}: start offset vs launch start: median {np.median(rows[:, 0] - t_start):.0f}, max {np.max(rows[:, 0] - t_start):.0f} ticks")
+    for k in (1, 10, 11, 12, 2, 3, 4, 5, 6, 7, 9):
+        v = rows[:, k]
+        if (v > 0).all():
+            print(f"   {labels[k]:34s} median {np.median(v - rows[:, 0]):9.0f}  max {np.max(v - rows[:, 0]):9.0f} ticks since workgroup start")
+    if (rows[:, 11] > 0).all():
+        print(f"   per L1 slab (slabs 2..12): {np.median((rows[:, 11] - rows[:, 10]) / 10):.0f} ticks; wait+barrier of slab 12: {np.median(rows[:, 12] - rows[:, 11]):.0f}")

@@ -24,3 +24,23 @@ with torch.cuda.stream(stream):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"run({n:5d}) from step {algo._step - n:5d}: {dt * 1e6:9.1f} us total, {dt * 1e6 / n:7.2f} us/step", flush=True)
+
+# ---- where the fixed cost of a short run() goes: host-side pieces timed separately (no device work in "pre")
+ctx = algo._fused_ctx
+import time as _t
+with torch.cuda.stream(stream):
+    for n in (20, 20, 20):
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        cfgs = algo._fused_adam_cfgs(algo._fused_keys)
+        ctx.ensure(algo.nets, ctx.sampler["rows"])
+        ctx.set_hyper(algo.params, cfgs[0], cfgs[1])
+        ctx.apply_external(ctx.sampler["rows"])
+        t1 = _t.perf_counter()
+        ctx.run_steps(algo._step, n)
+        t2 = _t.perf_counter()
+        algo._step += n
+        lo = ctx.engine.losses()
+        t3 = _t.perf_counter()
+        print(f"pieces of run({n}): python pre {1e6 * (t1 - t0):7.1f} us | graph launches (host) {1e6 * (t2 - t1):7.1f} us | "
+              f"wait + loss read-back {1e6 * (t3 - t2):7.1f} us | total {1e6 * (t3 - t0):7.1f}", flush=True)
