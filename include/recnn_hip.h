@@ -407,7 +407,7 @@ int recnn_engine_dp_sets(recnn_engine* e);
  * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
  * on purpose (tests). */
 void recnn_tune_mlp_fault(int mode);
-/* fused MLP forward: rows per workgroup (64 = csrc/mlp64.hip, the default; 32 = csrc/mlp.hip, bit-identical results) and
+/* fused MLP forward: rows per workgroup (32 = csrc/mlp.hip, the default; 64 = csrc/mlp64.hip, bit-identical results) and
  * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
 void recnn_tune_mlp_panel(int rows);
 void recnn_tune_mlp_map(int mode);

@@ -454,8 +454,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 
 int mlp64_init();
 int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
-static int g_mlp_panel = 64;   // rows per workgroup: 64 = mlp64.hip (default), 32 = the kernel in this file
-extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_panel = rows == 32 ? 32 : 64; }
+// rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
+// mlp64.hip (bit-identical results; faster at TD3 / 4096 rows, 47 us at DDPG / 2048 rows: see DESIGN.md section 5)
+static int g_mlp_panel = 32;
+extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_panel = rows == 64 ? 64 : 32; }
 static int g_mlp_waves = 16;
 static int g_mlp_fault = 0;
 // test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const unsigned char* st = wait_slab();   // (first pass: the h1 panel is complete behind this barrier)
-    if (j == 0 && P.h1) panel_to_global(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
+    if (j == 0 && P.h1 && !(probe & 8)) panel_to_global(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
     refill();
     mma_slab<2>(panel + j * PANEL_Q, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
   }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned char* st = wait_slab();   // (first pass: the h2 panel is complete)
-      if (j == 0 && P.h2) panel_to_global(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
+      if (j == 0 && P.h2 && !(probe & 8)) panel_to_global(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
       refill();
       mma_slab<1>(panel + j * PANEL_Q, st + A_BYTES, o, wm * 32, wn * 16, fr, fg);
     }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
             v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
           }
           const bf16_t hv = ncol ? f2bf(v) : (bf16_t)0;
-          if (ncol && m < P.rows) ((bf16_t*)P.out)[(int64_t)m * P.ldo + n] = hv;
+          if (ncol && m < P.rows && !(probe & 8)) ((bf16_t*)P.out)[(int64_t)m * P.ldo + n] = hv;
           // chained critics read the action panel from the (idle since layer 1) A slots of ring stages 0 and 1: two 64-k slabs
           if (P.n_tail) *(bf16_t*)(lds + (n >> 6) * STAGE + row * ROWB + ((((n & 63) >> 3) ^ swz(row)) * 16) + (n & 7) * 2) = hv;
         }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
   } else {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // h2 panel complete
-    if (P.h2) panel_to_global(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
+    if (P.h2 && !(probe & 8)) panel_to_global(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
   }
   if (!has_w3 && P.q) {
     // ---------------------------------------------------------------- critic head: q[m] = h2[m, :] . w3 + b3
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
         }
         const uint4 packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
         *(uint4*)cell = packed;
-        if (m < P.rows) *(uint4*)((bf16_t*)B.dz2 + (int64_t)m * P.ldh + n8) = packed;
+        if (m < P.rows && !(probe & 8)) *(uint4*)((bf16_t*)B.dz2 + (int64_t)m * P.ldh + n8) = packed;
       }
       // ---- U = (u2 W2) * scale * gate(h1): W2 k-slabs in the transposed-use image, B fragments by transpose reads
       f32x4 dacc[2][2];
