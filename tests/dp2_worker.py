@@ -56,7 +56,7 @@ def main():
         eng = StepEngine("ddpg", S, A, H, rows, dtype=dtype, mask_mode="external", seed=0, device=dev)
         for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
             eng.load_params(ni, p)
-        eng.set_hyper(policy_opt=dict(lr=1e-3, weight_decay=1e-2), value_opt=dict(lr=1e-3, weight_decay=1e-2),
+        eng.set_hyper(policy_opt=dict(lr=1e-4, weight_decay=1e-2), value_opt=dict(lr=1e-4, weight_decay=1e-2),
                       policy_every=pe)   # weight decay on both: no element sits in Adam's eps regime (|g| >= wd |p|)
         eng.set_counters()
         return eng
