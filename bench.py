@@ -210,6 +210,8 @@ def main():
         L.load().recnn_tune_sampler_f32_rows(int(os.environ["RECNN_SAMPLER_F32"]))
     if os.environ.get("RECNN_V0_MIN_WG"):
         L.load().recnn_tune_gemm_v0_threshold(int(os.environ["RECNN_V0_MIN_WG"]))
+    if os.environ.get("RECNN_MLP_KERNEL"):
+        L.load().recnn_tune_mlp_kernel(int(os.environ["RECNN_MLP_KERNEL"]))
     if os.environ.get("RECNN_MLP_PANEL"):
         L.load().recnn_tune_mlp_panel(int(os.environ["RECNN_MLP_PANEL"]))
     if os.environ.get("RECNN_MLP_MAP"):

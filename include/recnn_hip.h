@@ -410,6 +410,8 @@ void recnn_tune_mlp_fault(int mode);
 /* fused MLP forward: rows per workgroup (32 = csrc/mlp.hip, the default; 64 = csrc/mlp64.hip, bit-identical results) and
  * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
 void recnn_tune_mlp_panel(int rows);
+/* 0 = csrc/mlp.hip, 1 = csrc/mlp64.hip, 2 = csrc/mlpr.hip (64-row panels, weights from L2 straight into MFMA registers) */
+void recnn_tune_mlp_kernel(int k);
 void recnn_tune_mlp_map(int mode);
 void recnn_tune_mlp_probe(int bits);
 void recnn_tune_mlp_trace(void* device_u64_wg16);   /* shader-clock stamps of the kernel's phases, [workgroup][16] uint64, NULL = off */   /* timing experiments on the 64-row kernel's operand streams; results are garbage */

@@ -110,6 +110,7 @@ SIGNATURES = {
     "recnn_tune_mlp_fault": (None, [_I]),
     "recnn_tune_mlp_panel": (None, [_I]),
     "recnn_tune_mlp_map": (None, [_I]),
+    "recnn_tune_mlp_kernel": (None, [_I]),
     "recnn_tune_mlp_probe": (None, [_I]),
     "recnn_tune_mlp_trace": (None, [_P]),
     "recnn_engine_sampler_eager": (_I, [_P, _I]),

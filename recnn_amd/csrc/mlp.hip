@@ -454,10 +454,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 
 int mlp64_init();
 int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
+int mlp64_map_mode();
+int mlpr_init();
+int mlpr_launch(const MlpBatch& b, int nprob, int rows, int map_mode, hipStream_t s);
+// which fused-forward kernel runs: 0 = mlp.hip (32-row panels, weights through an LDS-DMA ring), 1 = mlp64.hip (64-row panels,
+// one 3-deep DMA ring), 2 = mlpr.hip (64-row panels, weights straight into registers).  All three agree bit for bit.
+static int g_mlp_kernel = 0;
+extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 2) ? k : 0; }
 // rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
 // mlp64.hip (bit-identical results; faster at TD3 / 4096 rows, 47 us at DDPG / 2048 rows: see DESIGN.md section 5)
-static int g_mlp_panel = 32;
-extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_panel = rows == 64 ? 64 : 32; }
+extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_kernel = rows == 64 ? 1 : 0; }
 static int g_mlp_waves = 16;
 static int g_mlp_fault = 0;
 // test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
@@ -468,6 +474,7 @@ extern "C" void recnn_tune_mlp_waves(int w) { g_mlp_waves = (w == 4 || w == 16) 
 int mlp_init() {
   int rc = mlp64_init();
   if (rc) return rc;
+  if ((rc = mlpr_init())) return rc;
   rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
                            "mlp_fwd_kernel<4> attr");
   if (rc) return rc;
@@ -501,7 +508,8 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
       if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
-  if (g_mlp_panel == 64 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);
+  if (g_mlp_kernel == 1 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);
+  if (g_mlp_kernel == 2 && g_mlp_waves == 16) return mlpr_launch(b, nprob, rows, mlp64_map_mode(), s);
   if (g_mlp_waves == 16)
     hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b);
   else if (g_mlp_waves == 8)

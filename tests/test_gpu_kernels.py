@@ -279,8 +279,9 @@ def test_flat_optimizer_kernels(cuda):
 
 @pytest.mark.parametrize("algo,B,steps", [("ddpg", 2048, 12), ("ddpg", 333, 4), ("ddpg", 77, 3), ("td3", 4096, 3), ("ddpg", 8192, 2)])
 def test_mlp_forward_64_row_panels_equal_32_row_panels(cuda, algo, B, steps):
-    """csrc/mlp64.hip (64-row panels, one 3-deep DMA ring for every weight byte of the workgroup) against csrc/mlp.hip
-    (32-row panels): same k order per output element, so whole learning steps -- chained target critic, TD head, unit
+    """csrc/mlp64.hip (64-row panels, one 3-deep DMA ring for every weight byte of the workgroup) and csrc/mlpr.hip (64-row
+    panels, weights from L2 straight into MFMA registers) against csrc/mlp.hip (32-row panels): same k order per output
+    element, so whole learning steps -- chained target critic, TD head, unit
     layer-2 backward, policy steps -- must agree BIT FOR BIT, with both workgroup maps, on full, ragged (333, 77 rows)
     and not-fully-resident (TD3 4096: 448 workgroups; 8192 rows) launches."""
     from recnn_amd import _lib as L
@@ -302,8 +303,8 @@ def test_mlp_forward_64_row_panels_equal_32_row_panels(cuda, algo, B, steps):
              "done": (torch.rand(B, generator=gen) < 0.1).float()}
     outs = []
     try:
-        for panel, wmap in ((32, 0), (64, 0), (64, 2)):
-            L.load().recnn_tune_mlp_panel(panel)
+        for kern, wmap in ((0, 0), (1, 0), (1, 2), (2, 0), (2, 2)):
+            L.load().recnn_tune_mlp_kernel(kern)
             L.load().recnn_tune_mlp_map(wmap)
             eng = StepEngine(algo, S, A, H, B, dtype="bf16", mask_mode="hash", seed=31)
             nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
@@ -325,7 +326,7 @@ def test_mlp_forward_64_row_panels_equal_32_row_panels(cuda, algo, B, steps):
                          {n: eng.buffer(n, B).clone() for n in ("expected", "q1", "gen_action", "next_action", "critic1_h1",
                                                                 "critic1_h2", "actor_h1", "actor_h2")}))
     finally:
-        L.load().recnn_tune_mlp_panel(32)
+        L.load().recnn_tune_mlp_kernel(0)
         L.load().recnn_tune_mlp_map(0)
     for other in outs[1:]:
         assert outs[0][0] == other[0], (outs[0][0], other[0])

@@ -8,6 +8,7 @@ from recnn_amd import _lib as L
 from recnn_amd.nn.engine import StepEngine
 
 probe = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 S, A, H, B = 1290, 128, 256, 2048
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -24,6 +25,7 @@ eng.set_counters()
 eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
 trace = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
 L.load().recnn_tune_mlp_probe(probe)
+L.load().recnn_tune_mlp_kernel(kernel)
 for t in range(5):
     eng.step(B, True, 1)
 torch.cuda.synchronize()
@@ -36,7 +38,7 @@ npanel = B // 64
 names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
 t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
 t_end = tr[:npanel * 4, 9].max()
-print(f"probe {probe}: launch span {t_end - t_start} ticks (first workgroup start -> last workgroup end)")
+print(f"kernel {kernel} probe {probe}: launch span {t_end - t_start} ticks (first workgroup start -> last workgroup end)")
 labels = {1: "setup done", 10: "L1 slab 2", 11: "L1 slab 12 (before wait)", 12: "L1 slab 12 (after wait+barrier)", 2: "L1 done", 3: "epilogue 1 done",
           4: "L2 done", 5: "epilogue 2 done", 6: "L3 done / critic head done", 7: "tails done", 9: "end"}
 for pi, nm in enumerate(names):
