@@ -457,8 +457,10 @@ int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
 int mlp64_map_mode();
 int mlpr_init();
 int mlpr_launch(const MlpBatch& b, int nprob, int rows, int map_mode, hipStream_t s);
-// which fused-forward kernel runs: 0 = mlp.hip (32-row panels, weights through an LDS-DMA ring), 1 = mlp64.hip (64-row panels,
-// one 3-deep DMA ring), 2 = mlpr.hip (64-row panels, weights straight into registers).  All three agree bit for bit.
+// which fused-forward kernel runs: 0 = mlp.hip (32-row panels, weights through an LDS-DMA ring; the default: 32.4 us for the
+// DDPG forward group at 2048 rows), 1 = mlp64.hip (64-row panels, one 3-deep DMA ring: 47 us there, 84 vs 88 us at TD3 / 4096
+// rows), 2 = mlpr.hip (64-row panels, weights straight into registers: 70 us).  All three agree bit for bit; DESIGN.md
+// section 5 has the in-kernel phase traces that explain the ranking.
 static int g_mlp_kernel = 0;
 extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 2) ? k : 0; }
 // rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
