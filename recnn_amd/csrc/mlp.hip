@@ -80,14 +80,14 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
 
 // hidden-layer epilogue: bias + relu + dropout; bf16 result into the LDS panel and (optionally) global memory
 template <int TNH>
-__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const float* bias, int H, int rows, int m0, int wave, int fr,
+__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const float (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
                                                 int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
                                                 unsigned char* panel, bf16_t* gout, int64_t ldg, uint32_t* gbits = nullptr) {
   uint32_t bits = 0;
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
     const int n = wave * (16 * TNH) + tn * 16 + fr;
-    const float bv = n < H ? bias[n] : 0.f;
+    const float bv = bias_v[tn];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int rb = tm * 16 + fg * 4;
@@ -114,8 +114,10 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const floa
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 }  // namespace
 
+// trace (tools/mlp_trace.py): lane 0 of wave 0 stamps the shader clock at the phase boundaries into trace[workgroup][16]
+#define MLP_STAMP(i) do { if (trace && threadIdx.x == 0) trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) {
+__global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, unsigned long long* trace) {
   constexpr int TNH = HP / (16 * NW);   // 16-column MFMA tiles per wave in the hidden layers (4 waves: 4, 8 waves: 2)
   constexpr int OW = NW > 8 ? 8 : NW;   // waves that take part in the actor's 128-column output layer
   constexpr int TNO = 128 / (16 * OW);  // 16-column tiles per participating wave there
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int row_max = P.rows - 1;
+  MLP_STAMP(0);
 
   f32x4 acc[2][TNH];
 #pragma unroll
@@ -136,24 +139,79 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
 #pragma unroll
     for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- biases of every epilogue of this workgroup, fetched BEFORE the first DMA: a compiler-visible load that is waited
+  // for while DMAs are in flight drains them (the compiler's s_waitcnt cannot count the asm DMAs), which used to serialise
+  // the W2 / W3 transfers with the epilogues they were meant to overlap (in-kernel trace: 7k of 8.7k ticks per epilogue)
+  float b1v[TNH], b2v[TNH], tb1[MLP_MAX_TAIL][TNH], tb2[MLP_MAX_TAIL][TNH];
+#pragma unroll
+  for (int tn = 0; tn < TNH; ++tn) {
+    const int n = wave * (16 * TNH) + tn * 16 + fr;
+    const bool in = n < P.H && !P.part_out;
+    b1v[tn] = in ? P.b1[n] : 0.f;
+    b2v[tn] = in ? P.b2[n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
+      tb1[ti][tn] = (in && ti < P.n_tail) ? batch.tail[ti].b1[n] : 0.f;
+      tb2[ti][tn] = (in && ti < P.n_tail) ? batch.tail[ti].b2[n] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TNH; ++tn) {       // the empty asm makes the compiler wait for the loads here
+    asm volatile("" : "+v"(b1v[tn]), "+v"(b2v[tn]));
+#pragma unroll
+    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) asm volatile("" : "+v"(tb1[ti][tn]), "+v"(tb2[ti][tn]));
+  }
+
   // ------------------------------------------------------------------ layer 1
   const int nt0 = P.K[0] / KB;
   const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
+  // per-lane source pointers of the layer-1 DMA, advanced by one k slab (256 B) per issue: the DMA statements clobber
+  // "memory", so anything read from P.* inside the loop would be re-fetched from the kernel-argument segment every time
+  const int q_row = lane >> 4, q_pos = lane & 15;
+  const int l_row = wave * 4 + q_row;                          // image row of DMA instruction `wave` (+ 4 NW per further one)
+  const int l_c = (q_pos ^ (l_row & 15)) * 16;                 // (rows 4 NW apart share row & 15)
+  constexpr int JA = BM / (4 * NW) > 0 ? BM / (4 * NW) : 1;    // A-panel DMA instructions per wave (BM / 4 in all)
+  const bool a_wave = wave * 4 < BM;
+  const char* a_ptr[JA];
+  const char* a_ptr1[JA];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int64_t gr = min(m0 + l_row + j * 4 * NW, row_max);
+    a_ptr[j] = (const char*)P.A[0] + gr * P.lda[0] * 2 + l_c;
+    a_ptr1[j] = P.nseg > 1 ? (const char*)P.A[1] + gr * P.lda[1] * 2 + l_c : a_ptr[j];
+  }
+  const int64_t w_step = (int64_t)4 * NW * P.ldw1 * 2;         // bytes between the rows of consecutive instructions of a wave
+  const char* w_ptr = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + P.w1_col[0]) * 2 + l_c;
+  const char* w_ptr1 = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + (P.nseg > 1 ? P.w1_col[1] : 0)) * 2 + l_c;
   auto issue1 = [&](int t) {
-    const int sg = t < nt0 ? 0 : 1;
-    const int k0 = (sg == 0 ? t : t - nt0) * KB;
+    if (t == nt0) {                                            // second contraction segment
+      w_ptr = w_ptr1;
+#pragma unroll
+      for (int j = 0; j < JA; ++j) a_ptr[j] = a_ptr1[j];
+    }
     const unsigned sb = lds0 + (t & 1) * STAGE;
-    dma_rows<NW>(P.A[sg], P.lda[sg], m0, row_max, k0, BM, sb, wave, lane);
-    dma_rows<NW>(P.W1, P.ldw1, 0, HP - 1, P.w1_col[sg] + k0, HP, sb + A_BYTES, wave, lane);
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+      if (a_wave) dma16(a_ptr[j], sb + (j * NW + wave) * 1024);
+      a_ptr[j] += 2 * KB;
+    }
+#pragma unroll
+    for (int j = 0; j < HP / (4 * NW); ++j) dma16(w_ptr + j * w_step, sb + A_BYTES + (j * NW + wave) * 1024);
+    w_ptr += 2 * KB;
   };
   issue1(0);
+  MLP_STAMP(1);
   for (int t = 0; t < nt; ++t) {
+    if (t == 2) MLP_STAMP(10);
+    if (t == 7) MLP_STAMP(11);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // slab t landed for every wave; slab t-1 is no longer being read
+    if (t == 7) MLP_STAMP(12);
     if (t + 1 < nt) issue1(t + 1);
     const unsigned char* st = lds + (t & 1) * STAGE;
     mma_slab<TNH>(st, st + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   }
+  MLP_STAMP(2);
   if (P.part_out) {
     // producer of a chained critic: hand the raw pre-activation part to the consumer workgroup of this panel
 #pragma unroll
@@ -166,6 +224,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
     }
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
     if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
+    MLP_STAMP(9);
     return;
   }
   __builtin_amdgcn_s_barrier();  // ring free
@@ -181,8 +240,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
   }
   unsigned char* panel = lds + PANEL_OFF;
   uint32_t gate1 = 0;  // relu/dropout gate of h1 for this lane's accumulator elements (bit tn*8 + tm*4 + r)
-  hidden_epilogue<TNH>(acc, P.b1, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh, &gate1);
+  hidden_epilogue<TNH>(acc, b1v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh, &gate1);
 
+  MLP_STAMP(3);
   // ------------------------------------------------------------------ layer 2
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -193,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
   mma_slab<TNH>(panel, lds + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   mma_slab<TNH>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   __builtin_amdgcn_s_barrier();  // everyone is done with W2 and the h1 panel
+  MLP_STAMP(4);
   f32x4 pacc[MLP_MAX_TAIL][2][TNH];  // chained critics: layer-1 state parts handed over by the producer workgroups
   if (P.W3) {                    // actor: both k slabs of W3 (128 rows each, 32 KB) into W slot 0 ...
     dma_rows<NW>(P.W3, P.ldw3, 0, 127, 0, 128, lds0 + A_BYTES, wave, lane);
@@ -228,7 +289,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
         }
     }
   }
-  hidden_epilogue<TNH>(acc, P.b2, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
+  hidden_epilogue<TNH>(acc, b2v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
+  MLP_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // h2 panel complete (and W3 landed)
 
@@ -264,6 +326,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
         }
     }
     }
+    MLP_STAMP(6);
     // ---------------------------------------------------------------- chained critics (target critic on the new action)
 #pragma unroll
     for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
@@ -281,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       mma_slab<TNH>(lds, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);  // + action panel x W1a
       __builtin_amdgcn_s_barrier();  // slot 1 free
       dma_rows<NW>(T.W2, T.ldw2, 0, HP - 1, KB, HP, lds0 + STAGE + A_BYTES, wave, lane);  // W2 slab 1 -> slot 1
-      hidden_epilogue<TNH>(acc, T.b1, P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
+      hidden_epilogue<TNH>(acc, tb1[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -295,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       __builtin_amdgcn_s_barrier();  // everyone is done reading the h1 panel and both slots
       if (ti + 1 < P.n_tail)
         dma_rows<NW>(batch.tail[ti + 1].W1a, batch.tail[ti + 1].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
-      hidden_epilogue<TNH>(acc, T.b2, P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
+      hidden_epilogue<TNH>(acc, tb2[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int i = 0; i < RW; ++i) {
@@ -316,6 +379,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
         }
       }
     }
+    MLP_STAMP(7);
     // ---------------------------------------------------------------- head of the learning critic(s)
     if (batch.head.n_critic > 0 && P.n_tail > 0) {
       const MlpHead& Hd = batch.head;
@@ -383,6 +447,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
           __hip_atomic_store((uint32_t*)batch.cbwd[P.cbwd_idx].q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    MLP_STAMP(6);
     if constexpr (NW == 16) {
       if (P.cbwd_idx >= 0) {
         const MlpCriticBwd& B = batch.cbwd[P.cbwd_idx];
@@ -450,6 +515,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch) 
       }
     }
   }
+  MLP_STAMP(9);
 }
 
 int mlp64_init();
@@ -466,6 +532,8 @@ extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 2)
 // rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
 // mlp64.hip (bit-identical results; faster at TD3 / 4096 rows, 47 us at DDPG / 2048 rows: see DESIGN.md section 5)
 extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_kernel = rows == 64 ? 1 : 0; }
+static unsigned long long* g_mlp32_trace = nullptr;
+void mlp32_set_trace(void* p) { g_mlp32_trace = (unsigned long long*)p; }
 static int g_mlp_waves = 16;
 static int g_mlp_fault = 0;
 // test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
@@ -513,10 +581,10 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   if (g_mlp_kernel == 1 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);
   if (g_mlp_kernel == 2 && g_mlp_waves == 16) return mlpr_launch(b, nprob, rows, mlp64_map_mode(), s);
   if (g_mlp_waves == 16)
-    hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b);
+    hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b, g_mlp32_trace);
   else if (g_mlp_waves == 8)
-    hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3((rows + BM - 1) / BM, nprob), dim3(512), LDS_TOTAL, s, b);
+    hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3((rows + BM - 1) / BM, nprob), dim3(512), LDS_TOTAL, s, b, g_mlp32_trace);
   else
-    hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b);
+    hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3((rows + BM - 1) / BM, nprob), dim3(256), LDS_TOTAL, s, b, g_mlp32_trace);
   return recnn_check_hip(hipGetLastError(), "mlp_fwd_kernel");
 }

@@ -34,7 +34,7 @@ eng.step(B, True, 1)
 torch.cuda.synchronize()
 L.load().recnn_tune_mlp_trace(None)
 tr = trace.cpu().numpy()
-npanel = B // 64
+npanel = B // (32 if kernel == 0 else 64)
 names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
 t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
 t_end = tr[:npanel * 4, 9].max()
@@ -49,4 +49,5 @@ for pi, nm in enumerate(names):
         if (v > 0).all():
             print(f"   {labels[k]:34s} median {np.median(v - rows[:, 0]):9.0f}  max {np.max(v - rows[:, 0]):9.0f} ticks since workgroup start")
     if (rows[:, 11] > 0).all():
-        print(f"   per L1 slab (slabs 2..12): {np.median((rows[:, 11] - rows[:, 10]) / 10):.0f} ticks; wait+barrier of slab 12: {np.median(rows[:, 12] - rows[:, 11]):.0f}")
+        nsl = 5 if kernel == 0 else 10
+        print(f"   per L1 slab: {np.median((rows[:, 11] - rows[:, 10]) / nsl):.0f} ticks; wait+barrier of one slab: {np.median(rows[:, 12] - rows[:, 11]):.0f}")
