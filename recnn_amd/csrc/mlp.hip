@@ -78,38 +78,59 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
   }
 }
 
-// hidden-layer epilogue: bias + relu + dropout; bf16 result into the LDS panel and (optionally) global memory
+// hidden-layer epilogue: bias + relu + dropout -> bf16 into the LDS panel (the next layer's A operand).  Kept lean on purpose
+// (in-kernel trace + ISA count: the first version spent 630 instructions per wave here, 80 per element, mostly on per-element
+// exec-masked 2-byte global stores and address arithmetic -- 7k ticks per epilogue, a third of the workgroup's time): the
+// activations now reach global memory from the finished panel as whole rows (panel_to_global), and the four rows of an
+// accumulator register group differ only by r in the swizzled chunk position ((c ^ (rb | r)) = (c ^ rb) ^ r).
 template <int TNH>
 __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const float (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
                                                 int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
-                                                unsigned char* panel, bf16_t* gout, int64_t ldg, uint32_t* gbits = nullptr) {
+                                                unsigned char* panel, uint32_t* gbits = nullptr) {
   uint32_t bits = 0;
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
     const int n = wave * (16 * TNH) + tn * 16 + fr;
     const float bv = bias_v[tn];
+    const bool live = n < H;
+    // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
+    unsigned char* col = panel + (n >> 7) * PANEL_HALF + (n & 7) * 2;
+    const int c = (n & 127) >> 3;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int rb = tm * 16 + fg * 4;
       uint32_t word = 0;
       if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)((m0 + rb) >> 2), (uint32_t)n);
+      unsigned char* cell = col + rb * 256;
+      const int pos0 = c ^ (fg * 4);            // rb & 15 == 4 fg
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = rb + r, m = m0 + row;
         float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
-        if (mask_mode == RECNN_MASK_EXTERNAL) v = (m < rows && n < H && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
-        else if (mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
-        if (n >= H) v = 0.f;
+        if (mask_mode == RECNN_MASK_EXTERNAL) {
+          const int m = m0 + rb + r;
+          v = (m < rows && live && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
+        } else if (mask_mode == RECNN_MASK_HASH) {
+          v = mask_keep(word, r) ? v * 2.f : 0.f;
+        }
+        if (!live) v = 0.f;
         const bf16_t hv = f2bf(v);
         if (bf2f(hv) > 0.f) bits |= 1u << (tn * 8 + tm * 4 + r);
-        // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
-        const int c = ((n & 127) >> 3) ^ (row & 15);
-        *(bf16_t*)(panel + (n >> 7) * PANEL_HALF + row * 256 + c * 16 + (n & 7) * 2) = hv;
-        if (gout && m < rows && n < H) gout[(int64_t)m * ldg + n] = hv;
+        *(bf16_t*)(cell + r * 256 + ((pos0 ^ r) << 4)) = hv;
       }
     }
   }
   if (gbits) *gbits = bits;
+}
+
+// the finished 32 x 256 panel -> global [rows, ldg] bf16: whole 512-byte rows, one 16-byte chunk per thread and pass
+template <int NW>
+__device__ __forceinline__ void panel_to_global(const unsigned char* panel, bf16_t* gout, int64_t ldg, int m0, int rows, int tid) {
+#pragma unroll
+  for (int j = 0; j < (BM * 32) / (NW * 64); ++j) {
+    const int idx = tid + j * NW * 64, row = idx >> 5, cc = idx & 31;
+    const uint4 v = *(const uint4*)(panel + (cc >> 4) * PANEL_HALF + row * 256 + (((cc & 15) ^ (row & 15)) << 4));
+    if (m0 + row < rows) *(uint4*)(gout + (int64_t)(m0 + row) * ldg + cc * 8) = v;
+  }
 }
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 }  // namespace
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
   }
   unsigned char* panel = lds + PANEL_OFF;
   uint32_t gate1 = 0;  // relu/dropout gate of h1 for this lane's accumulator elements (bit tn*8 + tm*4 + r)
-  hidden_epilogue<TNH>(acc, b1v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, (bf16_t*)P.h1, P.ldh, &gate1);
+  hidden_epilogue<TNH>(acc, b1v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask1, P.ld_mask, key1, panel, &gate1);
 
   MLP_STAMP(3);
   // ------------------------------------------------------------------ layer 2
@@ -250,6 +271,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
     for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // W2 landed, h1 panel complete (LDS writes drained before the raw barrier)
+  if (P.h1) panel_to_global<NW>(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
   mma_slab<TNH>(panel, lds + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   mma_slab<TNH>(panel + PANEL_HALF, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);
   __builtin_amdgcn_s_barrier();  // everyone is done with W2 and the h1 panel
@@ -289,10 +311,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
         }
     }
   }
-  hidden_epilogue<TNH>(acc, b2v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel, (bf16_t*)P.h2, P.ldh);
+  hidden_epilogue<TNH>(acc, b2v, P.H, P.rows, m0, wave, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel);
   MLP_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // h2 panel complete (and W3 landed)
+  if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
 
   // ------------------------------------------------------------------ layer 3
   if (P.W3) {
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
       mma_slab<TNH>(lds, lds + STAGE + A_BYTES, acc, wave * (16 * TNH), fr, fg);  // + action panel x W1a
       __builtin_amdgcn_s_barrier();  // slot 1 free
       dma_rows<NW>(T.W2, T.ldw2, 0, HP - 1, KB, HP, lds0 + STAGE + A_BYTES, wave, lane);  // W2 slab 1 -> slot 1
-      hidden_epilogue<TNH>(acc, tb1[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
+      hidden_epilogue<TNH>(acc, tb1[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
       __builtin_amdgcn_s_barrier();  // everyone is done reading the h1 panel and both slots
       if (ti + 1 < P.n_tail)
         dma_rows<NW>(batch.tail[ti + 1].W1a, batch.tail[ti + 1].ldw1, 0, HP - 1, 0, HP, lds0 + STAGE + A_BYTES, wave, lane);
-      hidden_epilogue<TNH>(acc, tb2[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel, nullptr, 0);
+      hidden_epilogue<TNH>(acc, tb2[ti], P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int i = 0; i < RW; ++i) {
