@@ -136,7 +136,7 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 }  // namespace
 
 // trace (tools/mlp_trace.py): lane 0 of wave 0 stamps the shader clock at the phase boundaries into trace[workgroup][16]
-#define MLP_STAMP(i) do { if (trace && threadIdx.x == 0) trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MLP_STAMP(i) do { if (trace && threadIdx.x == 0) trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, unsigned long long* trace) {
   constexpr int TNH = HP / (16 * NW);   // 16-column MFMA tiles per wave in the hidden layers (4 waves: 4, 8 waves: 2)

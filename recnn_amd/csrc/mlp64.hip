@@ -150,7 +150,7 @@ __device__ __forceinline__ float row_dot(const unsigned char* panel, int row, in
 
 // trace (tools / bench.py RECNN_MLP_TRACE): when non-null, lane 0 of wave 0 of every workgroup stamps the shader clock at the
 // phase boundaries into trace[logical workgroup id][16]
-#define MLP64_STAMP(i) do { if (trace && tid == 0) trace[(int64_t)bid * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MLP64_STAMP(i) do { if (trace && (tid == 0 || tid == 960)) trace[(int64_t)bid * 32 + (tid ? 16 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, int npanel, int map_mode, int probe, unsigned long long* trace) {
   int bid = blockIdx.x;
   if (map_mode == 2) bid = xcd_remap(bid, gridDim.x);
@@ -356,7 +356,9 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if (j == 2) MLP64_STAMP(13);
     const unsigned char* st = wait_slab();   // (first pass: the h1 panel is complete behind this barrier)
+    if (j == 2) MLP64_STAMP(14);
     if (j == 0 && P.h1 && !(probe & 8)) panel_to_global(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
     refill();
     mma_slab<2>(panel + j * PANEL_Q, st + A_BYTES, acc, wm * 32, wn * 32, fr, fg);
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void mlp64_kernel(const MlpBatch batch, in
       }
     }
   }
+  MLP64_STAMP(15);
   __builtin_amdgcn_s_barrier();   // everyone is done with the h1 panel; flags seen (tid 0's acquire dropped this CU's stale lines)
   hidden_epilogue(acc, bias_lds + HP, P.H, P.rows, m0, wm, wn, fr, fg, P.mask_mode, P.mask2, P.ld_mask, key2, panel);
 

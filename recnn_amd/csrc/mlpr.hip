@@ -140,7 +140,7 @@ __device__ __forceinline__ float row_dot(const unsigned char* panel, int row, in
 }
 }  // namespace
 
-#define MLPR_STAMP(i) do { if (trace && tid == 0) trace[(int64_t)bid * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MLPR_STAMP(i) do { if (trace && tid == 0) trace[(int64_t)bid * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __global__ __launch_bounds__(NT) void mlpr_kernel(const MlpBatch batch, int npanel, int map_mode, u64* trace) {
   int bid = blockIdx.x;

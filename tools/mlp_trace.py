@@ -23,7 +23,7 @@ for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1
 eng.set_hyper(policy_opt=dict(lr=1e-5), value_opt=dict(lr=1e-5))
 eng.set_counters()
 eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
-trace = torch.zeros(1024, 16, dtype=torch.int64, device=dev)
+trace = torch.zeros(1024, 32, dtype=torch.int64, device=dev)
 L.load().recnn_tune_mlp_probe(probe)
 L.load().recnn_tune_mlp_kernel(kernel)
 for t in range(5):
@@ -39,15 +39,15 @@ names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
 t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
 t_end = tr[:npanel * 4, 9].max()
 print(f"kernel {kernel} probe {probe}: launch span {t_end - t_start} ticks (first workgroup start -> last workgroup end)")
-labels = {1: "setup done", 10: "L1 slab 2", 11: "L1 slab 12 (before wait)", 12: "L1 slab 12 (after wait+barrier)", 2: "L1 done", 3: "epilogue 1 done",
+labels = {13: "L2 slab 2 before wait", 14: "L2 slab 2 after wait+barrier", 15: "L2 mma done (before barrier)", 1: "setup done", 10: "L1 slab 2", 11: "L1 slab 12 (before wait)", 12: "L1 slab 12 (after wait+barrier)", 2: "L1 done", 3: "epilogue 1 done",
           4: "L2 done", 5: "epilogue 2 done", 6: "L3 done / critic head done", 7: "tails done", 9: "end"}
 for pi, nm in enumerate(names):
     rows = tr[pi * npanel:(pi + 1) * npanel]
     print(f"== {nm}: start offset vs launch start: median {np.median(rows[:, 0] - t_start):.0f}, max {np.max(rows[:, 0] - t_start):.0f} ticks")
-    for k in (1, 10, 11, 12, 2, 3, 4, 5, 6, 7, 9):
+    for k in (1, 10, 11, 12, 2, 3, 13, 14, 4, 15, 5, 6, 7, 9, 16 + 2, 16 + 3, 16 + 13, 16 + 14, 16 + 4, 16 + 15, 16 + 5, 16 + 6, 16 + 9):
         v = rows[:, k]
         if (v > 0).all():
-            print(f"   {labels[k]:34s} median {np.median(v - rows[:, 0]):9.0f}  max {np.max(v - rows[:, 0]):9.0f} ticks since workgroup start")
+            print(f"   {('w15 ' if k >= 16 else '') + labels[k % 16 if k >= 16 else k]:34s} median {np.median(v - rows[:, 0]):9.0f}  max {np.max(v - rows[:, 0]):9.0f} ticks since workgroup start")
     if (rows[:, 11] > 0).all():
         nsl = 5 if kernel == 0 else 10
         print(f"   per L1 slab: {np.median((rows[:, 11] - rows[:, 10]) / nsl):.0f} ticks; wait+barrier of one slab: {np.median(rows[:, 12] - rows[:, 11]):.0f}")
