@@ -74,8 +74,9 @@ __device__ inline void tc_store(bf16_t* p, float v) { *p = f2bf(v); }
 // ---------------------------------------------------------------- dropout keep-mask generator
 // Counter-based: the keep bit of element (row, col) of mask stream `stream_id` at step `step` is a
 // pure function of (seed, step, stream_id, row, col) -- independent of tiling, so
-// recnn_hash_mask_dump reproduces exactly what the GEMM epilogues used.  One 32-bit word serves the
-// 4 consecutive rows (row & ~3 .. +3) of a column: that is what one lane of a 16x16 MFMA tile owns.
+// recnn_hash_mask_dump reproduces exactly what the GEMM epilogues used.  One 32-bit word serves a 4 x 4 block
+// (rows row & ~3 .. +3, columns col & ~3 .. +3): that is what one lane of a 16x16 MFMA tile owns in either operand order
+// (four rows of one column, or -- with the operands swapped, mlp.hip -- four columns of one row).
 __host__ __device__ inline uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
@@ -83,11 +84,11 @@ __host__ __device__ inline uint32_t mix32(uint32_t x) {
 __host__ __device__ inline uint32_t mask_key(uint32_t seed, int32_t step, uint32_t stream_id) {
   return mix32(seed ^ mix32((uint32_t)step * 0x9E3779B1u + stream_id * 0x7F4A7C15u + 0x1234567u));
 }
-__host__ __device__ inline uint32_t mask_word(uint32_t key, uint32_t row4, uint32_t col) {
-  return mix32((row4 * 0x9E3779B1u) ^ mix32(col * 0x85EBCA77u + key));
+__host__ __device__ inline uint32_t mask_word(uint32_t key, uint32_t row4, uint32_t col4) {
+  return mix32((row4 * 0x9E3779B1u) ^ mix32(col4 * 0x85EBCA77u + key));
 }
-// keep bit for row (row4*4 + r)
-__host__ __device__ inline bool mask_keep(uint32_t word, int r) { return (word >> (7 + 8 * r)) & 1u; }
+// keep bit for row (row4*4 + r), column (col4*4 + c)
+__host__ __device__ inline bool mask_keep(uint32_t word, int r, int c) { return (word >> (8 + 4 * r + c)) & 1u; }
 
 // ---------------------------------------------------------------- wave / block reductions
 // Cross-lane sums with DPP row operations (one VALU op per step) instead of ds_bpermute shuffles (LDS crossbar).

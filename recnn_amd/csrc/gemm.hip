@@ -200,7 +200,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
           const float bv = P.bias ? P.bias[n] : 0.f;
           const float dw = P.dot_w ? P.dot_w[n] : 0.f;
           uint32_t word = 0;
-          if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)n);
+          if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mb >> 2), (uint32_t)(n >> 2));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mb + r;
@@ -212,7 +212,7 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
               }
               if (P.relu) v = fmaxf(v, 0.f);
               if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
-              else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
+              else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r, n & 3) ? v * 2.f : 0.f;
               if (P.c_f32) {
                 ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
               } else {
@@ -1027,7 +1027,7 @@ __global__ void hash_mask_dump_kernel(uint32_t seed, int32_t step, uint32_t stre
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)M * N) return;
   int m = (int)(i / N), n = (int)(i % N);
-  out[i] = mask_keep(mask_word(key, (uint32_t)(m >> 2), (uint32_t)n), m & 3) ? 1 : 0;
+  out[i] = mask_keep(mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n >> 2)), m & 3, n & 3) ? 1 : 0;
 }
 extern "C" int recnn_hash_mask_dump(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N, uint8_t* out, void* stream) {
   RECNN_REQUIRE(out && M > 0 && N > 0, "hash_mask_dump: bad args");

@@ -57,7 +57,11 @@ __device__ __forceinline__ void dma_rows(const void* base, int64_t ld, int row0,
   }
 }
 
-// acc[tm][tn] += A(32 x 128) * B(rows wn0.. x 128)^T for one k slab already in LDS
+// acc[tm][tn] += A(32 x 128) * B(rows wn0.. x 128)^T for one k slab already in LDS.  The MFMA operands are SWAPPED (weights
+// first): a lane then holds four consecutive output COLUMNS of one batch row --
+//     acc[tm][tn][r] = C[row 16 tm + fr][column wn0 + 16 tn + 4 fg + r]
+// -- so the epilogues convert and store four neighbours at once (one 8-byte LDS / global access instead of four 2-byte
+// ones) and one dropout word serves them.  Same products, same k order: bit-identical to the unswapped form.
 template <int TN>
 __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned char* sb, f32x4 (&acc)[2][TN], int wn0, int fr,
                                          int fg) {
@@ -73,7 +77,7 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]), __builtin_bit_cast(bf16x8, b[tn]),
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]),
                                                               acc[tm][tn], 0, 0, 0);
   }
 }
@@ -84,39 +88,36 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
 // activations now reach global memory from the finished panel as whole rows (panel_to_global), and the four rows of an
 // accumulator register group differ only by r in the swizzled chunk position ((c ^ (rb | r)) = (c ^ rb) ^ r).
 template <int TNH>
-__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const float (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
+__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x4 (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
                                                 int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
                                                 unsigned char* panel, uint32_t* gbits = nullptr) {
   uint32_t bits = 0;
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
-    const int n = wave * (16 * TNH) + tn * 16 + fr;
-    const float bv = bias_v[tn];
-    const bool live = n < H;
+    const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;      // this lane's four columns n0 .. n0 + 3
     // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
-    unsigned char* col = panel + (n >> 7) * PANEL_HALF + (n & 7) * 2;
-    const int c = (n & 127) >> 3;
+    unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
+    const int c = (n0 & 127) >> 3;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-      const int rb = tm * 16 + fg * 4;
+      const int row = tm * 16 + fr, m = m0 + row;
       uint32_t word = 0;
-      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)((m0 + rb) >> 2), (uint32_t)n);
-      unsigned char* cell = col + rb * 256;
-      const int pos0 = c ^ (fg * 4);            // rb & 15 == 4 fg
+      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n0 >> 2));
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = fmaxf(acc[tm][tn][r] + bv, 0.f);
-        if (mask_mode == RECNN_MASK_EXTERNAL) {
-          const int m = m0 + rb + r;
-          v = (m < rows && live && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
-        } else if (mask_mode == RECNN_MASK_HASH) {
-          v = mask_keep(word, r) ? v * 2.f : 0.f;
-        }
-        if (!live) v = 0.f;
-        const bf16_t hv = f2bf(v);
-        if (bf2f(hv) > 0.f) bits |= 1u << (tn * 8 + tm * 4 + r);
-        *(bf16_t*)(cell + r * 256 + ((pos0 ^ r) << 4)) = hv;
+        v[r] = fmaxf(acc[tm][tn][r] + bias_v[tn][r], 0.f);
+        if (mask_mode == RECNN_MASK_EXTERNAL) v[r] = (m < rows && n0 + r < H && mask[(int64_t)m * ld_mask + n0 + r]) ? v[r] * 2.f : 0.f;
+        else if (mask_mode == RECNN_MASK_HASH) v[r] = mask_keep(word, m & 3, r) ? v[r] * 2.f : 0.f;
+        if (n0 + r >= H) v[r] = 0.f;
       }
+      const uint32_t lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
+      // gate bit = the ROUNDED activation is positive (what the backward kernels test on the stored bf16 value)
+      if (lo & 0x7FFFu) bits |= 1u << (tn * 8 + tm * 4 + 0);
+      if (lo & 0x7FFF0000u) bits |= 1u << (tn * 8 + tm * 4 + 1);
+      if (hi & 0x7FFFu) bits |= 1u << (tn * 8 + tm * 4 + 2);
+      if (hi & 0x7FFF0000u) bits |= 1u << (tn * 8 + tm * 4 + 3);
+      *(uint2*)(col + row * 256 + ((c ^ fr) << 4)) = make_uint2(lo, hi);   // row & 15 == fr
     }
   }
   if (gbits) *gbits = bits;
@@ -163,17 +164,20 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
   // ---- biases of every epilogue of this workgroup, fetched BEFORE the first DMA: a compiler-visible load that is waited
   // for while DMAs are in flight drains them (the compiler's s_waitcnt cannot count the asm DMAs), which used to serialise
   // the W2 / W3 transfers with the epilogues they were meant to overlap (in-kernel trace: 7k of 8.7k ticks per epilogue)
-  float b1v[TNH], b2v[TNH], tb1[MLP_MAX_TAIL][TNH], tb2[MLP_MAX_TAIL][TNH];
+  f32x4 b1v[TNH], b2v[TNH], tb1[MLP_MAX_TAIL][TNH], tb2[MLP_MAX_TAIL][TNH];
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
-    const int n = wave * (16 * TNH) + tn * 16 + fr;
-    const bool in = n < P.H && !P.part_out;
-    b1v[tn] = in ? P.b1[n] : 0.f;
-    b2v[tn] = in ? P.b2[n] : 0.f;
+    const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;
 #pragma unroll
-    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
-      tb1[ti][tn] = (in && ti < P.n_tail) ? batch.tail[ti].b1[n] : 0.f;
-      tb2[ti][tn] = (in && ti < P.n_tail) ? batch.tail[ti].b2[n] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const bool in = n0 + r < P.H && !P.part_out;
+      b1v[tn][r] = in ? P.b1[n0 + r] : 0.f;
+      b2v[tn][r] = in ? P.b2[n0 + r] : 0.f;
+#pragma unroll
+      for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
+        tb1[ti][tn][r] = (in && ti < P.n_tail) ? batch.tail[ti].b1[n0 + r] : 0.f;
+        tb2[ti][tn][r] = (in && ti < P.n_tail) ? batch.tail[ti].b2[n0 + r] : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -237,11 +241,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
     // producer of a chained critic: hand the raw pre-activation part to the consumer workgroup of this panel
 #pragma unroll
     for (int tn = 0; tn < TNH; ++tn) {
-      const int n = wave * (16 * TNH) + tn * 16 + fr;
+      const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P.part_out[(int64_t)(m0 + tm * 16 + fg * 4 + r) * HP + n] = acc[tm][tn][r];
+      for (int tm = 0; tm < 2; ++tm) *(f32x4*)(P.part_out + (int64_t)(m0 + tm * 16 + fr) * HP + n0) = acc[tm][tn];
     }
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
     if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
@@ -302,11 +304,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
         if (ti < P.n_tail) {
 #pragma unroll
           for (int tn = 0; tn < TNH; ++tn) {
-            const int n = wave * (16 * TNH) + tn * 16 + fr;
+            const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) pacc[ti][tm][tn][r] = batch.tail[ti].part[(int64_t)(m0 + tm * 16 + fg * 4 + r) * HP + n];
+            for (int tm = 0; tm < 2; ++tm) pacc[ti][tm][tn] = *(const f32x4*)(batch.tail[ti].part + (int64_t)(m0 + tm * 16 + fr) * HP + n0);
           }
         }
     }
@@ -329,24 +329,43 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
     mma_slab<TNO>(panel + PANEL_HALF, lds + A_BYTES + 128 * 256, o, wave * (16 * TNO), fr, fg);
 #pragma unroll
     for (int tn = 0; tn < TNO; ++tn) {
-      const int n = wave * (16 * TNO) + tn * 16 + fr;
-      const bool ncol = n < P.out_dim;
-      const float bv = ncol ? P.b3[n] : 0.f;
+      const int n0 = wave * (16 * TNO) + tn * 16 + fg * 4;    // this lane's four output columns
+      float bv[4];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int r = 0; r < 4; ++r) bv[r] = n0 + r < P.out_dim ? P.b3[n0 + r] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int row = tm * 16 + fr, m = m0 + row;
+        float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = tm * 16 + fg * 4 + r, m = m0 + row;
-          float v = o[tm][tn][r] + bv;
+          const bool ncol = n0 + r < P.out_dim;
+          v[r] = o[tm][tn][r] + bv[r];
           if (P.addend && ncol && m < P.rows) {
-            const float z = P.addend[(int64_t)m * P.ld_add + n];
-            v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+            const float z = P.addend[(int64_t)m * P.ld_add + n0 + r];
+            v[r] += fminf(fmaxf(z, -P.add_clip), P.add_clip);
           }
-          const bf16_t hv = ncol ? f2bf(v) : (bf16_t)0;
-          if (ncol && m < P.rows) ((bf16_t*)P.out)[(int64_t)m * P.ldo + n] = hv;
-          // chained critics read the action panel from the (idle) A slot of ring stage 0, same image as a k slab
-          if (P.n_tail) *(bf16_t*)(lds + row * 256 + (((n >> 3) ^ (row & 15)) * 16) + (n & 7) * 2) = hv;
+          if (!ncol) v[r] = 0.f;
         }
+        uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if (n0 + 3 >= P.out_dim) {                             // (padded columns hold bf16 +0, not -0)
+          if (n0 + 0 >= P.out_dim) packed.x &= 0xFFFF0000u;
+          if (n0 + 1 >= P.out_dim) packed.x &= 0x0000FFFFu;
+          if (n0 + 2 >= P.out_dim) packed.y &= 0xFFFF0000u;
+          if (n0 + 3 >= P.out_dim) packed.y &= 0x0000FFFFu;
+        }
+        if (m < P.rows) {
+          if (n0 + 3 < P.out_dim) {
+            *(uint2*)((bf16_t*)P.out + (int64_t)m * P.ldo + n0) = packed;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n0 + r < P.out_dim) ((bf16_t*)P.out)[(int64_t)m * P.ldo + n0 + r] = (bf16_t)((r < 2 ? packed.x : packed.y) >> ((r & 1) * 16));
+          }
+        }
+        // chained critics read the action panel from the (idle) A slot of ring stage 0, same image as a k slab
+        if (P.n_tail) *(uint2*)(lds + row * 256 + (((n0 >> 3) ^ fr) << 4) + (n0 & 7) * 2) = packed;
+      }
     }
     }
     MLP_STAMP(6);
@@ -522,19 +541,18 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
           struct { v4s16 lo, hi; } bv = {b[0], b[1]};
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
-            dacc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[tm]), __builtin_bit_cast(bf16x8, bv), dacc[tm], 0, 0, 0);
+            dacc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[tm]), dacc[tm], 0, 0, 0);
         }
-        const int n = wave * 16 + fr;
+        // (operands swapped as in mma_slab: dacc[tm][r] = U[row 16 tm + fr][column 16 wave + 4 fg + r], the layout of gate1)
+        const int n0 = wave * 16 + fg * 4;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < 2; ++tm) {
+          const int mm = m0 + tm * 16 + fr;
+          float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int mm = m0 + tm * 16 + fg * 4 + r;
-            if (mm < P.rows && n < P.H) {
-              const float v = ((gate1 >> (tm * 4 + r)) & 1u) ? dacc[tm][r] * B.scale : 0.f;
-              ((bf16_t*)B.dz1)[(int64_t)mm * P.ldh + n] = f2bf(v);
-            }
-          }
+          for (int r = 0; r < 4; ++r) v[r] = (((gate1 >> (tm * 4 + r)) & 1u) && n0 + r < P.H) ? dacc[tm][r] * B.scale : 0.f;
+          if (mm < P.rows) *(uint2*)((bf16_t*)B.dz1 + (int64_t)mm * P.ldh + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
       }
     }
   }

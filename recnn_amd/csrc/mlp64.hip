@@ -105,13 +105,13 @@ __device__ __forceinline__ uint32_t hidden_epilogue(f32x4 (&acc)[2][2], const fl
     for (int tm = 0; tm < 2; ++tm) {
       const int rb = wm * 32 + tm * 16 + fg * 4;
       uint32_t word = 0;
-      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)((m0 + rb) >> 2), (uint32_t)n);
+      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)((m0 + rb) >> 2), (uint32_t)(n >> 2));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rb + r, m = m0 + row;
         float v = fmaxf(acc[tm][tn][r] + bvn, 0.f);
         if (mask_mode == RECNN_MASK_EXTERNAL) v = (m < rows && n < H && mask[(int64_t)m * ld_mask + n]) ? v * 2.f : 0.f;
-        else if (mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r) ? v * 2.f : 0.f;
+        else if (mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r, n & 3) ? v * 2.f : 0.f;
         if (n >= H) v = 0.f;
         const bf16_t hv = f2bf(v);
         if (bf2f(hv) > 0.f) bits |= 1u << (tn * 8 + tm * 4 + r);
