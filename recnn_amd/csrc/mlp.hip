@@ -168,15 +168,27 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
     const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;
+    // (bias vectors start on 16-byte boundaries of the 16-byte aligned arenas whenever H % 4 == 0: one load per vector)
+    const bool in = n0 + 3 < P.H && !P.part_out && !(P.H & 3);
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    b1v[tn] = in ? *(const f32x4*)(P.b1 + n0) : z4;
+    b2v[tn] = in ? *(const f32x4*)(P.b2 + n0) : z4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool in = n0 + r < P.H && !P.part_out;
-      b1v[tn][r] = in ? P.b1[n0 + r] : 0.f;
-      b2v[tn][r] = in ? P.b2[n0 + r] : 0.f;
+    for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
+      tb1[ti][tn] = (in && ti < P.n_tail) ? *(const f32x4*)(batch.tail[ti].b1 + n0) : z4;
+      tb2[ti][tn] = (in && ti < P.n_tail) ? *(const f32x4*)(batch.tail[ti].b2 + n0) : z4;
+    }
+    if (!in && !P.part_out) {                                  // ragged hidden width: element by element
 #pragma unroll
-      for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
-        tb1[ti][tn][r] = (in && ti < P.n_tail) ? batch.tail[ti].b1[n0 + r] : 0.f;
-        tb2[ti][tn][r] = (in && ti < P.n_tail) ? batch.tail[ti].b2[n0 + r] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = n0 + r < P.H;
+        b1v[tn][r] = ok ? P.b1[n0 + r] : 0.f;
+        b2v[tn][r] = ok ? P.b2[n0 + r] : 0.f;
+#pragma unroll
+        for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
+          tb1[ti][tn][r] = (ok && ti < P.n_tail) ? batch.tail[ti].b1[n0 + r] : 0.f;
+          tb2[ti][tn][r] = (ok && ti < P.n_tail) ? batch.tail[ti].b2[n0 + r] : 0.f;
+        }
       }
     }
   }
