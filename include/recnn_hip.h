@@ -168,9 +168,9 @@ typedef struct recnn_gemm_args {
   const void* A[2];       /* fwd/dx: [M, lda] (k contiguous).  dw: [Kc, lda] (m = row index) */
   const void* B[2];       /* fwd: [N, ldb] (k contiguous).  dx/dw: [Kc, ldb]                 */
   int64_t lda[2], ldb[2];
-  int K[2];               /* contraction length per segment; K[1] = 0 if unused.  Must be a
-                             multiple of 64 for fwd/dx (zero padded operands); for dw it is the
-                             number of valid rows (any value). */
+  int K[2];               /* contraction length per segment; K[1] = 0 if unused.  fwd/dx: a multiple of
+                             one 16-byte chunk of the compute type (4 fp32 / 8 bf16); multiples of 64 (128 for
+                             bf16) take the LDS-DMA kernels.  dw: the number of valid rows (any value). */
   int a_f32[2];           /* segment's A operand is float in memory although tc is bf16 */
   int b_f32[2];           /* same for B (dw of layer 1: B = packed fp32 batch rows) */
   /* epilogue */
@@ -294,6 +294,31 @@ int recnn_engine_bind_slow(recnn_engine* e, int net, float* slow);
 int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold, int step_t,
                       float grad_scale, void* stream);
+
+/* =====================================================================================
+ * 3b. Categorical policy head (REINFORCE)
+ *    replaces F.softmax + torch.distributions.Categorical(probs).sample() / .log_prob() of
+ *    DiscreteActor (recnn/nn/models.py:95-99, :107-111, :116-141), their autograd backward, and the
+ *    one-hot action rows of batch_contstate_discaction (recnn/data/utils.py:108-109).
+ *    Rows are float[rows, ld] with ld % 4 == 0, 16-byte aligned; columns [n, ld) are padding.
+ * ===================================================================================== */
+#define RECNN_CAT_SOFTMAX 1 /* x holds logits; overwritten with p = softmax(x) (padding columns become 0) */
+#define RECNN_CAT_SAMPLE 2  /* draw actions[row] ~ p / sum p (else actions[row] is read; NULL = no action) */
+/* logprob[row] = log(clamp(p[a] / sum p, eps, 1 - eps)) (torch.distributions.Categorical arithmetic);
+ * rowstat[row] = {max logit, sum exp, sum p, 1.0 if the clamp was active}.  logprob / rowstat may be NULL.
+ * The uniform of row r is a pure function of (seed, step, r); the inverse-CDF walks items in a fixed order. */
+int recnn_categorical_rows(float* x, int64_t ld, int rows, int n, int flags, uint32_t seed, int32_t step,
+                           int64_t* actions, float* logprob, float* rowstat, void* stream);
+/* dlogits (+)= g[row] * (onehot(a) - p / sum p), zero for rows whose clamp was active (g NULL = zeros);
+ * colsum[n] (optional) = column sums of the resulting dlogits (bias gradient), scratch = float[ceil(rows/32) * round4(n)]. */
+int recnn_logprob_bwd(const float* p, int64_t ldp, int rows, int n, const int64_t* actions, const float* g,
+                      const float* rowstat, float* dlogits, int64_t ldd, int accumulate, float* colsum, float* scratch,
+                      void* stream);
+/* dlogits = p * (dprobs - sum_j dprobs_j p_j): backward of p = softmax(logits). */
+int recnn_softmax_bwd(const float* p, int64_t ldp, int rows, int n, const float* dprobs, int64_t lddp, float* dlogits,
+                      int64_t ldd, void* stream);
+/* out[r, :] = onehot(idx[r]) over n columns (columns [n, ld) zeroed). */
+int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t ld, void* stream);
 
 /* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
 int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);

@@ -16,6 +16,7 @@ F32, BF16 = 0, 1
 MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
 ALGO_DDPG, ALGO_TD3 = 0, 1
 OPT_ADAM, OPT_RANGER = 0, 1
+CAT_SOFTMAX, CAT_SAMPLE = 1, 2
 NET_POLICY, NET_TARGET_POLICY, NET_VALUE1, NET_TARGET_VALUE1, NET_VALUE2, NET_TARGET_VALUE2 = range(6)
 
 
@@ -135,6 +136,10 @@ SIGNATURES = {
     "recnn_engine_bind_net": (_I, [_P, _I, _P, _P, _P, _P]),
     "recnn_engine_bind_batch": (_I, [_P, _P, _P, _P, _P]),
     "recnn_engine_bind_slow": (_I, [_P, _I, _P]),
+    "recnn_categorical_rows": (_I, [_P, _L, _I, _I, _I, C.c_uint32, C.c_int32, _P, _P, _P, _P]),
+    "recnn_logprob_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "recnn_softmax_bwd": (_I, [_P, _L, _I, _I, _P, _L, _P, _L, _P]),
+    "recnn_onehot_rows": (_I, [_P, _I, _I, _P, _L, _P]),
     "recnn_ranger_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),

@@ -940,7 +940,9 @@ template <class TC, int MODE> static int launch_m(GemmLaunch* L, hipStream_t s) 
 int gemm_launch(GemmLaunch* L, hipStream_t stream) {
   if (L->nprob <= 0) return 0;
   if (L->nprob > GEMM_MAX_GROUP) { recnn_set_error("gemm group too large"); return RECNN_E_INVALID; }
-  const int BK = 64;  // zero-padding granularity of k-contiguous operands (16-byte chunks never straddle it)
+  // k-contiguous operands are read in 16-byte chunks of the compute type; a chunk never straddles the end of K (the tail of
+  // the last LDS stage is zero filled by the loaders).  The LDS-DMA kernels want whole stages and are only chosen for such K.
+  const int BK = L->dtype == RECNN_F32 ? 4 : 8;
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];
     for (int s = 0; s < p.nseg; ++s) {

@@ -11,7 +11,7 @@ import torch
 from .. import _lib as L
 from .pandas_backend import pd
 
-__all__ = ["rolling_window", "get_irsu", "batch_tensor_embeddings", "prepare_batch_static_size", "make_items_tensor",
+__all__ = ["rolling_window", "get_irsu", "batch_tensor_embeddings", "batch_contstate_discaction", "prepare_batch_static_size", "make_items_tensor",
            "sort_users_itemwise", "get_base_batch", "packed_ld", "FrameBatch"]
 
 
@@ -112,6 +112,19 @@ def batch_tensor_embeddings(batch, item_embeddings_tensor, frame_size, *args, **
     res = dict(out)
     res["done"] = done
     res["meta"] = {"users": users_t, "sizes": sizes_t}
+    return res
+
+
+def batch_contstate_discaction(batch, item_embeddings_tensor, frame_size, num_items, *args, **kwargs):
+    """Embed Batch: continuous state, discrete action (utils.py:84-120): as `batch_tensor_embeddings`, but the action is
+    the one-hot row of the item id at the end of the window (float[B, num_items]) -- what REINFORCE's critic and the
+    behaviour policy consume.  State / next_state / reward come from the HIP gather, the one-hot rows from
+    `recnn_onehot_rows`.  Use with a dataset truncated to `num_items` (`truncate_dataset`): ids must be < num_items."""
+    res = batch_tensor_embeddings(batch, item_embeddings_tensor, frame_size)
+    from ..nn.functional import onehot_rows
+    dev = item_embeddings_tensor.device
+    last = torch.as_tensor(batch["items"])[:, -1].to(dev)
+    res["action"] = onehot_rows(last, int(num_items))
     return res
 
 

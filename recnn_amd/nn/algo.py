@@ -20,7 +20,7 @@ import torch
 from .. import optim, utils
 from . import update
 
-__all__ = ["Algo", "DDPG", "TD3", "set_default_optimizer"]
+__all__ = ["Algo", "DDPG", "TD3", "Reinforce", "set_default_optimizer"]
 
 _DEFAULT_OPTIMIZER = "ranger"
 
@@ -188,3 +188,29 @@ class TD3(Algo):
                        "policy_lr": 1e-5, "value_lr": 1e-5, "actor_weight_init": 25e-2, "critic_weight_init": 6e-1}
         self.loss_layout = {"test": {"value1": [], "value2": [], "policy": [], "step": []},
                             "train": {"value1": [], "value2": [], "policy": [], "step": []}}
+
+
+class Reinforce(Algo):
+    """REINFORCE with a learned critic as reward model (algo.py:182-233): `policy_net` a DiscreteActor over the catalogue,
+    `value_net` a Critic over [state | action distribution].  `params["reinforce"]` selects the estimator
+    (`ChooseREINFORCE.basic_reinforce` / `reinforce_with_correction` / `reinforce_with_TopK_correction`), `params["K"]`
+    the top-K size of the latter."""
+
+    def __init__(self, policy_net, value_net):
+        super().__init__()
+        self.algorithm = update.reinforce_update
+        target_policy_net = copy.deepcopy(policy_net)
+        target_value_net = copy.deepcopy(value_net)
+        target_policy_net.eval()
+        target_value_net.eval()
+        _hard_sync(value_net, target_value_net)
+        _hard_sync(policy_net, target_policy_net)
+        value_optimizer = _default_opt(value_net.parameters())
+        policy_optimizer = _default_opt(policy_net.parameters())
+        self.nets = {"value_net": value_net, "target_value_net": target_value_net, "policy_net": policy_net,
+                     "target_policy_net": target_policy_net}
+        self.optimizers = {"policy_optimizer": policy_optimizer, "value_optimizer": value_optimizer}
+        self.params = {"reinforce": update.ChooseREINFORCE(update.ChooseREINFORCE.basic_reinforce), "K": 10, "gamma": 0.99,
+                       "min_value": -10, "max_value": 10, "policy_step": 10, "soft_tau": 0.001}
+        self.loss_layout = {"test": {"value": [], "policy": [], "step": []},
+                            "train": {"value": [], "policy": [], "step": []}}

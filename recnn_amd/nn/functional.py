@@ -70,7 +70,7 @@ def _dw(dz, M, x, N, out):
 
 class MLPFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks=None):
         if not x.is_cuda:
             raise L.RecnnHipError("recnn_amd networks run on the GPU only (no CPU fallback): move the module and its "
                                   "inputs to 'cuda'")
@@ -84,7 +84,9 @@ class MLPFunction(torch.autograd.Function):
         h2 = torch.zeros(B, Hp, device=dev)
         out = torch.empty(B, O, device=dev)
         m1 = m2 = None
-        if train:
+        if train and masks is not None:
+            m1, m2 = (m.to(device=dev, dtype=torch.uint8).contiguous() for m in masks)
+        elif train:
             key = next(_call_counter)
             m1 = torch.empty(B, H, dtype=torch.uint8, device=dev)
             m2 = torch.empty(B, H, dtype=torch.uint8, device=dev)
@@ -125,10 +127,145 @@ class MLPFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, K, device=dev)
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
-        return gx, gw1, cs1.sum(0), gw2, cs2.sum(0), gw3, gb3, None, None
+        return gx, gw1, cs1.sum(0), gw2, cs2.sum(0), gw3, gb3, None, None, None
 
 
 def mlp(x, module, train: bool):
+    """`module.forced_masks` (a list of (m1, m2) uint8 keep-mask pairs, consumed first-in first-out) replaces the hash masks
+    of the next train-mode calls: replaying logged masks, and the parity tests."""
     seed = torch.initial_seed()
+    masks = None
+    forced = getattr(module, "forced_masks", None)
+    if train and forced:
+        masks = forced.pop(0)
     return MLPFunction.apply(x.float(), module.linear1.weight, module.linear1.bias, module.linear2.weight,
-                             module.linear2.bias, module.linear3.weight, module.linear3.bias, train, seed)
+                             module.linear2.bias, module.linear3.weight, module.linear3.bias, train, seed, masks)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Categorical policy head of REINFORCE (SURVEY.md 8 row f1): DiscreteActor = linear1 -> relu -> linear2 -> softmax, plus
+# Categorical sampling / log-prob, as ONE autograd node over the HIP kernels (csrc/gemm.hip, csrc/policy.hip).
+# Replaces recnn/nn/models.py:95-111 and the autograd graph torch would record for it.
+
+def _r4(x):
+    return (x + 3) // 4 * 4
+
+
+def categorical(probs, actions=None, seed=None):
+    """Categorical(probs).sample() and .log_prob(action) of torch.distributions (probs / probs.sum, clamp to [eps, 1-eps], log)
+    over rows of an (unnormalised) probability matrix, no gradient.  actions=None draws them.  Returns (actions, log_prob)."""
+    if not probs.is_cuda:
+        raise L.RecnnHipError("recnn_amd categorical: needs a GPU tensor (no CPU fallback)")
+    p = probs.detach()
+    B, N = p.shape
+    if p.dtype != torch.float32 or p.stride(1) != 1 or p.stride(0) % 4 or p.data_ptr() % 16:
+        q = torch.zeros(B, _r4(N), dtype=torch.float32, device=p.device)
+        q[:, :N] = p
+        p = q
+    act = torch.empty(B, dtype=torch.int64, device=p.device) if actions is None else actions.to(torch.int64).contiguous()
+    lp = torch.empty(B, dtype=torch.float32, device=p.device)
+    flags = L.CAT_SAMPLE if actions is None else 0
+    seed = torch.initial_seed() if seed is None else seed
+    L.call("recnn_categorical_rows", L.ptr(p), p.stride(0), B, N, flags, seed & 0xFFFFFFFF, next(_call_counter) & 0x7FFFFFFF,
+           L.ptr(act), L.ptr(lp), None, L.current_stream())
+    return act, lp
+
+
+class DiscretePolicyFunction(torch.autograd.Function):
+    """(probs, action, log_prob) = head(x): h = relu(x W1^T + b1), p = softmax(h W2^T + b2), action ~ p (or given),
+    log_prob = log(clamp(p[action] / sum p)).  Backward takes d log_prob (REINFORCE) and / or d probs."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, actions, sample, seed):
+        if not x.is_cuda:
+            raise L.RecnnHipError("recnn_amd networks run on the GPU only (no CPU fallback): move the module and its "
+                                  "inputs to 'cuda'")
+        ctx.set_materialize_grads(False)
+        B, K = x.shape
+        H, N = w1.shape[0], w2.shape[0]
+        Kp, Hp, ldn = _r64(K), _r64(H), _r64(N)
+        dev = x.device
+        xp = _pad(x, B, Kp)
+        w1p = _pad(w1, H, Kp)
+        w2p = _pad(w2, _r4(N), Hp)     # no copy for the usual shapes (N % 4 == 0, H % 64 == 0)
+        h = torch.zeros(B, Hp, device=dev)
+        buf = torch.empty(B, ldn, device=dev)
+        if ldn != N:
+            buf[:, N:].zero_()
+        _fwd(xp, Kp, w1p, b1.detach().float().contiguous(), h, Hp, H, True, None)
+        _fwd(h, Hp, w2p, b2.detach().float().contiguous(), buf, ldn, N, False, None)
+        stat = torch.empty(B, 4, device=dev)
+        lp = torch.zeros(B, device=dev)
+        flags = L.CAT_SOFTMAX
+        if sample:
+            act = torch.empty(B, dtype=torch.int64, device=dev)
+            flags |= L.CAT_SAMPLE
+        elif actions is not None:
+            act = actions.to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            act = None
+        L.call("recnn_categorical_rows", L.ptr(buf), ldn, B, N, flags, seed & 0xFFFFFFFF, next(_call_counter) & 0x7FFFFFFF,
+               L.ptr(act), L.ptr(lp), L.ptr(stat), L.current_stream())
+        probs = buf[:, :N]
+        act_out = act if act is not None else torch.full((B,), -1, dtype=torch.int64, device=dev)
+        ctx.save_for_backward(xp, h, w1p, w2p, probs, act_out, stat)
+        ctx.dims = (B, K, H, N, Kp, Hp, ldn)
+        ctx.has_action = act is not None
+        ctx.mark_non_differentiable(act_out)
+        return probs, act_out, lp
+
+    @staticmethod
+    def backward(ctx, dprobs, _dact, dlp):
+        xp, h, w1p, w2p, probs, act, stat = ctx.saved_tensors
+        B, K, H, N, Kp, Hp, ldn = ctx.dims
+        dev = probs.device
+        s = L.current_stream()
+        if dprobs is None and (dlp is None or not ctx.has_action):
+            return (None,) * 8
+        dlog = torch.empty(B, ldn, device=dev)
+        if ldn != _r4(N):
+            dlog[:, _r4(N):].zero_()
+        acc = 0
+        if dprobs is not None:
+            dpr = dprobs.float().contiguous()
+            L.call("recnn_softmax_bwd", L.ptr(probs), probs.stride(0), B, N, L.ptr(dpr), dpr.stride(0), L.ptr(dlog), ldn, s)
+            acc = 1
+        g = None
+        if dlp is not None and ctx.has_action:
+            g = dlp.float().contiguous()
+        if not ctx.has_action:
+            act = torch.zeros(B, dtype=torch.int64, device=dev)
+        gb2 = torch.empty(N, device=dev)
+        scratch = torch.empty((B + 31) // 32, _r4(N), device=dev)
+        L.call("recnn_logprob_bwd", L.ptr(probs), probs.stride(0), B, N, L.ptr(act), L.ptr(g), L.ptr(stat), L.ptr(dlog), ldn, acc,
+               L.ptr(gb2), L.ptr(scratch), s)
+        del scratch
+        gw2 = torch.empty(N, H, device=dev)
+        _dw(dlog, N, h, H, gw2)
+        tiles = (B + 31) // 32
+        dz1 = torch.zeros(B, Hp, device=dev)
+        cs1 = torch.empty(tiles, H, device=dev)
+        _dx(dlog, _r4(N), w2p, H, dz1, h, 1.0, cs1)
+        del dlog
+        gw1 = torch.empty(H, K, device=dev)
+        _dw(dz1, H, xp, K, gw1)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, K, device=dev)
+            _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
+        return gx, gw1, cs1.sum(0), gw2, gb2, None, None, None
+
+
+def discrete_policy(x, module, actions=None, sample=False):
+    """probs, action, log_prob of `module` (a DiscreteActor) for a batch of states."""
+    return DiscretePolicyFunction.apply(x.float(), module.linear1.weight, module.linear1.bias, module.linear2.weight,
+                                        module.linear2.bias, actions, bool(sample), torch.initial_seed())
+
+
+def onehot_rows(idx, n):
+    """float[B, n] one-hot rows of int64 indices (recnn/data/utils.py:108-109: zeros + scatter_)."""
+    B = idx.numel()
+    ld = _r4(n)
+    out = torch.empty(B, ld, dtype=torch.float32, device=idx.device)
+    L.call("recnn_onehot_rows", L.ptr(idx.to(torch.int64).contiguous()), B, n, L.ptr(out), ld, L.current_stream())
+    return out if ld == n else out[:, :n]

@@ -1,4 +1,4 @@
-"""Actor / Critic (reference: recnn/nn/models.py:41-73, :187-213).
+"""Actor / Critic / DiscreteActor (reference: recnn/nn/models.py:41-73, :187-213, :76-184).
 
 Real nn.Modules with the reference's sub-module names (linear1/2/3, drop_layer), state_dict keys and
 constructor RNG consumption (nn.Linear default init for linear1, linear2, linear3 in that order, then
@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import functional as F_hip
 
-__all__ = ["Actor", "Critic"]
+__all__ = ["Actor", "Critic", "DiscreteActor"]
 
 
 class Actor(nn.Module):
@@ -45,3 +45,88 @@ class Critic(nn.Module):
 
     def forward(self, state, action):
         return F_hip.mlp(torch.cat([state, action], 1), self, self.training)
+
+
+class DiscreteActor(nn.Module):
+    """state -> probabilities over the catalogue: softmax(L2(relu(L1(state))))  (models.py:76-184), the REINFORCE policy.
+
+    Same attributes as the reference: `saved_log_probs`, `rewards`, `correction`, `lambda_k` (the episode the update
+    functions append to and `ChooseREINFORCE` consumes), `action_source` ({"pi": "pi", "beta": "beta"}; set pi to "beta"
+    to score the behaviour policy's action, issue #7 of the reference) and the re-bindable `select_action`.
+    Forward, sampling and log-prob are one autograd node on the HIP kernels (`functional.DiscretePolicyFunction`); the
+    sampler is an inverse-CDF walk with a counter-based uniform per row (torch's multinomial stream is not reproduced --
+    equal in distribution, tests/test_gpu_reinforce.py).  `forced_actions` (a list of int64 tensors, consumed first-in
+    first-out) replaces the next draws of the policy: replaying logged actions, and the parity tests.
+    """
+
+    def __init__(self, input_dim, action_dim, hidden_size, init_w=0):
+        super().__init__()
+        self.linear1 = nn.Linear(input_dim, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, action_dim)
+        self.saved_log_probs = []
+        self.rewards = []
+        self.correction = []
+        self.lambda_k = []
+        self.action_source = {"pi": "pi", "beta": "beta"}
+        self.select_action = self._select_action
+        self.forced_actions = []
+
+    def forward(self, inputs):
+        probs, _, _ = F_hip.discrete_policy(inputs, self)
+        return probs
+
+    def gc(self):
+        del self.rewards[:]
+        del self.saved_log_probs[:]
+        del self.correction[:]
+        del self.lambda_k[:]
+
+    def _act(self, state, actions=None):
+        """(probs, action, log_prob); draws the action unless one is given or queued in `forced_actions`."""
+        if actions is None and self.forced_actions:
+            actions = self.forced_actions.pop(0)
+        return F_hip.discrete_policy(state, self, actions=actions, sample=actions is None)
+
+    def _select_action(self, state, **kwargs):
+        # plain REINFORCE: there is no behaviour policy, `action_source` is not consulted (models.py:103-111)
+        pi_probs, _, log_prob = self._act(state)
+        self.saved_log_probs.append(log_prob)
+        return pi_probs
+
+    def pi_beta_sample(self, state, beta, action, **kwargs):
+        """log-probs of the target (pi) and behaviour (beta) policies for one action each (models.py:113-141).
+        `beta(state, action=...)` returns the behaviour policy's probabilities; no gradient flows into it."""
+        beta_probs = beta(state.detach(), action=action)
+        beta_action, beta_log_prob_own = F_hip.categorical(beta_probs)
+        if self.action_source["pi"] == "beta":
+            pi_probs, pi_action, pi_log_prob = self._act(state, actions=beta_action)
+        else:
+            pi_probs, pi_action, pi_log_prob = self._act(state)
+        if self.action_source["beta"] == "beta":
+            beta_log_prob = beta_log_prob_own
+        else:
+            _, beta_log_prob = F_hip.categorical(beta_probs, actions=pi_action)
+        return pi_log_prob, beta_log_prob, pi_probs
+
+    def _select_action_with_correction(self, state, beta, action, writer, step, **kwargs):
+        pi_log_prob, beta_log_prob, pi_probs = self.pi_beta_sample(state, beta, action)
+        corr = torch.exp(pi_log_prob) / torch.exp(beta_log_prob)      # off-policy importance weight
+        writer.add_histogram("correction", corr, step)
+        writer.add_histogram("pi_log_prob", pi_log_prob, step)
+        writer.add_histogram("beta_log_prob", beta_log_prob, step)
+        self.correction.append(corr)
+        self.saved_log_probs.append(pi_log_prob)
+        return pi_probs
+
+    def _select_action_with_TopK_correction(self, state, beta, action, K, writer, step, **kwargs):
+        pi_log_prob, beta_log_prob, pi_probs = self.pi_beta_sample(state, beta, action)
+        corr = torch.exp(pi_log_prob) / torch.exp(beta_log_prob)
+        l_k = K * (1 - torch.exp(pi_log_prob)) ** (K - 1)             # lambda_K = K (1 - pi)^(K-1)  (models.py:173)
+        writer.add_histogram("correction", corr, step)
+        writer.add_histogram("l_k", l_k, step)
+        writer.add_histogram("pi_log_prob", pi_log_prob, step)
+        writer.add_histogram("beta_log_prob", beta_log_prob, step)
+        self.correction.append(corr)
+        self.lambda_k.append(l_k)
+        self.saved_log_probs.append(pi_log_prob)
+        return pi_probs

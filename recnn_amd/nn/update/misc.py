@@ -30,8 +30,39 @@ def _log_value_debug(ctx, rows, debug, writer, step):
         writer.add_histogram("expected_value", eng.buffer("expected", rows), step)
 
 
+def _value_update_modules(batch, params, nets, optimizer, device, debug, writer, learn, step):
+    """The same critic update for networks the fused DDPG engine does not adopt (the REINFORCE pair: DiscreteActor +
+    a Critic over [state | action distribution], misc.py:10-55): module forwards / backward on the HIP GEMM and
+    policy-head kernels through autograd, TD target and loss on per-row vectors."""
+    from ... import data
+    state, action, reward, next_state, done = data.get_base_batch(batch)
+    with torch.no_grad():
+        next_action = nets["target_policy_net"](next_state)
+        target_value = nets["target_value_net"](next_state, next_action)
+        expected_value = temporal_difference(reward, done, params["gamma"], target_value)
+        expected_value = torch.clamp(expected_value, params["min_value"], params["max_value"])
+    value = nets["value_net"](state, action)
+    value_loss = torch.pow(value - expected_value, 2).mean()
+    if learn:
+        optimizer["value_optimizer"].zero_grad()
+        value_loss.backward()
+        optimizer["value_optimizer"].step()
+    else:
+        if debug is not None:
+            debug["next_action"] = next_action
+        if not isinstance(writer, utils.DummyWriter):
+            writer.add_figure("next_action", utils.pairwise_distances_fig(next_action[:50]), step)
+            writer.add_histogram("value", value, step)
+            writer.add_histogram("target_value", target_value, step)
+            writer.add_histogram("expected_value", expected_value, step)
+    return value_loss
+
+
 def value_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug=None, writer=utils.DummyWriter(),
                  learn=False, step=-1):
+    from ..models import Actor
+    if not isinstance(nets["target_policy_net"], Actor):
+        return _value_update_modules(batch, params, nets, optimizer, device, debug, writer, learn, step)
     ctx = fused.context_for("ddpg", nets)
     rows = batch["state"].shape[0]
     ctx.ensure(nets, rows)

@@ -1,0 +1,325 @@
+"""GPU parity of the REINFORCE row: policy-head kernels, DiscreteActor, reinforce_update / Reinforce
+against the CPU oracle and the fixtures generated from the real reference (tests/golden/reinforce_*.npz)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err
+from tests import reinforce_replay as RR
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from recnn_amd import _lib as L
+    return L
+
+
+def _rows(x, n, ld):
+    buf = torch.zeros(x.shape[0], ld, device="cuda")
+    buf[:, :n] = x.cuda()
+    return buf
+
+
+@pytest.mark.parametrize("B,N", [(5, 40), (3, 41), (7, 4099), (2, 100000), (1, 1)])
+def test_softmax_logprob_rows_match_torch(cuda, B, N):
+    from oracle import reinforce_oracle as R
+    L = _lib()
+    torch.manual_seed(N)
+    logits = torch.randn(B, N) * 3.0
+    act = torch.randint(0, N, (B,))
+    ld = (N + 3) // 4 * 4 + 8
+    buf = _rows(logits, N, ld)
+    buf[:, N:] = 7.0                      # padding content must not matter
+    a = act.cuda()
+    lp = torch.empty(B, device="cuda")
+    stat = torch.empty(B, 4, device="cuda")
+    L.call("recnn_categorical_rows", L.ptr(buf), ld, B, N, L.CAT_SOFTMAX, 1, 1, L.ptr(a), L.ptr(lp), L.ptr(stat), L.current_stream())
+    probs = torch.softmax(logits, dim=1)
+    ref_lp, ref_clamped = R.categorical_log_prob(probs, act)
+    assert rel_err(buf[:, :N], probs) < 5e-6     # 100k-term denominators: summation order
+    assert (buf[:, N:(N + 3) // 4 * 4] == 0).all()
+    assert torch.allclose(lp.cpu(), ref_lp, rtol=2e-6, atol=2e-6)
+    assert torch.allclose(stat[:, 2].cpu(), probs.sum(1), rtol=1e-5)
+    assert torch.equal(stat[:, 3].cpu() != 0, ref_clamped)   # p < eps or > 1 - eps (a single item): clamped, like Categorical
+
+
+def test_logprob_clamp_follows_categorical(cuda):
+    """probability below eps: Categorical clamps it (log_prob = log eps) and the gradient vanishes."""
+    L = _lib()
+    N = 64
+    logits = torch.zeros(2, N)
+    logits[0, 5] = -40.0
+    act = torch.tensor([5, 5])
+    buf = logits.cuda().contiguous()
+    lp = torch.empty(2, device="cuda")
+    stat = torch.empty(2, 4, device="cuda")
+    L.call("recnn_categorical_rows", L.ptr(buf), N, 2, N, L.CAT_SOFTMAX, 1, 1, L.ptr(act.cuda()), L.ptr(lp), L.ptr(stat), L.current_stream())
+    ref = torch.distributions.Categorical(torch.softmax(logits, 1)).log_prob(act)
+    assert torch.allclose(lp.cpu(), ref, rtol=1e-6)
+    assert stat[:, 3].tolist() == [1.0, 0.0]
+    g = torch.ones(2, device="cuda")
+    d = torch.empty(2, N, device="cuda")
+    cs = torch.empty(N, device="cuda")
+    scratch = torch.empty(1, N, device="cuda")
+    L.call("recnn_logprob_bwd", L.ptr(buf), N, 2, N, L.ptr(act.cuda()), L.ptr(g), L.ptr(stat), L.ptr(d), N, 0, L.ptr(cs), L.ptr(scratch),
+           L.current_stream())
+    assert (d[0] == 0).all() and d[1, 5] > 0.9
+    assert torch.allclose(cs, d.sum(0))
+
+
+def test_sampler_distribution_and_reproducibility(cuda):
+    """The inverse-CDF sampler draws from p (chi-square against the exact expectation over 40k rows of one distribution),
+    is a pure function of (seed, step, row), and changes with the step."""
+    L = _lib()
+    N, B = 23, 40000
+    torch.manual_seed(0)
+    p = torch.softmax(torch.randn(N) * 1.5, 0)
+    rows = p.log().repeat(B, 1)
+    ld = 24
+
+    def draw(seed, step):
+        buf = _rows(rows, N, ld)
+        a = torch.empty(B, dtype=torch.int64, device="cuda")
+        lp = torch.empty(B, device="cuda")
+        L.call("recnn_categorical_rows", L.ptr(buf), ld, B, N, L.CAT_SOFTMAX | L.CAT_SAMPLE, seed, step, L.ptr(a), L.ptr(lp), None,
+               L.current_stream())
+        return a.cpu(), lp.cpu()
+
+    a1, lp1 = draw(7, 3)
+    a2, _ = draw(7, 3)
+    a3, _ = draw(7, 4)
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+    assert a1.min() >= 0 and a1.max() < N
+    counts = torch.bincount(a1, minlength=N).double()
+    chi2 = float(((counts - B * p.double()) ** 2 / (B * p.double())).sum())
+    assert chi2 < 60.0, chi2                       # 22 degrees of freedom: P(chi2 > 60) ~ 2e-5
+    assert torch.allclose(lp1, p.log()[a1], rtol=1e-5, atol=1e-5)
+    # sampling from given (unnormalised) probabilities leaves them untouched
+    from recnn_amd.nn import functional as F_hip
+    q = (p * 3.0).repeat(B, 1).cuda()
+    keep = q.clone()
+    a4, lp4 = F_hip.categorical(q)
+    assert torch.equal(q, keep)
+    counts = torch.bincount(a4.cpu(), minlength=N).double()
+    assert float(((counts - B * p.double()) ** 2 / (B * p.double())).sum()) < 60.0
+    assert torch.allclose(lp4.cpu(), p.log()[a4.cpu()], rtol=1e-5, atol=1e-5)
+    a5, lp5 = F_hip.categorical(q, actions=a4)
+    assert torch.equal(a5, a4) and torch.equal(lp5, lp4)
+
+
+def test_sampler_large_catalogue_covers_tail(cuda):
+    """100k items, uniform: every draw is a valid id, ids spread over the whole range (the thread-major walk reaches all
+    residues), and a point mass is always found."""
+    L = _lib()
+    N, B = 100000, 512
+    buf = torch.zeros(B, N, device="cuda")
+    a = torch.empty(B, dtype=torch.int64, device="cuda")
+    L.call("recnn_categorical_rows", L.ptr(buf), N, B, N, L.CAT_SOFTMAX | L.CAT_SAMPLE, 5, 1, L.ptr(a), None, None, L.current_stream())
+    a = a.cpu()
+    assert a.min() >= 0 and a.max() < N and a.unique().numel() > B * 0.9
+    assert len(set((a % 4096).tolist())) > 400 and a.max() > 0.9 * N and a.min() < 0.1 * N
+    assert abs(float(buf.sum(1).mean()) - 1.0) < 1e-5
+    pm = torch.full((4, N), -1e4, device="cuda")
+    idx = torch.tensor([0, 1, 99999, 51234])
+    pm[torch.arange(4), idx] = 0.0
+    a = torch.empty(4, dtype=torch.int64, device="cuda")
+    L.call("recnn_categorical_rows", L.ptr(pm), N, 4, N, L.CAT_SOFTMAX | L.CAT_SAMPLE, 5, 2, L.ptr(a), None, None, L.current_stream())
+    assert torch.equal(a.cpu(), idx)
+
+
+def test_onehot_rows(cuda):
+    from recnn_amd.nn import functional as F_hip
+    for n in (40, 41, 5000):
+        idx = torch.randint(0, n, (9,))
+        out = F_hip.onehot_rows(idx.cuda(), n)
+        ref = torch.zeros(9, n)
+        ref.scatter_(1, idx.view(-1, 1), 1)
+        assert out.shape == (9, n) and torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("S,N,H,B", [(27, 40, 16, 12), (1290, 5000, 256, 33), (50, 301, 20, 5)])
+def test_discrete_actor_forward_backward_match_oracle(cuda, S, N, H, B):
+    """probs, log_prob and the parameter gradients of sum g * log_prob against the hand-written CPU backward; the
+    gradient through `forward()`'s probabilities against autograd of torch.softmax."""
+    import recnn_amd
+    from oracle import reinforce_oracle as R
+    torch.manual_seed(S + N)
+    net = recnn_amd.nn.DiscreteActor(S, N, H).cuda()
+    p = R.policy_params_from_module(net)
+    state = torch.randn(B, S)
+    act = torch.randint(0, N, (B,))
+    g = torch.randn(B)
+    probs_o, cache = R.policy_forward(p, state)
+    lp_o, cl = R.categorical_log_prob(probs_o, act)
+    grads_o = R.policy_backward(p, cache, probs_o, act, g, cl)
+
+    net.forced_actions.append(act.cuda())
+    probs = net.select_action(state=state.cuda())
+    lp = net.saved_log_probs[-1]
+    assert rel_err(probs, probs_o) < 1e-5 and torch.allclose(lp.cpu(), lp_o, rtol=1e-5, atol=1e-5)
+    (lp * g.cuda()).sum().backward()
+    for k, t in zip(R.POLICY_ORDER, net.parameters()):
+        assert rel_err(t.grad, grads_o[k]) < 2e-5, k
+    # d probs path
+    net.zero_grad()
+    w = torch.randn(B, N)
+    (net(state.cuda()) * w.cuda()).sum().backward()
+    ps = {k: v.clone().requires_grad_() for k, v in p.items()}
+    pr, _ = R.policy_forward(ps, state)
+    (pr * w).sum().backward()
+    for k, t in zip(R.POLICY_ORDER, net.parameters()):
+        assert rel_err(t.grad, ps[k].grad) < 2e-5, k
+
+
+def _run_fixture(name, golden_dir, optimizer):
+    import recnn_amd
+    fx = RR.load(os.path.join(golden_dir, name + ".npz"))
+    g = fx["g"]
+    dev = torch.device("cuda")
+    value = recnn_amd.nn.Critic(fx["S"], fx["N"], fx["H"], 54e-2)
+    policy = recnn_amd.nn.DiscreteActor(fx["S"], fx["N"], fx["H"])
+    with torch.no_grad():
+        for mod, tag in ((policy, "policy"), (value, "value")):
+            for lin, (wk, bk) in zip((m for m in mod.children() if isinstance(m, torch.nn.Linear)),
+                                     (("w1", "b1"), ("w2", "b2"), ("w3", "b3"))):
+                lin.weight.copy_(torch.from_numpy(g[f"{tag}.{wk}"]))
+                lin.bias.copy_(torch.from_numpy(g[f"{tag}.{bk}"]))
+    value, policy = value.to(dev), policy.to(dev)
+    algo = recnn_amd.nn.Reinforce(policy, value).to(dev)
+    algo.optimizers["value_optimizer"] = optimizer(value.parameters(), lr=fx["lr_v"], weight_decay=fx["wd_v"])
+    algo.optimizers["policy_optimizer"] = optimizer(policy.parameters(), lr=fx["lr_p"], weight_decay=fx["wd_p"])
+    beta = RR.beta_fn(fx, dev)
+    choose = recnn_amd.nn.ChooseREINFORCE
+    if fx["method"] == "corr":
+        policy.select_action = lambda state, action, K, writer, step, **kw: \
+            policy._select_action_with_correction(state, beta, action, writer=writer, step=step)
+        algo.params["reinforce"] = choose(choose.reinforce_with_correction)
+    elif fx["method"] == "topk":
+        policy.select_action = lambda state, action, K, writer, step, **kw: \
+            policy._select_action_with_TopK_correction(state, beta, action, K=K, writer=writer, step=step)
+        algo.params["reinforce"] = choose(choose.reinforce_with_TopK_correction)
+    algo.params["K"] = fx["K"]
+    policy.action_source = {"pi": fx["pi_source"], "beta": "beta"}
+    bs = RR.batches(fx, dev)
+    pi_draws, beta_draws = torch.from_numpy(g["pi_draws"]).to(dev), torch.from_numpy(g["beta_draws"]).to(dev)
+    value.forced_masks = []
+    losses = []
+    from recnn_amd.nn import functional as F_hip
+    orig_cat = F_hip.categorical
+    try:
+        for t in range(fx["steps"]):
+            masks = [torch.from_numpy(m).to(dev) for m in g["masks"][t]]
+            value.forced_masks[:] = [(masks[0], masks[1]), (masks[2], masks[3])]
+            if fx["method"] == "basic":
+                policy.forced_actions[:] = [pi_draws[t]]
+            else:
+                # the behaviour policy's draw is injected too: categorical(beta_probs) -> (beta_draws[t], its log-prob)
+                def cat(probs, actions=None, seed=None, _t=t):
+                    return orig_cat(probs, actions=beta_draws[_t] if actions is None else actions, seed=seed)
+                F_hip.categorical = cat
+                policy.forced_actions[:] = [pi_draws[t]] if fx["pi_source"] == "pi" else []
+            out = algo.update(bs[t % 2])
+            algo.step()
+            assert not value.forced_masks and not policy.forced_actions
+            if out is not None:
+                losses.append([t, out["value"], out["policy"]])
+    finally:
+        F_hip.categorical = orig_cat
+    return fx, np.asarray(losses), algo
+
+
+@pytest.mark.parametrize("name", ["reinforce_basic", "reinforce_corr", "reinforce_topk"])
+def test_reinforce_replays_reference_run(cuda, golden_dir, name):
+    """recnn_amd.nn.Reinforce, fed the reference run's batches / actions / dropout masks, reproduces its losses and all four
+    networks after 25-32 steps (2-3 policy updates, soft updates): fp32, tolerance 1e-4 relative."""
+    fx, losses, algo = _run_fixture(name, golden_dir, torch.optim.Adam)
+    ref = fx["g"]["losses"]
+    assert losses.shape == ref.shape and np.array_equal(losses[:, 0], ref[:, 0])
+    assert rel_err(losses[:, 1:], ref[:, 1:]) < 1e-4, (losses, ref)
+    from oracle import recnn_oracle as O
+    from oracle import reinforce_oracle as R
+    for tag, net, snap in (("policy", "policy_net", R.policy_params_from_module), ("value", "value_net", O.params_from_module),
+                           ("target_policy", "target_policy_net", R.policy_params_from_module),
+                           ("target_value", "target_value_net", O.params_from_module)):
+        for k, v in snap(algo.nets[net]).items():
+            assert rel_err(v, fx["g"][f"final.{tag}.{k}"]) < 1e-4, (tag, k)
+
+
+def test_reinforce_with_hip_adam_matches_torch_adam(cuda, golden_dir):
+    """The same replay with recnn_amd.optim.Adam (the HIP optimizer pass) instead of torch.optim.Adam."""
+    import recnn_amd
+    fx, losses, _ = _run_fixture("reinforce_basic", golden_dir, recnn_amd.optim.Adam)
+    assert rel_err(losses[:, 1:], fx["g"]["losses"][:, 1:]) < 1e-4
+
+
+def test_batch_contstate_discaction_matches_reference_layout(cuda):
+    """state / next_state / reward / done as batch_tensor_embeddings, action = one-hot of the window's last item
+    (utils.py:84-120)."""
+    import recnn_amd
+    rng = np.random.default_rng(4)
+    F, E, n_items, B = 3, 8, 50, 11
+    table = torch.from_numpy(rng.standard_normal((n_items, E)).astype(np.float32)).cuda()
+    items = torch.from_numpy(rng.integers(0, n_items, size=(B, F + 1)))
+    ratings = torch.from_numpy(rng.standard_normal((B, F + 1)).astype(np.float32))
+    batch = {"items": items, "ratings": ratings, "sizes": torch.tensor([F + 4, F + 7]), "users": torch.tensor([1, 2])}
+    out = recnn_amd.data.batch_contstate_discaction(batch, table, frame_size=F, num_items=n_items)
+    emb = table.cpu()[items]
+    state = torch.cat([emb[:, :-1].reshape(B, -1), ratings[:, :-1]], 1)
+    nstate = torch.cat([emb[:, 1:].reshape(B, -1), ratings[:, 1:]], 1)
+    onehot = torch.zeros(B, n_items)
+    onehot.scatter_(1, items[:, -1].view(-1, 1), 1)
+    done = torch.zeros(B)
+    done[torch.tensor([3, 10])] = 1
+    assert torch.equal(out["state"].cpu(), state) and torch.equal(out["next_state"].cpu(), nstate)
+    assert torch.equal(out["action"].cpu(), onehot) and torch.equal(out["reward"].cpu(), ratings[:, -1])
+    assert torch.equal(out["done"].cpu(), done)
+
+
+def test_reinforce_at_catalogue_scale(cuda):
+    """The notebook's configuration at a 100k-item catalogue (Critic(1290, N, 2048), DiscreteActor(1290, N, 2048), Ranger
+    defaults, own sampler, top-K correction with a fixed behaviour policy): 12 updates run, losses are finite, the policy
+    moves.  Writes the per-step time to gpurun_out/ for DESIGN.md."""
+    import json
+    import time
+    import recnn_amd
+    from recnn_amd.nn import algo as algo_mod
+    algo_mod.set_default_optimizer("ranger")
+    N, S, H, B = 100000, 1290, 2048, 256
+    torch.manual_seed(0)
+    value = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda()
+    policy = recnn_amd.nn.DiscreteActor(S, N, H).cuda()
+    algo = recnn_amd.nn.Reinforce(policy, value).to(torch.device("cuda"))
+    Wb = (torch.randn(S, N, device="cuda") * 0.02)
+
+    def beta(state, action=None):
+        return torch.softmax(state @ Wb, dim=1)
+    policy.select_action = lambda state, action, K, writer, step, **kw: \
+        policy._select_action_with_TopK_correction(state, beta, action, K=K, writer=writer, step=step)
+    ch = recnn_amd.nn.ChooseREINFORCE
+    algo.params["reinforce"] = ch(ch.reinforce_with_TopK_correction)
+    policy.action_source = {"pi": "beta", "beta": "beta"}
+    a = torch.randint(0, N, (B,), device="cuda")
+    from recnn_amd.nn import functional as F_hip
+    batch = {"state": torch.randn(B, S, device="cuda"), "action": F_hip.onehot_rows(a, N), "reward": torch.randn(B, device="cuda"),
+             "next_state": torch.randn(B, S, device="cuda"), "done": torch.zeros(B, device="cuda")}
+    w0 = policy.linear2.weight.detach()[:64].clone()
+    losses, times = [], []
+    for t in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = algo.update(batch)
+        algo.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        if out:
+            losses.append(out)
+    assert len(losses) == 1 and all(np.isfinite([l["value"], l["policy"]]).all() for l in losses)
+    assert not torch.equal(policy.linear2.weight.detach()[:64], w0)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/reinforce_scale.json", "w") as f:
+        json.dump({"n_items": N, "hidden": H, "rows": B, "step_ms": [round(1e3 * x, 2) for x in times], "losses": losses,
+                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}, f)

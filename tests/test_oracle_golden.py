@@ -142,3 +142,41 @@ def test_adam_eps_regime_amplifies_roundoff():
     worst = float((outs[0] - outs[1]).abs().max())
     assert worst > 0.02 * 1e-3                 # > 2% of lr on some element
     assert fro_err(outs[0], outs[1]) < 1e-3     # while the Frobenius error of the parameters stays small
+
+
+def test_reinforce_oracle_against_reference_fixtures(golden_dir):
+    """oracle/reinforce_oracle.py replays the three estimator runs of the real reference (basic, off-policy correction,
+    top-K correction with the behaviour policy's action) from their inputs: losses and all four networks agree."""
+    from tests import reinforce_replay as RR
+    for name in ("reinforce_basic", "reinforce_corr", "reinforce_topk"):
+        fx = RR.load(os.path.join(golden_dir, name + ".npz"))
+        losses, final = RR.replay_oracle(fx)
+        ref = fx["g"]["losses"]
+        assert losses.shape == ref.shape and np.array_equal(losses[:, 0], ref[:, 0])
+        assert rel_err(losses[:, 1:], ref[:, 1:]) < 5e-5, name
+        for tag, p in final.items():
+            for k, v in p.items():
+                assert rel_err(v, fx["g"][f"final.{tag}.{k}"]) < 5e-5, (name, tag, k)
+
+
+def test_reinforce_returns_and_estimator_gradients():
+    """The hand-written d loss / d log_prob of the three estimators equals autograd's (the correction weight is not
+    detached in the reference), and the return normalisation follows reinforce.py:45-53."""
+    from oracle import reinforce_oracle as R
+    torch.manual_seed(3)
+    T, B, K = 5, 7, 4
+    rewards = [torch.randn(()) for _ in range(T)]
+    ret = R.discounted_returns(rewards)
+    run, raw = 0.0, []
+    for r in reversed(rewards):
+        run = float(r) + 0.99 * run
+        raw.insert(0, run)
+    raw = np.asarray(raw)
+    assert np.allclose(ret.numpy(), (raw - raw.mean()) / (raw.std(ddof=1) + 1e-4), rtol=1e-5, atol=1e-6)
+    for method in ("basic", "corr", "topk"):
+        lps = [(-torch.rand(B) * 3).requires_grad_() for _ in range(T)]
+        blps = [-torch.rand(B) * 3 for _ in range(T)]
+        loss, glps = R.reinforce_loss(method, lps, blps, ret, K)
+        auto = torch.autograd.grad(loss, lps)
+        for a, g in zip(auto, glps):
+            assert torch.allclose(a, g.detach(), rtol=1e-5, atol=1e-6), method
