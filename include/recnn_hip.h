@@ -181,7 +181,9 @@ typedef struct recnn_gemm_args {
   const uint8_t* mask; int64_t ld_mask;      /* external keep mask [M, ld_mask] */
   uint32_t seed, stream_id; const int32_t* step_ptr;   /* hash mask key (step read from device) */
   const float* addend; int64_t ld_add; float add_clip; /* fwd: C += clamp(addend, +-add_clip) (TD3 noise) */
-  const void* yref; int64_t ldy; float dx_scale;       /* dx: C = acc * dx_scale * [yref > 0]; yref NULL = plain */
+  const void* yref; int64_t ldy; float dx_scale;       /* dx: C = acc * dx_scale * [yref > 0]; yref NULL = plain.
+                                                          fwd: same gate applied after bias/relu (a dX computed with
+                                                          pre-transposed weights through the k-contiguous kernels) */
   float* colsum;          /* dx: column sums per 32-row slab, float[ceil(M/32)][N] (bias gradients) */
   int dw_splits;          /* dw: number of K splits; slab s written at C + s*dw_slab_stride */
   int64_t dw_slab_stride;

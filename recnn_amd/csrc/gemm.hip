@@ -211,6 +211,10 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
                 v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
               }
               if (P.relu) v = fmaxf(v, 0.f);
+              if (P.yref) {  // gate of a backward pass run as a forward-layout GEMM (transposed weights): [yref > 0] * scale
+                const float y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
+                v = y > 0.f ? v * P.dx_scale : 0.f;
+              }
               if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
               else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r, n & 3) ? v * 2.f : 0.f;
               if (P.c_f32) {

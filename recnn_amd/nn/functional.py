@@ -30,6 +30,24 @@ def _pad(t, rows, cols):
     return out
 
 
+_derived = {}
+
+
+def _derived_of(w, kind, build):
+    """A layout derived from parameter `w` (transposed / padded copy), kept until `w` is written again.  Staleness is
+    detected through the autograd version counter: torch's in-place ops bump it, and so do recnn_amd's own writers
+    (optim.Adam / Ranger, utils.soft_update call torch.autograd.graph.increment_version)."""
+    import weakref
+    key = (id(w), kind)
+    tag = (w._version, w.data_ptr(), tuple(w.shape))
+    hit = _derived.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == tag:
+        return hit[2]
+    out = build(w.detach())
+    _derived[key] = (weakref.ref(w, lambda _r, k=key: _derived.pop(k, None)), tag, out)
+    return out
+
+
 def _args(M, N):
     a = L.GemmArgs()
     a.dtype = L.F32
@@ -39,11 +57,15 @@ def _args(M, N):
     return a
 
 
-def _fwd(x, K, w, bias, out, ldc, N, relu, mask):
+def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0):
     a = _args(x.shape[0], N)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = x.data_ptr(), w.data_ptr(), x.stride(0), w.stride(0), K
     a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 1
-    a.bias, a.relu = bias.data_ptr(), int(relu)
+    a.bias, a.relu = (bias.data_ptr() if bias is not None else None), int(relu)
+    if addend is not None:      # added before the relu (gemm.hip epilogue_fwd)
+        a.addend, a.ld_add, a.add_clip = addend.data_ptr(), addend.stride(0), float("inf")
+    if yref is not None:
+        a.yref, a.ldy, a.dx_scale = yref.data_ptr(), yref.stride(0), scale
     if mask is not None:
         a.mask_mode, a.mask, a.ld_mask = L.MASK_EXTERNAL, mask.data_ptr(), mask.stride(0)
     L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
@@ -70,7 +92,7 @@ def _dw(dz, M, x, N, out):
 
 class MLPFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks=None):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks=None, addend1=None):
         if not x.is_cuda:
             raise L.RecnnHipError("recnn_amd networks run on the GPU only (no CPU fallback): move the module and its "
                                   "inputs to 'cuda'")
@@ -94,7 +116,8 @@ class MLPFunction(torch.autograd.Function):
             L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 0, B, H, L.ptr(m1), s)
             L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
         b1c, b2c, b3c = b1.detach().float().contiguous(), b2.detach().float().contiguous(), b3.detach().float().contiguous()
-        _fwd(xp, Kp, w1p, b1c, h1, Hp, H, True, m1)
+        add1 = None if addend1 is None else addend1.detach().float().contiguous()
+        _fwd(xp, Kp, w1p, b1c, h1, Hp, H, True, m1, addend=add1)
         _fwd(h1, Hp, w2p, b2c, h2, Hp, H, True, m2)
         _fwd(h2, Hp, w3p, b3c, out, O, O, False, None)
         ctx.save_for_backward(xp, h1, h2, w1p, w2p, w3p)
@@ -127,19 +150,21 @@ class MLPFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, K, device=dev)
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
-        return gx, gw1, cs1.sum(0), gw2, cs2.sum(0), gw3, gb3, None, None, None
+        gadd = dz1[:, :H] if ctx.needs_input_grad[10] else None     # d/d addend1 = dZ1
+        return gx, gw1, cs1.sum(0), gw2, cs2.sum(0), gw3, gb3, None, None, None, gadd
 
 
 def mlp(x, module, train: bool):
     """`module.forced_masks` (a list of (m1, m2) uint8 keep-mask pairs, consumed first-in first-out) replaces the hash masks
     of the next train-mode calls: replaying logged masks, and the parity tests."""
-    seed = torch.initial_seed()
-    masks = None
-    forced = getattr(module, "forced_masks", None)
-    if train and forced:
-        masks = forced.pop(0)
     return MLPFunction.apply(x.float(), module.linear1.weight, module.linear1.bias, module.linear2.weight,
-                             module.linear2.bias, module.linear3.weight, module.linear3.bias, train, seed, masks)
+                             module.linear2.bias, module.linear3.weight, module.linear3.bias, train, torch.initial_seed(),
+                             _take_forced_masks(module, train), None)
+
+
+def _take_forced_masks(module, train):
+    forced = getattr(module, "forced_masks", None)
+    return forced.pop(0) if (train and forced) else None
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -209,6 +234,7 @@ class DiscretePolicyFunction(torch.autograd.Function):
         probs = buf[:, :N]
         act_out = act if act is not None else torch.full((B,), -1, dtype=torch.int64, device=dev)
         ctx.save_for_backward(xp, h, w1p, w2p, probs, act_out, stat)
+        ctx.w2_param = w2
         ctx.dims = (B, K, H, N, Kp, Hp, ldn)
         ctx.has_action = act is not None
         ctx.mark_non_differentiable(act_out)
@@ -242,18 +268,25 @@ class DiscretePolicyFunction(torch.autograd.Function):
         del scratch
         gw2 = torch.empty(N, H, device=dev)
         _dw(dlog, N, h, H, gw2)
-        tiles = (B + 31) // 32
         dz1 = torch.zeros(B, Hp, device=dev)
-        cs1 = torch.empty(tiles, H, device=dev)
-        _dx(dlog, _r4(N), w2p, H, dz1, h, 1.0, cs1)
+        # dZ1 = (dlogits W2) * [h > 0]: contraction over the catalogue.  W2 is [n_items, hidden], k-strided for this product;
+        # its transpose (made once per weight version, shared by the backward passes of a whole episode) puts the
+        # contraction on the contiguous axis, so the LDS-DMA forward kernel runs it (measured 4.2 -> 1.3 ms at 256 x 100k x 2048)
+        def transposed(w):
+            t = torch.zeros(H, ldn, device=dev)
+            t[:, :N] = w.float().t()
+            return t
+        w2t = _derived_of(ctx.w2_param, "transposed", transposed)
+        _fwd(dlog, ldn, w2t, None, dz1, Hp, H, False, None, yref=h, scale=1.0)
         del dlog
+        gb1 = dz1[:, :H].sum(0)
         gw1 = torch.empty(H, K, device=dev)
         _dw(dz1, H, xp, K, gw1)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(B, K, device=dev)
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
-        return gx, gw1, cs1.sum(0), gw2, gb2, None, None, None
+        return gx, gw1, gb1, gw2, gb2, None, None, None
 
 
 def discrete_policy(x, module, actions=None, sample=False):
@@ -263,9 +296,33 @@ def discrete_policy(x, module, actions=None, sample=False):
 
 
 def onehot_rows(idx, n):
-    """float[B, n] one-hot rows of int64 indices (recnn/data/utils.py:108-109: zeros + scatter_)."""
+    """float[B, n] one-hot rows of int64 indices (recnn/data/utils.py:108-109: zeros + scatter_).  The result remembers
+    its indices (`onehot_index`): a Critic reading it gathers the B weight columns instead of multiplying a [B, n] matrix
+    of zeros (`mlp_onehot`)."""
     B = idx.numel()
     ld = _r4(n)
+    idx = idx.to(torch.int64).contiguous()
     out = torch.empty(B, ld, dtype=torch.float32, device=idx.device)
-    L.call("recnn_onehot_rows", L.ptr(idx.to(torch.int64).contiguous()), B, n, L.ptr(out), ld, L.current_stream())
-    return out if ld == n else out[:, :n]
+    L.call("recnn_onehot_rows", L.ptr(idx), B, n, L.ptr(out), ld, L.current_stream())
+    out = out if ld == n else out[:, :n]
+    out.onehot_index = (idx, out._version)
+    return out
+
+
+def onehot_index_of(t):
+    """The indices of a tensor made by `onehot_rows`, or None (also when it was written to since)."""
+    tag = getattr(t, "onehot_index", None)
+    if tag is None or tag[1] != t._version or tag[0].numel() != t.shape[0]:
+        return None
+    return tag[0]
+
+
+def mlp_onehot(state, idx, n_state, module, train: bool):
+    """`mlp(cat([state, onehot(idx)], 1))` without the one-hot operand: layer 1 is state W1[:, :S]^T + W1[:, S + idx]^T + b1
+    (the column gather enters the GEMM epilogue before the relu); autograd scatters the gathered columns' gradient back."""
+    w1 = module.linear1.weight
+    w_state = w1[:, :n_state]
+    cols = w1.index_select(1, idx + n_state).t()          # [B, H]
+    return MLPFunction.apply(state.float(), w_state, module.linear1.bias, module.linear2.weight, module.linear2.bias,
+                             module.linear3.weight, module.linear3.bias, train, torch.initial_seed(),
+                             _take_forced_masks(module, train), cols)

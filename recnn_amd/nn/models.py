@@ -44,6 +44,11 @@ class Critic(nn.Module):
         self.linear3.bias.data.uniform_(-init_w, init_w)
 
     def forward(self, state, action):
+        idx = F_hip.onehot_index_of(action)
+        if idx is not None and state.is_cuda:
+            # one-hot action rows (REINFORCE's discrete-action batches, data.batch_contstate_discaction): gather the B
+            # weight columns instead of contracting over the whole catalogue
+            return F_hip.mlp_onehot(state, idx, state.shape[1], self, self.training)
         return F_hip.mlp(torch.cat([state, action], 1), self, self.training)
 
 

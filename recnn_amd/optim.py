@@ -55,6 +55,7 @@ class Adam(torch.optim.Optimizer):
                 L.call("recnn_adam_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                        int(st["step"]), 1.0, stream)
+                torch.autograd.graph.increment_version(p)    # the kernel wrote p behind autograd's back
         return loss
 
 
@@ -134,6 +135,7 @@ class Ranger(torch.optim.Optimizer):
                        L.ptr(st["slow_buffer"]), p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                        float(group["weight_decay"]), float(group["alpha"]), int(group["k"]), float(group["N_sma_threshhold"]),
                        int(st["step"]), 1.0, stream)
+                torch.autograd.graph.increment_version(p)
         return loss
 
     @torch.no_grad()

@@ -26,6 +26,7 @@ def soft_update(net, target_net, soft_tau=1e-2):
     for tp, p in pairs:
         src = p.data if p.dtype == torch.float32 else p.data.float()
         L.call("recnn_soft_update_flat", L.ptr(tp.data), L.ptr(src), tp.numel(), float(soft_tau), stream)
+        torch.autograd.graph.increment_version(tp)     # the kernel wrote tp behind autograd's back
     from ..nn import fused
     fused.notify_params_changed(target_net)
 

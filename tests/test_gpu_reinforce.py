@@ -175,7 +175,37 @@ def test_discrete_actor_forward_backward_match_oracle(cuda, S, N, H, B):
         assert rel_err(t.grad, ps[k].grad) < 2e-5, k
 
 
-def _run_fixture(name, golden_dir, optimizer):
+def test_critic_gathers_columns_for_onehot_actions(cuda):
+    """Critic(state, onehot_rows(idx)) takes the column-gather path: same values and parameter gradients as the dense
+    [state | one-hot] contraction (train mode, same dropout masks); a tensor written to after it was made loses the tag."""
+    import recnn_amd
+    from recnn_amd.nn import functional as F_hip
+    torch.manual_seed(5)
+    S, N, H, B = 27, 300, 32, 19
+    net = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda()
+    state = torch.randn(B, S, device="cuda")
+    idx = torch.randint(0, N, (B,), device="cuda")
+    idx[3] = idx[7]                                     # duplicates accumulate into one column
+    oh = F_hip.onehot_rows(idx, N)
+    assert F_hip.onehot_index_of(oh) is not None and F_hip.onehot_index_of(oh.clone()) is None
+    masks = [(torch.rand(B, H, device="cuda") < 0.5).to(torch.uint8) for _ in range(2)]
+    w = torch.randn(B, 1, device="cuda")
+    res = []
+    for action in (oh, oh.clone()):
+        net.zero_grad()
+        net.forced_masks = [tuple(masks)]
+        q = net(state, action)
+        (q * w).sum().backward()
+        res.append((q.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    assert rel_err(res[0][0], res[1][0]) < 1e-5
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel_err(a, b) < 1e-5
+    touched = F_hip.onehot_rows(idx, N)
+    touched.mul_(1.0)
+    assert F_hip.onehot_index_of(touched) is None
+
+
+def _run_fixture(name, golden_dir, optimizer, tagged=False):
     import recnn_amd
     fx = RR.load(os.path.join(golden_dir, name + ".npz"))
     g = fx["g"]
@@ -205,6 +235,9 @@ def _run_fixture(name, golden_dir, optimizer):
     algo.params["K"] = fx["K"]
     policy.action_source = {"pi": fx["pi_source"], "beta": "beta"}
     bs = RR.batches(fx, dev)
+    if tagged:      # actions made by recnn_onehot_rows: the critic gathers weight columns instead of the dense contraction
+        for b in bs:
+            b["action"] = F_hip_mod().onehot_rows(b["action"].argmax(1), fx["N"])
     pi_draws, beta_draws = torch.from_numpy(g["pi_draws"]).to(dev), torch.from_numpy(g["beta_draws"]).to(dev)
     value.forced_masks = []
     losses = []
@@ -247,6 +280,18 @@ def test_reinforce_replays_reference_run(cuda, golden_dir, name):
                            ("target_value", "target_value_net", O.params_from_module)):
         for k, v in snap(algo.nets[net]).items():
             assert rel_err(v, fx["g"][f"final.{tag}.{k}"]) < 1e-4, (tag, k)
+
+
+def F_hip_mod():
+    from recnn_amd.nn import functional as F_hip
+    return F_hip
+
+
+def test_reinforce_replay_with_gathered_onehot_actions(cuda, golden_dir):
+    """Same replay with the batch actions built by `onehot_rows` (what data.batch_contstate_discaction returns): the
+    critic's column-gather path inside the whole update."""
+    fx, losses, _ = _run_fixture("reinforce_corr", golden_dir, torch.optim.Adam, tagged=True)
+    assert rel_err(losses[:, 1:], fx["g"]["losses"][:, 1:]) < 1e-4
 
 
 def test_reinforce_with_hip_adam_matches_torch_adam(cuda, golden_dir):

@@ -1,0 +1,63 @@
+"""REINFORCE at a 100k-item catalogue: per-step time of recnn_amd.nn.Reinforce.update.
+usage: python tools/reinforce_bench.py [--items 100000] [--rows 256] [--hidden 2048] [--steps 31] [--method topk|basic]
+Prints one JSON line (median ms of ordinary steps, ms of policy-update steps, it/s over whole policy cycles)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import recnn_amd  # noqa: E402
+from recnn_amd.nn import functional as F_hip  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, default=100000)
+    ap.add_argument("--rows", type=int, default=256)
+    ap.add_argument("--hidden", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=31)
+    ap.add_argument("--method", default="topk")
+    ap.add_argument("--optimizer", default="ranger")
+    a = ap.parse_args()
+    recnn_amd.nn.algo.set_default_optimizer(a.optimizer)
+    N, S, H, B = a.items, 1290, a.hidden, a.rows
+    torch.manual_seed(0)
+    value = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda()
+    policy = recnn_amd.nn.DiscreteActor(S, N, H).cuda()
+    algo = recnn_amd.nn.Reinforce(policy, value).to(torch.device("cuda"))
+    if a.method == "topk":
+        Wb = torch.randn(S, N, device="cuda") * 0.02
+
+        def beta(state, action=None):
+            return torch.softmax(state @ Wb, dim=1)
+        policy.select_action = lambda state, action, K, writer, step, **kw: \
+            policy._select_action_with_TopK_correction(state, beta, action, K=K, writer=writer, step=step)
+        ch = recnn_amd.nn.ChooseREINFORCE
+        algo.params["reinforce"] = ch(ch.reinforce_with_TopK_correction)
+        policy.action_source = {"pi": "beta", "beta": "beta"}
+    idx = torch.randint(0, N, (B,), device="cuda")
+    batch = {"state": torch.randn(B, S, device="cuda"), "action": F_hip.onehot_rows(idx, N), "reward": torch.randn(B, device="cuda"),
+             "next_state": torch.randn(B, S, device="cuda"), "done": torch.zeros(B, device="cuda")}
+    times, kinds = [], []
+    for t in range(a.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = algo.update(batch)
+        algo.step()
+        torch.cuda.synchronize()
+        times.append(1e3 * (time.perf_counter() - t0))
+        kinds.append(out is not None)
+    ordinary = sorted(x for x, k in zip(times[1:], kinds[1:]) if not k)
+    pol = [x for x, k in zip(times, kinds) if k]
+    cyc = times[11:31] if len(times) >= 31 else times[1:]
+    print(json.dumps({"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer,
+                      "ordinary_step_ms": round(ordinary[len(ordinary) // 2], 3), "policy_step_ms": [round(x, 2) for x in pol],
+                      "it_per_s": round(1e3 * len(cyc) / sum(cyc), 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+
+
+if __name__ == "__main__":
+    main()
