@@ -398,6 +398,10 @@ int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy
  * (recnn_engine_read_counters). */
 int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
 int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream);
+/* Optional: a run graph made to order for requests of exactly n_steps (2..64) steps whose first step number is congruent
+ * to first_step modulo policy_every; recnn_engine_graph_run then serves such requests with ONE graph launch instead of
+ * composing them from the family.  Up to 4 are kept (oldest replaced); dropped with the other graphs. */
+int recnn_engine_graph_prepare(recnn_engine* e, int first_step, int n_steps, void* stream);
 
 /* Runs n_steps eager steps with a hipEvent pair around every kernel launch and returns, per
  * launch slot, the average device time in milliseconds (h_ms[i]), its name (h_names[i], static

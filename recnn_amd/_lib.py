@@ -158,6 +158,7 @@ SIGNATURES = {
     "recnn_engine_finish": (_I, [_P, _I, _I, _I, _P]),
     "recnn_engine_graph_build": (_I, [_P, _I, _P]),
     "recnn_engine_graph_run": (_I, [_P, _I, _I, _P]),
+    "recnn_engine_graph_prepare": (_I, [_P, _I, _I, _P]),
     "recnn_engine_dp_graph_build": (_I, [_P, _I, _F, _I, _P]),
     "recnn_engine_dp_graph_launch": (_I, [_P, _I, _P]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),

@@ -153,6 +153,11 @@ struct recnn_engine {
   hipGraphExec_t grun_p[RUN_MAX + 1] = {};
   hipGraphExec_t grun_multi = nullptr;
   int grun_multi_len = 0;
+  // run graphs made to order (recnn_engine_graph_prepare): one launch for a whole request (phase, n_steps)
+  static constexpr int CUSTOM_MAX = 4;
+  hipGraphExec_t grun_custom[CUSTOM_MAX] = {};
+  int grun_custom_phase[CUSTOM_MAX] = {}, grun_custom_len[CUSTOM_MAX] = {};
+  int grun_custom_next = 0;
   bool grun_look = false;    // run graphs alternate the two batch buffer sets (look-ahead gather)
   bool use_sampler = false;  // the step being issued / captured draws its batch from the bound sampler
   bool sampler_eager = false;  // eager public calls (recnn_engine_step, value_grads) draw from the sampler too
@@ -383,6 +388,10 @@ static void drop_graphs(recnn_engine* e) {
   }
   if (e->grun_multi) { (void)hipGraphExecDestroy(e->grun_multi); e->grun_multi = nullptr; }
   e->grun_multi_len = 0;
+  for (int i = 0; i < recnn_engine::CUSTOM_MAX; ++i) {
+    if (e->grun_custom[i]) { (void)hipGraphExecDestroy(e->grun_custom[i]); e->grun_custom[i] = nullptr; }
+    e->grun_custom_len[i] = 0;
+  }
   e->graph_rows = 0;
   for (int i = 0; i < 7; ++i)
     for (int k = 0; k < 2; ++k)
@@ -1553,8 +1562,9 @@ extern "C" void recnn_tune_graph_run(int steps) { g_graph_run_len = steps; }
 //   grun_multi  as many whole cycles as fit 64 steps
 // (policy_every <= 17: every k; larger: k in {1, 2, 4, 8, 16, 32} and greedy composition.)
 namespace {
-// One run of `len` steps captured into *out; pol_first: its first step is a policy step (then every policy_every-th).
-int capture_run(recnn_engine* e, int rows, hipStream_t s, bool pol_first, int len, hipGraphExec_t* out) {
+// One run of `len` steps captured into *out.  phase = (number of the run's first step) mod policy_every: step i of the run is
+// a policy step when (phase + i) is a multiple of policy_every; phase < 0: no policy step in the run.
+int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hipGraphExec_t* out) {
   if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
   const int pe = e->hy.policy_every;
   const bool look = lookahead_ok(e) && len > 1;
@@ -1564,7 +1574,7 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, bool pol_first, int le
   e->use_sampler = e->has_sampler;
   int n_pol = 0;
   for (int i = 0; i < len && !rc; ++i) {
-    const bool pol = pol_first && (i % pe) == 0;
+    const bool pol = phase >= 0 && ((phase + i) % pe) == 0;
     use_set(e, look ? (i & 1) : 0);
     // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
     e->run_off = i;
@@ -1610,23 +1620,45 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
   const int pe = e->hy.policy_every;
   int cap = g_graph_run_len < 0 ? recnn_engine::RUN_MAX : g_graph_run_len;   // longest run graph wanted
   if (cap > recnn_engine::RUN_MAX) cap = recnn_engine::RUN_MAX;
-  if ((rc = capture_run(e, rows, s, false, 1, &e->gexec[0]))) return rc;
-  if ((rc = capture_run(e, rows, s, true, 1, &e->gexec[1]))) return rc;
+  if ((rc = capture_run(e, rows, s, -1, 1, &e->gexec[0]))) return rc;
+  if ((rc = capture_run(e, rows, s, 0, 1, &e->gexec[1]))) return rc;
   if (cap >= 2) {
     const int o_max = pe - 1 < cap ? pe - 1 : cap;            // ordinary stretch: never across a policy step
     for (int k = 2; k <= o_max; ++k)
-      if (run_len_kept(k, o_max) && (rc = capture_run(e, rows, s, false, k, &e->grun_o[k]))) return rc;
+      if (run_len_kept(k, o_max) && (rc = capture_run(e, rows, s, -1, k, &e->grun_o[k]))) return rc;
     const int p_max = pe - 1 < cap - 1 ? pe - 1 : cap - 1;    // policy step + k ordinary ones
     for (int k = 1; k <= p_max; ++k)
-      if (run_len_kept(k, p_max) && (rc = capture_run(e, rows, s, true, k + 1, &e->grun_p[k]))) return rc;
+      if (run_len_kept(k, p_max) && (rc = capture_run(e, rows, s, 0, k + 1, &e->grun_p[k]))) return rc;
     const int cycles = cap / pe;
     if (cycles >= 2) {
-      if ((rc = capture_run(e, rows, s, true, cycles * pe, &e->grun_multi))) return rc;
+      if ((rc = capture_run(e, rows, s, 0, cycles * pe, &e->grun_multi))) return rc;
       e->grun_multi_len = cycles * pe;
     }
   }
   e->grun_look = lookahead_ok(e);
   e->graph_rows = rows;
+  return 0;
+}
+
+// A run graph made to order for requests of exactly n_steps steps starting at a step congruent to first_step modulo
+// policy_every: graph_run() then serves such a request with ONE launch instead of the [stretch][cycles][tail] composition
+// (each graph boundary costs ~45 us of GPU time plus a host launch).  Up to CUSTOM_MAX are kept, oldest replaced.
+extern "C" int recnn_engine_graph_prepare(recnn_engine* e, int first_step, int n_steps, void* stream) {
+  RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_prepare: build the graphs first (recnn_engine_graph_build)");
+  RECNN_REQUIRE(first_step >= 0 && n_steps >= 2 && n_steps <= recnn_engine::RUN_MAX, "graph_prepare: 2 <= n_steps <= %d",
+                recnn_engine::RUN_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  RECNN_REQUIRE(s != nullptr, "graph_prepare: capture needs a non-null stream");
+  const int phase = first_step % e->hy.policy_every;
+  for (int i = 0; i < recnn_engine::CUSTOM_MAX; ++i)
+    if (e->grun_custom[i] && e->grun_custom_phase[i] == phase && e->grun_custom_len[i] == n_steps) return 0;
+  const int slot = e->grun_custom_next;
+  e->grun_custom_next = (slot + 1) % recnn_engine::CUSTOM_MAX;
+  e->grun_custom_len[slot] = 0;
+  const int rc = capture_run(e, e->graph_rows, s, phase, n_steps, &e->grun_custom[slot]);
+  if (rc) return rc;
+  e->grun_custom_phase[slot] = phase;
+  e->grun_custom_len[slot] = n_steps;
   return 0;
 }
 
@@ -1636,6 +1668,12 @@ extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_ste
   RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_run: graphs not built");
   const int pe = e->hy.policy_every;
   hipStream_t s = (hipStream_t)stream;
+  for (int c = 0; c < recnn_engine::CUSTOM_MAX; ++c)
+    if (e->grun_custom[c] && e->grun_custom_len[c] == n_steps && e->grun_custom_phase[c] == first_step % pe) {
+      RECNN_HIP(hipGraphLaunch(e->grun_custom[c], s));
+      use_set(e, e->grun_look ? ((n_steps - 1) & 1) : 0);
+      return 0;
+    }
   int i = 0;
   while (i < n_steps) {
     const int step = first_step + i, rem = n_steps - i;

@@ -113,6 +113,20 @@ class Algo:
                              "torch.optim.Adam (both critics of TD3 with equal settings)")
         return cfgs
 
+    def prepare_run(self, n_steps: int, first_step: int = None):
+        """Build, ahead of time, everything `run(n_steps)` called at step number `first_step` (default: the current one)
+        replays: the graph family and -- for n_steps <= 64 -- a run graph made to order, so that the call is ONE graph launch.
+        (`run` does this by itself the second time it sees the same request shape.)"""
+        ctx = getattr(self, "_fused_ctx", None)
+        if ctx is None:
+            raise RuntimeError("call attach_env(env, rows_per_batch) first")
+        every = self.params["policy_update" if "value_net1" in self.nets else "policy_step"]
+        cfgs = self._fused_adam_cfgs(self._fused_keys)
+        ctx.ensure(self.nets, ctx.sampler["rows"])
+        ctx.set_hyper(self.params, cfgs[0], cfgs[1])
+        ctx.apply_external(ctx.sampler["rows"])
+        ctx.run_steps(self._step if first_step is None else first_step, n_steps, every=every, prepare=True)
+
     def run(self, n_steps: int, history: bool = False):
         """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync).
         history=True: returns (last losses, [losses of each of the n_steps steps]) -- what the reference's loop would
@@ -128,7 +142,7 @@ class Algo:
         ctx.ensure(self.nets, ctx.sampler["rows"])
         ctx.set_hyper(self.params, cfgs[0], cfgs[1])
         ctx.apply_external(ctx.sampler["rows"])
-        ctx.run_steps(first, n_steps)
+        ctx.run_steps(first, n_steps, every=every)
         self._step += n_steps
         n_policy = len(range(first + (-first) % every, first + n_steps, every))
         from . import fused

@@ -290,6 +290,9 @@ class StepEngine:
     def graph_build(self, rows: int):
         L.call("recnn_engine_graph_build", self.handle, rows, self._stream())
 
+    def graph_prepare(self, first_step: int, n_steps: int):
+        L.call("recnn_engine_graph_prepare", self.handle, first_step, n_steps, self._stream())
+
     def graph_run(self, first_step: int, n_steps: int):
         L.call("recnn_engine_graph_run", self.handle, first_step, n_steps, self._stream())
 

@@ -254,8 +254,11 @@ class FusedContext:
         order = torch.randperm(sm["train"].numel())[: self.perm.numel()].to(sm["train"].device)   # CPU generator, as RandomSampler
         self.perm.copy_(sm["train"][order].to(torch.int32))
 
-    def run_steps(self, first_step: int, n_steps: int):
-        """`n_steps` consecutive learn steps by hipGraph replay; the permutation is redrawn at every epoch boundary."""
+    def run_steps(self, first_step: int, n_steps: int, every: int = None, prepare: bool = False):
+        """`n_steps` consecutive learn steps by hipGraph replay; the permutation is redrawn at every epoch boundary.
+        `every` (the policy-update period) lets the context recognise repeated requests: the second time the same
+        (first_step mod every, n_steps <= 64) comes in, a run graph is made to order for it and such requests are one graph
+        launch from then on.  prepare=True only builds what the request needs (graphs, the made-to-order graph) and runs nothing."""
         eng, sm = self.engine, self.sampler
         # hipGraph capture/replay needs a real (non-null) stream: use a private one, ordered after and before
         # the caller's current stream
@@ -268,6 +271,16 @@ class FusedContext:
             if getattr(self, "graph_rows", None) != sm["rows"]:
                 eng.graph_build(sm["rows"])
                 self.graph_rows = sm["rows"]
+                self._run_seen = {}
+            if every and 2 <= n_steps <= 64:
+                key = (first_step % every, n_steps)
+                seen = self.__dict__.setdefault("_run_seen", {}).get(key, 0)
+                if seen == 1 or (prepare and seen < 2):
+                    eng.graph_prepare(first_step, n_steps)
+                    seen = 2
+                self._run_seen[key] = max(seen, 1)
+            if prepare:
+                n_steps = 0
             done = 0
             while done < n_steps:
                 chunk = min(n_steps - done, sm["n_batches"] - sm["cursor"])

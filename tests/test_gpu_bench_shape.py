@@ -70,14 +70,17 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
     from recnn_amd import _lib as L
     env, table = _bench_env(recnn_amd, cuda, n_users=(n + 2) * UPB)
     results = {}
-    for mode in ("one_call", "pieces", "loop"):
+    for mode in ("one_call", "pieces", "prepared", "loop"):
         ddpg = _make_algo(recnn_amd, cuda, env, dtype)
         ctx = ddpg._fused_ctx
         assert ctx.sampler["n_batches"] >= n and ctx.engine.dtype == dtype
         if mode == "one_call":
             out, hist = ddpg.run(n, history=True)
-        elif mode == "pieces":
+        elif mode in ("pieces", "prepared"):
             hist = []
+            if mode == "prepared":                         # bench.py: the timed 20-step call is ONE made-to-order run graph
+                ddpg.prepare_run(20, first_step=5)
+                assert ctx._run_seen[(5, 20)] == 2
             for k in (5, 20, n - 25):                      # the driver's bench: warm-up 5, then 20 steps from step 5
                 out, h = ddpg.run(k, history=True)
                 hist += h
@@ -100,7 +103,7 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
         assert ctx.engine.counters()[0] == n
         results[mode] = (hist, _snapshot(ddpg))
     # ---- the three ways of running the same n steps: parameters bit for bit
-    for other in ("pieces", "loop"):
+    for other in ("pieces", "prepared", "loop"):
         for net, sd in results["one_call"][1].items():
             for k, v in sd.items():
                 assert torch.equal(v, results[other][1][net][k]), (other, net, k)
