@@ -311,10 +311,12 @@ int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow,
  * The uniform of row r is a pure function of (seed, step, r); the inverse-CDF walks items in a fixed order. */
 int recnn_categorical_rows(float* x, int64_t ld, int rows, int n, int flags, uint32_t seed, int32_t step,
                            int64_t* actions, float* logprob, float* rowstat, void* stream);
+#define RECNN_LPB_ACCUMULATE 1 /* dlogits += ... (else =) */
+#define RECNN_LPB_BF16 2       /* dlogits is bfloat16[rows, ldd] (operand of the bf16 catalogue GEMMs); else float */
 /* dlogits (+)= g[row] * (onehot(a) - p / sum p), zero for rows whose clamp was active (g NULL = zeros);
  * colsum[n] (optional) = column sums of the resulting dlogits (bias gradient), scratch = float[ceil(rows/32) * round4(n)]. */
 int recnn_logprob_bwd(const float* p, int64_t ldp, int rows, int n, const int64_t* actions, const float* g,
-                      const float* rowstat, float* dlogits, int64_t ldd, int accumulate, float* colsum, float* scratch,
+                      const float* rowstat, void* dlogits, int64_t ldd, int flags, float* colsum, float* scratch,
                       void* stream);
 /* dlogits = p * (dprobs - sum_j dprobs_j p_j): backward of p = softmax(logits). */
 int recnn_softmax_bwd(const float* p, int64_t ldp, int rows, int n, const float* dprobs, int64_t lddp, float* dlogits,

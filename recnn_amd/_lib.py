@@ -17,6 +17,7 @@ MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
 ALGO_DDPG, ALGO_TD3 = 0, 1
 OPT_ADAM, OPT_RANGER = 0, 1
 CAT_SOFTMAX, CAT_SAMPLE = 1, 2
+LPB_ACCUMULATE, LPB_BF16 = 1, 2
 NET_POLICY, NET_TARGET_POLICY, NET_VALUE1, NET_TARGET_VALUE1, NET_VALUE2, NET_TARGET_VALUE2 = range(6)
 
 

@@ -183,9 +183,19 @@ __global__ __launch_bounds__(PT) void categorical_kernel(float* __restrict__ x, 
 // d logits of  sum_rows g[row] * log(clamp(p[a]/sum p)) :   g (onehot(a) - p / sum p),  zero where the clamp was active.
 // Grid: (column groups of 256 float4, slabs of 32 rows).  Also writes the column sums of each slab (bias gradient partials).
 constexpr int BWD_ROWS = 32;
+__device__ inline float4 load_out4(const float* p) { return *(const float4*)p; }
+__device__ inline float4 load_out4(const bf16_t* p) {
+  const uint2 u = *(const uint2*)p;
+  return make_float4(bf2f((bf16_t)(u.x & 0xFFFFu)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xFFFFu)), bf2f((bf16_t)(u.y >> 16)));
+}
+__device__ inline void store_out4(float* p, float4 v) { *(float4*)p = v; }
+__device__ inline void store_out4(bf16_t* p, float4 v) { *(uint2*)p = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
+
+// OUT = float, or bf16 for the bf16 catalogue GEMMs that consume dlogits (the column sums are taken before the rounding)
+template <class OUT>
 __global__ __launch_bounds__(256) void logprob_bwd_kernel(const float* __restrict__ p, int64_t ldp, int rows, int n,
                                                           const int64_t* __restrict__ actions, const float* __restrict__ g,
-                                                          const float* __restrict__ rowstat, float* __restrict__ d, int64_t ldd,
+                                                          const float* __restrict__ rowstat, OUT* __restrict__ d, int64_t ldd,
                                                           int accumulate, float* __restrict__ colpart) {
   __shared__ float gs[BWD_ROWS], is[BWD_ROWS];
   __shared__ int as[BWD_ROWS];
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256) void logprob_bwd_kernel(const float* __restric
     const int rel = as[j] - c0;
     if (rel == 0) o.x += gv; else if (rel == 1) o.y += gv; else if (rel == 2) o.z += gv; else if (rel == 3) o.w += gv;
     if (accumulate) {
-      const float4 old = *(const float4*)(d + r * ldd + c0);
+      const float4 old = load_out4(d + r * ldd + c0);
       o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
     }
     if (c0 + 3 >= n) {   // keep the padding columns zero (they are contraction padding of the dX GEMM)
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void logprob_bwd_kernel(const float* __restric
       if (c0 + 2 >= n) o.z = 0.f;
       o.w = 0.f;
     }
-    *(float4*)(d + r * ldd + c0) = o;
+    store_out4(d + r * ldd + c0, o);
     cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
   }
   if (colpart) *(float4*)(colpart + (int64_t)blockIdx.y * (4 * (int64_t)n4) + c0) = cs;
@@ -296,15 +306,20 @@ int recnn_categorical_rows(float* x, int64_t ld, int rows, int n, int flags, uin
 }
 
 int recnn_logprob_bwd(const float* p, int64_t ldp, int rows, int n, const int64_t* actions, const float* g, const float* rowstat,
-                      float* dlogits, int64_t ldd, int accumulate, float* colsum, float* scratch, void* stream) {
+                      void* dlogits, int64_t ldd, int flags, float* colsum, float* scratch, void* stream) {
   RECNN_REQUIRE(p && actions && rowstat && dlogits && rows >= 0 && n > 0, "logprob_bwd: bad arguments");
   RECNN_REQUIRE(aligned16(p) && aligned16(dlogits) && ldp % 4 == 0 && ldd % 4 == 0 && ldp >= ((n + 3) & ~3) && ldd >= ((n + 3) & ~3),
                 "logprob_bwd: rows must be 16-byte aligned and padded to 4 floats");
   RECNN_REQUIRE(!colsum || scratch, "logprob_bwd: column sums need the scratch buffer (ceil(rows/32) * round4(n) floats)");
   if (rows == 0) return 0;
   const int n4 = (n + 3) >> 2, slabs = (rows + BWD_ROWS - 1) / BWD_ROWS;
-  hipLaunchKernelGGL(logprob_bwd_kernel, dim3((n4 + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, p, ldp, rows, n, actions, g,
-                     rowstat, dlogits, ldd, accumulate, colsum ? scratch : nullptr);
+  const int accumulate = (flags & RECNN_LPB_ACCUMULATE) ? 1 : 0;
+  if (flags & RECNN_LPB_BF16)
+    hipLaunchKernelGGL(logprob_bwd_kernel<bf16_t>, dim3((n4 + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, p, ldp, rows, n,
+                       actions, g, rowstat, (bf16_t*)dlogits, ldd, accumulate, colsum ? scratch : nullptr);
+  else
+    hipLaunchKernelGGL(logprob_bwd_kernel<float>, dim3((n4 + 255) / 256, slabs), dim3(256), 0, (hipStream_t)stream, p, ldp, rows, n,
+                       actions, g, rowstat, (float*)dlogits, ldd, accumulate, colsum ? scratch : nullptr);
   if (colsum)
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, slabs, n4, n, colsum);
   return recnn_check_hip(hipGetLastError(), "logprob_bwd launch");

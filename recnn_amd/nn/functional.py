@@ -48,17 +48,35 @@ def _derived_of(w, kind, build):
     return out
 
 
-def _args(M, N):
+_catalogue_dtype = "fp32"
+
+
+def set_catalogue_dtype(dtype: str):
+    """Compute type of the catalogue-sized GEMMs of the REINFORCE path ([rows, hidden] x [hidden, n_items] of the policy
+    head and its backward, [rows, state + n_items] x [., hidden] of the critic over action distributions):
+    'fp32' (default; exact-fp32 MFMA, the parity mode) or 'bf16' (bf16 MFMA with fp32 accumulation over bf16 copies of the
+    weights kept per weight version; softmax, log-prob, optimizer and all small layers stay fp32)."""
+    global _catalogue_dtype
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(dtype)
+    _catalogue_dtype = dtype
+
+
+def _r128(x):
+    return (x + 127) // 128 * 128
+
+
+def _args(M, N, dtype=None):
     a = L.GemmArgs()
-    a.dtype = L.F32
+    a.dtype = L.F32 if dtype is None else dtype
     a.M, a.N = M, N
     a.dx_scale = 1.0
     a.dw_splits = 1
     return a
 
 
-def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0):
-    a = _args(x.shape[0], N)
+def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0, dtype=None):
+    a = _args(x.shape[0], N, dtype)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = x.data_ptr(), w.data_ptr(), x.stride(0), w.stride(0), K
     a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 1
     a.bias, a.relu = (bias.data_ptr() if bias is not None else None), int(relu)
@@ -82,8 +100,8 @@ def _dx(dz, Kc, w, N, out, yref, scale, colsum):
     L.call("recnn_gemm_dx", C.byref(a), L.current_stream())
 
 
-def _dw(dz, M, x, N, out):
-    a = _args(M, N)
+def _dw(dz, M, x, N, out, dtype=None):
+    a = _args(M, N, dtype)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = dz.data_ptr(), x.data_ptr(), dz.stride(0), x.stride(0), dz.shape[0]
     a.C, a.ldc = out.data_ptr(), N
     a.dw_splits, a.dw_slab_stride, a.dw_valid_cols, a.dw_col_rot = 1, M * N, N, 0
@@ -100,8 +118,18 @@ class MLPFunction(torch.autograd.Function):
         H, O = w1.shape[0], w3.shape[0]
         Kp, Hp, Op = _r64(K), _r64(H), _r64(O)
         dev = x.device
-        xp = _pad(x, B, Kp)
-        w1p, w2p, w3p = _pad(w1, Hp, Kp), _pad(w2, Hp, Hp), _pad(w3, Op, Hp)
+        # catalogue-wide layer 1 (the critic over action distributions) in bf16 mode: the fp32 operands are only
+        # materialised when a backward pass will need them
+        big16 = _catalogue_dtype == "bf16" and K >= 4096
+        lean = big16 and not any(ctx.needs_input_grad)
+        xp = None if lean else _pad(x, B, Kp)
+        if lean:
+            w1p = None
+        elif w1.numel() >= (1 << 22) and w1.is_leaf:
+            w1p = _derived_of(w1, "padded", lambda w: _pad(w, Hp, Kp))      # 100k-wide rows are not 16-byte aligned as stored
+        else:
+            w1p = _pad(w1, Hp, Kp)
+        w2p, w3p = _pad(w2, Hp, Hp), _pad(w3, Op, Hp)
         h1 = torch.zeros(B, Hp, device=dev)
         h2 = torch.zeros(B, Hp, device=dev)
         out = torch.empty(B, O, device=dev)
@@ -117,7 +145,19 @@ class MLPFunction(torch.autograd.Function):
             L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
         b1c, b2c, b3c = b1.detach().float().contiguous(), b2.detach().float().contiguous(), b3.detach().float().contiguous()
         add1 = None if addend1 is None else addend1.detach().float().contiguous()
-        _fwd(xp, Kp, w1p, b1c, h1, Hp, H, True, m1, addend=add1)
+        if big16:
+            # the critic over [state | action distribution]: layer 1 contracts over the catalogue
+            K16 = _r128(K)
+            x16 = torch.zeros(B, K16, dtype=torch.bfloat16, device=dev)
+            x16[:, :K] = x
+            def shadow(w):
+                t = torch.zeros(Hp, K16, dtype=torch.bfloat16, device=dev)
+                t[:H, :K] = w
+                return t
+            w16 = _derived_of(w1, "bf16_padded", shadow)
+            _fwd(x16, K16, w16, b1c, h1, Hp, H, True, m1, addend=add1, dtype=L.BF16)
+        else:
+            _fwd(xp, Kp, w1p, b1c, h1, Hp, H, True, m1, addend=add1)
         _fwd(h1, Hp, w2p, b2c, h2, Hp, H, True, m2)
         _fwd(h2, Hp, w3p, b3c, out, O, O, False, None)
         ctx.save_for_backward(xp, h1, h2, w1p, w2p, w3p)
@@ -208,17 +248,27 @@ class DiscretePolicyFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         B, K = x.shape
         H, N = w1.shape[0], w2.shape[0]
-        Kp, Hp, ldn = _r64(K), _r64(H), _r64(N)
+        bf16 = _catalogue_dtype == "bf16"
+        Kp, Hp, ldn = _r64(K), (_r128(H) if bf16 else _r64(H)), (_r128(N) if bf16 else _r64(N))
         dev = x.device
         xp = _pad(x, B, Kp)
-        w1p = _pad(w1, H, Kp)
-        w2p = _pad(w2, _r4(N), Hp)     # no copy for the usual shapes (N % 4 == 0, H % 64 == 0)
+        w1p = _pad(w1, Hp, Kp)
         h = torch.zeros(B, Hp, device=dev)
         buf = torch.empty(B, ldn, device=dev)
         if ldn != N:
             buf[:, N:].zero_()
         _fwd(xp, Kp, w1p, b1.detach().float().contiguous(), h, Hp, H, True, None)
-        _fwd(h, Hp, w2p, b2.detach().float().contiguous(), buf, ldn, N, False, None)
+        if bf16:
+            def shadow(w):
+                t = torch.zeros(N, Hp, dtype=torch.bfloat16, device=dev)
+                t[:, :H] = w
+                return t
+            w2p = _derived_of(w2, "bf16", shadow)
+            h16 = h.to(torch.bfloat16)
+            _fwd(h16, Hp, w2p, b2.detach().float().contiguous(), buf, ldn, N, False, None, dtype=L.BF16)
+        else:
+            w2p = _pad(w2, _r4(N), Hp)     # no copy for the usual shapes (N % 4 == 0, H % 64 == 0)
+            _fwd(h, Hp, w2p, b2.detach().float().contiguous(), buf, ldn, N, False, None)
         stat = torch.empty(B, 4, device=dev)
         lp = torch.zeros(B, device=dev)
         flags = L.CAT_SOFTMAX
@@ -235,6 +285,7 @@ class DiscretePolicyFunction(torch.autograd.Function):
         act_out = act if act is not None else torch.full((B,), -1, dtype=torch.int64, device=dev)
         ctx.save_for_backward(xp, h, w1p, w2p, probs, act_out, stat)
         ctx.w2_param = w2
+        ctx.bf16 = bf16
         ctx.dims = (B, K, H, N, Kp, Hp, ldn)
         ctx.has_action = act is not None
         ctx.mark_non_differentiable(act_out)
@@ -248,14 +299,17 @@ class DiscretePolicyFunction(torch.autograd.Function):
         s = L.current_stream()
         if dprobs is None and (dlp is None or not ctx.has_action):
             return (None,) * 8
-        dlog = torch.empty(B, ldn, device=dev)
+        bf16 = ctx.bf16 and dprobs is None      # (a gradient through the probabilities themselves stays on the fp32 path)
+        dlog = torch.empty(B, ldn, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
         if ldn != _r4(N):
             dlog[:, _r4(N):].zero_()
         acc = 0
         if dprobs is not None:
             dpr = dprobs.float().contiguous()
             L.call("recnn_softmax_bwd", L.ptr(probs), probs.stride(0), B, N, L.ptr(dpr), dpr.stride(0), L.ptr(dlog), ldn, s)
-            acc = 1
+            acc = L.LPB_ACCUMULATE
+        if bf16:
+            acc |= L.LPB_BF16
         g = None
         if dlp is not None and ctx.has_action:
             g = dlp.float().contiguous()
@@ -267,17 +321,19 @@ class DiscretePolicyFunction(torch.autograd.Function):
                L.ptr(gb2), L.ptr(scratch), s)
         del scratch
         gw2 = torch.empty(N, H, device=dev)
-        _dw(dlog, N, h, H, gw2)
+        gdt = L.BF16 if bf16 else None
+        h_op = h.to(torch.bfloat16) if bf16 else h       # [rows, hidden]: small next to the catalogue operands
+        _dw(dlog, N, h_op, H, gw2, dtype=gdt)
         dz1 = torch.zeros(B, Hp, device=dev)
         # dZ1 = (dlogits W2) * [h > 0]: contraction over the catalogue.  W2 is [n_items, hidden], k-strided for this product;
         # its transpose (made once per weight version, shared by the backward passes of a whole episode) puts the
         # contraction on the contiguous axis, so the LDS-DMA forward kernel runs it (measured 4.2 -> 1.3 ms at 256 x 100k x 2048)
         def transposed(w):
-            t = torch.zeros(H, ldn, device=dev)
-            t[:, :N] = w.float().t()
+            t = torch.zeros(H, ldn, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+            t[:, :N] = w.t()
             return t
-        w2t = _derived_of(ctx.w2_param, "transposed", transposed)
-        _fwd(dlog, ldn, w2t, None, dz1, Hp, H, False, None, yref=h, scale=1.0)
+        w2t = _derived_of(ctx.w2_param, "transposed_bf16" if bf16 else "transposed", transposed)
+        _fwd(dlog, ldn, w2t, None, dz1, Hp, H, False, None, yref=h_op, scale=1.0, dtype=gdt)
         del dlog
         gb1 = dz1[:, :H].sum(0)
         gw1 = torch.empty(H, K, device=dev)

@@ -368,3 +368,51 @@ def test_reinforce_at_catalogue_scale(cuda):
     with open("gpurun_out/reinforce_scale.json", "w") as f:
         json.dump({"n_items": N, "hidden": H, "rows": B, "step_ms": [round(1e3 * x, 2) for x in times], "losses": losses,
                    "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}, f)
+
+
+def test_bf16_catalogue_mode_tracks_fp32(cuda):
+    """set_catalogue_dtype('bf16'): the catalogue GEMMs (policy head forward / backward, critic layer 1 over a dense action
+    distribution) run on bf16 MFMA; probabilities, log-probs and gradients stay within bf16 operand rounding of the fp32
+    path (measured and bounded, not parity)."""
+    import recnn_amd
+    from recnn_amd.nn import functional as F_hip
+    from tests.helpers import fro_err
+    S, N, H, B = 1290, 5000, 256, 33
+    torch.manual_seed(8)
+    net = recnn_amd.nn.DiscreteActor(S, N, H).cuda()
+    crit = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda().eval()
+    state = torch.randn(B, S, device="cuda")
+    act = torch.randint(0, N, (B,), device="cuda")
+    g = torch.randn(B, device="cuda")
+    out = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            F_hip.set_catalogue_dtype(mode)
+            net.zero_grad()
+            net.forced_actions[:] = [act]
+            probs = net.select_action(state=state)
+            lp = net.saved_log_probs.pop()
+            (lp * g).sum().backward()
+            with torch.no_grad():
+                q = crit(state, probs.detach())
+            out[mode] = (probs.detach().clone(), lp.detach().clone(), [p.grad.clone() for p in net.parameters()], q.clone())
+    finally:
+        F_hip.set_catalogue_dtype("fp32")
+    a, b = out["bf16"], out["fp32"]
+    assert fro_err(a[0], b[0]) < 2e-2 and float((a[1] - b[1]).abs().max()) < 5e-2
+    assert abs(float(a[0].sum(1).mean()) - 1.0) < 1e-5
+    for x, y in zip(a[2], b[2]):
+        assert fro_err(x, y) < 3e-2
+    assert fro_err(a[3], b[3]) < 2e-2
+    assert not torch.equal(a[0], b[0])          # the bf16 kernels did run
+
+
+def test_bf16_catalogue_mode_replays_reference_run_loosely(cuda, golden_dir):
+    from recnn_amd.nn import functional as F_hip
+    try:
+        F_hip.set_catalogue_dtype("bf16")
+        fx, losses, _ = _run_fixture("reinforce_basic", golden_dir, torch.optim.Adam)
+    finally:
+        F_hip.set_catalogue_dtype("fp32")
+    ref = fx["g"]["losses"]
+    assert np.isfinite(losses).all() and rel_err(losses[:, 1], ref[:, 1]) < 5e-2

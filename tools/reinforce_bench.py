@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--steps", type=int, default=31)
     ap.add_argument("--method", default="topk")
     ap.add_argument("--optimizer", default="ranger")
+    ap.add_argument("--dtype", default="fp32", help="compute type of the catalogue GEMMs: fp32 | bf16")
     a = ap.parse_args()
     recnn_amd.nn.algo.set_default_optimizer(a.optimizer)
+    F_hip.set_catalogue_dtype(a.dtype)
     N, S, H, B = a.items, 1290, a.hidden, a.rows
     torch.manual_seed(0)
     value = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda()
@@ -54,7 +56,7 @@ def main():
     ordinary = sorted(x for x, k in zip(times[1:], kinds[1:]) if not k)
     pol = [x for x, k in zip(times, kinds) if k]
     cyc = times[11:31] if len(times) >= 31 else times[1:]
-    print(json.dumps({"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer,
+    print(json.dumps({"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer, "dtype": a.dtype,
                       "ordinary_step_ms": round(ordinary[len(ordinary) // 2], 3), "policy_step_ms": [round(x, 2) for x in pol],
                       "it_per_s": round(1e3 * len(cyc) / sum(cyc), 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
