@@ -218,6 +218,7 @@ def main():
         L.load().recnn_tune_mlp_map(int(os.environ["RECNN_MLP_MAP"]))
     if os.environ.get("RECNN_MLP_PROBE"):
         L.load().recnn_tune_mlp_probe(int(os.environ["RECNN_MLP_PROBE"]))
+        L.load().recnn_tune_mlp_fault(int(os.environ["RECNN_MLP_PROBE"]) << 8)   # the 32-row kernel's probe bits (0x100: no layer-1 MMA, 0x200: no layer-1 DMA)
     if os.environ.get("RECNN_MLP_WAVES"):
         L.load().recnn_tune_mlp_waves(int(os.environ["RECNN_MLP_WAVES"]))
     if os.environ.get("RECNN_GEMM_WAVES"):

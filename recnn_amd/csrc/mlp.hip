@@ -32,6 +32,15 @@ constexpr int STAGE = A_BYTES + W_BYTES;      // 72 KB
 constexpr int PANEL_OFF = 2 * STAGE;          // 144 KB
 constexpr int PANEL_HALF = BM * 256;          // one k half (128 columns) of the 32 x 256 activation panel
 constexpr int LDS_TOTAL = PANEL_OFF + 2 * PANEL_HALF;  // 160 KB
+// layer 1 streams through its OWN ring geometry over the same 144 KB: 4 stages of 64-k slabs (rows of 128 bytes), so that two
+// slabs are in flight while a third is multiplied.  Micro-benchmark (tools/dma_bw.hip, 256 CUs streaming the same L2-resident
+// 720 KB matrix): back-to-back slabs reach 102-111 GB/s per CU, a lone 72 KB burst followed by its wait 70 GB/s -- the
+// 2-stage ring paid that latency bubble on every slab (in-kernel trace: 1,290 of 2,150 ticks per slab spent waiting).
+constexpr int KB1 = 64;                       // bf16 k elements per layer-1 slab row (128 bytes)
+constexpr int A1_BYTES = BM * 128;            // 4 KB
+constexpr int W1_BYTES = HP * 128;            // 32 KB
+constexpr int STAGE1 = A1_BYTES + W1_BYTES;   // 36 KB
+constexpr int NSTAGE1 = 4;                    // 144 KB = the two 72 KB stages of the later layers
 
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
   unsigned keep;
@@ -73,6 +82,29 @@ __device__ __forceinline__ void mma_slab(const unsigned char* sa, const unsigned
     for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + pos);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pos);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]),
+                                                              acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// the same for a layer-1 slab of the 4-stage ring: 64 k per slab, rows of 128 bytes, chunk c of row r at position
+// c ^ ((r >> 1) & 7) (conflict-free for the 4 x 16 lane groups of ds_read_b128).  k order unchanged: bit-identical sums.
+template <int TN>
+__device__ __forceinline__ void mma_slab64(const unsigned char* sa, const unsigned char* sb, f32x4 (&acc)[2][TN], int wn0, int fr,
+                                           int fg) {
+  const int sw = (fr >> 1) & 7;               // (rows 16 apart share it)
+#pragma unroll
+  for (int ks = 0; ks < KB1 / 32; ++ks) {
+    const int pos = ((ks * 4 + fg) ^ sw) * 16;
+    uint4 a[2], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 128 + pos);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 128 + pos);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -200,53 +232,55 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
   }
 
   // ------------------------------------------------------------------ layer 1
-  const int nt0 = P.K[0] / KB;
-  const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
-  // per-lane source pointers of the layer-1 DMA, advanced by one k slab (256 B) per issue: the DMA statements clobber
-  // "memory", so anything read from P.* inside the loop would be re-fetched from the kernel-argument segment every time
-  const int q_row = lane >> 4, q_pos = lane & 15;
-  const int l_row = wave * 4 + q_row;                          // image row of DMA instruction `wave` (+ 4 NW per further one)
-  const int l_c = (q_pos ^ (l_row & 15)) * 16;                 // (rows 4 NW apart share row & 15)
-  constexpr int JA = BM / (4 * NW) > 0 ? BM / (4 * NW) : 1;    // A-panel DMA instructions per wave (BM / 4 in all)
-  const bool a_wave = wave * 4 < BM;
-  const char* a_ptr[JA];
-  const char* a_ptr1[JA];
-#pragma unroll
-  for (int j = 0; j < JA; ++j) {
-    const int64_t gr = min(m0 + l_row + j * 4 * NW, row_max);
-    a_ptr[j] = (const char*)P.A[0] + gr * P.lda[0] * 2 + l_c;
-    a_ptr1[j] = P.nseg > 1 ? (const char*)P.A[1] + gr * P.lda[1] * 2 + l_c : a_ptr[j];
-  }
-  const int64_t w_step = (int64_t)4 * NW * P.ldw1 * 2;         // bytes between the rows of consecutive instructions of a wave
+  const int nt0 = P.K[0] / KB1;
+  const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB1 : 0);
+  // per-lane source pointers of the layer-1 DMA, advanced by one k slab (128 B) per issue: the DMA statements clobber
+  // "memory", so anything read from P.* inside the loop would be re-fetched from the kernel-argument segment every time.
+  // One wave instruction moves 8 rows x 128 B; instruction i of a slab covers image rows 8 i .. 8 i + 7.
+  const int q_row = lane >> 3, q_pos = lane & 7;
+  const int l_row = wave * 8 + q_row;                          // image row of DMA instruction `wave` (+ 8 NW per further one)
+  const int l_c = (q_pos ^ ((l_row >> 1) & 7)) * 16;           // (rows 8 NW apart share (row >> 1) & 7)
+  const bool a_wave = wave * 8 < BM;                           // waves 0..3 also carry the A panel (one instruction each)
+  const int64_t gr_a = min(m0 + l_row, row_max);               // (only meaningful on the A waves)
+  const char* a_ptr = (const char*)P.A[0] + gr_a * P.lda[0] * 2 + l_c;
+  const char* a_ptr1 = P.nseg > 1 ? (const char*)P.A[1] + gr_a * P.lda[1] * 2 + l_c : a_ptr;
+  constexpr int NIW = HP / (8 * NW);                           // W instructions per wave and slab
+  const int64_t w_step = (int64_t)8 * NW * P.ldw1 * 2;         // bytes between the rows of consecutive instructions of a wave
   const char* w_ptr = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + P.w1_col[0]) * 2 + l_c;
   const char* w_ptr1 = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + (P.nseg > 1 ? P.w1_col[1] : 0)) * 2 + l_c;
   auto issue1 = [&](int t) {
     if (t == nt0) {                                            // second contraction segment
       w_ptr = w_ptr1;
-#pragma unroll
-      for (int j = 0; j < JA; ++j) a_ptr[j] = a_ptr1[j];
+      a_ptr = a_ptr1;
     }
-    const unsigned sb = lds0 + (t & 1) * STAGE;
+    const unsigned sb = lds0 + (t & (NSTAGE1 - 1)) * STAGE1;
+    if (a_wave) dma16(a_ptr, sb + wave * 1024);
+    a_ptr += 2 * KB1;
 #pragma unroll
-    for (int j = 0; j < JA; ++j) {
-      if (a_wave) dma16(a_ptr[j], sb + (j * NW + wave) * 1024);
-      a_ptr[j] += 2 * KB;
-    }
-#pragma unroll
-    for (int j = 0; j < HP / (4 * NW); ++j) dma16(w_ptr + j * w_step, sb + A_BYTES + (j * NW + wave) * 1024);
-    w_ptr += 2 * KB;
+    for (int j = 0; j < NIW; ++j) dma16(w_ptr + j * w_step, sb + A1_BYTES + (j * NW + wave) * 1024);
+    w_ptr += 2 * KB1;
   };
   issue1(0);
+  if (nt > 1) issue1(1);
+  if (nt > 2) issue1(2);
   MLP_STAMP(1);
   for (int t = 0; t < nt; ++t) {
-    if (t == 2) MLP_STAMP(10);
-    if (t == 7) MLP_STAMP(11);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // slab t landed for every wave; slab t-1 is no longer being read
-    if (t == 7) MLP_STAMP(12);
-    if (t + 1 < nt) issue1(t + 1);
-    const unsigned char* st = lds + (t & 1) * STAGE;
-    mma_slab<TNH>(st, st + A_BYTES, acc, wave * (16 * TNH), fr, fg);
+    // slab t of THIS wave has landed once at most the DMAs of the younger slabs in flight are outstanding (the loop holds
+    // no other vector-memory operation; A waves issue one instruction more per slab)
+    const int younger = min(NSTAGE1 - 2, nt - 1 - t);
+    if (a_wave) {
+      if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NIW + 1)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // slab t landed for every wave; the stage of slab t-1 (= slab t+3's) is no longer being read
+    if (t + NSTAGE1 - 1 < nt && !(batch.fault & 0x200)) issue1(t + NSTAGE1 - 1);
+    const unsigned char* st = lds + (t & (NSTAGE1 - 1)) * STAGE1;
+    if (!(batch.fault & 0x100)) mma_slab64<TNH>(st, st + A1_BYTES, acc, wave * (16 * TNH), fr, fg);
   }
   MLP_STAMP(2);
   if (P.part_out) {
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
       for (int tm = 0; tm < 2; ++tm) *(f32x4*)(P.part_out + (int64_t)(m0 + tm * 16 + fr) * HP + n0) = acc[tm][tn];
     }
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
-    if (tid == 0 && batch.fault != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
+    if (tid == 0 && (batch.fault & 3) != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // one L2 write-back
     MLP_STAMP(9);
     return;
   }
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fwd_kernel(const MlpBatch batch, 
       if (lane == 0 && m0 + row < P.rows) {
         const float qv = s + P.b3[0];
         P.q[m0 + row] = qv;
-        if (P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx].q_slot && batch.fault != 2)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
+        if (P.cbwd_idx >= 0 && batch.cbwd[P.cbwd_idx].q_slot && (batch.fault & 3) != 2)   // hand Q(s, a) to the workgroup that evaluates the head (value = flag)
           __hip_atomic_store((uint32_t*)batch.cbwd[P.cbwd_idx].q_slot + m0 + row, __builtin_bit_cast(uint32_t, qv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -613,7 +647,7 @@ int mlp_waves() { return g_mlp_waves; }
 int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   MlpBatch b = b_in;
   b.fault = g_mlp_fault;
-  if (g_mlp_fault) b.spin_limit = 1 << 12;
+  if (g_mlp_fault & 3) b.spin_limit = 1 << 12;
   int rows = 0;
   for (int i = 0; i < nprob; ++i) {
     const MlpProb& p = b.p[i];
@@ -628,7 +662,7 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
       return RECNN_E_INVALID;
     }
     for (int g = 0; g < p.nseg; ++g)
-      if (p.K[g] % KB || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
+      if (p.K[g] % KB1 || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
   if (g_mlp_kernel == 1 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);

@@ -1,0 +1,108 @@
+// dma_bw.hip -- micro-benchmark: how fast can ONE CU stream an L2-resident weight matrix?  (decides what bounds layer 1 of
+// csrc/mlp.hip).  Every workgroup (1 per CU, 1024 threads) streams the same [256 x K] bf16 matrix slab by slab.
+//   mode 0: global_load_lds_dwordx4, 4 rows x 256 B per wave instruction (the kernel's pattern), D slabs in flight
+//   mode 1: same, source pre-tiled (1 KiB contiguous per wave instruction)
+//   mode 2: global_load_dwordx4 into registers, 4 rows x 256 B per wave instruction
+//   mode 3: mode 2 with 1 KiB contiguous per wave instruction
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/_build/dma_bw tools/dma_bw.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+template <int MODE, int SLAB_ROWS, int DEPTH>
+__global__ __launch_bounds__(1024) void stream_kernel(const char* w, int ld_bytes, int nslab, int reps, unsigned long long* ticks, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NI = SLAB_ROWS / 64;                 // instructions per wave per slab (16 waves x 4 rows)
+  constexpr int STAGE = SLAB_ROWS * 256;
+  const int q_row = lane >> 4, q_pos = lane & 15;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 acc = {0, 0, 0, 0};
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int t = 0; t < nslab; ++t) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int inst = j * 16 + wave;              // 4 rows each
+        const char* src;
+        if (MODE == 0 || MODE == 2) src = w + (int64_t)(inst * 4 + q_row) * ld_bytes + t * 256 + q_pos * 16;
+        else src = w + ((int64_t)t * SLAB_ROWS * 256) + inst * 1024 + lane * 16;
+        if (MODE < 2) {
+          dma16(src, lds0 + (t % DEPTH) * STAGE + inst * 1024);
+        } else {
+          u32x4 v;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+          acc ^= v;      // (consumed only after the explicit waits below; 16 loads in flight need 64 VGPRs)
+        }
+      }
+      if (MODE < 2) {
+        // keep DEPTH-1 slabs in flight
+        if (t >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NI) : "memory");
+      } else {
+        if (t >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NI) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+  if (acc.x == 0x12345678u) sink[0] = 1.f;
+}
+
+template <int MODE, int SLAB_ROWS, int DEPTH>
+void run(const char* name, const char* w, int ld_bytes, int nslab, int nwg) {
+  unsigned long long* ticks;
+  float* sink;
+  hipMalloc(&ticks, nwg * sizeof(*ticks));
+  hipMalloc(&sink, 4);
+  const int reps = 8;
+  const int lds_bytes = DEPTH * SLAB_ROWS * 256;
+  hipFuncSetAttribute((const void*)stream_kernel<MODE, SLAB_ROWS, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((stream_kernel<MODE, SLAB_ROWS, DEPTH>), dim3(nwg), dim3(1024), lds_bytes, 0, w, ld_bytes, nslab, reps, ticks, sink);
+    hipEventRecord(e1);
+    hipError_t er = hipEventSynchronize(e1);
+    if (er != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s: FAILED %s\n", name, hipGetErrorString(er)); return; }
+  }
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(nwg);
+  hipMemcpy(h.data(), ticks, nwg * sizeof(*ticks), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto v : h) mean += (double)v;
+  mean /= nwg;
+  const double bytes = (double)reps * nslab * SLAB_ROWS * 256;
+  printf("%-52s wgs %3d  slab %3d KB depth %d: %8.0f ticks/WG, %6.1f B/tick/CU, kernel %7.1f us -> %6.1f GB/s per CU, %6.2f TB/s chip\n", name, nwg,
+         SLAB_ROWS / 4, DEPTH, mean, bytes / mean, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * nwg / (ms * 1e-3) / 1e12);
+  hipFree(ticks); hipFree(sink);
+}
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const int nwg = argc > 1 ? atoi(argv[1]) : 256;
+  const int K = 1408, rows = 256;
+  char* w;
+  hipMalloc(&w, (size_t)rows * K * 2 + 4096);
+  hipMemset(w, 1, (size_t)rows * K * 2 + 4096);
+  const int nslab = K / 128;
+  run<0, 256, 2>("lds-dma 4x256B rows", w, K * 2, nslab, nwg);
+  run<1, 256, 2>("lds-dma 1KiB contiguous", w, K * 2, nslab, nwg);
+  run<0, 128, 4>("lds-dma 4x256B rows (half slabs)", w, K * 2, nslab, nwg);
+  run<0, 64, 8>("lds-dma 4x256B rows (quarter slabs)", w, K * 2, nslab, nwg);
+  run<2, 256, 2>("global_load->vgpr 4x256B rows", w, K * 2, nslab, nwg);
+  run<3, 256, 2>("global_load->vgpr 1KiB contiguous", w, K * 2, nslab, nwg);
+  run<2, 256, 4>("global_load->vgpr 4x256B rows, deeper", w, K * 2, nslab, nwg);
+  return 0;
+}
