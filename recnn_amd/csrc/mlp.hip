@@ -21,16 +21,14 @@
 // (applied on the DMA source address / the panel write address), so MFMA fragment reads are bank-conflict free.
 // Whole 160 KiB of LDS per workgroup (1 workgroup per CU): 2 x (8 KB A + 64 KB W) + 16 KB panel.
 #include "mlp.h"
+#include "mlp_panel.h"
 
 namespace {
-constexpr int BM = 32;            // rows per workgroup
-constexpr int HP = 256;           // hidden width handled (4 waves x 64 columns)
 constexpr int KB = 128;           // bf16 k elements per stage row (256 bytes)
 constexpr int A_BYTES = BM * 256;             // 8 KB
 constexpr int W_BYTES = HP * 256;             // 64 KB
 constexpr int STAGE = A_BYTES + W_BYTES;      // 72 KB
 constexpr int PANEL_OFF = 2 * STAGE;          // 144 KB
-constexpr int PANEL_HALF = BM * 256;          // one k half (128 columns) of the 32 x 256 activation panel
 constexpr int LDS_TOTAL = PANEL_OFF + 2 * PANEL_HALF;  // 160 KB
 // layer 1 streams through its OWN ring geometry over the same 144 KB: 4 stages of 64-k slabs (rows of 128 bytes), so that two
 // slabs are in flight while a third is multiplied.  Micro-benchmark (tools/dma_bw.hip, 256 CUs streaming the same L2-resident
@@ -41,15 +39,6 @@ constexpr int A1_BYTES = BM * 128;            // 4 KB
 constexpr int W1_BYTES = HP * 128;            // 32 KB
 constexpr int STAGE1 = A1_BYTES + W1_BYTES;   // 36 KB
 constexpr int NSTAGE1 = 4;                    // 144 KB = the two 72 KB stages of the later layers
-
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst_uniform)
-      : "memory");
-}
 
 // DMA `nrows` rows x 256 bytes (k slab [k0, k0+128) of a bf16 matrix with row pitch ld elements) into LDS at
 // lds_dst; rows beyond row_max are clamped (their results are never stored).  4 rows per wave instruction.
@@ -114,57 +103,6 @@ __device__ __forceinline__ void mma_slab64(const unsigned char* sa, const unsign
   }
 }
 
-// hidden-layer epilogue: bias + relu + dropout -> bf16 into the LDS panel (the next layer's A operand).  Kept lean on purpose
-// (in-kernel trace + ISA count: the first version spent 630 instructions per wave here, 80 per element, mostly on per-element
-// exec-masked 2-byte global stores and address arithmetic -- 7k ticks per epilogue, a third of the workgroup's time): the
-// activations now reach global memory from the finished panel as whole rows (panel_to_global), and the four rows of an
-// accumulator register group differ only by r in the swizzled chunk position ((c ^ (rb | r)) = (c ^ rb) ^ r).
-template <int TNH>
-__device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x4 (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
-                                                int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
-                                                unsigned char* panel, uint32_t* gbits = nullptr) {
-  uint32_t bits = 0;
-#pragma unroll
-  for (int tn = 0; tn < TNH; ++tn) {
-    const int n0 = wave * (16 * TNH) + tn * 16 + fg * 4;      // this lane's four columns n0 .. n0 + 3
-    // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
-    unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
-    const int c = (n0 & 127) >> 3;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int row = tm * 16 + fr, m = m0 + row;
-      uint32_t word = 0;
-      if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n0 >> 2));
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = fmaxf(acc[tm][tn][r] + bias_v[tn][r], 0.f);
-        if (mask_mode == RECNN_MASK_EXTERNAL) v[r] = (m < rows && n0 + r < H && mask[(int64_t)m * ld_mask + n0 + r]) ? v[r] * 2.f : 0.f;
-        else if (mask_mode == RECNN_MASK_HASH) v[r] = mask_keep(word, m & 3, r) ? v[r] * 2.f : 0.f;
-        if (n0 + r >= H) v[r] = 0.f;
-      }
-      const uint32_t lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
-      // gate bit = the ROUNDED activation is positive (what the backward kernels test on the stored bf16 value)
-      if (lo & 0x7FFFu) bits |= 1u << (tn * 8 + tm * 4 + 0);
-      if (lo & 0x7FFF0000u) bits |= 1u << (tn * 8 + tm * 4 + 1);
-      if (hi & 0x7FFFu) bits |= 1u << (tn * 8 + tm * 4 + 2);
-      if (hi & 0x7FFF0000u) bits |= 1u << (tn * 8 + tm * 4 + 3);
-      *(uint2*)(col + row * 256 + ((c ^ fr) << 4)) = make_uint2(lo, hi);   // row & 15 == fr
-    }
-  }
-  if (gbits) *gbits = bits;
-}
-
-// the finished 32 x 256 panel -> global [rows, ldg] bf16: whole 512-byte rows, one 16-byte chunk per thread and pass
-template <int NW>
-__device__ __forceinline__ void panel_to_global(const unsigned char* panel, bf16_t* gout, int64_t ldg, int m0, int rows, int tid) {
-#pragma unroll
-  for (int j = 0; j < (BM * 32) / (NW * 64); ++j) {
-    const int idx = tid + j * NW * 64, row = idx >> 5, cc = idx & 31;
-    const uint4 v = *(const uint4*)(panel + (cc >> 4) * PANEL_HALF + row * 256 + (((cc & 15) ^ (row & 15)) << 4));
-    if (m0 + row < rows) *(uint4*)(gout + (int64_t)(m0 + row) * ldg + cc * 8) = v;
-  }
-}
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 }  // namespace
 
@@ -610,12 +548,14 @@ int mlp64_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
 int mlp64_map_mode();
 int mlpr_init();
 int mlpr_launch(const MlpBatch& b, int nprob, int rows, int map_mode, hipStream_t s);
+int mlps_init();
+int mlps_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
 // which fused-forward kernel runs: 0 = mlp.hip (32-row panels, weights through an LDS-DMA ring; the default: 32.4 us for the
 // DDPG forward group at 2048 rows), 1 = mlp64.hip (64-row panels, one 3-deep DMA ring: 47 us there, 84 vs 88 us at TD3 / 4096
 // rows), 2 = mlpr.hip (64-row panels, weights straight into registers: 70 us).  All three agree bit for bit; DESIGN.md
 // section 5 has the in-kernel phase traces that explain the ranking.
 static int g_mlp_kernel = 0;
-extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 2) ? k : 0; }
+extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 3) ? k : 0; }
 // rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
 // mlp64.hip (bit-identical results; faster at TD3 / 4096 rows, 47 us at DDPG / 2048 rows: see DESIGN.md section 5)
 extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_kernel = rows == 64 ? 1 : 0; }
@@ -632,6 +572,7 @@ int mlp_init() {
   int rc = mlp64_init();
   if (rc) return rc;
   if ((rc = mlpr_init())) return rc;
+  if ((rc = mlps_init())) return rc;
   rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL),
                            "mlp_fwd_kernel<4> attr");
   if (rc) return rc;
@@ -667,6 +608,11 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   if (rows <= 0 || nprob <= 0) return 0;
   if (g_mlp_kernel == 1 && g_mlp_waves == 16) return mlp64_launch(b, nprob, rows, s);
   if (g_mlp_kernel == 2 && g_mlp_waves == 16) return mlpr_launch(b, nprob, rows, mlp64_map_mode(), s);
+  if (g_mlp_kernel == 3 && g_mlp_waves == 16) {
+    bool ok = true;                                            // (mlps.hip wants hidden widths that are multiples of 4)
+    for (int i = 0; i < nprob; ++i) ok = ok && !(b.p[i].H & 3) && b.p[i].H >= 4;
+    if (ok) return mlps_launch(b, nprob, rows, s);
+  }
   if (g_mlp_waves == 16)
     hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3((rows + BM - 1) / BM, nprob), dim3(1024), LDS_TOTAL, s, b, g_mlp32_trace);
   else if (g_mlp_waves == 8)

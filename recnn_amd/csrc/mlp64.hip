@@ -621,10 +621,12 @@ extern "C" void recnn_tune_mlp_map(int mode) { g_mlp_map = mode == 2 ? 2 : 0; }
 static unsigned long long* g_mlp_trace = nullptr;
 void mlpr_set_trace(void* p);
 void mlp32_set_trace(void* p);
+void mlps_set_trace(void* p);
 extern "C" void recnn_tune_mlp_trace(void* device_u64_wg16) {
   g_mlp_trace = (unsigned long long*)device_u64_wg16;
   mlpr_set_trace(device_u64_wg16);
   mlp32_set_trace(device_u64_wg16);
+  mlps_set_trace(device_u64_wg16);
 }
 int mlp64_map_mode();
 int mlp64_map_mode() { return g_mlp_map; }

@@ -303,7 +303,7 @@ def test_mlp_forward_64_row_panels_equal_32_row_panels(cuda, algo, B, steps):
              "done": (torch.rand(B, generator=gen) < 0.1).float()}
     outs = []
     try:
-        for kern, wmap in ((0, 0), (1, 0), (1, 2), (2, 0), (2, 2)):
+        for kern, wmap in ((0, 0), (1, 0), (1, 2), (2, 0), (2, 2), (3, 0)):    # 3 = csrc/mlps.hip (one continuous weight stream)
             L.load().recnn_tune_mlp_kernel(kern)
             L.load().recnn_tune_mlp_map(wmap)
             eng = StepEngine(algo, S, A, H, B, dtype="bf16", mask_mode="hash", seed=31)

@@ -34,7 +34,7 @@ eng.step(B, True, 1)
 torch.cuda.synchronize()
 L.load().recnn_tune_mlp_trace(None)
 tr = trace.cpu().numpy()
-npanel = B // (32 if kernel == 0 else 64)
+npanel = B // (32 if kernel in (0, 3) else 64)
 names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
 t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
 t_end = tr[:npanel * 4, 9].max()
@@ -44,10 +44,13 @@ labels = {13: "L2 slab 2 before wait", 14: "L2 slab 2 after wait+barrier", 15: "
 for pi, nm in enumerate(names):
     rows = tr[pi * npanel:(pi + 1) * npanel]
     print(f"== {nm}: start offset vs launch start: median {np.median(rows[:, 0] - t_start):.0f}, max {np.max(rows[:, 0] - t_start):.0f} ticks")
-    for k in (1, 10, 11, 12, 2, 3, 13, 14, 4, 15, 5, 6, 7, 9, 16 + 2, 16 + 3, 16 + 13, 16 + 14, 16 + 4, 16 + 15, 16 + 5, 16 + 6, 16 + 9):
+    for k in ((1, 2, 3, 4, 5, 6, 7, 9) if kernel == 3 else (1, 10, 11, 12, 2, 3, 13, 14, 4, 15, 5, 6, 7, 9, 16 + 2, 16 + 3, 16 + 13, 16 + 14, 16 + 4, 16 + 15, 16 + 5, 16 + 6, 16 + 9)):
         v = rows[:, k]
         if (v > 0).all():
             print(f"   {('w15 ' if k >= 16 else '') + labels[k % 16 if k >= 16 else k]:34s} median {np.median(v - rows[:, 0]):9.0f}  max {np.max(v - rows[:, 0]):9.0f} ticks since workgroup start")
-    if (rows[:, 11] > 0).all():
+    if kernel == 3 and (rows[:, 15] > 0).all():
+        print("   L2 slab 1: enter %.0f -> waited %.0f -> barrier %.0f -> issued %.0f -> mma done %.0f -> slab 2 mma done %.0f (ticks since workgroup start)"
+              % tuple(np.median(rows[:, k] - rows[:, 0]) for k in (10, 11, 12, 13, 14, 15)))
+    elif (rows[:, 11] > 0).all():
         nsl = 5 if kernel == 0 else 10
         print(f"   per L1 slab: {np.median((rows[:, 11] - rows[:, 10]) / nsl):.0f} ticks; wait+barrier of one slab: {np.median(rows[:, 12] - rows[:, 11]):.0f}")
