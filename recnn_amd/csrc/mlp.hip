@@ -610,7 +610,11 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   if (g_mlp_kernel == 2 && g_mlp_waves == 16) return mlpr_launch(b, nprob, rows, mlp64_map_mode(), s);
   if (g_mlp_kernel == 3 && g_mlp_waves == 16) {
     bool ok = true;                                            // (mlps.hip wants hidden widths that are multiples of 4)
-    for (int i = 0; i < nprob; ++i) ok = ok && !(b.p[i].H & 3) && b.p[i].H >= 4;
+    for (int i = 0; i < nprob; ++i) {
+      const MlpProb& p = b.p[i];
+      ok = ok && !(p.H & 3) && p.H >= 4 && (!p.W3 || p.ldw3 == p.ldw2);
+      for (int t = 0; t < (p.W3 ? p.n_tail : 0); ++t) ok = ok && b.tail[t].ldw2 == p.ldw2;   // one lane offset serves every 256-pitch matrix
+    }
     if (ok) return mlps_launch(b, nprob, rows, s);
   }
   if (g_mlp_waves == 16)

@@ -32,6 +32,13 @@ constexpr int LDS_TOTAL = PANEL_OFF + 2 * PANEL_HALF;  // 160 KB
 constexpr int OW = 8;                         // waves of the actor's 128-column output layer
 constexpr int RW = BM / NW;                   // critic head rows per wave
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS at lds_dst + 16 lane.
+// M0 is written directly (the kernel uses no other M0 consumer: no movrel, no GWS, no LDS-direct loads); no "memory"
+// clobber: the ordering points are the waits and barriers of the consumer, and the argument block stays in registers.
+__device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "m0");
+}
+
 // wait until at most `n` of this wave's vector-memory operations are outstanding (n is wave-uniform, 0 .. 2 (NIW + 1))
 __device__ __forceinline__ void wait_vm(int n) {
   switch (n) {
@@ -124,35 +131,48 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB1 : 0);
   const int n_tail = P.W3 ? P.n_tail : 0;
 
-  // per-lane DMA geometry: one wave instruction moves 8 rows x 128 B; instruction i of a slab covers image rows 8 i .. 8 i + 7
+  // per-lane DMA geometry: one wave instruction moves 8 rows x 128 B; instruction i of a slab covers image rows 8 i .. 8 i + 7.
+  // Addresses are (uniform 64-bit base) + (per-lane 32-bit offset): the saddr form of global_load_lds keeps the address
+  // arithmetic of a slab to one VALU add per stream (16 waves issue every instruction of this bookkeeping: at one SALU / VALU
+  // issue slot per SIMD and 4 cycles, an instruction per wave costs 16 cycles of the CU -- the phases after layer 1 were
+  // bound by exactly that, not by bytes or flops).
   const int q_row = lane >> 3, q_pos = lane & 7;
   const int l_row = wave * 8 + q_row;                          // image row of this wave's first instruction (+ 128 for the second)
   const int l_c = (q_pos ^ ((l_row >> 1) & 7)) * 16;           // source chunk behind LDS position q_pos (same for row + 128)
   const bool a_wave = wave * 8 < BM;                           // waves 0..3 also carry the layer-1 A panel
-  const int64_t gr_a = min(m0 + l_row, row_max);
-  const char* a_ptr = (const char*)P.A[0] + gr_a * P.lda[0] * 2 + l_c;
-  const char* a_ptr1 = P.nseg > 1 ? (const char*)P.A[1] + gr_a * P.lda[1] * 2 + l_c : a_ptr;
-  const int64_t w_step = (int64_t)128 * P.ldw1 * 2;
-  const char* w_ptr = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + P.w1_col[0]) * 2 + l_c;
-  const char* w_ptr1 = (const char*)P.W1 + ((int64_t)l_row * P.ldw1 + (P.nseg > 1 ? P.w1_col[1] : 0)) * 2 + l_c;
+  const int gr_a = min(m0 + l_row, row_max);
+  unsigned voff_a = (unsigned)(gr_a * (int)P.lda[0] * 2 + l_c);                       // into A[0] (then A[1])
+  unsigned voff_w = (unsigned)((l_row * (int)P.ldw1 + P.w1_col[0]) * 2 + l_c);         // into W1, rows l_row / l_row + 128
+  const unsigned voff_a1 = (unsigned)(gr_a * (int)P.lda[P.nseg > 1 ? 1 : 0] * 2 + l_c);
+  const unsigned voff_w1 = (unsigned)((l_row * (int)P.ldw1 + (P.nseg > 1 ? P.w1_col[1] : 0)) * 2 + l_c);
+  const unsigned voff_sq = (unsigned)(l_row * (int)P.ldw2 * 2 + l_c);                  // into W2 / W3 / a chained critic's W2 (same pitch: mlp_launch)
+  const char* a_base = (const char*)P.A[0];
+  const char* w_base0 = (const char*)P.W1;
+  const char* w_base1 = w_base0 + (int64_t)128 * P.ldw1 * 2;
+  const unsigned wave_kb = wave * 1024;
+
   int issued = 0;     // slabs issued so far (stream index of the next one)
-  // layer-1 slab: A rows (waves 0..3) + 256 W1 rows, k-slab = the running pointers
+  // layer-1 slab: A rows (waves 0..3) + 256 W1 rows; the lane offsets run along k
   auto issue_l1 = [&]() {
     const int i = issued++;
-    if (i == nt0) { w_ptr = w_ptr1; a_ptr = a_ptr1; }          // second contraction segment
-    const unsigned sb = lds0 + (i & (NST - 1)) * STAGE1;
-    if (a_wave) if constexpr (!(PROBE & 2)) dma16(a_ptr, sb + wave * 1024);
-    a_ptr += 2 * KB1;
-    if constexpr (!(PROBE & 2)) dma16(w_ptr, sb + A1_BYTES + wave * 1024);
-    if constexpr (!(PROBE & 2)) dma16(w_ptr + w_step, sb + A1_BYTES + (NW + wave) * 1024);
-    w_ptr += 2 * KB1;
+    if (i == nt0) { voff_w = voff_w1; voff_a = voff_a1; a_base = (const char*)P.A[P.nseg > 1 ? 1 : 0]; }   // second contraction segment
+    const unsigned sb = lds0 + (i & (NST - 1)) * STAGE1 + wave_kb;
+    if constexpr (!(PROBE & 2)) {
+      if (a_wave) dma_s(voff_a, a_base, sb);
+      dma_s(voff_w, w_base0, sb + A1_BYTES);
+      dma_s(voff_w, w_base1, sb + A1_BYTES + NW * 1024);
+    }
+    voff_a += 2 * KB1;
+    voff_w += 2 * KB1;
   };
-  // k-slab q of a bf16 matrix [256 rows, ld]: rows l_row and l_row + 128 of this lane
-  auto issue_mat = [&](const void* base, int64_t ld, int q) {
-    const unsigned wb = lds0 + (issued++ & (NST - 1)) * STAGE1 + A1_BYTES + wave * 1024;
-    const char* p = (const char*)base + ((int64_t)l_row * ld + q * KB1) * 2 + l_c;
-    if constexpr (!(PROBE & 2)) dma16(p, wb);
-    if constexpr (!(PROBE & 2)) dma16(p + 256 * ld, wb + NW * 1024);
+  // k-slab q of a bf16 matrix [256 rows, ld]: rows l_row and l_row + 128 of this lane (voff = lane offset into k-slab 0)
+  auto issue_mat = [&](const void* base, int64_t ld, unsigned voff, int q) {
+    const unsigned wb = lds0 + (issued++ & (NST - 1)) * STAGE1 + A1_BYTES + wave_kb;
+    const char* b0 = (const char*)base + q * (2 * KB1);
+    if constexpr (!(PROBE & 2)) {
+      dma_s(voff, b0, wb);
+      dma_s(voff, b0 + 256 * ld, wb + NW * 1024);
+    }
   };
   // the producers' parts must be complete before their DMA is issued: one wave-0 acquire per chained critic, taken when its
   // part slab comes up for issue (three slabs before it is consumed: the producers -- lower workgroup ids, layer 1 only --
@@ -174,33 +194,34 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   const int npost = P.part_out ? 0 : 4 + (P.W3 ? 2 + 7 * n_tail : 0);
   auto issue_post = [&](int k) {
     if (k >= npost) return;
-    if (k < 4) { issue_mat(P.W2, P.ldw2, k); return; }
+    if (k < 4) { issue_mat(P.W2, P.ldw2, voff_sq, k); return; }
     if (k < 6) {
-      const unsigned wb = lds0 + (issued++ & (NST - 1)) * STAGE1 + A1_BYTES + wave * 1024;
-      const char* p = (const char*)P.W3 + ((int64_t)l_row * P.ldw3 + 2 * (k - 4) * KB1) * 2 + l_c;
-      if constexpr (!(PROBE & 2)) dma16(p, wb);
-      if constexpr (!(PROBE & 2)) dma16(p + 2 * KB1, wb + NW * 1024);
+      const unsigned wb = lds0 + (issued++ & (NST - 1)) * STAGE1 + A1_BYTES + wave_kb;
+      const char* b0 = (const char*)P.W3 + 2 * (k - 4) * (2 * KB1);
+      if constexpr (!(PROBE & 2)) {
+        dma_s(voff_sq, b0, wb);
+        dma_s(voff_sq, b0 + 2 * KB1, wb + NW * 1024);
+      }
       return;
     }
     const int ti = k >= 13 ? 1 : 0, r = k - 6 - 7 * ti;
     const MlpTail& T = batch.tail[ti];
     if (r == 0) {                                              // the producer's fp32 layer-1 part of these 32 rows, row i = 1 KB
       acquire_part(ti);
-      const unsigned sb = lds0 + (issued++ & (NST - 1)) * STAGE1;
-      const char* src = (const char*)(T.part + (int64_t)m0 * HP) + wave * 1024 + lane * 16;
-      if constexpr (!(PROBE & 2)) dma16(src, sb + A1_BYTES + wave * 1024);
-      if constexpr (!(PROBE & 2)) dma16(src + NW * 1024, sb + A1_BYTES + (NW + wave) * 1024);
-      // ... and the critic's b1 | b2 | w3 (fp32, one KB each) into the idle A part of the same stage: the epilogues and the
-      // q dots read them from LDS (kept in registers from the start they cost 24 VGPRs the kernel does not have).  One extra
-      // DMA on waves 0..2: their vmcnt waits get one instruction stricter while this slab is among the younger ones.
-      if (wave < 3) {
-        const float* v = wave == 0 ? T.b1 : (wave == 1 ? T.b2 : T.w3row);
-        if constexpr (!(PROBE & 2)) dma16((const char*)(v + min(lane * 4, P.H - 4)), sb + wave * 1024);
+      const unsigned sb = lds0 + (issued++ & (NST - 1)) * STAGE1 + wave_kb;
+      const char* src = (const char*)(T.part + (int64_t)m0 * HP) + wave_kb;
+      if constexpr (!(PROBE & 2)) {
+        dma_s(lane * 16, src, sb + A1_BYTES);
+        dma_s(lane * 16, src + NW * 1024, sb + A1_BYTES + NW * 1024);
+        // ... and the critic's b1 | b2 | w3 (fp32, one KB each) into the idle A part of the same stage: the epilogues and the
+        // q dots read them from LDS (kept in registers from the start they cost 24 VGPRs the kernel does not have).  One
+        // extra DMA on waves 0..2: their vmcnt waits get one instruction stricter while this slab is among the younger ones.
+        if (wave < 3) dma_s(min(lane * 4, P.H - 4) * 4, wave == 0 ? T.b1 : (wave == 1 ? T.b2 : T.w3row), sb);
       }
     } else if (r < 3) {
-      issue_mat(T.W1a, T.ldw1, r - 1);
+      issue_mat(T.W1a, T.ldw1, (unsigned)(l_row * (int)T.ldw1 * 2 + l_c), r - 1);
     } else {
-      issue_mat(T.W2, T.ldw2, r - 3);
+      issue_mat(T.W2, T.ldw2, voff_sq, r - 3);
     }
   };
 
@@ -211,16 +232,11 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   auto next_post = [&]() -> const unsigned char* {
     const int c = consumed++;
     const int y = issued - c - 1;
-    const bool stamp = trace && c == nt + 1;
-    if (stamp) MLPS_STAMP(10);
     if (y >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if (y == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (stamp) MLPS_STAMP(11);
     __builtin_amdgcn_s_barrier();  // slab c landed for every wave; everybody is done with slab c - 1 and with its LDS writes so far
-    if (stamp) MLPS_STAMP(12);
     issue_post(issued - nt);
-    if (stamp) MLPS_STAMP(13);
     return lds + (c & (NST - 1)) * STAGE1;
   };
 
@@ -315,8 +331,6 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
     const unsigned char* st = next_post();                     // (its barrier also completes the h1 panel for q = 0)
     if (q == 0 && P.h1) panel_to_global<NW>(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
     if constexpr (!(PROBE & 1)) mma_panel(panel, q, st + A1_BYTES, acc, wave * 16, fr, fg);
-    if (q == 1) MLPS_STAMP(14);
-    if (q == 2) MLPS_STAMP(15);
   }
   MLPS_STAMP(4);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

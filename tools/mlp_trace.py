@@ -25,6 +25,7 @@ eng.set_counters()
 eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
 trace = torch.zeros(1024, 32, dtype=torch.int64, device=dev)
 L.load().recnn_tune_mlp_probe(probe)
+L.load().recnn_tune_mlp_fault(probe << 8)
 L.load().recnn_tune_mlp_kernel(kernel)
 for t in range(5):
     eng.step(B, True, 1)
