@@ -550,15 +550,16 @@ int mlpr_init();
 int mlpr_launch(const MlpBatch& b, int nprob, int rows, int map_mode, hipStream_t s);
 int mlps_init();
 int mlps_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s);
-// which fused-forward kernel runs: 0 = mlp.hip (32-row panels, weights through an LDS-DMA ring; the default: 32.4 us for the
-// DDPG forward group at 2048 rows), 1 = mlp64.hip (64-row panels, one 3-deep DMA ring: 47 us there, 84 vs 88 us at TD3 / 4096
-// rows), 2 = mlpr.hip (64-row panels, weights straight into registers: 70 us).  All three agree bit for bit; DESIGN.md
-// section 5 has the in-kernel phase traces that explain the ranking.
-static int g_mlp_kernel = 0;
-extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 3) ? k : 0; }
+// which fused-forward kernel runs: 3 = mlps.hip (32-row panels, every operand of a workgroup as ONE weight stream through a
+// 4-stage ring; the default: 25.3 us for the DDPG forward group at 2048 rows), 0 = mlp.hip (32-row panels, per-phase bursts:
+// 30.4 us; also the fallback for ragged hidden widths), 1 = mlp64.hip (64-row panels, 3-deep ring: 47 us), 2 = mlpr.hip
+// (64-row panels, weights straight into registers: 70 us).  All four agree bit for bit; DESIGN.md section 5b has the
+// in-kernel phase traces that explain the ranking.
+static int g_mlp_kernel = 3;
+extern "C" void recnn_tune_mlp_kernel(int k) { g_mlp_kernel = (k >= 0 && k <= 3) ? k : 3; }
 // rows per workgroup: 32 = the kernel in this file (default: 32.4 us for the DDPG forward group at 2048 rows), 64 =
 // mlp64.hip (bit-identical results; faster at TD3 / 4096 rows, 47 us at DDPG / 2048 rows: see DESIGN.md section 5)
-extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_kernel = rows == 64 ? 1 : 0; }
+extern "C" void recnn_tune_mlp_panel(int rows) { g_mlp_kernel = rows == 64 ? 1 : 3; }
 static unsigned long long* g_mlp32_trace = nullptr;
 void mlp32_set_trace(void* p) { g_mlp32_trace = (unsigned long long*)p; }
 static int g_mlp_waves = 16;

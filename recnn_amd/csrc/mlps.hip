@@ -225,6 +225,11 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
     }
   };
 
+  // A parts after layer 1: the chained critics' constants land in the A parts of their part slabs' stages, ps0 and ps0 + 3
+  // (bytes 0 .. 3071); the action slabs take the A parts of the two other stages, the Q' scratch the last KB of stage ps0's.
+  // (Issuing the part later than three slabs ahead -- to take the producers' acquire off the early chain -- was tried with
+  // placeholder transfers in its slot: 25.3 -> 26.8 us, the late transfer is exposed; kept as is.)
+  const int ps0 = (nt + 6) & (NST - 1);
   int consumed = 0;
   // The next slab of the sequence after layer 1: waits until it has landed for every wave (every slab after layer 1 is two
   // DMA instructions per wave, so "at most 2 y outstanding" leaves the y younger slabs in flight; global stores issued
@@ -381,14 +386,14 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
               if (no + r < P.out_dim) ((bf16_t*)P.out)[(int64_t)m * P.ldo + no + r] = (bf16_t)((r < 2 ? packed.x : packed.y) >> ((r & 1) * 16));
           }
         }
-        // the chained critics read the action as two 64-k A slabs: quarter q in the (idle since layer 1) A part of stage 1 + q
+        // the chained critics read the action as two 64-k A slabs: quarter q in the (idle since layer 1) A part of stage ps0 + 1 + q
         if (n_tail)
-          *(uint2*)(lds + (1 + (no >> 6)) * STAGE1 + row * 128 + (((((no & 63) >> 3)) ^ ((fr >> 1) & 7)) << 4) + (no & 7) * 2) = packed;
+          *(uint2*)(lds + ((ps0 + 1 + (no >> 6)) & (NST - 1)) * STAGE1 + row * 128 + (((((no & 63) >> 3)) ^ ((fr >> 1) & 7)) << 4) + (no & 7) * 2) = packed;
       }
     }
     MLPS_STAMP(6);
     // ---------------------------------------------------------------- chained critics (target critic on the new action)
-    float* qscratch = (float*)lds;                             // A part of stage 0: idle after layer 1
+    float* qscratch = (float*)(lds + ps0 * STAGE1 + 3072);     // last KB of an A part the constants never touch
 #pragma unroll
     for (int ti = 0; ti < MLP_MAX_TAIL; ++ti) {
       if (ti >= n_tail) break;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
       f32x4 tbv[1];
       for (int q = 0; q < 2; ++q) {                            // + action x W1[:, action columns]
         const unsigned char* st = next_post();                 // (the action slabs are complete after the part slab's barrier)
-        if constexpr (!(PROBE & 1)) mma_stage(lds + (1 + q) * STAGE1, st + A1_BYTES, acc, wave * 16, fr, fg);
+        if constexpr (!(PROBE & 1)) mma_stage(lds + ((ps0 + 1 + q) & (NST - 1)) * STAGE1, st + A1_BYTES, acc, wave * 16, fr, fg);
       }
       if (ti > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -4,6 +4,7 @@
 //   mode 1: same, source pre-tiled (1 KiB contiguous per wave instruction)
 //   mode 2: global_load_dwordx4 into registers, 4 rows x 256 B per wave instruction
 //   mode 3: mode 2 with 1 KiB contiguous per wave instruction
+//   mode 4: global_load_lds_dwordx4, 8 rows x 128 B per wave instruction (64-k slabs of a 256-row matrix), row pitch = ld_bytes
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/_build/dma_bw tools/dma_bw.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,9 +35,10 @@ __global__ __launch_bounds__(1024) void stream_kernel(const char* w, int ld_byte
       for (int j = 0; j < NI; ++j) {
         const int inst = j * 16 + wave;              // 4 rows each
         const char* src;
-        if (MODE == 0 || MODE == 2) src = w + (int64_t)(inst * 4 + q_row) * ld_bytes + t * 256 + q_pos * 16;
+        if (MODE == 4) src = w + (int64_t)(inst * 8 + (lane >> 3)) * ld_bytes + (t % (ld_bytes / 128 > 0 ? ld_bytes / 128 : 1)) * 128 + (lane & 7) * 16;
+        else if (MODE == 0 || MODE == 2) src = w + (int64_t)(inst * 4 + q_row) * ld_bytes + t * 256 + q_pos * 16;
         else src = w + ((int64_t)t * SLAB_ROWS * 256) + inst * 1024 + lane * 16;
-        if (MODE < 2) {
+        if (MODE < 2 || MODE == 4) {
           dma16(src, lds0 + (t % DEPTH) * STAGE + inst * 1024);
         } else {
           u32x4 v;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(1024) void stream_kernel(const char* w, int ld_byte
           acc ^= v;      // (consumed only after the explicit waits below; 16 loads in flight need 64 VGPRs)
         }
       }
-      if (MODE < 2) {
+      if (MODE < 2 || MODE == 4) {
         // keep DEPTH-1 slabs in flight
         if (t >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NI) : "memory");
       } else {
@@ -97,6 +99,13 @@ int main(int argc, char** argv) {
   hipMalloc(&w, (size_t)rows * K * 2 + 4096);
   hipMemset(w, 1, (size_t)rows * K * 2 + 4096);
   const int nslab = K / 128;
+  // mode 4: SLAB_ROWS = 128 -> 16 waves x 2 instructions x 8 rows = 256 image rows of 128 B = 32 KB per slab
+  run<4, 128, 4>("lds-dma 8x128B rows, pitch 2816 (W1)", w, 2816, 22, nwg);
+  run<4, 128, 4>("lds-dma 8x128B rows, pitch 512 (W2 as stored)", w, 512, 22, nwg);
+  run<4, 128, 4>("lds-dma 8x128B rows, pitch 640", w, 640, 22, nwg);
+  run<4, 128, 4>("lds-dma 8x128B rows, pitch 528", w, 528, 22, nwg);
+  run<4, 128, 4>("lds-dma 8x128B rows, pitch 1024", w, 1024, 22, nwg);
+  return 0;
   run<0, 256, 2>("lds-dma 4x256B rows", w, K * 2, nslab, nwg);
   run<1, 256, 2>("lds-dma 1KiB contiguous", w, K * 2, nslab, nwg);
   run<0, 128, 4>("lds-dma 4x256B rows (half slabs)", w, K * 2, nslab, nwg);
