@@ -123,8 +123,9 @@ def _worker(rank, world, port, q):
     drift = dp.check_replicas(list(eng.st.policy.values()) + list(eng.st.value.values()) + list(eng.st.target_value.values()))
     assert shard_users(torch.arange(10), rank, world).tolist() == list(range(rank, 10, world))
     if rank == 0:
-        q.put(({k: v.clone() for k, v in eng.st.policy.items()}, {k: v.clone() for k, v in eng.st.value.items()},
-               {k: v.clone() for k, v in eng.st.target_policy.items()}, drift))
+        # numpy, not tensors: a tensor travels as a shared fd that dies with this process if the parent is slow
+        q.put(({k: v.numpy().copy() for k, v in eng.st.policy.items()}, {k: v.numpy().copy() for k, v in eng.st.value.items()},
+               {k: v.numpy().copy() for k, v in eng.st.target_policy.items()}, float(drift)))
     dist.destroy_process_group()
 
 
@@ -138,6 +139,7 @@ def test_two_ranks_equal_one_rank_on_the_full_batch():
     for p in procs:
         p.start()
     pol, val, tpol, drift = q.get(timeout=120)
+    pol, val, tpol = ({k: torch.from_numpy(v) for k, v in d.items()} for d in (pol, val, tpol))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
