@@ -106,8 +106,9 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
             "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s"}
 
 
-# launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports
-KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlp_fwd_kernel", "mlp_l1_nets": "mlp_l1_kernel", "mlp_tail_nets": "mlp_tail_kernel",
+# launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports (the default fused forward
+# is mlps.hip's mlps_fwd_kernel; the opt-in variants mlp_fwd_kernel / mlp64 / mlpr are reached through recnn_tune_*)
+KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_l1_nets": "mlp_l1_kernel", "mlp_tail_nets": "mlp_tail_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel"}
 
