@@ -324,6 +324,33 @@ int recnn_softmax_bwd(const float* p, int64_t ldp, int rows, int n, const float*
 /* out[r, :] = onehot(idx[r]) over n columns (columns [n, ld) zeroed). */
 int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t ld, void* stream);
 
+/* =====================================================================================
+ * 3c. Conditional-VAE latent layer and loss (BCQ)
+ *    replaces the ATen chain of bcqGenerator.forward between the encoder and decoder GEMMs
+ *    (recnn/nn/models.py:271-277: clamp(log_std, -4, 15), exp, z = mean + std * eps) and the generator loss of
+ *    bcq_update (recnn/nn/update/bcq.py:78-81: mse(recon, action) + 0.5 * KL), with their autograd backward.
+ *    All operands float[rows, ld]; `ml` holds [mean | raw log_std] side by side (2 * latent columns).
+ * ===================================================================================== */
+#define RECNN_VAE_LOG_STD_MIN (-4.0f)
+#define RECNN_VAE_LOG_STD_MAX (15.0f)
+/* std = exp(clamp(ml[:, L:2L])), z = ml[:, :L] + std * eps */
+int recnn_vae_latent_fwd(const float* ml, int64_t ld_ml, const float* eps, int64_t ld_eps, int rows, int latent, float* z,
+                         int64_t ldz, float* std_out, int64_t ld_std, void* stream);
+/* dml[:, :L] = dz + dmean;  dml[:, L:] = (dz * eps + dstd) * std * [min <= raw <= max];  dz / dmean / dstd may be NULL */
+int recnn_vae_latent_bwd(const float* ml, int64_t ld_ml, const float* eps, int64_t ld_eps, const float* std_in, int64_t ld_std,
+                         const float* dz, int64_t ld_dz, const float* dmean, int64_t ld_dmean, const float* dstd,
+                         int64_t ld_dstd, int rows, int latent, float* dml, int64_t ld_dml, void* stream);
+/* out3 = { mean((recon - action)^2), -0.5 * mean(1 + log(std^2) - mean^2 - std^2), out3[0] + kl_weight * out3[1] };
+ * scratch: 512 floats.  Fixed summation order (bit-reproducible). */
+int recnn_vae_loss_fwd(const float* recon, int64_t ld_recon, const float* action, int64_t ld_action, const float* mean,
+                       int64_t ld_mean, const float* std_in, int64_t ld_std, int rows, int action_dim, int latent,
+                       float kl_weight, float* out3, float* scratch, void* stream);
+/* gradients of sum_i gout[i] * out3[i] w.r.t. recon, mean and std (gout: float[3] on the device) */
+int recnn_vae_loss_bwd(const float* recon, int64_t ld_recon, const float* action, int64_t ld_action, const float* mean,
+                       int64_t ld_mean, const float* std_in, int64_t ld_std, int rows, int action_dim, int latent,
+                       const float* gout, float kl_weight, float* d_recon, int64_t ld_drecon, float* d_mean, int64_t ld_dmean,
+                       float* d_std, int64_t ld_dstd, void* stream);
+
 /* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
 int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);
 

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Generate `tests/golden/bcq_small.npz` from the REAL reference and pin `oracle/bcq_oracle.py` against it.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the reference is mounted read-only at /root/reference).
+
+Drives `recnn.nn.update.bcq_update` (update/bcq.py:11-179) with `bcqGenerator` / `bcqPerturbator` / `Critic`
+(models.py:187-295) of the reference on seeded inputs, `torch.optim.Adam` in the `optimizer` dict.  ONE repair is made to
+the reference from outside: bcq.py:2 imports `torch.functional as F`, which has no `mse_loss`, so the function raises as
+written; the module attribute `F` is re-pointed at `torch.nn.functional` (what the notebook the function was lifted from
+imports, examples/99.To be released, but working/2. BCQ).  The draws of the global generator (Normal samples of the VAE,
+dropout keep-masks) are recorded by replaying the generator state, in the order bcq_update consumes them.
+
+The generator's hidden width is hard-coded to 750 in the reference; the fixture stores the construction seed instead of the
+initial weights (recnn_amd's modules consume the generator exactly like the reference's: tests assert the stored
+checksums), per-step losses and a strided sample of every final tensor.
+
+Usage:  python oracle/make_golden_bcq.py      (from the repo root)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("RECNN_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "_stubs"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import recnn as ref  # noqa: E402  (the reference)
+
+assert ref.__file__.startswith(REF), ref.__file__
+import recnn.nn.update.bcq as ref_bcq  # noqa: E402
+from oracle import recnn_oracle as O  # noqa: E402
+from oracle import bcq_oracle as Q  # noqa: E402
+from oracle.reinforce_oracle import AdamDict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(1)
+
+assert not hasattr(ref_bcq.F, "mse_loss"), "the reference was fixed upstream: re-read bcq.py:2"
+ref_bcq.F = torch.nn.functional           # the one repair (see the module docstring)
+
+SAMPLE = 257     # stride of the stored sample of each final tensor
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def build_nets(mod, S, A, L, H, seed):
+    """Construction order is part of the fixture: the test rebuilds recnn_amd's modules the same way."""
+    torch.manual_seed(seed)
+    gen = mod.bcqGenerator(S, A, L)
+    pert = mod.bcqPerturbator(S, A, H)
+    tpert = mod.bcqPerturbator(S, A, H)
+    v1, v2 = mod.Critic(S, A, H, 2e-1), mod.Critic(S, A, H, 2e-1)
+    tv1, tv2 = mod.Critic(S, A, H), mod.Critic(S, A, H)
+    for t in (tpert, tv1, tv2):
+        t.eval()
+    return gen, pert, tpert, v1, v2, tv1, tv2
+
+
+def draw_inputs(S, A, L, B, n, n_batches, steps):
+    batches = [{"state": torch.randn(B, S), "action": torch.randn(B, A) * 0.5, "reward": torch.randn(B) * 2.0,
+                "next_state": torch.randn(B, S), "done": (torch.rand(B) < 0.15).float()} for _ in range(n_batches)]
+    return batches
+
+
+def run(name, S, A, L, H, B, n, steps, seed, lr_g, lr_v, lr_p, pstep):
+    gen, pert, tpert, v1, v2, tv1, tv2 = build_nets(ref.nn.models, S, A, L, H, seed)
+    init_sum = {k: float(v.double().abs().sum()) for k, v in Q.generator_params_from_module(gen).items()}
+    init_sum.update({"pert." + k: float(v.double().abs().sum()) for k, v in O.params_from_module(pert).items()})
+    init_sum.update({"v1." + k: float(v.double().abs().sum()) for k, v in O.params_from_module(v1).items()})
+    ref.utils.soft_update(v1, tv1, soft_tau=1.0)
+    ref.utils.soft_update(v2, tv2, soft_tau=1.0)
+    ref.utils.soft_update(pert, tpert, soft_tau=1.0)
+    nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+            "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+    optimizer = {"generator_optimizer": torch.optim.Adam(gen.parameters(), lr=lr_g),
+                 "value_optimizer1": torch.optim.Adam(v1.parameters(), lr=lr_v, weight_decay=1e-2),
+                 "value_optimizer2": torch.optim.Adam(v2.parameters(), lr=lr_v, weight_decay=1e-2),
+                 "perturbator_optimizer": torch.optim.Adam(pert.parameters(), lr=lr_p)}
+    params = {"gamma": 0.99, "soft_tau": 0.01, "n_generator_samples": n, "perturbator_step": pstep}
+    batches = draw_inputs(S, A, L, B, n, 2, steps)
+
+    st = Q.BCQState(Q.generator_params_from_module(gen), O.params_from_module(pert), O.params_from_module(tpert),
+                    O.params_from_module(v1), O.params_from_module(tv1), O.params_from_module(v2), O.params_from_module(tv2),
+                    AdamDict(Q.GEN_ORDER, lr=lr_g), AdamDict(O.PARAM_ORDER, lr=lr_p),
+                    AdamDict(O.PARAM_ORDER, lr=lr_v, weight_decay=1e-2), params=dict(params))
+    normal = torch.distributions.Normal(0, 1)
+    losses, olosses = [], []
+    all_eps, all_zn, all_zc, all_masks = [], [], [], []
+    for t in range(steps):
+        b = batches[t % 2]
+        rng = torch.get_rng_state()
+        eps = normal.sample([B, L])                        # generator.forward: normal.sample(std.size())
+        z_next = normal.sample([B * n, L])                 # decode(state_rep)
+        m = O.draw_dropout_masks(2, B, H)                  # value_net1(state, action)
+        z_cur = normal.sample([B, L])                      # decode(state)
+        m += O.draw_dropout_masks(4, B, H)                 # perturbator_net, value_net1
+        torch.set_rng_state(rng)
+        out = ref.nn.update.bcq_update(b, params, nets, optimizer, torch.device("cpu"), None, ref.utils.DummyWriter(),
+                                       learn=True, step=t)
+        oo = Q.bcq_step(st, {k: v.numpy() for k, v in b.items()}, eps, z_next, z_cur, m, step=t)
+        losses.append([out["value"], out["perturbator"], out["generator"]])
+        olosses.append([oo["value"], oo["perturbator"], oo["generator"]])
+        all_eps.append(eps.numpy()); all_zn.append(z_next.numpy()); all_zc.append(z_cur.numpy())
+        all_masks.append(torch.stack(m).numpy())
+    e = max(rel_err(np.asarray(olosses)[:, j], np.asarray(losses)[:, j]) for j in range(3))
+    assert e < 5e-5, (name, "loss", e)
+    blob = {}
+    worst = 0.0
+    final = {"generator": Q.generator_params_from_module(gen), "perturbator": O.params_from_module(pert),
+             "target_perturbator": O.params_from_module(tpert), "value1": O.params_from_module(v1),
+             "target_value1": O.params_from_module(tv1), "value2": O.params_from_module(v2),
+             "target_value2": O.params_from_module(tv2)}
+    for tag, op in (("generator", st.generator), ("perturbator", st.perturbator), ("target_perturbator", st.target_perturbator),
+                    ("value1", st.value1), ("target_value1", st.target_value1), ("value2", st.value2),
+                    ("target_value2", st.target_value2)):
+        for k, v in final[tag].items():
+            ek = rel_err(op[k], v)
+            worst = max(worst, ek)
+            assert ek < 1e-4, (name, tag, k, ek)
+            blob[f"final.{tag}.{k}"] = v.numpy().reshape(-1)[::SAMPLE].copy()
+            blob[f"final_abs.{tag}.{k}"] = np.asarray(float(v.double().abs().sum()))
+    print(f"{name}: {steps} steps; oracle vs reference (F re-pointed at torch.nn.functional): losses {e:.2e}, params {worst:.2e}")
+    for i, b in enumerate(batches):
+        blob.update({f"batch{i}.{k}": v.numpy() for k, v in b.items()})
+    blob["eps"] = np.stack(all_eps)
+    blob["z_next"] = np.stack(all_zn)
+    blob["z_cur"] = np.stack(all_zc)
+    blob["masks"] = np.stack(all_masks)                    # [steps, 6, B, H] uint8
+    blob["losses"] = np.asarray(losses, dtype=np.float64)  # columns: value, perturbator, generator
+    blob["hyper"] = np.asarray([lr_g, lr_v, lr_p, 1e-2, params["gamma"], params["soft_tau"]], dtype=np.float64)
+    blob["dims"] = np.asarray([S, A, L, H, B, n, steps, seed, pstep, SAMPLE])
+    blob["init_keys"] = np.asarray(sorted(init_sum))
+    blob["init_abs"] = np.asarray([init_sum[k] for k in sorted(init_sum)])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
+
+
+if __name__ == "__main__":
+    run("bcq_small", S=27, A=8, L=5, H=16, B=12, n=4, steps=9, seed=21, lr_g=1e-3, lr_v=1e-3, lr_p=1e-3, pstep=3)

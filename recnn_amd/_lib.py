@@ -141,6 +141,10 @@ SIGNATURES = {
     "recnn_logprob_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "recnn_softmax_bwd": (_I, [_P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_onehot_rows": (_I, [_P, _I, _I, _P, _L, _P]),
+    "recnn_vae_latent_fwd": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
+    "recnn_vae_latent_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
+    "recnn_vae_loss_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
+    "recnn_vae_loss_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _F, _P, _L, _P, _L, _P, _L, _P]),
     "recnn_ranger_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),

@@ -172,26 +172,33 @@ class MLPFunction(torch.autograd.Function):
         dev = dout.device
         scale = 2.0 if ctx.train else 1.0
         tiles = (B + 31) // 32
+        need = ctx.needs_input_grad      # frozen weights (a critic scoring a policy's action) skip their dW GEMMs
         doutp = _pad(dout, B, Op)
-        gw3 = torch.empty(O, H, device=dev)
-        _dw(doutp, O, h2, H, gw3)
-        gb3 = dout.sum(0)
+        gw3 = gb3 = gw2 = gw1 = None
+        if need[5]:
+            gw3 = torch.empty(O, H, device=dev)
+            _dw(doutp, O, h2, H, gw3)
+        if need[6]:
+            gb3 = dout.sum(0)
         dz2 = torch.zeros(B, Hp, device=dev)
         cs2 = torch.empty(tiles, H, device=dev)
         _dx(doutp, Op, w3p, H, dz2, h2, scale, cs2)
-        gw2 = torch.empty(H, H, device=dev)
-        _dw(dz2, H, h1, H, gw2)
+        if need[3]:
+            gw2 = torch.empty(H, H, device=dev)
+            _dw(dz2, H, h1, H, gw2)
         dz1 = torch.zeros(B, Hp, device=dev)
         cs1 = torch.empty(tiles, H, device=dev)
         _dx(dz2, Hp, w2p, H, dz1, h1, scale, cs1)
-        gw1 = torch.empty(H, K, device=dev)
-        _dw(dz1, H, xp, K, gw1)
+        if need[1]:
+            gw1 = torch.empty(H, K, device=dev)
+            _dw(dz1, H, xp, K, gw1)
         gx = None
-        if ctx.needs_input_grad[0]:
+        if need[0]:
             gx = torch.empty(B, K, device=dev)
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
-        gadd = dz1[:, :H] if ctx.needs_input_grad[10] else None     # d/d addend1 = dZ1
-        return gx, gw1, cs1.sum(0), gw2, cs2.sum(0), gw3, gb3, None, None, None, gadd
+        gadd = dz1[:, :H] if need[10] else None     # d/d addend1 = dZ1
+        return (gx, gw1, cs1.sum(0) if need[2] else None, gw2, cs2.sum(0) if need[4] else None, gw3, gb3, None, None, None,
+                gadd)
 
 
 def mlp(x, module, train: bool):
@@ -200,6 +207,102 @@ def mlp(x, module, train: bool):
     return MLPFunction.apply(x.float(), module.linear1.weight, module.linear1.bias, module.linear2.weight,
                              module.linear2.bias, module.linear3.weight, module.linear3.bias, train, torch.initial_seed(),
                              _take_forced_masks(module, train), None)
+
+
+def mlp_frozen(x, module, train: bool):
+    """`mlp` with the module's weights taken as constants: the gradient reaches `x` only (a critic scoring the action of the
+    policy being trained -- its own dW / db GEMMs would be thrown away by the next zero_grad)."""
+    d = lambda t: t.detach()
+    return MLPFunction.apply(x.float(), d(module.linear1.weight), d(module.linear1.bias), d(module.linear2.weight),
+                             d(module.linear2.bias), d(module.linear3.weight), d(module.linear3.bias), train,
+                             torch.initial_seed(), _take_forced_masks(module, train), None)
+
+
+def mlp3(x, l1, l2, w3, b3):
+    """relu(l1) -> relu(l2) -> x W3^T + b3 without dropout (the VAE encoder / decoder stacks of bcqGenerator)."""
+    return MLPFunction.apply(x.float(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, False, 0, None, None)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Conditional VAE of BCQ (SURVEY.md 8 row f4): latent layer and loss as autograd nodes over csrc/vae.hip.
+# Replaces recnn/nn/models.py:271-277 and recnn/nn/update/bcq.py:78-81 (and the graph torch would record for them).
+
+class VaeLatentFunction(torch.autograd.Function):
+    """(z, std) = latent(ml, eps): ml = [mean | raw log_std]; std = exp(clamp(raw, -4, 15)); z = mean + std * eps."""
+
+    @staticmethod
+    def forward(ctx, ml, eps):
+        if not ml.is_cuda:
+            raise L.RecnnHipError("recnn_amd VAE latent layer: needs GPU tensors (no CPU fallback)")
+        ml = ml.float().contiguous()
+        eps = eps.to(device=ml.device, dtype=torch.float32).contiguous()
+        B, L2 = ml.shape
+        Ld = L2 // 2
+        z = torch.empty(B, Ld, device=ml.device)
+        std = torch.empty(B, Ld, device=ml.device)
+        L.call("recnn_vae_latent_fwd", L.ptr(ml), ml.stride(0), L.ptr(eps), eps.stride(0), B, Ld, L.ptr(z), z.stride(0),
+               L.ptr(std), std.stride(0), L.current_stream())
+        ctx.save_for_backward(ml, eps, std)
+        return z, std
+
+    @staticmethod
+    def backward(ctx, dz, dstd):
+        ml, eps, std = ctx.saved_tensors
+        B, L2 = ml.shape
+        Ld = L2 // 2
+        rows = lambda t: None if t is None else (t.float() if t.stride(1) == 1 else t.float().contiguous())
+        dz, dstd = rows(dz), rows(dstd)        # dz is usually the latent columns of the decoder's dX: strided rows
+        dml = torch.empty_like(ml)
+        L.call("recnn_vae_latent_bwd", L.ptr(ml), ml.stride(0), L.ptr(eps), eps.stride(0), L.ptr(std), std.stride(0),
+               L.ptr(dz), 0 if dz is None else dz.stride(0), None, 0, L.ptr(dstd), 0 if dstd is None else dstd.stride(0),
+               B, Ld, L.ptr(dml), dml.stride(0), L.current_stream())
+        return dml, None
+
+
+def vae_latent(ml, eps):
+    return VaeLatentFunction.apply(ml, eps)
+
+
+class VaeLossFunction(torch.autograd.Function):
+    """out3 = (mse(recon, action), KL, mse + kl_weight * KL), KL = -0.5 mean(1 + log(std^2) - mean^2 - std^2)."""
+
+    @staticmethod
+    def forward(ctx, recon, action, mean, std, kl_weight):
+        if not recon.is_cuda:
+            raise L.RecnnHipError("recnn_amd VAE loss: needs GPU tensors (no CPU fallback)")
+        recon, action = recon.float(), action.detach().float()
+        mean, std = mean.float(), std.float()
+        for t in (recon, action, mean, std):
+            if t.stride(1) != 1:
+                raise L.RecnnHipError("recnn_amd VAE loss: rows must be contiguous")
+        B, A = recon.shape
+        Ld = mean.shape[1]
+        out = torch.empty(3, device=recon.device)
+        scratch = torch.empty(512, device=recon.device)
+        L.call("recnn_vae_loss_fwd", L.ptr(recon), recon.stride(0), L.ptr(action), action.stride(0), L.ptr(mean), mean.stride(0),
+               L.ptr(std), std.stride(0), B, A, Ld, float(kl_weight), L.ptr(out), L.ptr(scratch), L.current_stream())
+        ctx.save_for_backward(recon, action, mean, std)
+        ctx.kl_weight = float(kl_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        recon, action, mean, std = ctx.saved_tensors
+        B, A = recon.shape
+        Ld = mean.shape[1]
+        g = g.float().contiguous()
+        d_recon = torch.empty(B, A, device=recon.device)
+        d_mean = torch.empty(B, Ld, device=recon.device)
+        d_std = torch.empty(B, Ld, device=recon.device)
+        L.call("recnn_vae_loss_bwd", L.ptr(recon), recon.stride(0), L.ptr(action), action.stride(0), L.ptr(mean), mean.stride(0),
+               L.ptr(std), std.stride(0), B, A, Ld, L.ptr(g), ctx.kl_weight, L.ptr(d_recon), A, L.ptr(d_mean), Ld,
+               L.ptr(d_std), Ld, L.current_stream())
+        return d_recon, None, d_mean, d_std, None
+
+
+def vae_loss(recon, action, mean, std, kl_weight=0.5):
+    """float[3] = (reconstruction loss, KL loss, reconstruction + kl_weight * KL)  (bcq.py:78-81)."""
+    return VaeLossFunction.apply(recon, action, mean, std, kl_weight)
 
 
 def _take_forced_masks(module, train):

@@ -1,4 +1,5 @@
-"""Actor / Critic / DiscreteActor (reference: recnn/nn/models.py:41-73, :187-213, :76-184).
+"""Actor / Critic / DiscreteActor / bcqPerturbator / bcqGenerator
+(reference: recnn/nn/models.py:41-73, :187-213, :76-184, :216-242, :245-295).
 
 Real nn.Modules with the reference's sub-module names (linear1/2/3, drop_layer), state_dict keys and
 constructor RNG consumption (nn.Linear default init for linear1, linear2, linear3 in that order, then
@@ -11,7 +12,7 @@ import torch.nn as nn
 
 from . import functional as F_hip
 
-__all__ = ["Actor", "Critic", "DiscreteActor"]
+__all__ = ["Actor", "Critic", "DiscreteActor", "bcqPerturbator", "bcqGenerator"]
 
 
 class Actor(nn.Module):
@@ -135,3 +136,63 @@ class DiscreteActor(nn.Module):
         self.lambda_k.append(l_k)
         self.saved_log_probs.append(pi_log_prob)
         return pi_probs
+
+
+class bcqPerturbator(nn.Module):
+    """(state, action) -> action + MLP([state | action]): BCQ's perturbation network (models.py:216-242).  Same sub-module
+    names, state_dict keys and constructor RNG consumption as the reference; forward / backward on the HIP GEMM kernels."""
+
+    def __init__(self, num_inputs, num_actions, hidden_size, init_w=3e-1):
+        super().__init__()
+        self.drop_layer = nn.Dropout(p=0.5)
+        self.linear1 = nn.Linear(num_inputs + num_actions, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, hidden_size)
+        self.linear3 = nn.Linear(hidden_size, num_actions)
+        self.linear3.weight.data.uniform_(-init_w, init_w)
+        self.linear3.bias.data.uniform_(-init_w, init_w)
+
+    def forward(self, state, action):
+        return F_hip.mlp(torch.cat([state, action], 1), self, self.training) + action
+
+
+class bcqGenerator(nn.Module):
+    """BCQ's conditional VAE (models.py:245-295): encoder e1, e2 -> (mean, log_std), z = mean + std * eps, decoder d1, d2, d3
+    over [state | z].  `forward` returns (reconstructed action, mean, std); `decode(state)` draws z ~ clamp(N(0, 1), +-0.5).
+
+    The encoder and the decoder each run as one 3-layer stack on the HIP GEMM kernels (the `mean` and `log_std` heads share
+    one [2 latent, 750] GEMM); clamp / exp / reparametrisation are one kernel (csrc/vae.hip).  The reference draws its
+    normals on the CPU from the global generator and copies them over; here they are drawn on the device
+    (`torch.randn(device=...)`) -- equal in distribution.  `forced_noise` (a list of tensors, consumed first-in first-out)
+    replaces the next draws: replaying logged noise, and the parity tests."""
+
+    def __init__(self, state_dim, action_dim, latent_dim):
+        super().__init__()
+        self.e1 = nn.Linear(state_dim + action_dim, 750)
+        self.e2 = nn.Linear(750, 750)
+        self.mean = nn.Linear(750, latent_dim)
+        self.log_std = nn.Linear(750, latent_dim)
+        self.d1 = nn.Linear(state_dim + latent_dim, 750)
+        self.d2 = nn.Linear(750, 750)
+        self.d3 = nn.Linear(750, action_dim)
+        self.latent_dim = latent_dim
+        self.normal = torch.distributions.Normal(0, 1)
+        self.forced_noise = []
+
+    def _noise(self, rows, device):
+        if self.forced_noise:
+            z = self.forced_noise.pop(0)
+            if tuple(z.shape) != (rows, self.latent_dim):
+                raise ValueError(f"forced_noise entry has shape {tuple(z.shape)}, the call needs {(rows, self.latent_dim)}")
+            return z.to(device=device, dtype=torch.float32)
+        return torch.randn(rows, self.latent_dim, device=device)
+
+    def forward(self, state, action):
+        ml = F_hip.mlp3(torch.cat([state, action], 1), self.e1, self.e2,
+                        torch.cat([self.mean.weight, self.log_std.weight], 0), torch.cat([self.mean.bias, self.log_std.bias], 0))
+        z, std = F_hip.vae_latent(ml, self._noise(state.shape[0], state.device))
+        return self.decode(state, z), ml[:, :self.latent_dim], std
+
+    def decode(self, state, z=None):
+        if z is None:
+            z = self._noise(state.shape[0], state.device).clamp(-0.5, 0.5)
+        return F_hip.mlp3(torch.cat([state, z], 1), self.d1, self.d2, self.d3.weight, self.d3.bias)

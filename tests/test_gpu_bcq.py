@@ -1,0 +1,257 @@
+"""GPU parity of the BCQ row: csrc/vae.hip, bcqGenerator / bcqPerturbator, bcq_update against torch
+autograd, the CPU oracle, and the fixture generated from the real reference (tests/golden/bcq_small.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel_err
+from tests import bcq_replay as BR
+
+pytestmark = pytest.mark.gpu
+
+
+def _optimizers(gen, pert, v1, v2, fx, kind):
+    if kind == "torch":
+        A = torch.optim.Adam
+    else:
+        from recnn_amd import optim
+        A = optim.Adam
+    return {"generator_optimizer": A(gen.parameters(), lr=fx["lr_g"]),
+            "value_optimizer1": A(v1.parameters(), lr=fx["lr_v"], weight_decay=fx["wd_v"]),
+            "value_optimizer2": A(v2.parameters(), lr=fx["lr_v"], weight_decay=fx["wd_v"]),
+            "perturbator_optimizer": A(pert.parameters(), lr=fx["lr_p"])}
+
+
+def _snapshot(gen, pert, tpert, v1, tv1, v2, tv2):
+    from oracle import recnn_oracle as O
+    from oracle import bcq_oracle as Q
+    P = O.params_from_module
+    return {"generator": Q.generator_params_from_module(gen), "perturbator": P(pert), "target_perturbator": P(tpert),
+            "value1": P(v1), "target_value1": P(tv1), "value2": P(v2), "target_value2": P(tv2)}
+
+
+def _torch_vae(ml, eps, u, a, w, L):
+    """the reference's own op sequence (models.py:271-277, bcq.py:78-81) under torch autograd"""
+    mr = ml.clone().requires_grad_()
+    ur = u.clone().requires_grad_()
+    mean = mr[:, :L]
+    std = torch.exp(mr[:, L:].clamp(-4, 15))
+    z = mean + std * eps
+    recon_l = torch.nn.functional.mse_loss(ur, a)
+    kl = -0.5 * (1 + torch.log(std.pow(2)) - mean.pow(2) - std.pow(2)).mean()
+    loss = recon_l + 0.5 * kl
+    (loss + (z * w).sum() * 1e-3).backward()
+    return z, std, recon_l, kl, loss, ur.grad, mr.grad
+
+
+def _hip_vae(ml, eps, u, a, w, L):
+    from recnn_amd.nn import functional as F_hip
+    mg = ml.cuda().requires_grad_()
+    ug = u.cuda().requires_grad_()
+    zg, sg = F_hip.vae_latent(mg, eps.cuda())
+    out = F_hip.vae_loss(ug, a.cuda(), mg[:, :L], sg, 0.5)
+    (out[2] + (zg * w.cuda()).sum() * 1e-3).backward()
+    return zg, sg, out, ug.grad, mg.grad
+
+
+@pytest.mark.parametrize("B,A,L", [(12, 8, 5), (257, 128, 32), (1, 3, 1), (2048, 128, 256)])
+def test_vae_latent_and_loss_match_torch_autograd(cuda, B, A, L):
+    torch.manual_seed(B)
+    ml, eps = torch.randn(B, 2 * L) * 1.5, torch.randn(B, L)
+    u, a, w = torch.randn(B, A), torch.randn(B, A), torch.randn(B, L)
+    z, std, recon_l, kl, loss, du, dml = _torch_vae(ml, eps, u, a, w, L)
+    zg, sg, out, dug, dmlg = _hip_vae(ml, eps, u, a, w, L)
+    assert rel_err(zg, z) < 2e-6 and rel_err(sg, std) < 2e-6
+    for got, want in ((out[0].detach(), recon_l.detach()), (out[1].detach(), kl.detach()), (out[2].detach(), loss.detach())):
+        assert abs(float(got) - float(want)) <= 5e-6 * abs(float(want)), (float(got), float(want))
+    assert torch.allclose(dug.cpu(), du, rtol=1e-5, atol=1e-6 * float(du.abs().max()))
+    assert torch.allclose(dmlg.cpu(), dml, rtol=2e-5, atol=1e-6 * float(dml.abs().max()))
+
+
+def test_vae_log_std_clamp_blocks_the_gradient(cuda):
+    """raw log_std outside [-4, 15]: std is exp of the bound and no gradient reaches the raw value (clamp backward)."""
+    L = 4
+    ml = torch.zeros(3, 2 * L)
+    ml[0, L] = 20.0
+    ml[1, L + 1] = -9.0
+    ml[2, L + 2] = 15.0        # on the bound: the gradient passes
+    eps, u, a, w = torch.ones(3, L), torch.zeros(3, 2), torch.ones(3, 2), torch.ones(3, L)
+    z, std, _, _, _, _, dml = _torch_vae(ml, eps, u, a, w, L)
+    zg, sg, _, _, dmlg = _hip_vae(ml, eps, u, a, w, L)
+    assert rel_err(sg, std) < 2e-6 and rel_err(zg, z) < 2e-6
+    assert dmlg[0, L].item() == 0.0 == dml[0, L].item() and dmlg[1, L + 1].item() == 0.0 == dml[1, L + 1].item()
+    assert dmlg[2, L + 2].item() != 0.0
+    assert torch.allclose(dmlg.cpu(), dml, rtol=2e-5, atol=1e-30)
+
+
+def test_generator_and_perturbator_modules_match_the_oracle(cuda):
+    """forward + backward of the two BCQ modules on the HIP kernels against the oracle's hand-written passes, at the
+    reference's widths (state 1290, action 128, VAE hidden 750)."""
+    from oracle import recnn_oracle as O
+    from oracle import bcq_oracle as Q
+    from recnn_amd.nn import models as M
+    S, A, L, H, B = 1290, 128, 64, 256, 96
+    torch.manual_seed(3)
+    gen, pert = M.bcqGenerator(S, A, L), M.bcqPerturbator(S, A, H)
+    g0, p0 = Q.generator_params_from_module(gen), O.params_from_module(pert)
+    state, action, eps = torch.randn(B, S), torch.randn(B, A) * 0.5, torch.randn(B, L)
+    loss_ref, gg, aux = Q.generator_loss_and_grads(g0, state, action, eps)
+    gen.cuda(); pert.cuda()
+    gen.forced_noise = [eps]
+    from recnn_amd.nn import functional as F_hip
+    recon, mean, std = gen(state.cuda(), action.cuda())
+    out = F_hip.vae_loss(recon, action.cuda(), mean, std, 0.5)
+    out[2].backward()
+    assert rel_err(recon, aux["recon"]) < 1e-4 and rel_err(mean, aux["mean"]) < 1e-4 and rel_err(std, aux["std"]) < 1e-4
+    assert abs(float(out[2].detach()) - loss_ref) <= 1e-5 * abs(loss_ref)
+    for name in ("e1", "e2", "mean", "log_std", "d1", "d2", "d3"):
+        lin = getattr(gen, name)
+        assert rel_err(lin.weight.grad, gg[name + ".w"]) < 1e-4, name
+        assert rel_err(lin.bias.grad, gg[name + ".b"]) < 1e-4, name
+    # perturbator: train-mode masks, gradient of sum(out * w)
+    m1 = (torch.rand(B, H) < 0.5).to(torch.uint8)
+    m2 = (torch.rand(B, H) < 0.5).to(torch.uint8)
+    w = torch.randn(B, A)
+    out_ref, cache = Q.perturbator_forward(p0, state, action, m1, m2)
+    gp, dx, _ = O.mlp_backward(p0, cache, w, need_dx=True)
+    pert.train()
+    pert.forced_masks = [(m1, m2)]
+    ag = action.cuda().requires_grad_()
+    got = pert(state.cuda(), ag)
+    (got * w.cuda()).sum().backward()
+    assert rel_err(got, out_ref) < 1e-4
+    assert rel_err(ag.grad, dx[:, S:] + w) < 1e-4           # residual path + the MLP's action columns
+    for k, lin in (("1", pert.linear1), ("2", pert.linear2), ("3", pert.linear3)):
+        assert rel_err(lin.weight.grad, gp["w" + k]) < 1e-4, k
+        assert rel_err(lin.bias.grad, gp["b" + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("opt", ["torch", "hip"])
+def test_bcq_update_replays_the_reference_run(cuda, golden_dir, opt):
+    """The 9 steps of the real reference stored in bcq_small.npz (its normal draws and dropout masks injected) through
+    recnn_amd.nn.bcq_update on the GPU: per-step losses to 1e-4, every stored final-parameter sample to 2e-4 of the
+    tensor's scale -- with torch.optim.Adam (the fixture's optimizer) and with recnn_amd's fused HIP Adam."""
+    from recnn_amd import utils
+    from recnn_amd.nn import bcq_update
+    fx = BR.load(os.path.join(golden_dir, "bcq_small.npz"))
+    gen, pert, tpert, v1, v2, tv1, tv2 = BR.build_nets(fx)
+    BR.check_init(fx, gen, pert, v1)
+    for m in (gen, pert, tpert, v1, v2, tv1, tv2):
+        m.cuda()
+    utils.soft_update(v1, tv1, soft_tau=1.0)
+    utils.soft_update(v2, tv2, soft_tau=1.0)
+    utils.soft_update(pert, tpert, soft_tau=1.0)
+    nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+            "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+    optimizer = _optimizers(gen, pert, v1, v2, fx, opt)
+    g, bs, params = fx["g"], BR.batches(fx, "cuda"), BR.params_of(fx)
+    losses = []
+    for t in range(fx["steps"]):
+        mk = [torch.from_numpy(m) for m in g["masks"][t]]
+        gen.forced_noise = [torch.from_numpy(g["eps"][t]), torch.from_numpy(g["z_next"][t]), torch.from_numpy(g["z_cur"][t])]
+        v1.forced_masks = [(mk[0], mk[1]), (mk[4], mk[5])]
+        pert.forced_masks = [(mk[2], mk[3])]
+        out = bcq_update(bs[t % 2], params, nets, optimizer, torch.device("cuda"), learn=True, step=t)
+        assert not gen.forced_noise and not v1.forced_masks and not pert.forced_masks
+        losses.append([out["value"], out["perturbator"], out["generator"]])
+    losses, ref = np.asarray(losses), g["losses"]
+    for j, name in enumerate(("value", "perturbator", "generator")):
+        e = np.abs(losses[:, j] - ref[:, j]).max() / np.abs(ref[:, j]).max()
+        assert e < 1e-4, (name, e)
+    worst = BR.compare_final(fx, _snapshot(gen, pert, tpert, v1, tv1, v2, tv2), rtol=2e-4)
+    print(f"bcq replay ({opt} Adam): worst final-parameter sample error {worst:.2e}")
+
+
+def test_bcq_update_at_reference_widths_matches_the_oracle(cuda):
+    """state 1290 / action 128 / latent 256 (2 x action, the BCQ paper's choice) / hidden 256, 128 rows x 10 candidates, 4 steps
+    including a perturbator step: losses, TD targets and parameters against the CPU oracle fed the same draws."""
+    from oracle import recnn_oracle as O
+    from oracle import bcq_oracle as Q
+    from oracle.reinforce_oracle import AdamDict
+    from recnn_amd import utils
+    from recnn_amd.nn import bcq_update
+    from recnn_amd.nn import models as M
+    S, A, L, H, B, n, steps = 1290, 128, 256, 256, 128, 10, 4
+    lr = 1e-5                      # the reference's learning rate (bcq.py:43-46)
+    torch.manual_seed(5)
+    gen, pert, v1, v2 = M.bcqGenerator(S, A, L), M.bcqPerturbator(S, A, H), M.Critic(S, A, H, 2e-1), M.Critic(S, A, H, 2e-1)
+    import copy
+    tpert, tv1, tv2 = copy.deepcopy(pert).eval(), copy.deepcopy(v1).eval(), copy.deepcopy(v2).eval()
+    P = O.params_from_module
+    params = {"gamma": 0.99, "soft_tau": 0.01, "n_generator_samples": n, "perturbator_step": 2}
+    st = Q.BCQState(Q.generator_params_from_module(gen), P(pert), P(tpert), P(v1), P(tv1), P(v2), P(tv2),
+                    AdamDict(Q.GEN_ORDER, lr=lr), AdamDict(O.PARAM_ORDER, lr=lr), AdamDict(O.PARAM_ORDER, lr=lr),
+                    params=dict(params))
+    for m in (gen, pert, tpert, v1, v2, tv1, tv2):
+        m.cuda()
+    nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+            "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+    fx = dict(lr_g=lr, lr_v=lr, lr_p=lr, wd_v=0.0)
+    optimizer = _optimizers(gen, pert, v1, v2, fx, "hip")
+    gcpu = torch.Generator().manual_seed(9)
+    for t in range(steps):
+        b = {"state": torch.randn(B, S, generator=gcpu), "action": torch.randn(B, A, generator=gcpu) * 0.5,
+             "reward": torch.randn(B, generator=gcpu) * 2.0, "next_state": torch.randn(B, S, generator=gcpu),
+             "done": (torch.rand(B, generator=gcpu) < 0.1).float()}
+        eps, zn, zc = torch.randn(B, L, generator=gcpu), torch.randn(B * n, L, generator=gcpu), torch.randn(B, L, generator=gcpu)
+        mk = [(torch.rand(B, H, generator=gcpu) < 0.5).to(torch.uint8) for _ in range(6)]
+        ref = Q.bcq_step(st, b, eps, zn, zc, mk, step=t)
+        gen.forced_noise = [eps, zn, zc]
+        v1.forced_masks = [(mk[0], mk[1]), (mk[4], mk[5])]
+        pert.forced_masks = [(mk[2], mk[3])]
+        dbg = {}
+        out = bcq_update({k: v.cuda() for k, v in b.items()}, params, nets, optimizer, torch.device("cuda"), dbg, learn=True, step=t)
+        for k in ("value", "perturbator", "generator"):
+            assert abs(out[k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-7, (t, k, out[k], ref[k])
+    got = _snapshot(gen, pert, tpert, v1, tv1, v2, tv2)
+    # final parameters element-wise: |got - ref| <= 1e-4 |ref| + 1e-4 rms(ref); elements in Adam's eps regime (sqrt(v_hat) <
+    # 1e3 eps, where lr*m/(sqrt(v)+eps) amplifies round-off by up to lr/eps) are excluded and counted, as in
+    # tests/test_gpu_bench_shape.py; an update that did not happen at all would sit 4 lr = 13 x the bound away
+    excluded = failed = failed_all = total = 0
+    max_dev = 0.0
+    for net, refp, opt in (("generator", st.generator, st.generator_opt), ("perturbator", st.perturbator, st.perturbator_opt),
+                           ("value1", st.value1, st.value_opt)):
+        for k, ref in refp.items():
+            g_ = got[net][k]
+            dev = (g_ - ref).abs()
+            bad = dev > 1e-4 * ref.abs() + 1e-4 * ref.pow(2).mean().sqrt()
+            regime = (opt.v[k] / (1.0 - opt.beta2 ** opt.t)).sqrt() < 1e3 * opt.eps
+            excluded += int(regime.sum()); failed += int((bad & ~regime).sum()); failed_all += int(bad.sum()); total += ref.numel()
+            max_dev = max(max_dev, float(dev.max()))
+            assert float((g_ - ref).norm() / ref.norm()) <= 1e-4, (net, k)
+    report = dict(param_elements=total, eps_regime=excluded, outside_rtol_1e4=failed, outside_rtol_1e4_incl_eps_regime=failed_all,
+                  max_abs_dev_in_lr=max_dev / lr)
+    print("bcq @ reference widths:", report)
+    # (the perturbator's L1-normalised gradient -- the clip quirk -- and the 1 / (B A) of the VAE loss put ~40 % of the
+    # elements into the eps regime here; measured: no element outside the bound, eps regime included)
+    assert failed == 0 and failed_all <= 0.01 * total and max_dev <= 20 * lr, report
+    for net, refp in (("target_perturbator", st.target_perturbator), ("target_value1", st.target_value1),
+                      ("value2", st.value2), ("target_value2", st.target_value2)):
+        for k, ref in refp.items():
+            assert float((got[net][k] - ref).norm() / ref.norm()) <= 1e-5, (net, k)
+
+
+def test_bcq_update_evaluation_call_fills_debug_and_changes_nothing(cuda):
+    from recnn_amd.nn import bcq_update
+    from recnn_amd.nn import models as M
+    import copy
+    S, A, L, H, B = 40, 16, 8, 32, 20
+    torch.manual_seed(1)
+    gen, pert, v1, v2 = M.bcqGenerator(S, A, L).cuda(), M.bcqPerturbator(S, A, H).cuda(), M.Critic(S, A, H).cuda(), M.Critic(S, A, H).cuda()
+    tpert, tv1, tv2 = copy.deepcopy(pert).eval(), copy.deepcopy(v1).eval(), copy.deepcopy(v2).eval()
+    nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+            "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+    before = {k: [p.detach().clone() for p in m.parameters()] for k, m in nets.items()}
+    b = {"state": torch.randn(B, S).cuda(), "action": torch.randn(B, A).cuda(), "reward": torch.randn(B).cuda(),
+         "next_state": torch.randn(B, S).cuda(), "done": torch.zeros(B).cuda()}
+    params = {"gamma": 0.99, "soft_tau": 0.001, "n_generator_samples": 3, "perturbator_step": 30}
+    dbg = {}
+    out = bcq_update(b, params, nets, {}, debug=dbg, learn=False, step=7)
+    assert set(out) == {"value", "perturbator", "generator", "step"} and out["step"] == 7
+    assert all(np.isfinite(out[k]) for k in ("value", "perturbator", "generator"))
+    assert dbg["recon"].shape == (B, A) and dbg["sampled_actions"].shape == (B, A) and dbg["perturbed_actions"].shape == (B, A)
+    for k, m in nets.items():
+        for p, q in zip(m.parameters(), before[k]):
+            assert torch.equal(p, q), k

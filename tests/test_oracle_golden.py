@@ -180,3 +180,18 @@ def test_reinforce_returns_and_estimator_gradients():
         auto = torch.autograd.grad(loss, lps)
         for a, g in zip(auto, glps):
             assert torch.allclose(a, g.detach(), rtol=1e-5, atol=1e-6), method
+
+
+def test_bcq_oracle_reproduces_the_reference_run(golden_dir):
+    """tests/golden/bcq_small.npz: 9 bcq_update steps of the real reference (F re-pointed at torch.nn.functional) -- the
+    oracle restatement reproduces losses to 5e-5 and every stored final-parameter sample to 1e-4; the modules of
+    recnn_amd built under the fixture's seed start from the reference's initial weights (checksums)."""
+    import os
+    from tests import bcq_replay as BR
+    fx = BR.load(os.path.join(golden_dir, "bcq_small.npz"))
+    losses, final = BR.replay_oracle(fx)
+    ref = fx["g"]["losses"]
+    for j in range(3):
+        assert np.abs(losses[:, j] - ref[:, j]).max() <= 5e-5 * np.abs(ref[:, j]).max(), j
+    worst = BR.compare_final(fx, final, rtol=1e-4)
+    assert worst < 1e-4
