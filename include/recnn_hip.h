@@ -181,6 +181,9 @@ typedef struct recnn_gemm_args {
   const uint8_t* mask; int64_t ld_mask;      /* external keep mask [M, ld_mask] */
   uint32_t seed, stream_id; const int32_t* step_ptr;   /* hash mask key (step read from device) */
   const float* addend; int64_t ld_add; float add_clip; /* fwd: C += clamp(addend, +-add_clip) (TD3 noise) */
+  int add_row_div;        /* fwd: output row m reads addend row m / add_row_div (0 or 1: row m).  One addend row serves a
+                             run of consecutive output rows: the state part of layer 1 shared by the n candidate actions
+                             scored per state (BCQ, recnn/nn/update/bcq.py:98-104).  Sits in what used to be padding. */
   const void* yref; int64_t ldy; float dx_scale;       /* dx: C = acc * dx_scale * [yref > 0]; yref NULL = plain.
                                                           fwd: same gate applied after bias/relu (a dX computed with
                                                           pre-transposed weights through the k-contiguous kernels) */

@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("relu", C.c_int), ("mask_mode", C.c_int),
         ("mask", C.c_void_p), ("ld_mask", C.c_int64),
         ("seed", C.c_uint32), ("stream_id", C.c_uint32), ("step_ptr", C.c_void_p),
-        ("addend", C.c_void_p), ("ld_add", C.c_int64), ("add_clip", C.c_float),
+        ("addend", C.c_void_p), ("ld_add", C.c_int64), ("add_clip", C.c_float), ("add_row_div", C.c_int),
         ("yref", C.c_void_p), ("ldy", C.c_int64), ("dx_scale", C.c_float),
         ("colsum", C.c_void_p),
         ("dw_splits", C.c_int), ("dw_slab_stride", C.c_int64),

@@ -32,6 +32,7 @@ struct GemmProb {
   const float* addend;
   int64_t ld_add;
   float add_clip;
+  int add_row_div;         // addend row of output row m is m / add_row_div (<= 1: m)
   // forward epilogue, optional: partial sums of sum_{m,n} C[m][n] * dot_w[n] (C as stored, i.e. rounded to the output
   // type), one per wave: dot_part[workgroup * waves + wave]; the launcher sets dot_parts to their number
   const float* dot_w;

@@ -207,7 +207,8 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
             if (m < P.M) {
               float v = acc[tm][tn][r] + bv;
               if (P.addend) {
-                float z = P.addend[(int64_t)m * P.ld_add + n];
+                const int ma = P.add_row_div > 1 ? m / P.add_row_div : m;
+                float z = P.addend[(int64_t)ma * P.ld_add + n];
                 v += fminf(fmaxf(z, -P.add_clip), P.add_clip);
               }
               if (P.relu) v = fmaxf(v, 0.f);
@@ -1001,7 +1002,7 @@ int gemm_from_args(const recnn_gemm_args* a, int mode, GemmLaunch* L) {
   p.bias = a->bias; p.relu = a->relu; p.mask_mode = a->mask_mode;
   p.mask = a->mask; p.ld_mask = a->ld_mask;
   p.seed = a->seed; p.stream_id = a->stream_id; p.step_ptr = a->step_ptr;
-  p.addend = a->addend; p.ld_add = a->ld_add; p.add_clip = a->add_clip;
+  p.addend = a->addend; p.ld_add = a->ld_add; p.add_clip = a->add_clip; p.add_row_div = a->add_row_div;
   p.yref = a->yref; p.ldy = a->ldy; p.dx_scale = a->dx_scale; p.colsum = a->colsum;
   p.dw_splits = a->dw_splits > 0 ? a->dw_splits : 1;
   p.dw_slab_stride = a->dw_slab_stride;

@@ -75,13 +75,14 @@ def _args(M, N, dtype=None):
     return a
 
 
-def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0, dtype=None):
+def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0, dtype=None, add_row_div=0):
     a = _args(x.shape[0], N, dtype)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = x.data_ptr(), w.data_ptr(), x.stride(0), w.stride(0), K
     a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 1
     a.bias, a.relu = (bias.data_ptr() if bias is not None else None), int(relu)
     if addend is not None:      # added before the relu (gemm.hip epilogue_fwd)
         a.addend, a.ld_add, a.add_clip = addend.data_ptr(), addend.stride(0), float("inf")
+        a.add_row_div = add_row_div
     if yref is not None:
         a.yref, a.ldy, a.dx_scale = yref.data_ptr(), yref.stride(0), scale
     if mask is not None:
@@ -221,6 +222,35 @@ def mlp_frozen(x, module, train: bool):
 def mlp3(x, l1, l2, w3, b3):
     """relu(l1) -> relu(l2) -> x W3^T + b3 without dropout (the VAE encoder / decoder stacks of bcqGenerator)."""
     return MLPFunction.apply(x.float(), l1.weight, l1.bias, l2.weight, l2.bias, w3, b3, False, 0, None, None)
+
+
+def mlp_candidates(state, x, n, w1, b1, w2, b2, w3, b3):
+    """MLP([repeat_interleave(state, n, 0) | x]) for `x` holding n consecutive candidate rows per state row -- relu, relu,
+    linear, no dropout, no gradient (the target side of BCQ's critic step, recnn/nn/update/bcq.py:98-106, where the
+    reference materialises the repeated states and multiplies them n times over).  Layer 1 is split along its input:
+    the state part  S1 = state W1[:, :S]^T + b1  is computed ONCE per state row, the candidate part adds it back per row
+    through the GEMM epilogue (`add_row_div`: output row m reads S1 row m / n) before the relu.  10 candidates per state at
+    state 1290 / candidate 128..512 wide: 4..8 x fewer layer-1 FLOPs and no [B n, 1290] operand in memory."""
+    if not state.is_cuda:
+        raise L.RecnnHipError("recnn_amd networks run on the GPU only (no CPU fallback)")
+    with torch.no_grad():
+        B, S = state.shape
+        R, Kx = x.shape
+        if R != B * n or w1.shape[1] != S + Kx:
+            raise ValueError(f"mlp_candidates: {R} candidate rows for {B} states x {n}, layer 1 takes {w1.shape[1]} inputs")
+        H, O = w1.shape[0], w3.shape[0]
+        Sp, Kp, Hp, Op = _r64(S), _r64(Kx), _r64(H), _r64(O)
+        dev = state.device
+        f = lambda t: t.detach().float().contiguous()
+        s1 = torch.zeros(B, Hp, device=dev)
+        _fwd(_pad(state, B, Sp), Sp, _pad(w1[:, :S], Hp, Sp), f(b1), s1, Hp, H, False, None)
+        h1 = torch.zeros(R, Hp, device=dev)
+        _fwd(_pad(x, R, Kp), Kp, _pad(w1[:, S:], Hp, Kp), None, h1, Hp, H, True, None, addend=s1, add_row_div=n)
+        h2 = torch.zeros(R, Hp, device=dev)
+        _fwd(h1, Hp, _pad(w2, Hp, Hp), f(b2), h2, Hp, H, True, None)
+        out = torch.empty(R, O, device=dev)
+        _fwd(h2, Hp, _pad(w3, Op, Hp), f(b3), out, O, O, False, None)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------------------------------

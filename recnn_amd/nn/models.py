@@ -52,6 +52,12 @@ class Critic(nn.Module):
             return F_hip.mlp_onehot(state, idx, state.shape[1], self, self.training)
         return F_hip.mlp(torch.cat([state, action], 1), self, self.training)
 
+    def candidates(self, state, actions, n):
+        """self(repeat_interleave(state, n, 0), actions) for n consecutive candidate actions per state row, without
+        dropout or gradient (`functional.mlp_candidates`: the state part of layer 1 once per state)."""
+        return F_hip.mlp_candidates(state, actions, n, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                    self.linear2.bias, self.linear3.weight, self.linear3.bias)
+
 
 class DiscreteActor(nn.Module):
     """state -> probabilities over the catalogue: softmax(L2(relu(L1(state))))  (models.py:76-184), the REINFORCE policy.
@@ -154,6 +160,11 @@ class bcqPerturbator(nn.Module):
     def forward(self, state, action):
         return F_hip.mlp(torch.cat([state, action], 1), self, self.training) + action
 
+    def candidates(self, state, actions, n):
+        """self(repeat_interleave(state, n, 0), actions) without dropout or gradient (see Critic.candidates)."""
+        return F_hip.mlp_candidates(state, actions, n, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                    self.linear2.bias, self.linear3.weight, self.linear3.bias) + actions
+
 
 class bcqGenerator(nn.Module):
     """BCQ's conditional VAE (models.py:245-295): encoder e1, e2 -> (mean, log_std), z = mean + std * eps, decoder d1, d2, d3
@@ -196,3 +207,9 @@ class bcqGenerator(nn.Module):
         if z is None:
             z = self._noise(state.shape[0], state.device).clamp(-0.5, 0.5)
         return F_hip.mlp3(torch.cat([state, z], 1), self.d1, self.d2, self.d3.weight, self.d3.bias)
+
+    def decode_candidates(self, state, n):
+        """decode(repeat_interleave(state, n, 0)): n sampled actions per state row, [B n, action_dim], no gradient."""
+        z = self._noise(state.shape[0] * n, state.device).clamp(-0.5, 0.5)
+        return F_hip.mlp_candidates(state, z, n, self.d1.weight, self.d1.bias, self.d2.weight, self.d2.bias,
+                                    self.d3.weight, self.d3.bias)

@@ -26,6 +26,7 @@ import torch
 
 from ... import data, utils
 from .. import functional as F_hip
+from ..models import Critic, bcqGenerator, bcqPerturbator
 from .misc import temporal_difference
 
 __all__ = ["bcq_update"]
@@ -33,7 +34,6 @@ __all__ = ["bcq_update"]
 
 def _score(critic, state, action):
     """critic(state, action) with the critic's weights held constant (gradient w.r.t. the action only)."""
-    from ..models import Critic
     if type(critic) is Critic and state.is_cuda:
         return F_hip.mlp_frozen(torch.cat([state, action], 1), critic, critic.training)
     return critic(state, action)
@@ -78,11 +78,21 @@ def bcq_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug
 
     # ---- critic: TD target from the best of n perturbed candidates per next state -------------------------------------
     with torch.no_grad():
-        state_rep = torch.repeat_interleave(next_state, params["n_generator_samples"], 0)
-        sampled_action = generator.decode(state_rep)
-        perturbed_action = nets["target_perturbator_net"](state_rep, sampled_action)
-        target_Q1 = nets["target_value_net1"](state_rep, perturbed_action)
-        target_Q2 = nets["target_value_net1"](state_rep, perturbed_action) if nets["target_value_net1"].training else target_Q1
+        n = params["n_generator_samples"]
+        tpert, tvalue = nets["target_perturbator_net"], nets["target_value_net1"]
+        if (type(generator) is bcqGenerator and type(tpert) is bcqPerturbator and type(tvalue) is Critic and next_state.is_cuda
+                and not tpert.training and not tvalue.training):
+            # the three networks read [state | candidate]: the state part of each layer 1 is computed once per state row,
+            # the repeated states are never materialised (functional.mlp_candidates)
+            sampled_action = generator.decode_candidates(next_state, n)
+            perturbed_action = tpert.candidates(next_state, sampled_action, n)
+            target_Q1 = target_Q2 = tvalue.candidates(next_state, perturbed_action, n)
+        else:
+            state_rep = torch.repeat_interleave(next_state, n, 0)
+            sampled_action = generator.decode(state_rep)
+            perturbed_action = tpert(state_rep, sampled_action)
+            target_Q1 = tvalue(state_rep, perturbed_action)
+            target_Q2 = tvalue(state_rep, perturbed_action) if tvalue.training else target_Q1
         target_value = 0.75 * torch.min(target_Q1, target_Q2)
         target_value += 0.25 * torch.max(target_Q1, target_Q2)
         target_value = target_value.view(batch_size, -1).max(1)[0].view(-1, 1)

@@ -255,3 +255,22 @@ def test_bcq_update_evaluation_call_fills_debug_and_changes_nothing(cuda):
     for k, m in nets.items():
         for p, q in zip(m.parameters(), before[k]):
             assert torch.equal(p, q), k
+
+
+@pytest.mark.parametrize("B,n,S,A,H", [(7, 3, 27, 8, 16), (64, 10, 1290, 128, 256), (5, 1, 40, 16, 750)])
+def test_candidate_scoring_equals_the_repeated_state_forward(cuda, B, n, S, A, H):
+    """Critic / bcqPerturbator / bcqGenerator candidates(): layer 1 split into a once-per-state part and a per-candidate part
+    (gemm epilogue add_row_div) against the reference's formulation, the module called on repeat_interleave(state, n)."""
+    from recnn_amd.nn import models as M
+    torch.manual_seed(B + n)
+    critic, pert, gen = M.Critic(S, A, H, 0.2).cuda().eval(), M.bcqPerturbator(S, A, H).cuda().eval(), M.bcqGenerator(S, A, 12).cuda()
+    state, acts = torch.randn(B, S, device="cuda"), torch.randn(B * n, A, device="cuda")
+    rep = torch.repeat_interleave(state, n, 0)
+    with torch.no_grad():
+        assert rel_err(critic.candidates(state, acts, n), critic(rep, acts)) < 2e-5
+        assert rel_err(pert.candidates(state, acts, n), pert(rep, acts)) < 2e-5
+        z = torch.randn(B * n, 12)
+        gen.forced_noise = [z]
+        got = gen.decode_candidates(state, n)
+        assert rel_err(got, gen.decode(rep, z.cuda().clamp(-0.5, 0.5))) < 2e-5
+    assert got.shape == (B * n, A) and not got.requires_grad
