@@ -354,6 +354,26 @@ int recnn_vae_loss_bwd(const float* recon, int64_t ld_recon, const float* action
                        const float* gout, float kl_weight, float* d_recon, int64_t ld_drecon, float* d_mean, int64_t ld_dmean,
                        float* d_std, int64_t ld_dstd, void* stream);
 
+/* =====================================================================================
+ * 3d. Replay-store builder: ratings rows -> CSR ordered by (user, time)   
+ *    replaces recnn/data/dataset_functions.py:84-126 (prepare_dataset: rating transform and movieId -> dense id map as
+ *    per-row Python lambdas, sort_values(by="timestamp"), a Python callback per user group).  All pointers are device
+ *    memory except host_counts.  Rows with equal (user, timestamp) keep their input order (pandas' unstable sort leaves
+ *    that order host-dependent; everything else is bit-identical to the reference).
+ * ===================================================================================== */
+int recnn_csr_workspace_bytes(int64_t n_rows, int64_t* bytes);
+/* in : user_ids / item_keys / timestamps int64[n_rows], ratings double[n_rows] (raw, e.g. 0.5..5);
+ *      map_keys (ascending) / map_vals int64[n_map]: item key -> dense id, NULL = keep the keys;
+ * out: items_out int64[n_rows] (-1 where the key is not in the map), ratings_out double[n_rows] = 2 (r - 2.5),
+ *      users_out int64[<= n_rows] ascending user ids, user_off_out int64[users + 1], order_out int64[n_rows] or NULL
+ *      (output row i is input row order_out[i]), mapped_rows_out int64[n_rows] or NULL (dense id of INPUT row i);
+ *      host_counts[3] (HOST memory) = { users, rows with an unmapped item key, key bits sorted }.
+ * Synchronises the stream twice (key ranges decide the number of radix passes; the user count is returned). */
+int recnn_csr_build(const int64_t* user_ids, const int64_t* item_keys, const double* ratings, const int64_t* timestamps,
+                    int64_t n_rows, const int64_t* map_keys, const int64_t* map_vals, int n_map, int64_t* items_out,
+                    double* ratings_out, int64_t* users_out, int64_t* user_off_out, int64_t* order_out, int64_t* mapped_rows_out,
+                    int64_t* host_counts, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Packed batch buffers (float[x_rows, ld_x]) + reward/done (float[max_rows]). */
 int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward, float* done);
 

@@ -145,6 +145,8 @@ SIGNATURES = {
     "recnn_vae_latent_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "recnn_vae_loss_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
     "recnn_vae_loss_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _F, _P, _L, _P, _L, _P, _L, _P]),
+    "recnn_csr_workspace_bytes": (_I, [_L, C.POINTER(_L)]),
+    "recnn_csr_build": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(_L), _P, _L, _P]),
     "recnn_ranger_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),

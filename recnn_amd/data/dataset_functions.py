@@ -10,7 +10,8 @@ import numpy as np
 
 from .pandas_backend import pd
 
-__all__ = ["DataFuncKwargs", "DataFuncArgsMut", "prepare_dataset", "truncate_dataset", "build_data_pipeline", "csr_from_ratings"]
+__all__ = ["DataFuncKwargs", "DataFuncArgsMut", "prepare_dataset", "prepare_dataset_device", "truncate_dataset",
+           "build_data_pipeline", "csr_from_ratings", "csr_from_ratings_device"]
 
 
 class DataFuncKwargs:
@@ -60,6 +61,57 @@ def csr_from_ratings(user_ids: np.ndarray, item_ids: np.ndarray, ratings: np.nda
     user_off[:-1] = first
     user_off[-1] = len(order)
     return users, user_off, item_ids[order], ratings[order]
+
+
+def csr_from_ratings_device(user_ids, item_keys, ratings, timestamps, key_to_id=None, device="cuda", want_mapped_rows=False):
+    """`csr_from_ratings` on the GPU (csrc/csr.hip, `recnn_csr_build`): composite (user, timestamp) key, stable LSD radix
+    sort, gather, first-row flags + scan -- with the two per-row transforms of `prepare_dataset` folded into the gather
+    (rating 2 (r - 2.5) in fp64; item key -> dense id through `key_to_id` by binary search).  Takes the RAW columns.
+
+    Order of rows with equal (user, timestamp): input order (pandas' unstable sort leaves it host-dependent in the
+    reference); everything else is bit-identical to `csr_from_ratings`.  No CPU fallback: raises without the HIP library
+    or a GPU.  Returns (users, user_off, items int64, ratings float64) as numpy arrays [+ the mapped id column in input
+    row order when `want_mapped_rows`], or None if some item key is missing from `key_to_id` (the caller then takes the
+    host path, which reproduces pandas' NaN semantics)."""
+    import ctypes as C
+    import torch
+    from .. import _lib as L
+    if not torch.cuda.is_available():
+        raise L.RecnnHipError("csr_from_ratings_device: needs a GPU (use csr_from_ratings for the host path)")
+    n = len(user_ids)
+    if n == 0:
+        e = np.zeros(0, dtype=np.int64)
+        out = (e, np.zeros(1, dtype=np.int64), e.copy(), np.zeros(0, dtype=np.float64))
+        return out + (e.copy(),) if want_mapped_rows else out
+    dev = torch.device(device)
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dt)).to(dev)
+    d_user, d_item, d_ts = up(user_ids, np.int64), up(item_keys, np.int64), up(timestamps, np.int64)
+    d_rating = up(ratings, np.float64)
+    mk = mv = None
+    n_map = 0
+    if key_to_id is not None:
+        keys = np.fromiter(key_to_id.keys(), dtype=np.int64, count=len(key_to_id))
+        vals = np.fromiter(key_to_id.values(), dtype=np.int64, count=len(key_to_id))
+        o = np.argsort(keys)
+        mk, mv, n_map = up(keys[o], np.int64), up(vals[o], np.int64), len(keys)
+    need = C.c_int64(0)
+    L.call("recnn_csr_workspace_bytes", n, C.byref(need))
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    items = torch.empty(n, dtype=torch.int64, device=dev)
+    rates = torch.empty(n, dtype=torch.float64, device=dev)
+    users = torch.empty(n, dtype=torch.int64, device=dev)
+    off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    mapped = torch.empty(n, dtype=torch.int64, device=dev) if want_mapped_rows else None
+    counts = (C.c_int64 * 3)()
+    with torch.cuda.device(dev):
+        L.call("recnn_csr_build", L.ptr(d_user), L.ptr(d_item), L.ptr(d_rating), L.ptr(d_ts), n, L.ptr(mk), L.ptr(mv), n_map,
+               L.ptr(items), L.ptr(rates), L.ptr(users), L.ptr(off), None, L.ptr(mapped), counts, L.ptr(ws), need.value,
+               L.current_stream())
+    n_users, missing = int(counts[0]), int(counts[1])
+    if missing:
+        return None
+    out = (users[:n_users].cpu().numpy(), off[:n_users + 1].cpu().numpy(), items.cpu().numpy(), rates.cpu().numpy())
+    return out + (mapped.cpu().numpy(),) if want_mapped_rows else out
 
 
 def _stable_argsort_ids(x: np.ndarray) -> np.ndarray:
@@ -113,6 +165,36 @@ def prepare_dataset(args_mut: DataFuncArgsMut, kwargs: DataFuncKwargs):
     user_dict = {u: {"items": items[a:b], "ratings": ratings[a:b]}
                  for u, a, b in zip(users_sorted.tolist(), user_off[:-1].tolist(), user_off[1:].tolist())}
     assert len(lens) == len(user_dict)
+    args_mut.df = df
+    args_mut.user_dict = user_dict
+    args_mut.users = users
+    args_mut.csr = (users_sorted, user_off, items, ratings)
+    return args_mut, kwargs
+
+
+def prepare_dataset_device(args_mut: DataFuncArgsMut, kwargs: DataFuncKwargs):
+    """`prepare_dataset` with the sort / map / transform / grouping on the GPU (`csr_from_ratings_device`); same outputs
+    (`user_dict`, `users`, `csr`, the mutated frame).  Pass it as `FrameEnv(..., prepare_dataset=prepare_dataset_device)`.
+    Differs from `prepare_dataset` only in the order of rows that share (user, timestamp): input order here (see
+    csrc/csr.hip).  Frames holding an item key that `key_to_id` lacks go through the host path."""
+    frame_size = kwargs.get("frame_size")
+    df = args_mut.df
+    if pd.get_type() == "modin":
+        df = df._to_pandas()
+    res = csr_from_ratings_device(df["userId"].to_numpy(), df["movieId"].to_numpy(), df["rating"].to_numpy(),
+                                  df["timestamp"].to_numpy(), key_to_id=args_mut.base.key_to_id, want_mapped_rows=True)
+    if res is None:
+        return prepare_dataset(args_mut, kwargs)
+    users_sorted, user_off, items, ratings, mapped = res
+    df["rating"] = 2.0 * (df["rating"] - 2.5)
+    df["movieId"] = mapped
+    lens = np.diff(user_off)
+    # groupby("userId").size() is this Series (ascending user ids): the same sort_values call as the host path then
+    # orders users with equal counts the same way
+    counts = pd.get().Series(lens, index=pd.get().Index(users_sorted, name="userId"))
+    users = counts[counts > frame_size].sort_values(ascending=False).index
+    user_dict = {u: {"items": items[a:b], "ratings": ratings[a:b]}
+                 for u, a, b in zip(users_sorted.tolist(), user_off[:-1].tolist(), user_off[1:].tolist())}
     args_mut.df = df
     args_mut.user_dict = user_dict
     args_mut.users = users

@@ -128,3 +128,25 @@ def test_csr_from_ratings_edge_cases():
     users, off, items, ratings = F.csr_from_ratings(u, np.array([10, 11, 12, 13, 14]), np.ones(5), np.array([5, 4, 3, 2, 1]))
     assert users.tolist() == [1, 2, 3] and off.tolist() == [0, 2, 3, 5] and items.tolist() == [13, 11, 14, 12, 10]
     assert F._stable_argsort_ids(np.array([-1, 5, 2])).tolist() == [0, 2, 1]          # negative ids: generic stable sort
+
+
+def test_stable_order_etl_oracle_against_reference_fixtures(golden_dir):
+    """oracle/etl_oracle.py (the order the device builder produces: ties inside (user, timestamp) in input order) against
+    the REAL reference's prepare_dataset: identical without ties, identical up to the order inside tie groups with them."""
+    from oracle import etl_oracle as E
+    for name, exact in (("etl_unique.npz", True), ("etl_ties.npz", False)):
+        g = np.load(os.path.join(golden_dir, name))
+        key_to_id = {int(k): i for i, k in enumerate(g["keys"])}
+        dense = np.asarray([key_to_id[int(k)] for k in g["in_movieId"]], dtype=np.int64)
+        users, off, items, ratings = E.csr_stable(g["in_userId"], dense, g["in_rating"], g["in_timestamp"])
+        assert np.array_equal(users, g["uids"]) and np.array_equal(off, g["user_off"])
+        if exact:
+            assert np.array_equal(items, g["items"]) and np.array_equal(ratings, g["ratings"])
+        else:
+            assert not np.array_equal(items, g["items"])          # the fixture does exercise the tie order
+            assert E.same_up_to_tie_order(users, off, items, ratings, g["items"], g["ratings"], g["in_userId"],
+                                          g["in_timestamp"], dense)
+            swapped = g["items"].copy()
+            swapped[[0, len(swapped) - 1]] = swapped[[len(swapped) - 1, 0]]      # a swap ACROSS groups must be caught
+            assert not E.same_up_to_tie_order(users, off, items, ratings, swapped, g["ratings"], g["in_userId"],
+                                              g["in_timestamp"], dense)

@@ -1,7 +1,8 @@
 """Ratings ETL: time the vectorised CSR builder against the reference's prepare_dataset on a
 synthetic ML20M-shaped frame.  CPU only; needs the reference at /root/reference (build container).  Prints one JSON line.
 
-  python tools/bench_etl.py [n_rows]
+  python tools/bench_etl.py [n_rows] [--device]     (--device: also time prepare_dataset_device on cuda:0, incl. H2D/D2H,
+                                                     and the bare recnn_csr_build call with inputs resident in HBM)
 """
 import json
 import os
@@ -13,7 +14,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import pandas
 
-n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+DEVICE = "--device" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_rows = int(argv[0]) if argv else 2_000_000
 n_users = max(100, int(138_493 * n_rows / 20_000_263))
 n_items = 26_744
 rng = np.random.default_rng(0)
@@ -27,18 +30,59 @@ class Base:
     pass
 
 
-def run(mod):
+def run(mod, fn="prepare_dataset"):
     base = Base()
     base.key_to_id = dict(key_to_id)
     args = mod.DataFuncArgsMut(df=pandas.DataFrame(frame), base=base, users=None, user_dict=None)
     t0 = time.perf_counter()
-    args, _ = mod.prepare_dataset(args, mod.DataFuncKwargs(frame_size=10))
+    args, _ = getattr(mod, fn)(args, mod.DataFuncKwargs(frame_size=10))
     return time.perf_counter() - t0, args
 
 
 from recnn_amd.data import dataset_functions as ours
 t_ours, a = run(ours)
 out = {"metric": "ratings ETL: prepare_dataset seconds", "n_rows": n_rows, "n_users": n_users, "ours_s": t_ours, "host_threads": os.cpu_count()}
+if DEVICE:
+    import ctypes as C
+    import torch
+    from recnn_amd import _lib as L
+    from oracle import etl_oracle as E          # checker only
+    run(ours, "prepare_dataset_device")         # first call: library load, allocator warm-up
+    t_dev, d = run(ours, "prepare_dataset_device")
+    out["device_prepare_dataset_s"] = t_dev
+    out["device_users_equal_host"] = bool(list(a.users) == list(d.users))
+    # the builder alone, inputs resident in HBM: HIP events around recnn_csr_build
+    dev = torch.device("cuda:0")
+    up = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(dev)
+    du, di, dr, dt_ = up(frame["userId"], np.int64), up(frame["movieId"], np.int64), up(frame["rating"], np.float64), up(frame["timestamp"], np.int64)
+    mk, mv = up(keys, np.int64), up(np.arange(n_items), np.int64)
+    need = C.c_int64(0)
+    L.call("recnn_csr_workspace_bytes", n_rows, C.byref(need))
+    ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    o_items, o_rat = torch.empty(n_rows, dtype=torch.int64, device=dev), torch.empty(n_rows, dtype=torch.float64, device=dev)
+    o_users, o_off = torch.empty(n_rows, dtype=torch.int64, device=dev), torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+    counts = (C.c_int64 * 3)()
+    best = None
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.call("recnn_csr_build", L.ptr(du), L.ptr(di), L.ptr(dr), L.ptr(dt_), n_rows, L.ptr(mk), L.ptr(mv), n_items, L.ptr(o_items),
+               L.ptr(o_rat), L.ptr(o_users), L.ptr(o_off), None, None, counts, L.ptr(ws), need.value, L.current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    out["device_csr_build_ms"] = best
+    out["device_key_bits"] = int(counts[2])
+    # algorithmic bytes: per radix pass 8 + (8 + 4) read and (8 + 4) written per row; inputs 32 B read, outputs 16 B + flags
+    passes = (int(counts[2]) + 7) // 8
+    bytes_alg = n_rows * (passes * (8 + 12 + 12) + 32 + 12 + 12 + 16 + 8 + 20)
+    out["device_csr_build_GBps"] = bytes_alg / (best * 1e-3) / 1e9
+    out["device_csr_build_frac_of_8TBps"] = out["device_csr_build_GBps"] / 8000.0
+    ref = E.csr_stable(frame["userId"], np.searchsorted(keys, frame["movieId"]), frame["rating"], frame["timestamp"])
+    nu = int(counts[0])
+    out["device_equals_stable_oracle"] = bool(np.array_equal(o_users[:nu].cpu().numpy(), ref[0]) and np.array_equal(o_off[:nu + 1].cpu().numpy(), ref[1])
+                                              and np.array_equal(o_items.cpu().numpy(), ref[2]) and np.array_equal(o_rat.cpu().numpy(), ref[3]))
 ref_root = os.environ.get("RECNN_REFERENCE", "/root/reference")
 if os.path.isdir(ref_root):
     sys.path.insert(0, ref_root)
