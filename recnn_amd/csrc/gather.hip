@@ -9,9 +9,9 @@
 //
 // HBM-bound copy kernel.  One workgroup builds R consecutive batch rows.  Consecutive rows of one
 // user share F of their F+1 embedding rows (sliding window) and state / next_state / action of one
-// row share all of them, so each distinct (row, slot) embedding line is fetched ONCE into LDS
-// ((R+F)..R*(F+1) lines of E floats) with 16-byte coalesced loads and then streamed out to the
-// three outputs with the widest store the output alignment allows.
+// row share all of them, so each distinct (row, slot) embedding line is fetched ONCE (16-byte coalesced
+// loads, (R+F)..R*(F+1) lines of E floats per workgroup) by the threads that own it and stored straight
+// to every output that uses it with the widest store the output alignment allows (gather_dev.h).
 #include "gather_dev.h"
 
 // ------------------------------------------------------------------ plan: row prefix sums
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
 
 size_t frame_gather_lds_bytes(const GatherArgs& a, int R) {
   const int F1 = a.frame + 1;
-  size_t lds = (size_t)R * F1 * a.emb * 4 + (size_t)R * F1 * 4 + 4 * R * 4 + R * 8 + 16;
+  (void)F1;
+  size_t lds = (size_t)R * 8 + (size_t)R * 4 + 16;      // per-row window offsets and flags (no line staging since round 2)
   if (a.inline_plan) lds += (size_t)a.n_users * 8 + (size_t)(a.n_users + 1 + 4) * 4;
   return lds;
 }

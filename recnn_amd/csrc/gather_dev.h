@@ -8,22 +8,33 @@ template <> struct VecT<4> { using type = float4; };
 template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<1> { using type = float; };
 
+template <int W> __device__ __forceinline__ void store_f4(float* p, const float4 v) {
+  if constexpr (W == 4) {
+    *(float4*)p = v;
+  } else if constexpr (W == 2) {
+    *(float2*)p = make_float2(v.x, v.y);
+    *(float2*)(p + 2) = make_float2(v.z, v.w);
+  } else {
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+  }
+}
+
 // R rows per workgroup; W = floats per output store (4/2/1 by output alignment).  `block` is the workgroup's index
 // among the gather workgroups (the body also runs as extra workgroups of the optimizer launch, optim.hip).
+//
+// Round 2: no LDS staging.  Consecutive rows of one user share F of their F+1 embedding lines (sliding window) and
+// state / next_state / action of one row share all of them; every DISTINCT line of the workgroup's R rows has one owner
+// (the first row of the workgroup that contains it) whose threads load its 16-byte chunks once and store them straight
+// to every (row, slot) that uses the line -- the LDS round trip (write, barrier, read) of round 1 sat on a dependent chain
+// users -> offsets -> items -> table -> stores that is latency, not bandwidth.  LDS only holds the per-row metadata (and
+// the inline plan's prefix sums).
 template <int R, int W>
 __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int block, unsigned char* smem_raw) {
-  using V = typename VecT<W>::type;
   const int F = a.frame, E = a.emb, F1 = F + 1;
-  float* lines = (float*)smem_raw;                 // [R*F1][E]
-  float* rat = lines + (size_t)R * F1 * E;         // [R*F1]
-  int* meta = (int*)(rat + R * F1);                // per row: base line, cont flag, done flag; + src offset (2 ints)
-  int* m_base = meta;
-  int* m_cont = meta + R;
-  int* m_done = meta + 2 * R;
-  int* m_valid = meta + 3 * R;
-  long long* m_src = (long long*)(meta + 4 * R);   // CSR offset of the window start
+  long long* m_src = (long long*)smem_raw;         // CSR offset of the window start, per row
   long long* s_start = m_src + R;                  // inline plan: CSR offset of each batch user's history [n_users]
-  int* s_off = (int*)(s_start + (a.inline_plan ? a.n_users : 0));  // inline plan: row prefix sums [n_users + 1]
+  int* m_flag = (int*)(s_start + (a.inline_plan ? a.n_users : 0));   // per row: bit 0 valid, bit 1 done
+  int* s_off = m_flag + R;                         // inline plan: row prefix sums [n_users + 1]
   int* s_sc = s_off + a.n_users + 1;               // inline plan: per-wave totals [4]
 
   const int tid = threadIdx.x;
@@ -82,8 +93,8 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
   if (tid < R) {
     const int r = row0 + tid;
     // rows past the planned total (fewer windows than requested) are left untouched
-    int valid = r < a.rows && r < row_off[a.n_users];
-    int u = 0, t = 0, last = 0;
+    const int valid = r < a.rows && r < row_off[a.n_users];
+    int last = 0;
     long long src = 0;
     if (valid) {
       // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
@@ -92,96 +103,104 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
         int mid = (lo + hi) >> 1;
         if (row_off[mid] <= r) lo = mid; else hi = mid;
       }
-      u = lo;
-      t = r - row_off[lo];
+      const int t = r - row_off[lo];
       last = t == row_off[lo + 1] - row_off[lo] - 1;  // the user's final window: done = 1 (utils.py:70-71)
-      src = (a.inline_plan ? s_start[u] : a.user_off[users[u]]) + t;
+      src = (a.inline_plan ? s_start[lo] : a.user_off[users[lo]]) + t;
     }
-    m_valid[tid] = valid;
     m_src[tid] = src;
-    m_done[tid] = valid && last;
-    // continuation of the previous row's window (same user => shifted by one)
-    m_cont[tid] = 0;
-    m_base[tid] = u;  // temporarily the user index
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int base = 0, prev_u = -1, prev_valid = 0;
-    for (int r = 0; r < R; ++r) {
-      int u = m_base[r];
-      int cont = r > 0 && prev_valid && m_valid[r] && u == prev_u;
-      if (r > 0) base += cont ? 1 : F1;
-      m_cont[r] = cont;
-      prev_u = u;
-      prev_valid = m_valid[r];
-      m_base[r] = base;
-    }
+    m_flag[tid] = valid | ((valid && last) << 1);
+    if (valid) a.done[r] = last ? 1.f : 0.f;
   }
   __syncthreads();
 
-  // ---- stage the distinct embedding lines + ratings into LDS
-  const int E4 = E >> 2;
-  for (int idx = tid; idx < R * F1 * E4; idx += 256) {
-    const int pair = idx / E4, e4 = idx - pair * E4;
-    const int r = pair / F1, j = pair - r * F1;
-    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
-    const int item = a.items[m_src[r] + j];
-    const float4 v = *(const float4*)(a.table + (int64_t)item * E + e4 * 4);
-    *(float4*)(lines + (size_t)(m_base[r] + j) * E + e4 * 4) = v;
+  // ---- every thread: the R rows' metadata, which rows continue the previous row's window, and the owned-line prefix
+  long long src[R];
+  bool valid[R], cont[R];
+  int base[R + 1];
+  base[0] = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    src[r] = m_src[r];
+    const int fl = m_flag[r];
+    valid[r] = fl & 1;
+    // window shifted by one against the previous row's (same user, previous row not the user's last): shares F lines with it
+    cont[r] = r > 0 && valid[r] && valid[r - 1] && !(m_flag[r - 1] & 2) && src[r] == src[r - 1] + 1;
+    base[r + 1] = base[r] + (valid[r] ? (cont[r] ? 1 : F1) : 0);
   }
-  for (int pair = tid; pair < R * F1; pair += 256) {
-    const int r = pair / F1, j = pair - r * F1;
-    if (!m_valid[r] || (m_cont[r] && j < F)) continue;
-    rat[m_base[r] + j] = a.ratings[m_src[r] + j];
-  }
-  __syncthreads();
+  const int total = base[R];
+  const int FE = F * E, E4 = E >> 2;
 
-  // ---- stream out: state / next_state embedding parts and the action
-  const int FE = F * E;
-  const int per_row = FE / W;
-  for (int idx = tid; idx < R * per_row; idx += 256) {
-    const int r = idx / per_row, q = idx - r * per_row;
-    if (!m_valid[r]) continue;
-    const float* src = lines + (size_t)m_base[r] * E + q * W;
-    if (a.state) {
-      *(V*)(a.state + (int64_t)(row0 + r) * a.ld_state + q * W) = *(const V*)src;
-      *(V*)(a.next_state + (int64_t)(row0 + r) * a.ld_next + q * W) = *(const V*)(src + E);
-    }
-    if constexpr (W == 4) {
+  // ---- ratings: one thread per owned (row, slot); state / next_state tails and the reward
+  for (int l = tid; l < total; l += 256) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < R; ++q) r = l >= base[q] ? q : r;
+    const int j = cont[r] ? F : l - base[r];
+    const float v = a.ratings[src[r] + j];
+    if (j == F) a.reward[row0 + r] = v;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int rr = r + k, jj = j - k;
+      if (rr >= R || jj < 0 || (k > 0 && !cont[rr])) break;
+      const int64_t row = row0 + rr;
+      if (a.state) {
+        if (jj < F) a.state[row * a.ld_state + FE + jj] = v;
+        if (jj >= 1) a.next_state[row * a.ld_next + FE + jj - 1] = v;
+      }
       if (a.state_h) {
-        *(uint2*)(a.state_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
-        *(uint2*)(a.next_h + (int64_t)(row0 + r) * a.ld_h + q * 4) =
-            make_uint2(pack_bf2(src[E], src[E + 1]), pack_bf2(src[E + 2], src[E + 3]));
+        if (jj < F) a.state_h[row * a.ld_h + FE + jj] = f2bf(v);
+        if (jj >= 1) a.next_h[row * a.ld_h + FE + jj - 1] = f2bf(v);
       }
     }
   }
-  const int per_act = E / W;
-  for (int idx = tid; idx < R * per_act; idx += 256) {
-    const int r = idx / per_act, q = idx - r * per_act;
-    if (!m_valid[r]) continue;
-    const float* src = lines + (size_t)(m_base[r] + F) * E + q * W;
-    if (a.action) *(V*)(a.action + (int64_t)(row0 + r) * a.ld_action + q * W) = *(const V*)src;
-    if constexpr (W == 4) {
-      if (a.action_h)
-        *(uint2*)(a.action_h + (int64_t)(row0 + r) * a.ld_h + q * 4) = make_uint2(pack_bf2(src[0], src[1]), pack_bf2(src[2], src[3]));
+
+  // ---- embedding lines: 16-byte chunk `e4` of owned line l; U chunks per thread in flight (ids, then lines, then stores)
+  constexpr int U = 4;
+  const int nchunk = total * E4;
+  for (int c0 = 0; c0 < nchunk; c0 += 256 * U) {
+    int rr0[U], jj0[U], ee[U];
+    int item[U];
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = c0 + u * 256 + tid;
+      rr0[u] = -1;
+      if (idx < nchunk) {
+        const int l = idx / E4;
+        ee[u] = (idx - l * E4) * 4;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < R; ++q) r = l >= base[q] ? q : r;
+        rr0[u] = r;
+        jj0[u] = cont[r] ? F : l - base[r];
+        item[u] = a.items[src[r] + jj0[u]];
+      }
     }
-  }
-  // ---- ratings tails, reward, done
-  for (int idx = tid; idx < R * F; idx += 256) {
-    const int r = idx / F, j = idx - r * F;
-    if (!m_valid[r]) continue;
-    if (a.state) {
-      a.state[(int64_t)(row0 + r) * a.ld_state + FE + j] = rat[m_base[r] + j];
-      a.next_state[(int64_t)(row0 + r) * a.ld_next + FE + j] = rat[m_base[r] + 1 + j];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (rr0[u] >= 0) v[u] = *(const float4*)(a.table + (int64_t)item[u] * E + ee[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (rr0[u] < 0) continue;
+      const uint2 h = make_uint2(pack_bf2(v[u].x, v[u].y), pack_bf2(v[u].z, v[u].w));
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int rr = rr0[u] + k, jj = jj0[u] - k;
+        if (rr >= R || jj < 0 || (k > 0 && !cont[rr])) break;
+        const int64_t row = row0 + rr;
+        if (a.state) {
+          if (jj < F) store_f4<W>(a.state + row * a.ld_state + jj * E + ee[u], v[u]);
+          if (jj >= 1) store_f4<W>(a.next_state + row * a.ld_next + (jj - 1) * E + ee[u], v[u]);
+          if (jj == F) store_f4<W>(a.action + row * a.ld_action + ee[u], v[u]);
+        }
+        if constexpr (W == 4) {
+          if (a.state_h) {
+            if (jj < F) *(uint2*)(a.state_h + row * a.ld_h + jj * E + ee[u]) = h;
+            if (jj >= 1) *(uint2*)(a.next_h + row * a.ld_h + (jj - 1) * E + ee[u]) = h;
+            if (jj == F) *(uint2*)(a.action_h + row * a.ld_h + ee[u]) = h;
+          }
+        }
+      }
     }
-    if (a.state_h) {
-      a.state_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + j]);
-      a.next_h[(int64_t)(row0 + r) * a.ld_h + FE + j] = f2bf(rat[m_base[r] + 1 + j]);
-    }
-  }
-  if (tid < R && m_valid[tid]) {
-    a.reward[row0 + tid] = rat[m_base[tid] + F];
-    a.done[row0 + tid] = m_done[tid] ? 1.f : 0.f;
   }
 }
-
