@@ -383,6 +383,11 @@ int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward
  * the cursor (mod n_batches).  This makes the whole hot path -- sampler, gather, networks,
  * optimizer, soft update -- one launch sequence / one hipGraph.
  *   replaces the DataLoader + collate of recnn/data/env.py:225-252. */
+/* Plan table of a whole epoch permutation: plan[b * rows + r] = (CSR offset of the window start of row r of batch b) << 1 |
+ * (1 if that window is its user's last: done), -1 where batch b has fewer than r + 1 rows.  One workgroup per batch.
+ *   replaces, ahead of time, the per-step users -> offsets -> prefix scan -> row search of recnn_frame_gather. */
+int recnn_frame_plan_rows(const int64_t* user_off, const int32_t* perm, int users_per_batch, int n_batches, int frame,
+                          int rows, int64_t* plan, void* stream);
 typedef struct recnn_sampler {
   const int32_t* items; const float* ratings; const int64_t* user_off;  /* CSR replay store */
   const int32_t* perm;        /* epoch permutation of store user slots, int32[n_batches*users_per_batch] */
@@ -392,6 +397,9 @@ typedef struct recnn_sampler {
   const float* table;         /* float[n_items, emb_dim] */
   int32_t* row_off;           /* scratch int32[users_per_batch + 1] */
   int32_t* cursor;            /* device int32: next batch index */
+  const int64_t* plan;        /* optional: int64[n_batches * plan_rows] made by recnn_frame_plan_rows for THIS perm (NULL = the
+                                 gather plans its rows itself); must be re-made whenever perm changes */
+  int plan_rows;              /* rows per batch the plan covers (steps of at most this many rows use it) */
 } recnn_sampler;
 int recnn_engine_bind_sampler(recnn_engine* e, const recnn_sampler* h_sampler);  /* NULL unbinds */
 /* Who draws from a bound sampler: graph replays (recnn_engine_graph_run), the data-parallel phase graphs and

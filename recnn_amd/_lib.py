@@ -78,6 +78,7 @@ class Sampler(C.Structure):
         ("items", C.c_void_p), ("ratings", C.c_void_p), ("user_off", C.c_void_p), ("perm", C.c_void_p),
         ("users_per_batch", C.c_int), ("n_batches", C.c_int), ("frame", C.c_int), ("emb_dim", C.c_int),
         ("table", C.c_void_p), ("row_off", C.c_void_p), ("cursor", C.c_void_p),
+        ("plan", C.c_void_p), ("plan_rows", C.c_int),
     ]
 
 
@@ -121,6 +122,7 @@ SIGNATURES = {
     "recnn_engine_read_counters": (_I, [_P, _P, _P]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
+    "recnn_frame_plan_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     "recnn_pack_batch": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P]),

@@ -1314,7 +1314,7 @@ void use_set(recnn_engine* e, int k) {
   }
 }
 bool lookahead_ok(const recnn_engine* e) {
-  return e->has_sampler && e->bf16 && !g_sampler_f32_rows && e->smp.users_per_batch <= 1024 && g_pregather;
+  return e->has_sampler && e->bf16 && !g_sampler_f32_rows && (e->smp.users_per_batch <= 1024 || e->smp.plan) && g_pregather;
 }
 
 // gather of the batch `cursor_add` steps ahead of the device cursor into buffer set `set`
@@ -1333,6 +1333,7 @@ GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add)
   g.cursor = m.cursor; g.cursor_stride = m.users_per_batch;
   g.cursor_add = cursor_add; g.cursor_mod = m.n_batches;
   g.inline_plan = inl;
+  if (m.plan && rows <= m.plan_rows) { g.plan = m.plan; g.plan_stride = m.plan_rows; }
   if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
     char* hs = set ? e->xsh2 : e->xsh;
     char* hn = set ? e->xnh2 : e->xnh;
@@ -1347,7 +1348,7 @@ GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add)
 
 int frame_gather_packed(recnn_engine* e, int rows, hipStream_t s) {
   const recnn_sampler& m = e->smp;
-  const bool inl = m.users_per_batch <= 1024;
+  const bool inl = m.users_per_batch <= 1024 || (m.plan && rows <= m.plan_rows);
   if (!inl) {
     int rc = slot(e, "frame_plan", 0, s, [&] {
       return recnn_frame_plan(m.user_off, m.perm, m.users_per_batch, m.frame, m.row_off, m.cursor, m.users_per_batch, s);

@@ -19,6 +19,10 @@ struct GatherArgs {
   int cursor_stride;
   int cursor_add, cursor_mod;  // batch index = (*cursor + cursor_add) mod cursor_mod (cursor_mod 0: no wrap)
   int inline_plan;  // row_off == NULL: every workgroup scans the batch's history lengths itself (n_users <= 1024)
+  // optional per-epoch plan table (recnn_frame_plan_rows): plan[batch * plan_stride + row] = (CSR offset of the row's window
+  // start << 1) | done, -1 for rows the batch does not have; replaces users -> offsets -> scan -> search by ONE load
+  const int64_t* plan;
+  int64_t plan_stride;
   // optional bf16 twins of the packed rows (engine, bf16 compute mode): same columns, row stride ld_h (elements)
   bf16_t* state_h;
   bf16_t* next_h;

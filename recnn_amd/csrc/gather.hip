@@ -56,6 +56,70 @@ extern "C" int recnn_frame_plan(const int64_t* user_off, const int32_t* batch_us
   return recnn_check_hip(hipGetLastError(), "frame_plan");
 }
 
+// ------------------------------------------------------------------ per-epoch plan table
+// One workgroup per batch of the epoch permutation: prefix sums of the batch users' window counts (256 users per pass),
+// then every batch row looks itself up once: plan[batch][row] = (CSR offset of the window start << 1) | last-window flag,
+// -1 past the batch's last row.  The gather of a step then reaches a row's window with ONE load (GatherArgs.plan).
+__global__ __launch_bounds__(256) void frame_plan_rows_kernel(const int64_t* __restrict__ user_off, const int32_t* __restrict__ perm, int n,
+                                                              int frame, int rows, int64_t* __restrict__ plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char plan_smem[];
+  long long* s_start = (long long*)plan_smem;      // [n]
+  int* s_off = (int*)(s_start + n);                // [n + 1]
+  int* sc = s_off + n + 1;                         // [256]
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int32_t* users = perm + (int64_t)blockIdx.x * n;
+  if (tid == 0) { carry = 0; s_off[0] = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    int v = 0;
+    if (i < n) {
+      const int u = users[i];
+      const long long o0 = user_off[u];
+      v = max((int)(user_off[u + 1] - o0) - frame, 0);
+      s_start[i] = o0;
+    }
+    sc[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
+      const int t = tid >= o ? sc[tid - o] : 0;
+      __syncthreads();
+      sc[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) s_off[i + 1] = carry + sc[tid];
+    __syncthreads();
+    if (tid == 0) carry += sc[255];
+    __syncthreads();
+  }
+  const int total = s_off[n];
+  int64_t* out = plan + (int64_t)blockIdx.x * rows;
+  for (int r = tid; r < rows; r += 256) {
+    long long p = -1;
+    if (r < total) {
+      int lo = 0, hi = n;     // largest i with s_off[i] <= r
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= r) lo = mid; else hi = mid;
+      }
+      const int t = r - s_off[lo];
+      p = ((s_start[lo] + t) << 1) | (t == s_off[lo + 1] - s_off[lo] - 1 ? 1 : 0);
+    }
+    out[r] = p;
+  }
+}
+
+extern "C" int recnn_frame_plan_rows(const int64_t* user_off, const int32_t* perm, int users_per_batch, int n_batches, int frame, int rows,
+                                     int64_t* plan, void* stream) {
+  RECNN_REQUIRE(user_off && perm && plan && users_per_batch > 0 && n_batches > 0 && frame > 0 && rows > 0, "frame_plan_rows: bad arguments");
+  const size_t lds = (size_t)users_per_batch * 8 + (size_t)(users_per_batch + 1 + 256) * 4;
+  RECNN_REQUIRE(lds <= 64 * 1024, "frame_plan_rows: at most ~5000 users per batch (%d given)", users_per_batch);
+  hipLaunchKernelGGL(frame_plan_rows_kernel, dim3(n_batches), dim3(256), lds, (hipStream_t)stream, user_off, perm, users_per_batch, frame, rows,
+                     plan);
+  return recnn_check_hip(hipGetLastError(), "frame_plan_rows");
+}
+
 // ------------------------------------------------------------------ gather
 template <int R, int W>
 __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
@@ -67,7 +131,7 @@ size_t frame_gather_lds_bytes(const GatherArgs& a, int R) {
   const int F1 = a.frame + 1;
   (void)F1;
   size_t lds = (size_t)R * 8 + (size_t)R * 4 + 16;      // per-row window offsets and flags (no line staging since round 2)
-  if (a.inline_plan) lds += (size_t)a.n_users * 8 + (size_t)(a.n_users + 1 + 4) * 4;
+  if (a.inline_plan && !a.plan) lds += (size_t)a.n_users * 8 + (size_t)(a.n_users + 1 + 4) * 4;
   return lds;
 }
 

@@ -33,98 +33,115 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
   const int F = a.frame, E = a.emb, F1 = F + 1;
   long long* m_src = (long long*)smem_raw;         // CSR offset of the window start, per row
   long long* s_start = m_src + R;                  // inline plan: CSR offset of each batch user's history [n_users]
-  int* m_flag = (int*)(s_start + (a.inline_plan ? a.n_users : 0));   // per row: bit 0 valid, bit 1 done
+  const bool scan = a.inline_plan && !a.plan;      // (must match frame_gather_lds_bytes)
+  int* m_flag = (int*)(s_start + (scan ? a.n_users : 0));   // per row: bit 0 valid, bit 1 done
   int* s_off = m_flag + R;                         // inline plan: row prefix sums [n_users + 1]
   int* s_sc = s_off + a.n_users + 1;               // inline plan: per-wave totals [4]
 
   const int tid = threadIdx.x;
   const int row0 = block * R;
   const int32_t* users = a.users;
+  int cur = 0;
   if (a.cursor) {  // device-side batch cursor (graph replay); cursor_add looks ahead (batch of the NEXT step)
-    int cur = *a.cursor + a.cursor_add;
+    cur = *a.cursor + a.cursor_add;
     if (a.cursor_mod > 0 && cur >= a.cursor_mod) cur -= a.cursor_mod;
     users += (int64_t)cur * a.cursor_stride;
   }
 
-  const int* row_off = a.row_off;
-  if (a.inline_plan) {
-    // exclusive prefix sum of max(L_u - F, 0) over the batch's users, recomputed per workgroup (a few hundred
-    // L2-resident loads) instead of a separate single-workgroup plan launch ahead of the gather
-    const int n = a.n_users;
-    const int per = (n + 255) / 256;
-    int lens[4], sum = 0;
-    long long starts[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid * per + j;
-      int v = 0;
-      long long o0 = 0;
-      if (j < per && i < n) {
-        const int su = users[i];
-        o0 = a.user_off[su];
-        v = max((int)(a.user_off[su + 1] - o0) - F, 0);
-      }
-      lens[j] = v;
-      starts[j] = o0;
-      sum += v;
-    }
-    // block-wide exclusive scan: shuffles inside a wave, one barrier to combine the four wave totals
-    const int lane = tid & 63, wave = tid >> 6;
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_sc[wave] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += s_sc[w];
-    if (tid == 0) s_off[0] = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid * per + j;
-      if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; s_start[i] = starts[j]; }
-    }
-    __syncthreads();
-    row_off = s_off;
-  }
-
-  if (tid < R) {
-    const int r = row0 + tid;
-    // rows past the planned total (fewer windows than requested) are left untouched
-    const int valid = r < a.rows && r < row_off[a.n_users];
-    int last = 0;
-    long long src = 0;
-    if (valid) {
-      // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
-      int lo = 0, hi = a.n_users;
-      while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (row_off[mid] <= r) lo = mid; else hi = mid;
-      }
-      const int t = r - row_off[lo];
-      last = t == row_off[lo + 1] - row_off[lo] - 1;  // the user's final window: done = 1 (utils.py:70-71)
-      src = (a.inline_plan ? s_start[lo] : a.user_off[users[lo]]) + t;
-    }
-    m_src[tid] = src;
-    m_flag[tid] = valid | ((valid && last) << 1);
-    if (valid) a.done[r] = last ? 1.f : 0.f;
-  }
-  __syncthreads();
-
-  // ---- every thread: the R rows' metadata, which rows continue the previous row's window, and the owned-line prefix
+  // ---- every thread: the R rows' window starts and flags (bit 0 valid, bit 1 done)
   long long src[R];
+  int fl[R];
+  if (a.plan) {
+    // per-epoch plan table: a row's window start and done flag are ONE load away from the cursor (R entries of one or two
+    // cache lines, the same for every thread: no LDS, no barrier)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long p = row0 + r < a.rows ? a.plan[(int64_t)cur * a.plan_stride + row0 + r] : -1;
+      src[r] = p >> 1;
+      fl[r] = p >= 0 ? (1 | ((int)(p & 1) << 1)) : 0;
+    }
+  } else {
+    const int* row_off = a.row_off;
+    if (scan) {
+      // exclusive prefix sum of max(L_u - F, 0) over the batch's users, recomputed per workgroup (a few hundred
+      // L2-resident loads) instead of a separate single-workgroup plan launch ahead of the gather
+      const int n = a.n_users;
+      const int per = (n + 255) / 256;
+      int lens[4], sum = 0;
+      long long starts[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid * per + j;
+        int v = 0;
+        long long o0 = 0;
+        if (j < per && i < n) {
+          const int su = users[i];
+          o0 = a.user_off[su];
+          v = max((int)(a.user_off[su + 1] - o0) - F, 0);
+        }
+        lens[j] = v;
+        starts[j] = o0;
+        sum += v;
+      }
+      // block-wide exclusive scan: shuffles inside a wave, one barrier to combine the four wave totals
+      const int lane = tid & 63, wave = tid >> 6;
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) s_sc[wave] = incl;
+      __syncthreads();
+      int run = incl - sum;
+      for (int w = 0; w < wave; ++w) run += s_sc[w];
+      if (tid == 0) s_off[0] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = tid * per + j;
+        if (j < per && i < n) { run += lens[j]; s_off[i + 1] = run; s_start[i] = starts[j]; }
+      }
+      __syncthreads();
+      row_off = s_off;
+    }
+    if (tid < R) {
+      const int r = row0 + tid;
+      // rows past the planned total (fewer windows than requested) are left untouched
+      const int valid = r < a.rows && r < row_off[a.n_users];
+      int last = 0;
+      long long s0 = 0;
+      if (valid) {
+        // largest i with row_off[i] <= r   (row_off is non-decreasing, row_off[n_users] > r)
+        int lo = 0, hi = a.n_users;
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (row_off[mid] <= r) lo = mid; else hi = mid;
+        }
+        const int t = r - row_off[lo];
+        last = t == row_off[lo + 1] - row_off[lo] - 1;  // the user's final window: done = 1 (utils.py:70-71)
+        s0 = (scan ? s_start[lo] : a.user_off[users[lo]]) + t;
+      }
+      m_src[tid] = s0;
+      m_flag[tid] = valid | ((valid && last) << 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      src[r] = m_src[r];
+      fl[r] = m_flag[r];
+    }
+  }
+
+  // which rows continue the previous row's window, and the owned-line prefix
   bool valid[R], cont[R];
   int base[R + 1];
   base[0] = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    src[r] = m_src[r];
-    const int fl = m_flag[r];
-    valid[r] = fl & 1;
+    valid[r] = fl[r] & 1;
+    if (valid[r] && tid == r) a.done[row0 + r] = (fl[r] & 2) ? 1.f : 0.f;
     // window shifted by one against the previous row's (same user, previous row not the user's last): shares F lines with it
-    cont[r] = r > 0 && valid[r] && valid[r - 1] && !(m_flag[r - 1] & 2) && src[r] == src[r - 1] + 1;
+    cont[r] = r > 0 && valid[r] && valid[r - 1] && !(fl[r - 1] & 2) && src[r] == src[r - 1] + 1;
     base[r + 1] = base[r] + (valid[r] ? (cont[r] ? 1 : F1) : 0);
   }
   const int total = base[R];

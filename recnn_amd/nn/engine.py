@@ -212,8 +212,11 @@ class StepEngine:
                 self._bind_external()
             self.ext_noise[:noise.shape[0]].copy_(noise.to(self.device, torch.float32))
 
-    def bind_sampler(self, items, ratings, user_off, perm, users_per_batch: int, frame: int, emb_dim: int, table):
-        """Attach a device-resident replay store: every step then builds its own batch on the GPU."""
+    def bind_sampler(self, items, ratings, user_off, perm, users_per_batch: int, frame: int, emb_dim: int, table,
+                     plan_rows: int = 0):
+        """Attach a device-resident replay store: every step then builds its own batch on the GPU.
+        plan_rows > 0 also makes the per-epoch plan table (`recnn_frame_plan_rows`: one int64 per batch row) that lets the
+        gather reach a row's window with one load; whoever rewrites `perm` afterwards must call `plan_sampler()`."""
         dev = self.device
         assert items.dtype == torch.int32 and ratings.dtype == torch.float32 and user_off.dtype == torch.int64
         assert perm.dtype == torch.int32 and table.dtype == torch.float32
@@ -222,11 +225,26 @@ class StepEngine:
         self._row_off = torch.zeros(users_per_batch + 1, dtype=torch.int32, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self._smp_keep = (items, ratings, user_off, perm, table)
+        self._plan = None
+        self._plan_args = None
+        if plan_rows > 0 and users_per_batch <= 4096:
+            self._plan = torch.empty(n_batches * plan_rows, dtype=torch.int64, device=dev)
+            self._plan_args = (user_off, perm, users_per_batch, n_batches, frame, plan_rows)
+            self.plan_sampler()
         m = L.Sampler(items.data_ptr(), ratings.data_ptr(), user_off.data_ptr(), perm.data_ptr(), users_per_batch,
-                      n_batches, frame, emb_dim, table.data_ptr(), self._row_off.data_ptr(), self.cursor.data_ptr())
+                      n_batches, frame, emb_dim, table.data_ptr(), self._row_off.data_ptr(), self.cursor.data_ptr(),
+                      None if self._plan is None else self._plan.data_ptr(), plan_rows if self._plan is not None else 0)
         L.call("recnn_engine_bind_sampler", self.handle, C.byref(m))
         self.n_batches = n_batches
         self.has_sampler = True
+
+    def plan_sampler(self):
+        """(Re)make the plan table for the current contents of the bound permutation (stream-ordered on the current stream)."""
+        if getattr(self, "_plan", None) is None:
+            return
+        user_off, perm, upb, n_batches, frame, rows = self._plan_args
+        L.call("recnn_frame_plan_rows", L.ptr(user_off), L.ptr(perm), upb, n_batches, frame, rows, L.ptr(self._plan),
+               L.current_stream())
 
     def unbind_sampler(self):
         L.call("recnn_engine_bind_sampler", self.handle, None)

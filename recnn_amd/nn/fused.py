@@ -14,6 +14,8 @@ import weakref
 from typing import Dict, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from .. import _lib as L
@@ -246,13 +248,16 @@ class FusedContext:
                             n_batches=len(train) // users_per_batch, cursor=0)
         self.perm = torch.empty(self.sampler["n_batches"] * users_per_batch, dtype=torch.int32, device=eng.device)
         self._reshuffle()
-        eng.bind_sampler(st.items, st.ratings, st.user_off, self.perm, users_per_batch, env.frame_size, self.A, env.table)
+        eng.bind_sampler(st.items, st.ratings, st.user_off, self.perm, users_per_batch, env.frame_size, self.A, env.table,
+                         plan_rows=rows if os.environ.get("RECNN_SAMPLER_PLAN", "1") != "0" else 0)
         self.graph_rows = None
 
     def _reshuffle(self):
         sm = self.sampler
         order = torch.randperm(sm["train"].numel())[: self.perm.numel()].to(sm["train"].device)   # CPU generator, as RandomSampler
         self.perm.copy_(sm["train"][order].to(torch.int32))
+        if getattr(self.engine, "has_sampler", False):
+            self.engine.plan_sampler()          # the plan table follows the permutation (same stream as the copy)
 
     def run_steps(self, first_step: int, n_steps: int, every: int = None, prepare: bool = False):
         """`n_steps` consecutive learn steps by hipGraph replay; the permutation is redrawn at every epoch boundary.

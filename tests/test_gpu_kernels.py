@@ -120,6 +120,34 @@ def _args(L, dtype, M, N):
     return a
 
 
+@pytest.mark.parametrize("upb,rows", [(7, 300), (256, 2048), (1500, 96)])
+def test_plan_table_rows_match_the_window_arithmetic(cuda, upb, rows):
+    """recnn_frame_plan_rows (one workgroup per batch of an epoch permutation): plan[b][r] = (CSR offset of the window start
+    of row r << 1) | done, -1 past the batch's rows -- against the prefix-sum / search arithmetic of
+    prepare_batch_static_size in numpy (users with fewer than frame + 1 ratings contribute no rows, repeated users,
+    more than 256 users per batch)."""
+    L = _lib()
+    rng = np.random.default_rng(upb)
+    n_store, frame, n_batches = 400, 10, 5
+    lens = rng.integers(3, 60, n_store)                       # some histories are shorter than a window
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    perm = rng.integers(0, n_store, n_batches * upb).astype(np.int32)       # with repeats
+    plan = torch.full((n_batches * rows,), 123, dtype=torch.int64, device=cuda)
+    off_d, perm_d = torch.from_numpy(off).to(cuda), torch.from_numpy(perm).to(cuda)       # (kept alive across the launch)
+    L.call("recnn_frame_plan_rows", L.ptr(off_d), L.ptr(perm_d), upb, n_batches, frame, rows, L.ptr(plan), L.current_stream())
+    torch.cuda.synchronize()
+    got = plan.cpu().numpy().reshape(n_batches, rows)
+    for b in range(n_batches):
+        want = []
+        for u in perm[b * upb:(b + 1) * upb]:
+            n = max(int(lens[u]) - frame, 0)
+            want += [((int(off[u]) + t) << 1) | (1 if t == n - 1 else 0) for t in range(n)]
+        want = (want + [-1] * rows)[:rows]
+        want = np.asarray(want, dtype=np.int64)
+        bad = np.flatnonzero(got[b] != want)
+        assert bad.size == 0, (b, bad[:8], got[b][bad[:8]], want[bad[:8]])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 1472), (100, 128, 256), (33, 16, 64), (4096, 256, 256)])
 def test_gemm_fwd(cuda, dtype, M, N, K):
