@@ -334,6 +334,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   const int w2_first = consumed;                               // stream index of W2's k-slab 0 (= nt)
   for (int q = 0; q < 4; ++q) {
     const unsigned char* st = next_post();                     // (its barrier also completes the h1 panel for q = 0)
+    MLPS_STAMP(10 + q);
     if (q == 0 && P.h1) panel_to_global<NW>(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
     if constexpr (!(PROBE & 1)) mma_panel(panel, q, st + A1_BYTES, acc, wave * 16, fr, fg);
   }
@@ -349,12 +350,14 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
     o[0][0] = o[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < 2; ++p) {
       const unsigned char* st = next_post();                   // (completes the h2 panel for p = 0)
+      MLPS_STAMP(14 + p);
       if (p == 0 && P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
       if (wave < OW) {
         if constexpr (!(PROBE & 1)) mma_panel(panel, 2 * p, st + A1_BYTES, o, wave * 16, fr, fg);
         if constexpr (!(PROBE & 1)) mma_panel(panel, 2 * p + 1, st + A1_BYTES, o, 128 + wave * 16, fr, fg);
       }
     }
+    MLPS_STAMP(16);
     if (wave < OW) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
       if (ti >= n_tail) break;
       const MlpTail& T = batch.tail[ti];
       const unsigned char* tc = next_post();                   // the producer's layer-1 part (fp32 rows of 1 KB) + b1 | b2 | w3
+      if (ti == 0) MLPS_STAMP(17);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) acc[tm][0] = *(const f32x4*)(tc + A1_BYTES + (tm * 16 + fr) * 1024 + n0 * 4);
       f32x4 tbv[1];
@@ -406,21 +410,25 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
         const unsigned char* st = next_post();                 // (the action slabs are complete after the part slab's barrier)
         if constexpr (!(PROBE & 1)) mma_stage(lds + ((ps0 + 1 + q) & (NST - 1)) * STAGE1, st + A1_BYTES, acc, wave * 16, fr, fg);
       }
+      if (ti == 0) MLPS_STAMP(18);
       if (ti > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // the previous critic's q dots are done with the panel
       }
       tbv[0] = *(const f32x4*)(tc + n0 * 4);
       hidden_epilogue<1>(acc, tbv, P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
+      if (ti == 0) MLPS_STAMP(19);
       acc[0][0] = acc[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < 4; ++q) {
         const unsigned char* st = next_post();
         if constexpr (!(PROBE & 1)) mma_panel(panel, q, st + A1_BYTES, acc, wave * 16, fr, fg);
       }
+      if (ti == 0) MLPS_STAMP(20);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everyone is done reading the h1 panel
       tbv[0] = *(const f32x4*)(tc + 1024 + n0 * 4);
       hidden_epilogue<1>(acc, tbv, P.H, P.rows, m0, wave, fr, fg, RECNN_MASK_NONE, nullptr, 0, 0u, panel);
+      if (ti == 0) MLPS_STAMP(21);
       const f32x4 tw = *(const f32x4*)(tc + 2048 + lane * 16);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // h2 panel complete

@@ -45,6 +45,19 @@ labels = {13: "L2 slab 2 before wait", 14: "L2 slab 2 after wait+barrier", 15: "
 for pi, nm in enumerate(names):
     rows = tr[pi * npanel:(pi + 1) * npanel]
     print(f"== {nm}: start offset vs launch start: median {np.median(rows[:, 0] - t_start):.0f}, max {np.max(rows[:, 0] - t_start):.0f} ticks")
+    if kernel == 3:
+        seq = [(1, "setup done"), (2, "L1 done"), (3, "epilogue 1 done"), (10, "L2 slab 0 landed+issued"), (11, "L2 slab 1"), (12, "L2 slab 2"),
+               (13, "L2 slab 3"), (4, "L2 mma done"), (5, "epilogue 2 done"), (14, "L3 slab 0 landed+issued"), (15, "L3 slab 1"), (16, "L3 mma done"),
+               (6, "outputs stored / critic q done"), (17, "tail: part slab landed"), (18, "tail: action slabs multiplied"),
+               (19, "tail: epilogue 1"), (20, "tail: W2 multiplied"), (21, "tail: epilogue 2"), (7, "tails done (q dots)"), (9, "end")]
+        prev = None
+        for k, lab in seq:
+            v = rows[:, k]
+            if (v > 0).all():
+                t = np.median(v - rows[:, 0])
+                print(f"   {lab:34s} {t:9.0f}   (+{t - prev:6.0f})" if prev is not None else f"   {lab:34s} {t:9.0f}")
+                prev = t
+        continue
     for k in ((1, 2, 3, 4, 5, 6, 7, 9) if kernel == 3 else (1, 10, 11, 12, 2, 3, 13, 14, 4, 15, 5, 6, 7, 9, 16 + 2, 16 + 3, 16 + 13, 16 + 14, 16 + 4, 16 + 15, 16 + 5, 16 + 6, 16 + 9)):
         v = rows[:, k]
         if (v > 0).all():
