@@ -38,3 +38,13 @@ with torch.cuda.stream(stream):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"run(300) from cursor {cur:4d} ({'crosses' if cur + 300 >= nb else 'inside '}): {dt * 1e3:8.2f} ms, {dt * 1e6 / 300:7.2f} us/step")
+    # one long call vs the same steps as short calls (is a long run() slower per step than its pieces?)
+    for rep in range(3):
+        for n, k in ((2000, 1), (200, 10), (540, 4), (4000, 1)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                algo.run(n)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"rep {rep}: {k:2d} x run({n:4d}): {dt * 1e3:8.2f} ms, {dt * 1e6 / (n * k):7.2f} us/step")
