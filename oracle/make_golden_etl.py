@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 REF = os.environ.get("RECNN_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, "_stubs"))
-sys.path.insert(0, ROOT)
+sys.path.append(ROOT)     # after the reference: `import recnn` must find /root/reference, not the repository's `recnn` shim
 
 import numpy as np  # noqa: E402
 import pandas  # noqa: E402

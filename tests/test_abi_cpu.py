@@ -63,3 +63,22 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_import_recnn_resolves_to_this_implementation():
+    """With the repository on sys.path, `import recnn` (what the reference's notebooks do) IS recnn_amd -- no install_as call,
+    no changed line; sub-module imports and from-imports work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import recnn\n"
+            "import recnn.nn, recnn.data.env, recnn.utils\n"
+            "from recnn.nn import DDPG, TD3, Actor, Critic, ddpg_update\n"
+            "from recnn.data.env import FrameEnv, DataPath\n"
+            "import recnn_amd\n"
+            "assert recnn is recnn_amd and recnn.nn.DDPG is recnn_amd.nn.DDPG and FrameEnv is recnn_amd.data.env.FrameEnv\n"
+            "assert recnn.data.get_base_batch is recnn_amd.data.get_base_batch and recnn.utils.soft_update is recnn_amd.utils.soft_update\n"
+            "print('ok')\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
