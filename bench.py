@@ -246,6 +246,8 @@ def main():
         L.load().recnn_tune_dw_splits(int(os.environ["RECNN_DW_SPLITS"]))
     if os.environ.get("RECNN_GEMM_TGF"):
         L.load().recnn_tune_gemm_ks_layout(int(os.environ["RECNN_GEMM_TGF"]))
+    if os.environ.get("RECNN_LD_PAD"):
+        L.load().recnn_tune_ld_pad(int(os.environ["RECNN_LD_PAD"]))
     if os.environ.get("RECNN_GATHER_ROWS"):
         L.load().recnn_tune_gather_rows(int(os.environ["RECNN_GATHER_ROWS"]))
 

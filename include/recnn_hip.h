@@ -72,6 +72,9 @@ void recnn_tune_gemm_dma_waves(int waves);
 void recnn_tune_gemm_waves(int waves);
 /* tuning knob: waves per workgroup of the fused MLP forward kernel, 8 (default) or 4. */
 void recnn_tune_mlp_waves(int waves);
+/* tuning knob: extra elements (rounded up to 8) on every leading dimension the MFMA kernels stream through (weight shadows,
+ * packed batch rows); applies to engines created afterwards. */
+void recnn_tune_ld_pad(int elems);
 /* 0 (default): a bf16 engine that samples its own batches (recnn_engine_bind_sampler) writes the batch rows in
  * bf16 only; 1: it also fills the bound fp32 packed rows. */
 void recnn_tune_sampler_f32_rows(int on);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "recnn_engine_dp_sets": (_I, [_P]),
     "recnn_engine_read_counters": (_I, [_P, _P, _P]),
     "recnn_tune_sampler_f32_rows": (None, [_I]),
+    "recnn_tune_ld_pad": (None, [_I]),
     "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),

@@ -47,6 +47,7 @@ constexpr int W1 = 0, B1 = 1, W2 = 2, B2 = 3, W3 = 4, B3 = 5;
 int SP_W1 = 8;  // batch splits of the layer-1 dW GEMM (tunable)
 constexpr int SP_W1_MAX = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
 
+int ld_pad();   // recnn_tune_ld_pad (defined with the other tuning knobs below)
 struct Net {
   bool critic = false, bound = false;
   float *p = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // canonical flat arenas (caller owned)
@@ -212,9 +213,9 @@ void net_dims(recnn_engine* e, int ni) {
   n.off[W3] = n.off[B2] + H;
   n.off[B3] = n.off[W3] + (int64_t)n.out_dim * H;
   n.n_params = n.off[B3] + n.out_dim;
-  n.ld_w1 = n.critic ? e->K1c : e->K1a;
-  n.ld_w2 = e->Hp;
-  n.ld_w3 = e->Hp;
+  n.ld_w1 = (n.critic ? e->K1c : e->K1a) + ld_pad();
+  n.ld_w2 = e->Hp + ld_pad();
+  n.ld_w3 = e->Hp + ld_pad();
   n.sh_off[W1] = 0;
   n.sh_off[W2] = (int64_t)e->Hp * n.ld_w1;
   int64_t tot = n.sh_off[W2] + (int64_t)e->Hp * n.ld_w2;
@@ -329,6 +330,7 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   e->K1c = (int)ru(e->S + e->A, 128);
   e->ldx = (int)ru(e->A + e->K1a, 128);
   if (e->ldx < e->K1c) e->ldx = e->K1c;
+  e->ldx += ld_pad();
   e->Bc = (int)ru(cfg->max_rows, 64);
   e->bf16 = cfg->dtype == RECNN_BF16;
   e->esz = e->bf16 ? 2 : 4;
@@ -698,6 +700,12 @@ static int g_defer_policy_fwd = 1;
 extern "C" void recnn_tune_defer_policy_fwd(int on) { g_defer_policy_fwd = on; }
 static int g_pregather = 1;
 extern "C" void recnn_tune_pregather(int on) { g_pregather = on; }
+// Extra elements added to every leading dimension the MFMA kernels stream through (weight shadows, packed batch rows): the
+// natural pitches are multiples of 256 B (W2 / W3: 512 B, critic W1 and the batch rows: 3072 B), which may map a k-slab's
+// row segments onto a few L2 channels only.  Set before an engine is created.
+static int g_ld_pad = 0;
+extern "C" void recnn_tune_ld_pad(int elems) { g_ld_pad = elems > 0 ? (elems + 7) & ~7 : 0; }
+int ld_pad() { return g_ld_pad; }
 static int g_sampler_f32_rows = 0;
 extern "C" void recnn_tune_sampler_f32_rows(int on) { g_sampler_f32_rows = on; }
 extern "C" void recnn_tune_dw_splits(int s) { SP_W1 = s < 1 ? 1 : (s > SP_W1_MAX ? SP_W1_MAX : s); }

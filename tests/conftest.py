@@ -22,6 +22,9 @@ def cuda():
     import torch
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no GPU is visible")
+    if os.environ.get("RECNN_LD_PAD"):          # run the GPU suite on a different leading-dimension padding (tuning knob)
+        from recnn_amd import _lib as L
+        L.load().recnn_tune_ld_pad(int(os.environ["RECNN_LD_PAD"]))
     return torch.device("cuda")
 
 
