@@ -90,7 +90,10 @@ __device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, con
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 }  // namespace
 
-#define MLPS_STAMP(i) do { if (trace && threadIdx.x == 0) trace[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (the row pointer is computed ONCE, before any DMA is in flight: gridDim.x is a load from the dispatch packet, and the compiler's
+// vmcnt(0) for it inside a stamp drained the whole DMA queue of wave 0 at every stamp -- the first traces of this kernel charged
+// that drain to whatever phase a stamp followed)
+#define MLPS_STAMP(i) do { if (trow) trow[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // PROBE (timing experiments, recnn_tune_mlp_fault bits 0x100 / 0x200 = bench.py RECNN_MLP_PROBE 1 / 2): 1 = no MFMA work, 2 = no DMA
 template <int PROBE>
@@ -104,6 +107,8 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int row_max = P.rows - 1;
+  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  asm volatile("" : "+v"(trow));
   MLPS_STAMP(0);
 
   // ---- pull every kernel-argument cache line this workgroup will read into the scalar cache NOW.  The argument block is
@@ -234,13 +239,15 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   // The next slab of the sequence after layer 1: waits until it has landed for every wave (every slab after layer 1 is two
   // DMA instructions per wave, so "at most 2 y outstanding" leaves the y younger slabs in flight; global stores issued
   // meanwhile only make the wait stricter), refills the stage the previous slab occupied, returns the slab's stage.
-  auto next_post = [&]() -> const unsigned char* {
+  auto next_post = [&](int stamp = -1) -> const unsigned char* {
     const int c = consumed++;
     const int y = issued - c - 1;
     if (y >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if (y == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (stamp >= 0) MLPS_STAMP(stamp);
     __builtin_amdgcn_s_barrier();  // slab c landed for every wave; everybody is done with slab c - 1 and with its LDS writes so far
+    if (stamp >= 0) MLPS_STAMP(stamp + 1);
     issue_post(issued - nt);
     return lds + (c & (NST - 1)) * STAGE1;
   };
@@ -333,10 +340,12 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   acc[0][0] = acc[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int w2_first = consumed;                               // stream index of W2's k-slab 0 (= nt)
   for (int q = 0; q < 4; ++q) {
-    const unsigned char* st = next_post();                     // (its barrier also completes the h1 panel for q = 0)
+    const unsigned char* st = next_post(q == 1 ? 22 : -1);     // (its barrier also completes the h1 panel for q = 0)
     MLPS_STAMP(10 + q);
     if (q == 0 && P.h1) panel_to_global<NW>(panel, (bf16_t*)P.h1, P.ldh, m0, P.rows, tid);
+    if (q == 0) MLPS_STAMP(24);
     if constexpr (!(PROBE & 1)) mma_panel(panel, q, st + A1_BYTES, acc, wave * 16, fr, fg);
+    if (q == 0) MLPS_STAMP(25);
   }
   MLPS_STAMP(4);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

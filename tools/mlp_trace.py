@@ -46,7 +46,8 @@ for pi, nm in enumerate(names):
     rows = tr[pi * npanel:(pi + 1) * npanel]
     print(f"== {nm}: start offset vs launch start: median {np.median(rows[:, 0] - t_start):.0f}, max {np.max(rows[:, 0] - t_start):.0f} ticks")
     if kernel == 3:
-        seq = [(1, "setup done"), (2, "L1 done"), (3, "epilogue 1 done"), (10, "L2 slab 0 landed+issued"), (11, "L2 slab 1"), (12, "L2 slab 2"),
+        seq = [(1, "setup done"), (2, "L1 done"), (3, "epilogue 1 done"), (10, "L2 slab 0 landed+issued"), (24, "  h1 panel stored (issued)"), (25, "  slab 0 multiplied"), (22, "  slab 1: vmcnt wait over"),
+               (23, "  slab 1: barrier passed"), (11, "L2 slab 1 (next slab issued)"), (12, "L2 slab 2"),
                (13, "L2 slab 3"), (4, "L2 mma done"), (5, "epilogue 2 done"), (14, "L3 slab 0 landed+issued"), (15, "L3 slab 1"), (16, "L3 mma done"),
                (6, "outputs stored / critic q done"), (17, "tail: part slab landed"), (18, "tail: action slabs multiplied"),
                (19, "tail: epilogue 1"), (20, "tail: W2 multiplied"), (21, "tail: epilogue 2"), (7, "tails done (q dots)"), (9, "end")]
