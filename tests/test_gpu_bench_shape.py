@@ -219,3 +219,56 @@ def test_learn_false_update_sees_its_own_batch(cuda):
     got1, got2 = ddpg.update(b1, learn=False), ddpg.update(b2, learn=False)
     assert got1["value"] == ref1["value"] and got2["value"] == ref2["value"], (got1, ref1, got2, ref2)
     assert got1["policy"] == ref1["policy"] and got2["policy"] == ref2["policy"]
+
+
+def test_td3_b4096_run_graphs_equal_pieces_and_update_loop(cuda):
+    """BASELINE configs[2] (TD3, twin critics, delayed actor, 4096 rows per step, bf16, hash dropout masks and on-device target
+    noise): `Algo.run(45)` in one call == the same steps as run(5); run(20); run(20) (mid-cycle starts, made-to-order graph) ==
+    the reference-shaped loop `update(batch); step()` on the same batches -- parameters of all six networks bit for bit, per-step
+    losses (value1, value2, policy) to summation order."""
+    import recnn_amd
+    from recnn_amd.nn import fused
+    rows, upb, n = 4096, 512, 45
+    env, _ = _bench_env(recnn_amd, cuda, n_users=(n + 2) * upb, seed=5)
+    env.rows_per_batch = rows                  # (the helper builds a 2048-row env)
+    names = ("policy_net", "value_net1", "value_net2", "target_policy_net", "target_value_net1", "target_value_net2")
+    results = {}
+    for mode in ("one_call", "pieces", "loop"):
+        fused.set_defaults(dtype="bf16", mask_mode="hash", seed=SEED)
+        torch.manual_seed(21)
+        td3 = recnn_amd.nn.TD3(recnn_amd.nn.Actor(1290, 128, 256, 6e-1), recnn_amd.nn.Critic(1290, 128, 256, 54e-2),
+                               recnn_amd.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+        every = td3.params["policy_update"]
+        torch.manual_seed(77)
+        td3.attach_env(env, rows_per_batch=rows, users_per_batch=upb)
+        ctx = td3._fused_ctx
+        assert ctx.sampler["n_batches"] >= n
+        if mode == "one_call":
+            out, hist = td3.run(n, history=True)
+        elif mode == "pieces":
+            hist = []
+            td3.prepare_run(20, first_step=5)
+            for k in (5, 20, n - 25):
+                out, h = td3.run(k, history=True)
+                hist += h
+        else:
+            perm = ctx.perm.cpu().numpy()
+            hist = []
+            for i in range(n):
+                batch = env.collate_users([int(u) for u in perm[i * upb:(i + 1) * upb]])
+                assert batch["state"].shape[0] == rows
+                out = td3.update(batch, learn=True)
+                hist.append(dict(out))
+                td3.step()
+        torch.cuda.synchronize()
+        assert td3._step == n and len(hist) == n
+        results[mode] = (hist, {nm: {k: v.detach().clone() for k, v in td3.nets[nm].state_dict().items()} for nm in names}, every)
+    for other in ("pieces", "loop"):
+        for net, sd in results["one_call"][1].items():
+            for k, v in sd.items():
+                assert torch.equal(v, results[other][1][net][k]), (other, net, k)
+        for a, b in zip(results["one_call"][0], results[other][0]):
+            assert a["step"] == b["step"]
+            for k in ("value1", "value2", "policy"):
+                assert abs(a[k] - b[k]) <= 1e-5 * max(abs(b[k]), 1.0), (other, k, a, b)
+    assert all(np.isfinite(h[k]) for h in results["one_call"][0] for k in ("value1", "value2", "policy"))
