@@ -66,6 +66,20 @@ def _r128(x):
     return (x + 127) // 128 * 128
 
 
+_mlp_dtype = "fp32"
+
+
+def set_mlp_dtype(dtype: str):
+    """Compute type of the module-level MLP stacks (`Actor` / `Critic` / `bcqPerturbator` / `bcqGenerator` called directly, and
+    therefore of `bcq_update`): 'fp32' (default; exact-fp32 MFMA, the parity mode) or 'bf16' (bf16 MFMA with fp32 accumulation:
+    bf16 copies of the weights kept per weight version, activations and backward tensors in bf16, weight / bias gradients,
+    outputs and every optimizer in fp32).  The fused DDPG / TD3 engine has its own switch (`fused.set_defaults(dtype=...)`)."""
+    global _mlp_dtype
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(dtype)
+    _mlp_dtype = dtype
+
+
 def _args(M, N, dtype=None):
     a = L.GemmArgs()
     a.dtype = L.F32 if dtype is None else dtype
@@ -75,10 +89,10 @@ def _args(M, N, dtype=None):
     return a
 
 
-def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0, dtype=None, add_row_div=0):
+def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1.0, dtype=None, add_row_div=0, c_f32=1):
     a = _args(x.shape[0], N, dtype)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = x.data_ptr(), w.data_ptr(), x.stride(0), w.stride(0), K
-    a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 1
+    a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, c_f32
     a.bias, a.relu = (bias.data_ptr() if bias is not None else None), int(relu)
     if addend is not None:      # added before the relu (gemm.hip epilogue_fwd)
         a.addend, a.ld_add, a.add_clip = addend.data_ptr(), addend.stride(0), float("inf")
@@ -90,10 +104,10 @@ def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1
     L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
 
 
-def _dx(dz, Kc, w, N, out, yref, scale, colsum):
-    a = _args(dz.shape[0], N)
+def _dx(dz, Kc, w, N, out, yref, scale, colsum, dtype=None, c_f32=1):
+    a = _args(dz.shape[0], N, dtype)
     a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = dz.data_ptr(), w.data_ptr(), dz.stride(0), w.stride(0), Kc
-    a.C, a.ldc, a.c_f32 = out.data_ptr(), out.stride(0), 1
+    a.C, a.ldc, a.c_f32 = out.data_ptr(), out.stride(0), c_f32
     if yref is not None:
         a.yref, a.ldy, a.dx_scale = yref.data_ptr(), yref.stride(0), scale
     if colsum is not None:
@@ -117,8 +131,10 @@ class MLPFunction(torch.autograd.Function):
                                   "inputs to 'cuda'")
         B, K = x.shape
         H, O = w1.shape[0], w3.shape[0]
-        Kp, Hp, Op = _r64(K), _r64(H), _r64(O)
         dev = x.device
+        if _mlp_dtype == "bf16" and K < 4096:
+            return MLPFunction._forward_bf16(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks, addend1)
+        Kp, Hp, Op = _r64(K), _r64(H), _r64(O)
         # catalogue-wide layer 1 (the critic over action distributions) in bf16 mode: the fp32 operands are only
         # materialised when a backward pass will need them
         big16 = _catalogue_dtype == "bf16" and K >= 4096
@@ -164,10 +180,91 @@ class MLPFunction(torch.autograd.Function):
         ctx.save_for_backward(xp, h1, h2, w1p, w2p, w3p)
         ctx.dims = (B, K, H, O, Kp, Hp, Op)
         ctx.train = bool(train)
+        ctx.bf16 = False
+        return out
+
+    # ---- bf16 compute mode (set_mlp_dtype): the same three GEMM + epilogue launches on bf16 operands
+    @staticmethod
+    def _shadow16(w, rows, cols):
+        def build(t):
+            out = torch.zeros(rows, cols, dtype=torch.bfloat16, device=t.device)
+            out[: t.shape[0], : t.shape[1]] = t
+            return out
+        return _derived_of(w, f"bf16_{rows}x{cols}", build) if w.is_leaf else build(w.detach())
+
+    @staticmethod
+    def _forward_bf16(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks, addend1):
+        B, K = x.shape
+        H, O = w1.shape[0], w3.shape[0]
+        Kp, Hp, Op = _r128(K), _r128(H), _r64(O)
+        dev = x.device
+        x16 = torch.zeros(B, Kp, dtype=torch.bfloat16, device=dev)
+        x16[:, :K] = x.detach()
+        w1s, w2s, w3s = MLPFunction._shadow16(w1, Hp, Kp), MLPFunction._shadow16(w2, Hp, Hp), MLPFunction._shadow16(w3, Op, Hp)
+        m1 = m2 = None
+        if train and masks is not None:
+            m1, m2 = (m.to(device=dev, dtype=torch.uint8).contiguous() for m in masks)
+        elif train:
+            key = next(_call_counter)
+            m1 = torch.empty(B, H, dtype=torch.uint8, device=dev)
+            m2 = torch.empty(B, H, dtype=torch.uint8, device=dev)
+            s = L.current_stream()
+            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 0, B, H, L.ptr(m1), s)
+            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
+        f = lambda t: t.detach().float().contiguous()
+        add1 = None if addend1 is None else f(addend1)
+        h1 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        h2 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(B, O, device=dev)
+        _fwd(x16, Kp, w1s, f(b1), h1, Hp, H, True, m1, addend=add1, dtype=L.BF16, c_f32=0)
+        _fwd(h1, Hp, w2s, f(b2), h2, Hp, H, True, m2, dtype=L.BF16, c_f32=0)
+        _fwd(h2, Hp, w3s, f(b3), out, O, O, False, None, dtype=L.BF16)
+        ctx.save_for_backward(x16, h1, h2, w1s, w2s, w3s)
+        ctx.dims = (B, K, H, O, Kp, Hp, Op)
+        ctx.train = bool(train)
+        ctx.bf16 = True
         return out
 
     @staticmethod
+    def _backward_bf16(ctx, dout):
+        x16, h1, h2, w1s, w2s, w3s = ctx.saved_tensors
+        B, K, H, O, Kp, Hp, Op = ctx.dims
+        dev = dout.device
+        scale = 2.0 if ctx.train else 1.0
+        tiles = (B + 31) // 32
+        need = ctx.needs_input_grad
+        d16 = torch.zeros(B, Op, dtype=torch.bfloat16, device=dev)
+        d16[:, :O] = dout
+        gw3 = gb3 = gw2 = gw1 = None
+        if need[5]:
+            gw3 = torch.empty(O, H, device=dev)
+            _dw(d16, O, h2, H, gw3, dtype=L.BF16)
+        if need[6]:
+            gb3 = dout.float().sum(0)
+        dz2 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        cs2 = torch.empty(tiles, H, device=dev)
+        _dx(d16, Op, w3s, H, dz2, h2, scale, cs2, dtype=L.BF16, c_f32=0)
+        if need[3]:
+            gw2 = torch.empty(H, H, device=dev)
+            _dw(dz2, H, h1, H, gw2, dtype=L.BF16)
+        dz1 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        cs1 = torch.empty(tiles, H, device=dev)
+        _dx(dz2, Hp, w2s, H, dz1, h1, scale, cs1, dtype=L.BF16, c_f32=0)
+        if need[1]:
+            gw1 = torch.empty(H, K, device=dev)
+            _dw(dz1, H, x16, K, gw1, dtype=L.BF16)
+        gx = None
+        if need[0]:
+            gx = torch.empty(B, K, device=dev)
+            _dx(dz1, Hp, w1s, K, gx, None, 1.0, None, dtype=L.BF16)
+        gadd = dz1[:, :H].float() if need[10] else None
+        return (gx, gw1, cs1.sum(0) if need[2] else None, gw2, cs2.sum(0) if need[4] else None, gw3, gb3, None, None, None,
+                gadd)
+
+    @staticmethod
     def backward(ctx, dout):
+        if ctx.bf16:
+            return MLPFunction._backward_bf16(ctx, dout)
         xp, h1, h2, w1p, w2p, w3p = ctx.saved_tensors
         B, K, H, O, Kp, Hp, Op = ctx.dims
         dev = dout.device
@@ -242,6 +339,21 @@ def mlp_candidates(state, x, n, w1, b1, w2, b2, w3, b3):
         Sp, Kp, Hp, Op = _r64(S), _r64(Kx), _r64(H), _r64(O)
         dev = state.device
         f = lambda t: t.detach().float().contiguous()
+        if _mlp_dtype == "bf16":
+            Sp, Kp, Hp = _r128(S), _r128(Kx), _r128(H)
+            def to16(t, rows, cols):
+                o = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
+                o[: t.shape[0], : t.shape[1]] = t.detach()
+                return o
+            s1 = torch.zeros(B, Hp, device=dev)                 # the shared state part stays fp32 (it is an epilogue addend)
+            _fwd(to16(state, B, Sp), Sp, to16(w1[:, :S], Hp, Sp), f(b1), s1, Hp, H, False, None, dtype=L.BF16)
+            h1 = torch.zeros(R, Hp, dtype=torch.bfloat16, device=dev)
+            _fwd(to16(x, R, Kp), Kp, to16(w1[:, S:], Hp, Kp), None, h1, Hp, H, True, None, addend=s1, add_row_div=n, dtype=L.BF16, c_f32=0)
+            h2 = torch.zeros(R, Hp, dtype=torch.bfloat16, device=dev)
+            _fwd(h1, Hp, MLPFunction._shadow16(w2, Hp, Hp), f(b2), h2, Hp, H, True, None, dtype=L.BF16, c_f32=0)
+            out = torch.empty(R, O, device=dev)
+            _fwd(h2, Hp, MLPFunction._shadow16(w3, Op, Hp), f(b3), out, O, O, False, None, dtype=L.BF16)
+            return out
         s1 = torch.zeros(B, Hp, device=dev)
         _fwd(_pad(state, B, Sp), Sp, _pad(w1[:, :S], Hp, Sp), f(b1), s1, Hp, H, False, None)
         h1 = torch.zeros(R, Hp, device=dev)

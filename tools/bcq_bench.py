@@ -37,9 +37,12 @@ def main():
     ap.add_argument("--latent", type=int, default=512)
     ap.add_argument("--candidates", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="compute type of the GEMMs (functional.set_mlp_dtype)")
     ap.add_argument("--no-split", action="store_true", help="score candidates on materialised repeated states (the reference's formulation)")
     args = ap.parse_args()
     from recnn_amd import optim
+    from recnn_amd.nn import functional as F_hip
+    F_hip.set_mlp_dtype(args.dtype)
     from recnn_amd.nn import bcq_update
     from recnn_amd.nn import models as M
     S, A, L, H, B, n = 1290, 128, args.latent, 256, args.rows, args.candidates
@@ -98,7 +101,7 @@ def main():
     f_ref, f_split = flops_per_step(B, S, A, L, 256, 750, n, 30)
     line = {"metric": "BCQ update steps/sec (batch %d, %d candidates/state, latent %d)" % (B, n, L), "value": 1000.0 / ms,
             "unit": "steps/s", "ms_per_step": ms, "wall_ms_per_step": 1000.0 * wall / args.steps, "steps": args.steps,
-            "dtype": "f32 (exact-fp32 MFMA)", "candidate_path": "materialised" if args.no_split else "shared state part",
+            "dtype": "f32 (exact-fp32 MFMA)" if args.dtype == "fp32" else "bf16 MFMA (fp32 accumulation, master weights, optimizer)", "candidate_path": "materialised" if args.no_split else "shared state part",
             "gflop_per_step_reference_formulation": f_ref / 1e9, "gflop_per_step_executed": (f_ref if args.no_split else f_split) / 1e9,
             "tflops_executed": (f_ref if args.no_split else f_split) / (ms * 1e-3) / 1e12, "final_losses": out, "cpu_baseline": cpu}
     print(json.dumps(line))
