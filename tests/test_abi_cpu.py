@@ -82,3 +82,19 @@ def test_import_recnn_resolves_to_this_implementation():
             "print('ok')\n") % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_csr_workspace_query_is_host_only_and_validates():
+    """recnn_csr_workspace_bytes is pure host arithmetic (no GPU needed): grows with the row count, refuses row counts whose
+    indices would not fit the 32-bit payload of the radix sort; recnn_frame_plan_rows refuses null pointers with an error code
+    and a message instead of launching."""
+    import ctypes as C
+    from recnn_amd import _lib as L
+    lib = L.load()
+    a, b = C.c_int64(0), C.c_int64(0)
+    assert lib.recnn_csr_workspace_bytes(1000, C.byref(a)) == 0 and lib.recnn_csr_workspace_bytes(20_000_263, C.byref(b)) == 0
+    assert 0 < a.value < b.value and b.value >= 20_000_263 * (8 + 8 + 4 + 4 + 4)
+    assert lib.recnn_csr_workspace_bytes(1 << 33, C.byref(a)) != 0
+    assert b"rows" in lib.recnn_last_error()
+    assert lib.recnn_frame_plan_rows(None, None, 4, 1, 10, 8, None, None) != 0
+    assert b"frame_plan_rows" in lib.recnn_last_error()
