@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 
 // One wave per tile, rows taken 64 at a time in order: a row's slot is start(digit, tile) + rows of this tile with the
 // same digit seen so far + its rank among the equal-digit lanes below it (8 ballots) -- stable by construction.
+// The running per-digit offsets live in LDS and are touched by this one wave only: LDS instructions of a wave execute in
+// program order, so the lanes' reads of off[d] are done before the group leaders' updates are -- no barrier inside the loop
+// (the asm statements only stop the compiler from reordering across them).  The next round's rows are loaded while the
+// current round is ranked and stored (the loop would otherwise pay one global-memory latency per 64 rows).
 __global__ __launch_bounds__(WAVE) void radix_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int64_t n,
                                                              int shift, const uint32_t* __restrict__ start, int nblocks,
                                                              uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
@@ -83,12 +87,16 @@ __global__ __launch_bounds__(WAVE) void radix_scatter_kernel(const uint64_t* __r
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
   const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int j = 0; j < TILE; j += WAVE) {
-    const int64_t i = base + j + lane;
+  const int rounds = (int)(((n - base < TILE ? n - base : TILE) + WAVE - 1) / WAVE);
+  uint64_t k_next = 0;
+  uint32_t v_next = 0;
+  if (rounds > 0 && base + lane < n) { k_next = keys[base + lane]; v_next = idx[base + lane]; }
+  for (int r = 0; r < rounds; ++r) {
+    const int64_t i = base + (int64_t)r * WAVE + lane;
     const bool valid = i < n;
-    if (base + j >= n) break;       // uniform
-    const uint64_t k = valid ? keys[i] : 0ull;
-    const uint32_t v = valid ? idx[i] : 0u;
+    const uint64_t k = k_next;
+    const uint32_t v = v_next;
+    if (r + 1 < rounds && i + WAVE < n) { k_next = keys[i + WAVE]; v_next = idx[i + WAVE]; }
     const uint32_t d = (uint32_t)(k >> shift) & (NB - 1);
     uint64_t same = __ballot(valid);
 #pragma unroll
@@ -100,9 +108,9 @@ __global__ __launch_bounds__(WAVE) void radix_scatter_kernel(const uint64_t* __r
     const uint32_t rank = (uint32_t)__popcll(same & below);
     uint32_t slot = 0;
     if (valid) slot = off[d] + rank;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every lane holds its slot before a leader moves the offset on
     if (valid && rank == 0) off[d] += (uint32_t)__popcll(same);
-    __syncthreads();
+    asm volatile("" ::: "memory");
     if (valid) {
       keys_out[slot] = k;
       idx_out[slot] = v;
