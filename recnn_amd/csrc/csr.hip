@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int RB = 8, NB = 1 << RB;    // digit bits, buckets
-constexpr int TILE = 4096;             // rows per workgroup in the histogram / scatter kernels
+constexpr int TILE = 2048;             // rows per workgroup in the histogram / scatter kernels
 constexpr int ST = 256, SI = 8, SCAN_TILE = ST * SI;   // scan: threads, items per thread
 
 struct MinMax { long long umin, umax, tmin, tmax; };
@@ -72,31 +72,64 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
   hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// One wave per tile, rows taken 64 at a time in order: a row's slot is start(digit, tile) + rows of this tile with the
-// same digit seen so far + its rank among the equal-digit lanes below it (8 ballots) -- stable by construction.
-// The running per-digit offsets live in LDS and are touched by this one wave only: LDS instructions of a wave execute in
-// program order, so the lanes' reads of off[d] are done before the group leaders' updates are -- no barrier inside the loop
-// (the asm statements only stop the compiler from reordering across them).  The next round's rows are loaded while the
-// current round is ranked and stored (the loop would otherwise pay one global-memory latency per 64 rows).
+// One wave per tile, rows taken 64 at a time in order: a row's rank inside its digit = rows of this tile with the same
+// digit seen so far + its rank among the equal-digit lanes below it (8 ballots) -- stable by construction.  The tile is
+// first sorted INSIDE LDS (slot = local start of the digit + rank), then written out position by position: neighbouring LDS
+// positions of one digit are neighbouring global slots, so the stores leave as whole runs (~16 rows = 128 B of keys per
+// digit and tile) instead of 8-byte and 4-byte writes scattered over 256 runs (0.63 -> see DESIGN.md ms per pass at 20 M rows).
+// The running per-digit offsets are touched by this one wave only: LDS instructions of a wave execute in program order, so
+// the lanes' reads of off[d] are done before the group leaders' updates -- no barrier inside the loop.  The next round's rows
+// are loaded while the current round is ranked.
 __global__ __launch_bounds__(WAVE) void radix_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, int64_t n,
                                                              int shift, const uint32_t* __restrict__ start, int nblocks,
                                                              uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
-  __shared__ uint32_t off[NB];
+  __shared__ uint64_t sk[TILE];
+  __shared__ uint32_t sv[TILE];
+  __shared__ uint32_t off[NB];      // running local slot of each digit
+  __shared__ uint32_t lstart[NB];   // local start of each digit inside the sorted tile
+  __shared__ uint32_t gstart[NB];   // global start of (digit, this tile)
   const int lane = threadIdx.x;
-  for (int d = lane; d < NB; d += WAVE) off[d] = start[(int64_t)d * nblocks + blockIdx.x];
-  __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
+  const int rows = (int)(n - base < TILE ? n - base : TILE);
+  // counts of this tile = differences of the scanned digit-major histogram (entry (d, b) is followed by (d, b + 1), the
+  // last tile of digit d by the first tile of digit d + 1, the very last entry by n)
+  uint32_t cnt[NB / WAVE], run = 0;
+#pragma unroll
+  for (int j = 0; j < NB / WAVE; ++j) {
+    const int d = lane * (NB / WAVE) + j;
+    const int64_t e = (int64_t)d * nblocks + blockIdx.x;
+    const uint32_t s0 = start[e];
+    const uint32_t s1 = e + 1 < (int64_t)NB * nblocks ? start[e + 1] : (uint32_t)n;
+    gstart[d] = s0;
+    cnt[j] = s1 - s0;
+    run += cnt[j];
+  }
+  uint32_t incl = run;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, WAVE);
+    if (lane >= o) incl += t;
+  }
+  uint32_t ex = incl - run;
+#pragma unroll
+  for (int j = 0; j < NB / WAVE; ++j) {
+    const int d = lane * (NB / WAVE) + j;
+    lstart[d] = ex;
+    off[d] = ex;
+    ex += cnt[j];
+  }
+  __syncthreads();
   const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const int rounds = (int)(((n - base < TILE ? n - base : TILE) + WAVE - 1) / WAVE);
+  const int rounds = (rows + WAVE - 1) / WAVE;
   uint64_t k_next = 0;
   uint32_t v_next = 0;
-  if (rounds > 0 && base + lane < n) { k_next = keys[base + lane]; v_next = idx[base + lane]; }
+  if (lane < rows) { k_next = keys[base + lane]; v_next = idx[base + lane]; }
   for (int r = 0; r < rounds; ++r) {
-    const int64_t i = base + (int64_t)r * WAVE + lane;
-    const bool valid = i < n;
+    const int p = r * WAVE + lane;
+    const bool valid = p < rows;
     const uint64_t k = k_next;
     const uint32_t v = v_next;
-    if (r + 1 < rounds && i + WAVE < n) { k_next = keys[i + WAVE]; v_next = idx[i + WAVE]; }
+    if (p + WAVE < rows) { k_next = keys[base + p + WAVE]; v_next = idx[base + p + WAVE]; }
     const uint32_t d = (uint32_t)(k >> shift) & (NB - 1);
     uint64_t same = __ballot(valid);
 #pragma unroll
@@ -110,11 +143,20 @@ __global__ __launch_bounds__(WAVE) void radix_scatter_kernel(const uint64_t* __r
     if (valid) slot = off[d] + rank;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every lane holds its slot before a leader moves the offset on
     if (valid && rank == 0) off[d] += (uint32_t)__popcll(same);
-    asm volatile("" ::: "memory");
     if (valid) {
-      keys_out[slot] = k;
-      idx_out[slot] = v;
+      sk[slot] = k;
+      sv[slot] = v;
     }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+  // write-out: LDS position p of digit d -> global slot gstart[d] + (p - lstart[d])
+  for (int p = lane; p < rows; p += WAVE) {
+    const uint64_t k = sk[p];
+    const uint32_t d = (uint32_t)(k >> shift) & (NB - 1);
+    const uint32_t g = gstart[d] + ((uint32_t)p - lstart[d]);
+    keys_out[g] = k;
+    idx_out[g] = sv[p];
   }
 }
 
