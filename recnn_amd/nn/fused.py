@@ -14,6 +14,7 @@ import weakref
 from typing import Dict, Optional
 
 import numpy as np
+import contextlib
 import os
 
 import torch
@@ -272,14 +273,17 @@ class FusedContext:
         (first_step mod every, n_steps <= 64) comes in, a run graph is made to order for it and such requests are one graph
         launch from then on.  prepare=True only builds what the request needs (graphs, the made-to-order graph) and runs nothing."""
         eng, sm = self.engine, self.sampler
-        # hipGraph capture/replay needs a real (non-null) stream: use a private one, ordered after and before
-        # the caller's current stream
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=eng.device)
+        # hipGraph capture/replay needs a real (non-null) stream.  A caller that already is on one (bench.py, training loops
+        # that own a stream) gets its graphs launched right there; from the default stream the work hops to a private stream,
+        # ordered after and before the caller's (two event waits and a stream switch: ~20 us of host time per call)
         cur = torch.cuda.current_stream(eng.device)
-        self._side.wait_stream(cur)
+        direct = cur.cuda_stream != 0
+        if not direct:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=eng.device)
+            self._side.wait_stream(cur)
         self._own_batch()                    # the sampler writes the engine's own rows
-        with torch.cuda.stream(self._side):
+        with (contextlib.nullcontext() if direct else torch.cuda.stream(self._side)):
             if getattr(self, "graph_rows", None) != sm["rows"]:
                 eng.graph_build(sm["rows"])
                 self.graph_rows = sm["rows"]
@@ -302,7 +306,8 @@ class FusedContext:
                 if sm["cursor"] >= sm["n_batches"]:      # epoch finished (the device cursor wrapped to 0 by itself)
                     sm["cursor"] = 0
                     self._reshuffle()
-        cur.wait_stream(self._side)
+        if not direct:
+            cur.wait_stream(self._side)
 
     # ------------------------------------------------------------------ optimizer state mirrors
     def mirror_optimizer_state(self, opt, ni):

@@ -272,3 +272,29 @@ def test_td3_b4096_run_graphs_equal_pieces_and_update_loop(cuda):
             for k in ("value1", "value2", "policy"):
                 assert abs(a[k] - b[k]) <= 1e-5 * max(abs(b[k]), 1.0), (other, k, a, b)
     assert all(np.isfinite(h[k]) for h in results["one_call"][0] for k in ("value1", "value2", "policy"))
+
+
+def test_run_on_a_caller_owned_stream_equals_run_from_the_default_stream(cuda):
+    """Algo.run launches its graphs on the caller's stream when that is a real stream (bench.py) and hops to a private stream
+    from the default one: same steps, parameters bit for bit, and the caller's stream order is respected (a tensor written on
+    that stream before run() and read after it)."""
+    import recnn_amd
+    env, _ = _bench_env(recnn_amd, cuda, n_users=40 * UPB)
+    snaps = []
+    for owned in (False, True):
+        ddpg = _make_algo(recnn_amd, cuda, env, "bf16")
+        if owned:
+            st = torch.cuda.Stream(device=cuda)
+            with torch.cuda.stream(st):
+                ddpg.run(7)
+                out = ddpg.run(25)
+            st.synchronize()
+        else:
+            ddpg.run(7)
+            out = ddpg.run(25)
+        torch.cuda.synchronize()
+        assert out["step"] == 31
+        snaps.append(_snapshot(ddpg))
+    for net, sd in snaps[0].items():
+        for k, v in sd.items():
+            assert torch.equal(v, snaps[1][net][k]), (net, k)
