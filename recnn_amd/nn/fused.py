@@ -115,8 +115,18 @@ class FusedContext:
                                       "(the reference's value) or none (put the nets in eval mode / set_defaults(mask_mode='none'))")
 
     def ensure(self, nets, rows: int):
-        self._check_modules(nets)
-        dev = nets["policy_net"].linear1.weight.device
+        # the module checks (devices, shapes, train / eval mix, dropout p) walk ~40 nn.Module attributes: repeat them only when
+        # something they look at may have changed -- another module object, a mode flip, another dropout p, a parameter that
+        # moved (the adoption test below sees that), another mask mode
+        key = tuple((id(nets[n]), nets[n].training, getattr(nets[n]._modules.get("drop_layer"), "p", None)) for n in self.names)
+        key = key + (self.mask_mode,)
+        stale = [ni for name, ni in self.names.items()
+                 if self.engine is None or self.modules.get(ni) is not nets[name] or not self._is_adopted(ni, nets[name])]
+        if stale or key != getattr(self, "_checked_key", None):
+            self._checked_key = None
+            self._check_modules(nets)
+            self._checked_key = key
+        dev = _module_params(nets["policy_net"])[0].device
         if self.engine is None or rows > self.engine.max_rows or self.engine.device != dev:
             cap = max(DEFAULTS["min_capacity"], 1 << (max(rows, 1) - 1).bit_length())
             old = self.engine
@@ -131,10 +141,10 @@ class FusedContext:
             self.modules = {}
             self.hyper_key = None
             eng.set_counters(self.opt_t[L.NET_POLICY], self.opt_t[L.NET_VALUE1], self.opt_t[L.NET_VALUE2], 0)
+            stale = list(self.names.values())
         for name, ni in self.names.items():
-            m = nets[name]
-            if self.modules.get(ni) is not m or not self._is_adopted(ni, m):
-                self._adopt(ni, m)
+            if ni in stale:
+                self._adopt(ni, nets[name])
         self._sync_versions()
 
     def _is_adopted(self, ni, m):
