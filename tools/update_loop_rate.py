@@ -1,0 +1,38 @@
+"""Throughput of the reference-shaped loop `for batch in loader: algo.update(batch); algo.step()` (one host sync per step, like the
+reference's .item() calls) at the bench shape, next to Algo.run.  usage: python tools/update_loop_rate.py [bf16|fp32]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import recnn_amd
+from recnn_amd.nn import fused
+
+dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+dev = torch.device("cuda", 0)
+items, ratings, off, lens = bench.synthetic_store(0)
+table = torch.randn(bench.N_ITEMS, bench.EMB, generator=torch.Generator().manual_seed(0))
+env = recnn_amd.data.env.FrameEnv.from_store(table, items, ratings, off, frame_size=10, batch_size=25, device=dev, test_fraction=0.0,
+                                             rows_per_batch=2048)
+fused.set_defaults(dtype=dtype, mask_mode="hash", seed=1)
+recnn_amd.nn.algo.set_default_optimizer("adam")
+torch.manual_seed(0)
+algo = recnn_amd.nn.DDPG(recnn_amd.nn.Actor(1290, 128, 256, 6e-1), recnn_amd.nn.Critic(1290, 128, 256, 54e-2)).to(dev)
+users = env.base.train_user_dataset.users
+batches = [env.collate_users([int(u) for u in users[i * 256:(i + 1) * 256]]) for i in range(8)]
+for i in range(30):
+    algo.update(batches[i % 8], learn=True); algo.step()
+torch.cuda.synchronize()
+n = 400
+t0 = time.perf_counter()
+for i in range(n):
+    algo.update(batches[i % 8], learn=True); algo.step()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"update() loop, {dtype}, 2048 rows, batches resident: {n / dt:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step")
+t0 = time.perf_counter()
+for i in range(n):
+    b = env.collate_users([int(u) for u in users[(i % 8) * 256:(i % 8 + 1) * 256]])
+    algo.update(b, learn=True); algo.step()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"collate + update() loop, {dtype}:                        {n / dt:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step")
