@@ -98,3 +98,28 @@ def test_csr_workspace_query_is_host_only_and_validates():
     assert b"rows" in lib.recnn_last_error()
     assert lib.recnn_frame_plan_rows(None, None, 4, 1, 10, 8, None, None) != 0
     assert b"frame_plan_rows" in lib.recnn_last_error()
+
+
+def test_new_rows_fail_loudly_without_a_gpu():
+    """No CPU fallback anywhere: the device ETL, the VAE kernels, the BCQ modules and the candidate scoring raise RecnnHipError on
+    CPU inputs instead of computing something else."""
+    import numpy as np
+    import recnn_amd
+    from recnn_amd import _lib as L
+    from recnn_amd.data import dataset_functions as F
+    from recnn_amd.nn import functional as F_hip
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only behaviour")
+    with pytest.raises(L.RecnnHipError):
+        F.csr_from_ratings_device(np.arange(5), np.arange(5), np.ones(5), np.arange(5))
+    with pytest.raises(L.RecnnHipError):
+        F_hip.vae_latent(torch.zeros(2, 4), torch.zeros(2, 2))
+    with pytest.raises(L.RecnnHipError):
+        F_hip.vae_loss(torch.zeros(2, 3), torch.zeros(2, 3), torch.zeros(2, 2), torch.ones(2, 2))
+    gen = recnn_amd.nn.bcqGenerator(6, 2, 3)
+    with pytest.raises(L.RecnnHipError):
+        gen(torch.zeros(4, 6), torch.zeros(4, 2))
+    with pytest.raises(L.RecnnHipError):
+        recnn_amd.nn.bcqPerturbator(6, 2, 8)(torch.zeros(4, 6), torch.zeros(4, 2))
+    with pytest.raises(L.RecnnHipError):
+        recnn_amd.nn.Critic(6, 2, 8).candidates(torch.zeros(4, 6), torch.zeros(8, 2), 2)
