@@ -102,8 +102,9 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s and n >= 3:
             break
-    return {"value": n / el, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s"}
+    return {"value": n / el, "unit": "steps/s", "cores": ncpu, "threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s with {torch.get_num_threads()} "
+                      f"intra-op threads (fastest of 8/16/32/64 on this {ncpu}-core host)"}
 
 
 # launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports (the default fused forward
@@ -113,21 +114,22 @@ KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_l1_nets": "mlp_l1_kern
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel"}
 
 
-def measure_traffic(argv_tail, kernel_substr, timeout_s=240):
-    """HBM bytes per launch of one kernel from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3
+def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):
+    """HBM bytes per launch of the named kernels from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3
     sections) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a child
     run of this same benchmark, counter unit KB, FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B),
-    WRITE_SIZE as is.  Returns (bytes or None, note)."""
+    WRITE_SIZE as is.  Returns {substr: (bytes or None, note)}."""
     import csv
     import shutil
     import subprocess
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    fail = lambda note: {k: (None, note) for k in kernel_substrs}
     if not os.path.isfile(rocprof):
-        return None, "rocprofv3 not found"
+        return fail("rocprofv3 not found")
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None, "already running under a profiler"
-    means = {}
+        return fail("already running under a profiler")
+    means = {k: {} for k in kernel_substrs}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"recnn_pmc_{ctr}_", dir="/tmp")
         cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
@@ -135,23 +137,49 @@ def measure_traffic(argv_tail, kernel_substr, timeout_s=240):
         try:
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
                            env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
-            vals = []
+            vals = {k: [] for k in kernel_substrs}
             for root, _, files in os.walk(d):
                 for f in files:
                     if f.endswith("counter_collection.csv"):
                         for r in csv.DictReader(open(os.path.join(root, f))):
-                            if kernel_substr in r["Kernel_Name"] and r.get("Counter_Name", ctr) == ctr:
-                                vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return None, f"no {ctr} rows for {kernel_substr}"
-            means[ctr] = sum(vals) / len(vals)
+                            if r.get("Counter_Name", ctr) != ctr:
+                                continue
+                            for k in kernel_substrs:
+                                if k in r["Kernel_Name"]:
+                                    vals[k].append(float(r["Counter_Value"]))
+            for k in kernel_substrs:
+                if vals[k]:
+                    means[k][ctr] = sum(vals[k]) / len(vals[k])
         except Exception as ex:                                    # profiler unavailable on this box: report null
-            return None, f"{ctr} pass failed: {type(ex).__name__}"
+            return fail(f"{ctr} pass failed: {type(ex).__name__}")
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    total = means["FETCH_SIZE"] * 1024.0 * 2.0 + means["WRITE_SIZE"] * 1024.0
-    return total, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on a child run of this command, mean per "
-                   f"launch of {kernel_substr}: fetch 2 x {means['FETCH_SIZE'] * 1024:.0f} B + write {means['WRITE_SIZE'] * 1024:.0f} B")
+    out = {}
+    for k in kernel_substrs:
+        m = means[k]
+        if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
+            out[k] = (None, f"no counter rows for {k}")
+            continue
+        out[k] = (m["FETCH_SIZE"] * 1024.0 * 2.0 + m["WRITE_SIZE"] * 1024.0,
+                  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on a child run of this command, mean per "
+                  f"launch of {k}: fetch 2 x {m['FETCH_SIZE'] * 1024:.0f} B + write {m['WRITE_SIZE'] * 1024:.0f} B")
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`), and pass
+    rank 0's JSON line through.  RECNN_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 over gloo (functional test of the
+    N>1 path on a one-GPU box)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RECNN_BENCH_SPAWNED="1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -169,15 +197,19 @@ def main():
                          "each rank takes rows/N of it")
     ap.add_argument("--overlap", action="store_true", help="data parallel: overlap the critic all-reduce with the actor forward")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of `--steps` steps each; value = their median")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                 # no launcher around us: be the launcher (does not return)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     if os.environ.get("RECNN_BENCH_SINGLE_DEVICE"):      # functional test of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
+        os.environ.setdefault("RECNN_BENCH_BACKEND", "gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rows = args.rows
@@ -201,55 +233,8 @@ def main():
             dist.init_process_group(backend)
 
     from recnn_amd import _lib as L
-    if os.environ.get("RECNN_GEMM_VARIANT"):
-        L.load().recnn_tune_gemm_variant(int(os.environ["RECNN_GEMM_VARIANT"]))
-    if os.environ.get("RECNN_GEMM_DMA"):
-        L.load().recnn_tune_gemm_dma(int(os.environ["RECNN_GEMM_DMA"]))
-    if os.environ.get("RECNN_FUSED_MLP"):
-        L.load().recnn_tune_fused_mlp(int(os.environ["RECNN_FUSED_MLP"]))
-    if os.environ.get("RECNN_SAMPLER_F32"):
-        L.load().recnn_tune_sampler_f32_rows(int(os.environ["RECNN_SAMPLER_F32"]))
-    if os.environ.get("RECNN_V0_MIN_WG"):
-        L.load().recnn_tune_gemm_v0_threshold(int(os.environ["RECNN_V0_MIN_WG"]))
-    if os.environ.get("RECNN_MLP_KERNEL"):
-        L.load().recnn_tune_mlp_kernel(int(os.environ["RECNN_MLP_KERNEL"]))
-    if os.environ.get("RECNN_MLP_PANEL"):
-        L.load().recnn_tune_mlp_panel(int(os.environ["RECNN_MLP_PANEL"]))
-    if os.environ.get("RECNN_MLP_MAP"):
-        L.load().recnn_tune_mlp_map(int(os.environ["RECNN_MLP_MAP"]))
-    if os.environ.get("RECNN_MLP_PROBE"):
-        L.load().recnn_tune_mlp_probe(int(os.environ["RECNN_MLP_PROBE"]))
-        L.load().recnn_tune_mlp_fault(int(os.environ["RECNN_MLP_PROBE"]) << 8)   # the 32-row kernel's probe bits (0x100: no layer-1 MMA, 0x200: no layer-1 DMA)
-    if os.environ.get("RECNN_MLP_WAVES"):
-        L.load().recnn_tune_mlp_waves(int(os.environ["RECNN_MLP_WAVES"]))
-    if os.environ.get("RECNN_GEMM_WAVES"):
-        L.load().recnn_tune_gemm_waves(int(os.environ["RECNN_GEMM_WAVES"]))
-    if os.environ.get("RECNN_DMA_WAVES"):
-        L.load().recnn_tune_gemm_dma_waves(int(os.environ["RECNN_DMA_WAVES"]))
-    if os.environ.get("RECNN_DMA_DEEP"):
-        L.load().recnn_tune_gemm_dma_depth(int(os.environ["RECNN_DMA_DEEP"]))
-    if os.environ.get("RECNN_DEFER_PC"):
-        L.load().recnn_tune_defer_policy_fwd(int(os.environ["RECNN_DEFER_PC"]))
-    if os.environ.get("RECNN_PREGATHER"):
-        L.load().recnn_tune_pregather(int(os.environ["RECNN_PREGATHER"]))
-    if os.environ.get("RECNN_GRAPH_RUN"):
-        L.load().recnn_tune_graph_run(int(os.environ["RECNN_GRAPH_RUN"]))
-    if os.environ.get("RECNN_POLICY_CHAIN"):
-        L.load().recnn_tune_policy_chain(int(os.environ["RECNN_POLICY_CHAIN"]))
-    if os.environ.get("RECNN_BWD_PANEL"):
-        L.load().recnn_tune_bwd_panel(int(os.environ["RECNN_BWD_PANEL"]))
-    if os.environ.get("RECNN_CHAIN_TC"):
-        L.load().recnn_tune_chain_target_critic(int(os.environ["RECNN_CHAIN_TC"]))
-    if os.environ.get("RECNN_DW_DMA"):
-        L.load().recnn_tune_dw_dma(int(os.environ["RECNN_DW_DMA"]))
-    if os.environ.get("RECNN_DW_SPLITS"):
-        L.load().recnn_tune_dw_splits(int(os.environ["RECNN_DW_SPLITS"]))
-    if os.environ.get("RECNN_GEMM_TGF"):
-        L.load().recnn_tune_gemm_ks_layout(int(os.environ["RECNN_GEMM_TGF"]))
-    if os.environ.get("RECNN_LD_PAD"):
-        L.load().recnn_tune_ld_pad(int(os.environ["RECNN_LD_PAD"]))
-    if os.environ.get("RECNN_GATHER_ROWS"):
-        L.load().recnn_tune_gather_rows(int(os.environ["RECNN_GATHER_ROWS"]))
+    from recnn_amd._tune import apply_env_knobs
+    apply_env_knobs()            # RECNN_* tuning knobs for A/B runs from the shell (recnn_amd/_tune.py)
 
     import recnn_amd
     from recnn_amd.nn import fused
@@ -293,21 +278,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # Timed regions: `--repeats` (default 5) regions of EXACTLY `--steps` steps, each bracketed by barrier + synchronize on both
+    # sides; every region's time is the MAX over ranks; `value` is computed from the MEDIAN region, the spread is reported
+    # (one 20-step region is ~1.3 ms: a single sample of that moves +-8 % from box to box and call to call).
+    reps = max(1, args.repeats)
+    samples = []
     with torch.cuda.stream(stream):
         if not use_dp and 2 <= args.steps <= 64:
-            # setup, like the rest of the graph family: the timed `run(steps)` call gets a run graph made to order for
-            # (first step mod policy_step, steps), i.e. ONE graph launch instead of [5 ordinary][cycle][policy + 4]
-            algo.prepare_run(args.steps, first_step=args.warmup)
+            # setup, like the rest of the graph family: every timed `run(steps)` call gets a run graph made to order for
+            # (first step mod policy_step, steps), i.e. ONE graph launch instead of [ordinary stretch][cycles][policy + tail]
+            for r in range(reps):
+                algo.prepare_run(args.steps, first_step=args.warmup + r * args.steps)
         run(0, args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        run(args.warmup, args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        for r in range(reps):
+            barrier()
+            t0 = time.perf_counter()
+            run(args.warmup + r * args.steps, args.steps)
+            barrier()
+            samples.append(time.perf_counter() - t0)
     if use_dp:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor(samples, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        samples = [float(x) for x in t.tolist()]
+    elapsed = float(np.median(samples))
     losses = eng.losses()
     assert os.environ.get("RECNN_MLP_PROBE") or all(np.isfinite(v) for v in losses.values()), losses
 
@@ -320,6 +313,8 @@ def main():
             # strong scaling: the ranks share ONE `args.rows`-row batch per step -> `steps` updates in total
             "value": (world if args.scaling == "weak" else 1) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "repeats": reps, "ms_per_step_samples": [round(x / args.steps * 1e3, 6) for x in samples],
+            "spread": (max(samples) - min(samples)) / elapsed,     # (slowest - fastest region) / median region
             "scaling": args.scaling,
             # synchronised optimizer updates per second (one per step whatever N is) and transition rows consumed per second
             "global_updates_per_s": args.steps / elapsed, "rows_per_s": world * rows * args.steps / elapsed,
@@ -338,10 +333,14 @@ def main():
         dom = max(prof, key=lambda r: r[1])
         # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
         traffic, traffic_note = None, "skipped"
+        gather_traffic, gather_note = None, "skipped"
         if world == 1 and not args.no_traffic and not use_dp:
-            tail = ["--steps", "40", "--warmup", "20", "--no-cpu-baseline", "--no-traffic", "--dtype", args.dtype,
+            tail = ["--steps", "40", "--warmup", "20", "--repeats", "1", "--no-cpu-baseline", "--no-traffic", "--dtype", args.dtype,
                     "--algo", args.algo, "--rows", str(args.rows)]
-            traffic, traffic_note = measure_traffic(tail, KERNEL_OF_SLOT.get(dom[0], dom[0]))
+            dom_k = KERNEL_OF_SLOT.get(dom[0], dom[0])
+            tr = measure_traffic(tail, [dom_k, "frame_gather_kernel"])
+            traffic, traffic_note = tr[dom_k]
+            gather_traffic, gather_note = tr["frame_gather_kernel"]
         if dom[2] > 0:
             ach = dom[2] / (dom[1] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -358,7 +357,7 @@ def main():
             gbs = per_row * rows / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                      "traffic": None, "avg_ms": g[0][1],
+                                      "traffic": gather_traffic, "traffic_source": gather_note, "avg_ms": g[0][1],
                                       "bytes_per_launch": per_row * rows,
                                       "rows_dtype": "fp32+bf16" if (f32_rows and args.dtype == "bf16") else args.dtype}
         gemm_fl = sum(r[2] for r in prof)

@@ -62,7 +62,7 @@ void recnn_tune_gemm_v0_threshold(int workgroups);
  * 3-stage pipeline, 0 = always the register-staged kernel. */
 void recnn_tune_gemm_dma(int on);
 /* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
- * launch (csrc/mlp.hip); 0 = layer-by-layer GEMM launches. */
+ * launch (csrc/mlps.hip); 0 = layer-by-layer GEMM launches. */
 void recnn_tune_fused_mlp(int on);
 /* tuning knob: 1 (default) = single-problem forward GEMM launches use a 5-stage LDS-DMA ring, 0 = always 3. */
 void recnn_tune_gemm_dma_depth(int deep);
@@ -70,8 +70,6 @@ void recnn_tune_gemm_dma_depth(int deep);
 void recnn_tune_gemm_dma_waves(int waves);
 /* tuning knob: waves per workgroup of the register-staged dX / dW GEMM (same block tiles), 8 (default) or 4. */
 void recnn_tune_gemm_waves(int waves);
-/* tuning knob: waves per workgroup of the fused MLP forward kernel, 8 (default) or 4. */
-void recnn_tune_mlp_waves(int waves);
 /* tuning knob: extra elements (rounded up to 8) on every leading dimension the MFMA kernels stream through (weight shadows,
  * packed batch rows); applies to engines created afterwards. */
 void recnn_tune_ld_pad(int elems);
@@ -501,14 +499,9 @@ int recnn_engine_dp_sets(recnn_engine* e);
  * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
  * on purpose (tests). */
 void recnn_tune_mlp_fault(int mode);
-/* fused MLP forward: rows per workgroup (32 = csrc/mlp.hip, the default; 64 = csrc/mlp64.hip, bit-identical results) and
- * the workgroup -> (network, panel) map of the 64-row kernel (0 = network-major, 2 = XCD-contiguous chunks). */
-void recnn_tune_mlp_panel(int rows);
-/* 0 = csrc/mlp.hip, 1 = csrc/mlp64.hip, 2 = csrc/mlpr.hip (64-row panels, weights from L2 straight into MFMA registers) */
-void recnn_tune_mlp_kernel(int k);
-void recnn_tune_mlp_map(int mode);
+/* timing experiments on the fused forward (csrc/mlps.hip): bit 0 = no MFMA work / fragment reads, bit 1 = no DMA; results are garbage */
 void recnn_tune_mlp_probe(int bits);
-void recnn_tune_mlp_trace(void* device_u64_wg16);   /* shader-clock stamps of the kernel's phases, [workgroup][16] uint64, NULL = off */   /* timing experiments on the 64-row kernel's operand streams; results are garbage */
+void recnn_tune_mlp_trace(void* device_u64_wg32);   /* shader-clock stamps of the kernel's phases, [workgroup][32] uint64, NULL = off */
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

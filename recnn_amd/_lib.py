@@ -101,7 +101,6 @@ SIGNATURES = {
     "recnn_tune_gemm_dma_depth": (None, [_I]),
     "recnn_tune_gemm_dma_waves": (None, [_I]),
     "recnn_tune_gemm_waves": (None, [_I]),
-    "recnn_tune_mlp_waves": (None, [_I]),
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_dw_dma": (None, [_I]),
     "recnn_tune_chain_target_critic": (None, [_I]),
@@ -111,9 +110,6 @@ SIGNATURES = {
     "recnn_tune_pregather": (None, [_I]),
     "recnn_tune_defer_policy_fwd": (None, [_I]),
     "recnn_tune_mlp_fault": (None, [_I]),
-    "recnn_tune_mlp_panel": (None, [_I]),
-    "recnn_tune_mlp_map": (None, [_I]),
-    "recnn_tune_mlp_kernel": (None, [_I]),
     "recnn_tune_mlp_probe": (None, [_I]),
     "recnn_tune_mlp_trace": (None, [_P]),
     "recnn_engine_sampler_eager": (_I, [_P, _I]),

@@ -155,7 +155,7 @@ struct recnn_engine {
   hipGraphExec_t grun_multi = nullptr;
   int grun_multi_len = 0;
   // run graphs made to order (recnn_engine_graph_prepare): one launch for a whole request (phase, n_steps)
-  static constexpr int CUSTOM_MAX = 4;
+  static constexpr int CUSTOM_MAX = 8;
   hipGraphExec_t grun_custom[CUSTOM_MAX] = {};
   int grun_custom_phase[CUSTOM_MAX] = {}, grun_custom_len[CUSTOM_MAX] = {};
   int grun_custom_next = 0;

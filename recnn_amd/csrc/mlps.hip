@@ -1,6 +1,6 @@
 // mlps.hip -- the fused row-panel forward of a whole Actor / Critic MLP as ONE continuous weight stream (bf16, gfx950).
 //
-// Same contract, panel layout and arithmetic (bit for bit) as mlp.hip: one 16-wave workgroup owns 32 batch rows of one
+// One 16-wave workgroup owns 32 batch rows of one
 // network application and all 256 hidden columns; recnn/nn/models.py:66-73 / :207-213 (cat + 3 x (addmm, relu, dropout)),
 // the chained target critics, the TD head and the critic's layer-2 backward tail (mlp.h).
 //
@@ -592,9 +592,14 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
 }
 
 static unsigned long long* g_mlps_trace = nullptr;
-void mlps_set_trace(void* p) { g_mlps_trace = (unsigned long long*)p; }
+extern "C" void recnn_tune_mlp_trace(void* device_u64_wg32) { g_mlps_trace = (unsigned long long*)device_u64_wg32; }
+static int g_mlp_fault = 0;
+// test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
+// error path (tests/test_gpu_engine.py::test_broken_handoff_is_reported); bits 0x100 / 0x200 select the timing probes
+extern "C" void recnn_tune_mlp_fault(int mode) { g_mlp_fault = mode; }
+extern "C" void recnn_tune_mlp_probe(int bits) { g_mlp_fault = (g_mlp_fault & 0xFF) | ((bits & 3) << 8); }
 
-int mlps_init() {
+int mlp_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlps_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlps attr");
   if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlps_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlps attr");
   if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlps_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlps attr");
@@ -602,7 +607,38 @@ int mlps_init() {
   return rc;
 }
 
-int mlps_launch(const MlpBatch& b, int nprob, int rows, hipStream_t s) {
+int mlp_waves() { return NW; }
+
+// Round 3: this is the only fused row-panel forward left.  mlp.hip (burst-and-wait schedule), mlp64.hip (64-row panels) and
+// mlpr.hip (weights straight into MFMA registers) were measured slower at every shape the engine produces (47 and 70 us vs
+// 26 at DDPG / 2048 rows) and are gone; their bit-for-bit agreement with this kernel was tested up to their removal
+// (tests/test_gpu_kernels.py history, profiles/r02_gpu_tests_v7.log).
+int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
+  MlpBatch b = b_in;
+  b.fault = g_mlp_fault;
+  if (g_mlp_fault & 3) b.spin_limit = 1 << 12;
+  int rows = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const MlpProb& p = b.p[i];
+    if (p.rows > rows) rows = p.rows;
+    if (p.H > HP || p.out_dim > 128) { recnn_set_error("mlp_fwd: hidden > 256 or out_dim > 128"); return RECNN_E_UNSUPPORTED; }
+    if ((p.H & 3) || p.H < 4) { recnn_set_error("mlp_fwd: hidden width must be a multiple of 4"); return RECNN_E_UNSUPPORTED; }
+    if (p.cbwd_idx >= 2 || (p.cbwd_idx >= 0 && (p.W3 || !p.q || !b.cbwd[p.cbwd_idx].dz2 || !b.cbwd[p.cbwd_idx].dz1))) {
+      recnn_set_error("mlp_fwd: critic backward tail needs a critic problem and its buffers");
+      return RECNN_E_INVALID;
+    }
+    if (p.n_tail < 0 || p.n_tail > MLP_MAX_TAIL || (p.n_tail && !p.W3) || (p.part_out && !p.part_flag)) {
+      recnn_set_error("mlp_fwd: bad chained-critic description");
+      return RECNN_E_INVALID;
+    }
+    // one lane offset serves every 256-pitch matrix of a workgroup's stream
+    if (p.W3 && p.ldw3 != p.ldw2) { recnn_set_error("mlp_fwd: W2 / W3 shadows must share one pitch"); return RECNN_E_INVALID; }
+    for (int t = 0; t < (p.W3 ? p.n_tail : 0); ++t)
+      if (b.tail[t].ldw2 != p.ldw2) { recnn_set_error("mlp_fwd: chained critics must share the W2 pitch"); return RECNN_E_INVALID; }
+    for (int g = 0; g < p.nseg; ++g)
+      if (p.K[g] % KB1 || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
+  }
+  if (rows <= 0 || nprob <= 0) return 0;
   const dim3 grid((rows + BM - 1) / BM, nprob), block(NW * 64);
   switch ((b.fault >> 8) & 3) {
     case 1: hipLaunchKernelGGL(mlps_fwd_kernel<1>, grid, block, LDS_TOTAL, s, b, g_mlps_trace); break;

@@ -272,16 +272,20 @@ __global__ __launch_bounds__(PT) void softmax_bwd_kernel(const float* __restrict
 }
 
 // out[r, :] = onehot(idx[r])  (rows of ld floats; columns [n, ld) zeroed too)
-__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ idx, int n, float* __restrict__ out, int64_t ld) {
-  const int r = blockIdx.y;
+// Rows are walked with a grid stride (gridDim.y is capped at 65535); an index outside [0, n) leaves its row all zero -- it
+// never lands in the padding columns [n, ld) -- and the host wrapper refuses such indices like the reference's scatter_.
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ idx, int rows, int n, float* __restrict__ out, int64_t ld) {
   const int i4 = blockIdx.x * 256 + threadIdx.x;
   if (4 * (int64_t)i4 >= ld) return;
-  const int rel = (int)(idx[r] - 4 * (int64_t)i4);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (4 * i4 < n) {
-    if (rel == 0) v.x = 1.f; else if (rel == 1) v.y = 1.f; else if (rel == 2) v.z = 1.f; else if (rel == 3) v.w = 1.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t id = idx[r];
+    const int64_t rel = id - 4 * (int64_t)i4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0 && id < n) {
+      if (rel == 0) v.x = 1.f; else if (rel == 1) v.y = 1.f; else if (rel == 2) v.z = 1.f; else if (rel == 3) v.w = 1.f;
+    }
+    *(float4*)(out + (int64_t)r * ld + 4 * (int64_t)i4) = v;
   }
-  *(float4*)(out + (int64_t)r * ld + 4 * (int64_t)i4) = v;
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -339,7 +343,7 @@ int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t l
   RECNN_REQUIRE(aligned16(out) && ld % 4 == 0, "onehot: rows must be 16-byte aligned");
   if (rows == 0) return 0;
   const int l4 = (int)(ld / 4);
-  hipLaunchKernelGGL(onehot_kernel, dim3((l4 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, idx, n, out, ld);
+  hipLaunchKernelGGL(onehot_kernel, dim3((l4 + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, (hipStream_t)stream, idx, rows, n, out, ld);
   return recnn_check_hip(hipGetLastError(), "onehot_kernel launch");
 }
 

@@ -148,6 +148,7 @@ class Algo:
         from . import fused
         for k, ni in zip(self._fused_keys, (fused.L.NET_POLICY, fused.L.NET_VALUE1, fused.L.NET_VALUE2)):
             ctx.bump(self.optimizers[k], ni, n_policy if ni == fused.L.NET_POLICY else n_steps)
+        ctx.mark_stepped(list(ctx.modules))     # the graphs wrote every network's parameters in place
         losses = ctx.engine.losses()
         losses["step"] = self._step - 1
         if history:

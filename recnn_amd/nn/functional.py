@@ -31,20 +31,34 @@ def _pad(t, rows, cols):
 
 
 _derived = {}
+_written = {}     # id(parameter) -> number of writes the HIP engine made behind autograd's back (mark_written)
+
+
+def mark_written(params):
+    """The fused engine (ddpg_update / td3_update / value_update / Algo.run) writes adopted parameters in place from its
+    kernels: no torch op runs, so their autograd version counters do not move.  Every caller that lets the engine step a
+    network reports its parameters here; `_derived_of` folds the count into its staleness tag, so a cached bf16 shadow /
+    padded / transposed copy made before the step is rebuilt at the next module-level forward.  (A user's own
+    `p.data.copy_()` is invisible to both counters -- `.data` carries its own version; call
+    `fused.notify_params_changed(module)` after such a write.)"""
+    for p in params:
+        k = id(p)
+        _written[k] = _written.get(k, 0) + 1
 
 
 def _derived_of(w, kind, build):
     """A layout derived from parameter `w` (transposed / padded copy), kept until `w` is written again.  Staleness is
-    detected through the autograd version counter: torch's in-place ops bump it, and so do recnn_amd's own writers
-    (optim.Adam / Ranger, utils.soft_update call torch.autograd.graph.increment_version)."""
+    detected through the autograd version counter -- torch's in-place ops bump it, and so do recnn_amd's own torch-side
+    writers (optim.Adam / Ranger, utils.soft_update call torch.autograd.graph.increment_version) -- plus the engine's
+    write count (`mark_written`) for the kernels that update adopted parameters without any torch op."""
     import weakref
     key = (id(w), kind)
-    tag = (w._version, w.data_ptr(), tuple(w.shape))
+    tag = (w._version, w.data_ptr(), tuple(w.shape), _written.get(id(w), 0))
     hit = _derived.get(key)
     if hit is not None and hit[0]() is w and hit[1] == tag:
         return hit[2]
     out = build(w.detach())
-    _derived[key] = (weakref.ref(w, lambda _r, k=key: _derived.pop(k, None)), tag, out)
+    _derived[key] = (weakref.ref(w, lambda _r, k=key: (_derived.pop(k, None), _written.pop(k[0], None))), tag, out)
     return out
 
 
@@ -603,6 +617,10 @@ def onehot_rows(idx, n):
     B = idx.numel()
     ld = _r4(n)
     idx = idx.to(torch.int64).contiguous()
+    if B:
+        lo, hi = torch.aminmax(idx)
+        if int(lo) < 0 or int(hi) >= n:      # the reference's scatter_ raises for such ids (utils.py:108-109)
+            raise IndexError(f"onehot_rows: index range [{int(lo)}, {int(hi)}] outside the catalogue [0, {n})")
     out = torch.empty(B, ld, dtype=torch.float32, device=idx.device)
     L.call("recnn_onehot_rows", L.ptr(idx), B, n, L.ptr(out), ld, L.current_stream())
     out = out if ld == n else out[:, :n]

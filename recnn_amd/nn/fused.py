@@ -48,6 +48,8 @@ def notify_params_changed(module):
     ctx = _by_module.get(module)
     if ctx is not None:
         ctx.dirty.add(id(module))
+    from . import functional
+    functional.mark_written(_module_params(module))      # cached derived layouts of the module-level forward are stale too
 
 
 def _module_params(m):
@@ -179,6 +181,16 @@ class FusedContext:
                 self.engine.refresh(ni)
                 self.versions[ni] = cur
                 self.dirty.discard(id(m))
+
+    def mark_stepped(self, nis):
+        """The engine just wrote the parameters of networks `nis` from its kernels (optimizer step / soft update): tell the
+        module-level forward path, whose derived weight layouts (`functional._derived_of`) are keyed on version counters the
+        kernels never touch (a bf16 `policy_net(state)` after fused training used the pre-training weights)."""
+        from . import functional
+        for ni in nis:
+            m = self.modules.get(ni)
+            if m is not None:
+                functional.mark_written(_module_params(m))
 
     def attach_grads(self, ni):
         m = self.modules[ni]

@@ -107,15 +107,26 @@ class DiscreteActor(nn.Module):
 
     def pi_beta_sample(self, state, beta, action, **kwargs):
         """log-probs of the target (pi) and behaviour (beta) policies for one action each (models.py:113-141).
-        `beta(state, action=...)` returns the behaviour policy's probabilities; no gradient flows into it."""
+        `beta(state, action=...)` returns the behaviour policy's probabilities.  The HIP sampler (`F_hip.categorical`) is
+        not differentiable: for a beta that detaches its output (the reference notebook's `Beta` does) nothing is lost; a
+        beta that returns probabilities still on the autograd graph gets its log-prob recomputed with torch ops below so
+        that the gradient through `corr = exp(pi_lp) / exp(beta_lp)` reaches it, as in the reference."""
         beta_probs = beta(state.detach(), action=action)
         beta_action, beta_log_prob_own = F_hip.categorical(beta_probs)
+        if beta_probs.requires_grad:
+            def _lp(act):   # Categorical(probs).log_prob(act): probs normalised, clamped to [eps, 1 - eps], log, gather
+                pr = beta_probs / beta_probs.sum(-1, keepdim=True)
+                eps = torch.finfo(pr.dtype).eps
+                return torch.log(pr.clamp(eps, 1 - eps)).gather(-1, act.reshape(-1, 1).to(torch.int64)).reshape(act.shape)
+            beta_log_prob_own = _lp(beta_action)
         if self.action_source["pi"] == "beta":
             pi_probs, pi_action, pi_log_prob = self._act(state, actions=beta_action)
         else:
             pi_probs, pi_action, pi_log_prob = self._act(state)
         if self.action_source["beta"] == "beta":
             beta_log_prob = beta_log_prob_own
+        elif beta_probs.requires_grad:
+            beta_log_prob = _lp(pi_action)
         else:
             _, beta_log_prob = F_hip.categorical(beta_probs, actions=pi_action)
         return pi_log_prob, beta_log_prob, pi_probs

@@ -50,6 +50,7 @@ def ddpg_update(batch, params, nets, optimizer, device=torch.device("cpu"), debu
             ctx.bump(optimizer["value_optimizer"], L.NET_VALUE1)
             if policy_step:
                 ctx.bump(optimizer["policy_optimizer"], L.NET_POLICY)
+            ctx.mark_stepped((L.NET_VALUE1,) + ((L.NET_POLICY, L.NET_TARGET_POLICY, L.NET_TARGET_VALUE1) if policy_step else ()))
     else:
         # arbitrary torch optimizers: the engine produces gradients, torch applies them
         L.call("recnn_engine_value_grads", eng.handle, rows, 1, s)

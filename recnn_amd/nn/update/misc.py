@@ -35,7 +35,8 @@ def _value_update_modules(batch, params, nets, optimizer, device, debug, writer,
     a Critic over [state | action distribution], misc.py:10-55): module forwards / backward on the HIP GEMM and
     policy-head kernels through autograd, TD target and loss on per-row vectors."""
     from ... import data
-    state, action, reward, next_state, done = data.get_base_batch(batch)
+    # the networks' device, not get_base_batch's default "cuda" (= cuda:0): misc.py:25 passes device=device (ADVICE r2)
+    state, action, reward, next_state, done = data.get_base_batch(batch, device=next(nets["value_net"].parameters()).device)
     with torch.no_grad():
         next_action = nets["target_policy_net"](next_state)
         target_value = nets["target_value_net"](next_state, next_action)
@@ -61,7 +62,8 @@ def _value_update_modules(batch, params, nets, optimizer, device, debug, writer,
 def value_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug=None, writer=utils.DummyWriter(),
                  learn=False, step=-1):
     from ..models import Actor
-    if not isinstance(nets["target_policy_net"], Actor):
+    # the fused engine implements exactly Actor's forward: a subclass with another forward goes through the modules
+    if type(nets["target_policy_net"]) is not Actor:
         return _value_update_modules(batch, params, nets, optimizer, device, debug, writer, learn, step)
     ctx = fused.context_for("ddpg", nets)
     rows = batch["state"].shape[0]
@@ -79,6 +81,7 @@ def value_update(batch, params, nets, optimizer, device=torch.device("cpu"), deb
             ctx.mirror_optimizer_state(opt, L.NET_VALUE1)
             L.call("recnn_engine_value_apply", eng.handle, 0, 1.0, s)
             ctx.bump(opt, L.NET_VALUE1)
+            ctx.mark_stepped((L.NET_VALUE1,))
         else:
             ctx.attach_grads(L.NET_VALUE1)
             opt.step()

@@ -47,6 +47,8 @@ def td3_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug
             ctx.bump(optimizer["value_optimizer2"], L.NET_VALUE2)
             if policy_step:
                 ctx.bump(optimizer["policy_optimizer"], L.NET_POLICY)
+            ctx.mark_stepped((L.NET_VALUE1, L.NET_VALUE2)
+                             + ((L.NET_POLICY, L.NET_TARGET_VALUE1, L.NET_TARGET_VALUE2) if policy_step else ()))
     else:
         L.call("recnn_engine_value_grads", eng.handle, rows, 1, s)
         ctx.attach_grads(L.NET_VALUE1)

@@ -48,8 +48,10 @@ class DataParallelStepper:
         self.overlap = bool(self.graphs and overlap and (self.world > 1 or always_reduce))
         if self.graphs:
             engine.dp_graph_build(rows, self.scale, self.overlap)
-        elif getattr(engine, "has_sampler", False):
-            engine.sampler_eager(True)      # eager phases: value_grads builds the step's batch from the sampler
+        # eager phases draw the step's batch from the bound sampler -- but ONLY inside this stepper's own phase calls: the
+        # engine flag is raised around them (_eager_scope) and dropped again, so that a later `algo.update(batch)` on the same
+        # engine evaluates the batch it was given and leaves the device cursor alone
+        self._eager_sampler = (not self.graphs) and bool(getattr(engine, "has_sampler", False))
 
     def _allreduce(self, t: torch.Tensor):
         if self.world > 1 or self.always_reduce:
@@ -76,16 +78,22 @@ class DataParallelStepper:
                 self._allreduce(e.grad_arena(L.NET_POLICY))
                 e.dp_graph_launch(3)
             return
-        e.value_grads(self.rows, learn)
-        if learn:
-            for ni in e.value_nets():
-                self._allreduce(e.grad_arena(ni))
-            e.value_apply(policy, self.scale)
-        e.policy_grads(self.rows, policy)
-        if policy:
-            self._allreduce(e.grad_arena(L.NET_POLICY))
-            e.policy_apply(True, self.scale)
-        e.finish(self.rows, learn, policy)
+        if self._eager_sampler:
+            e.sampler_eager(True)
+        try:
+            e.value_grads(self.rows, learn)
+            if learn:
+                for ni in e.value_nets():
+                    self._allreduce(e.grad_arena(ni))
+                e.value_apply(policy, self.scale)
+            e.policy_grads(self.rows, policy)
+            if policy:
+                self._allreduce(e.grad_arena(L.NET_POLICY))
+                e.policy_apply(True, self.scale)
+            e.finish(self.rows, learn, policy)
+        finally:
+            if self._eager_sampler:
+                e.sampler_eager(False)
 
     def run(self, first: int, n: int, learn: bool = True):
         """`n` consecutive steps.  With phase graphs (and no overlap mode) the tail of step t and the head of step t+1

@@ -303,62 +303,3 @@ def test_flat_optimizer_kernels(cuda):
     scratch, out = torch.zeros(1024, device=cuda), torch.zeros(1, device=cuda)
     L.call("recnn_l1_norm_flat", L.ptr(gd), n, L.ptr(scratch), L.ptr(out), L.current_stream())
     assert abs(out.item() / gr.double().abs().sum().item() - 1) < 1e-5
-
-
-@pytest.mark.parametrize("algo,B,steps", [("ddpg", 2048, 12), ("ddpg", 333, 4), ("ddpg", 77, 3), ("td3", 4096, 3), ("ddpg", 8192, 2)])
-def test_mlp_forward_64_row_panels_equal_32_row_panels(cuda, algo, B, steps):
-    """csrc/mlp64.hip (64-row panels, one 3-deep DMA ring for every weight byte of the workgroup) and csrc/mlpr.hip (64-row
-    panels, weights from L2 straight into MFMA registers) against csrc/mlp.hip (32-row panels): same k order per output
-    element, so whole learning steps -- chained target critic, TD head, unit
-    layer-2 backward, policy steps -- must agree BIT FOR BIT, with both workgroup maps, on full, ragged (333, 77 rows)
-    and not-fully-resident (TD3 4096: 448 workgroups; 8192 rows) launches."""
-    from recnn_amd import _lib as L
-    from recnn_amd.nn.engine import StepEngine
-    S, A, H = 1290, 128, 256
-    td3 = algo == "td3"
-    torch.manual_seed(5)
-
-    def mk(inp, out, init_w):
-        l1, l2, l3 = torch.nn.Linear(inp, H), torch.nn.Linear(H, H), torch.nn.Linear(H, out)
-        l3.weight.data.uniform_(-init_w, init_w); l3.bias.data.uniform_(-init_w, init_w)
-        return {"w1": l1.weight.data.clone(), "b1": l1.bias.data.clone(), "w2": l2.weight.data.clone(),
-                "b2": l2.bias.data.clone(), "w3": l3.weight.data.clone(), "b3": l3.bias.data.clone()}
-    critics = [mk(S + A, 1, 54e-2) for _ in range(2 if td3 else 1)]
-    actor = mk(S, A, 6e-1)
-    gen = torch.Generator().manual_seed(11)
-    batch = {"state": torch.randn(B, S, generator=gen), "action": torch.randn(B, A, generator=gen),
-             "reward": torch.randn(B, generator=gen) * 3.0, "next_state": torch.randn(B, S, generator=gen),
-             "done": (torch.rand(B, generator=gen) < 0.1).float()}
-    outs = []
-    try:
-        for kern, wmap in ((0, 0), (1, 0), (1, 2), (2, 0), (2, 2), (3, 0)):    # 3 = csrc/mlps.hip (one continuous weight stream)
-            L.load().recnn_tune_mlp_kernel(kern)
-            L.load().recnn_tune_mlp_map(wmap)
-            eng = StepEngine(algo, S, A, H, B, dtype="bf16", mask_mode="hash", seed=31)
-            nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
-            if td3:
-                nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
-            for ni, p in nets:
-                eng.load_params(ni, p)
-            eng.set_hyper(policy_opt=dict(lr=1e-3, weight_decay=1e-2), value_opt=dict(lr=1e-3, weight_decay=1e-2), policy_every=3)
-            eng.set_counters()
-            eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
-            hist = []
-            for t in range(steps):
-                eng.step(B, True, t)
-                hist.append(eng.losses())
-            eng.step(B, False, steps)                 # a learn=False evaluation as well (head kernels, no backward)
-            hist.append(eng.losses())
-            torch.cuda.synchronize()
-            outs.append((hist, {ni: eng.params[ni].clone() for ni, _ in nets},
-                         {n: eng.buffer(n, B).clone() for n in ("expected", "q1", "gen_action", "next_action", "critic1_h1",
-                                                                "critic1_h2", "actor_h1", "actor_h2")}))
-    finally:
-        L.load().recnn_tune_mlp_kernel(3)
-        L.load().recnn_tune_mlp_map(0)
-    for other in outs[1:]:
-        assert outs[0][0] == other[0], (outs[0][0], other[0])
-        for ni in outs[0][1]:
-            assert torch.equal(outs[0][1][ni], other[1][ni]), ni
-        for n in outs[0][2]:
-            assert torch.equal(outs[0][2][n], other[2][n]), n

@@ -1,5 +1,5 @@
-"""Phase timeline of the 64-row fused MLP forward (csrc/mlp64.hip) from in-kernel shader-clock stamps.
-usage: python tools/mlp_trace.py [probe_bits]"""
+"""Phase timeline of the fused row-panel MLP forward (csrc/mlps.hip) from in-kernel shader-clock stamps.
+usage: python tools/mlp_trace.py [probe_bits]   (1 = no MFMA work, 2 = no DMA)"""
 import os, sys
 import numpy as np
 import torch
@@ -8,7 +8,7 @@ from recnn_amd import _lib as L
 from recnn_amd.nn.engine import StepEngine
 
 probe = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+kernel = 3   # csrc/mlps.hip, the only fused forward left
 S, A, H, B = 1290, 128, 256, 2048
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -25,8 +25,6 @@ eng.set_counters()
 eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
 trace = torch.zeros(1024, 32, dtype=torch.int64, device=dev)
 L.load().recnn_tune_mlp_probe(probe)
-L.load().recnn_tune_mlp_fault(probe << 8)
-L.load().recnn_tune_mlp_kernel(kernel)
 for t in range(5):
     eng.step(B, True, 1)
 torch.cuda.synchronize()
@@ -35,7 +33,7 @@ eng.step(B, True, 1)
 torch.cuda.synchronize()
 L.load().recnn_tune_mlp_trace(None)
 tr = trace.cpu().numpy()
-npanel = B // (32 if kernel in (0, 3) else 64)
+npanel = B // 32
 names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]
 t_start = tr[:npanel * 4, 0][tr[:npanel * 4, 0] > 0].min()
 t_end = tr[:npanel * 4, 9].max()
