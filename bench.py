@@ -111,7 +111,8 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
 # is mlps.hip's mlps_fwd_kernel; the opt-in variants mlp_fwd_kernel / mlp64 / mlpr are reached through recnn_tune_*)
 KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_l1_nets": "mlp_l1_kernel", "mlp_tail_nets": "mlp_tail_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
-                  "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel"}
+                  "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",
+                  "dw_adam_critic": "dw_opt_kernel", "dw_adam_critic+gather": "dw_opt_kernel"}
 
 
 def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):

@@ -499,6 +499,14 @@ int recnn_engine_dp_sets(recnn_engine* e);
  * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
  * on purpose (tests). */
 void recnn_tune_mlp_fault(int mode);
+/* 1: on the bf16 fused path the critic's weight-gradient GEMMs contract the whole batch per tile and finish the
+ * optimizer step (recnn_engine_step / graph replays) or the flat gradient arena (recnn_engine_value_grads, data parallel) in
+ * their epilogue (csrc/dwopt.hip: no gradient slabs, no separate Adam launch; 2 / 3 = the same with 8 / 4 waves per workgroup
+ * instead of 16); 0 (default: faster at 2048 rows, see csrc/engine.hip) = split-batch slabs + reduce / Adam launches. */
+void recnn_tune_dw_fuse(int on);
+/* timing experiments on csrc/dwopt.hip (results are garbage): 1 = no per-row scale, 2 = no LDS reads / MFMA, 4 = no DMA */
+void recnn_tune_dw_probe(int bits);
+void recnn_tune_dw_trace(void* device_u64_wg8);   /* shader-clock stamps of dw_opt_kernel, [workgroup][8] uint64, NULL = off */
 /* timing experiments on the fused forward (csrc/mlps.hip): bit 0 = no MFMA work / fragment reads, bit 1 = no DMA; results are garbage */
 void recnn_tune_mlp_probe(int bits);
 void recnn_tune_mlp_trace(void* device_u64_wg32);   /* shader-clock stamps of the kernel's phases, [workgroup][32] uint64, NULL = off */

@@ -33,6 +33,7 @@
 #include "mlp.h"
 #include "bwd.h"
 #include "optim.h"
+#include "dwopt.h"
 
 constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
 
@@ -129,6 +130,10 @@ struct recnn_engine {
   float* coef_out;                         // device float[1]
   int32_t* counters;                       // device int32[8]: step, t_policy, t_value1, t_value2
   float* l1_scratch;
+  // step scalars of the optimizers (bias corrections ...: fp64 chains, optim.h) for every step of the run being issued:
+  // [RUN_MAX][3] = {policy, value1, value2}; filled by one small launch at the start of a run graph / an eager step
+  OptScalars* opt_tab = nullptr;
+  bool scal_on = false;                    // the table holds the step being issued
   // device-resident sampler (optional)
   recnn_sampler smp;
   bool has_sampler = false;
@@ -313,6 +318,7 @@ int64_t carve(recnn_engine* e, char* base) {
   e->coef_out = (float*)c.take(16);
   e->counters = (int32_t*)c.take(64);
   e->l1_scratch = (float*)c.take(4096);
+  e->opt_tab = (OptScalars*)c.take((int64_t)OPT_TABLE_STEPS * 3 * sizeof(OptScalars));
   return ru(c.off, 256);
 }
 
@@ -365,6 +371,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = gemm_init())) { delete e; return rc; }
   if ((rc = mlp_init())) { delete e; return rc; }
   if ((rc = bwd_init())) { delete e; return rc; }
+  if ((rc = dwopt_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
@@ -545,11 +552,11 @@ inline char* sh_ptr(const recnn_engine* e, int ni, int which) {
   return n.shadow + n.sh_off[which] * e->esz;
 }
 
-int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni,
-              float tau, hipStream_t s, bool from_slabs = false) {
+// The optimizer / soft-update description of network `ni` (shared by apply_kernel launches and the fused dW epilogue).
+int fill_apply_args(recnn_engine* e, int ni, const NetLayout& L, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni,
+                    float tau, ApplyArgs* out) {
   Net& n = e->net[ni];
-  NetLayout L = make_layout(e, ni, rows);
-  ApplyArgs a;
+  ApplyArgs& a = *out;
   memset(&a, 0, sizeof(a));
   a.p = n.p; a.g = n.g; a.m = n.m; a.v = n.v;
   a.shadow = n.shadow;
@@ -567,8 +574,9 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
       a.slow = n.slow; a.la_alpha = e->hy.la_alpha[opt_idx]; a.la_k = e->hy.la_k[opt_idx]; a.nsma_thr = e->hy.nsma_threshold[opt_idx];
     }
   }
+  if (do_adam && e->scal_on && e->run_off < OPT_TABLE_STEPS)
+    a.scal = e->opt_tab + e->run_off * 3 + (ni == RECNN_NET_POLICY ? 0 : (ni == RECNN_NET_VALUE1 ? 1 : 2));
   a.grad_scale = grad_scale;
-  a.from_slabs = from_slabs && do_adam && rows > 0;
   a.g_out = n.g;
   a.l1part = clip ? n.l1part : nullptr;
   a.n_l1 = clip ? L.nblk : 0;
@@ -578,6 +586,17 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
     a.tgt_shadow = e->net[target_ni].shadow;
     a.tau = tau;
   }
+  return 0;
+}
+
+int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni,
+              float tau, hipStream_t s, bool from_slabs = false) {
+  Net& n = e->net[ni];
+  NetLayout L = make_layout(e, ni, rows);
+  ApplyArgs a;
+  int rc = fill_apply_args(e, ni, L, do_adam, opt_idx, grad_scale, clip, target_ni, tau, &a);
+  if (rc) return rc;
+  a.from_slabs = from_slabs && do_adam && rows > 0;
   const GatherArgs* pg = (do_adam && ni == RECNN_NET_VALUE1) ? e->pregather : nullptr;
   return slot(e, do_adam ? (n.critic ? (pg ? "adam_critic+gather" : "adam_critic") : "adam_actor") : "shadow_refresh", 0, s,
               [&] { return apply_launch(L, a, s, pg); }, !do_adam && target_ni < 0);
@@ -718,6 +737,15 @@ extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic =
 
 int g_policy_chain = 1;
 extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
+// 1: the critic's weight-gradient GEMMs contract the whole batch per tile and finish the optimizer step (single GPU) or the
+// flat gradient arena (phase API / data parallel) in their epilogue (dwopt.hip: no slabs, no Adam launch, results identical
+// to "arena + apply_kernel" bit for bit); 0 (default): split-batch slabs + grad_reduce / slab-summing Adam launches.
+// Measured (round 3, DDPG 2048 rows): the fused launch takes 26.7 us against 12.7 + 5 for the two it replaces -- with 108
+// tiles of K = 2048 only 42 % of the CUs work, and a tile's k loop is bound by the VALU work of applying the per-row loss seed
+// to the unit backward tensors (13k of 44k cycles) and by DMA latency at one workgroup per CU (20 B/cycle).  Off until the
+// forward hands over already-scaled backward tensors.
+int g_dw_fuse = 0;
+extern "C" void recnn_tune_dw_fuse(int on) { g_dw_fuse = on; if (on) dwopt_set_groups(on == 2 ? 2 : (on == 3 ? 1 : 4)); }
 int g_bwd_panel = 2;  // 0: head + dX launches, 1: row-panel launch (bwd.hip), 2: inside the critic's forward workgroup (mlp.hip)
 extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
 
@@ -1056,11 +1084,19 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   return 0;
 }
 
-// Backward of the critic(s) into gradient slabs, then slab reduction into the bound grad arenas.
-int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
+// What the caller wants done with the critic gradients beyond producing them (fused single-GPU step): the optimizer step
+// (+ soft target update on policy steps) inside the dW launch's epilogue.
+struct ValueFuse { bool soft; float grad_scale; };
+
+// Backward of the critic(s).  Round-3 default on the bf16 unit-backward path (dwopt.hip): ONE launch contracts the whole batch
+// per 64 x 64 tile and either applies the optimizer in its epilogue (vf != NULL: *applied is set, the caller skips
+// value_apply) or writes the finished gradients to the bound flat arenas (reduce: what the phase API / data parallel
+// all-reduce).  Otherwise (fp32, generic shapes, recnn_tune_dw_fuse(0)): gradient slabs, then slab reduction into the arenas.
+int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, const ValueFuse* vf = nullptr, bool* applied = nullptr) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
-  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   int rc;
+  if (applied) *applied = false;
   if (!e->panel_bwd_done) {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
@@ -1068,21 +1104,49 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
     if ((rc = g.run(s, "dx_critic_l2"))) return rc;
   }
   NetLayout L0 = make_layout(e, VAL[0], rows);
+  const bool fuse = g_dw_fuse && e->bf16 && e->unit_bwd && (vf || reduce);
   {
     Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1 and dW1 = dz1^T [a|s], split over the batch into slabs
     DwVec vec;
     memset(&vec, 0, sizeof(vec));
+    DwOpt o;
+    memset(&o, 0, sizeof(o));
     for (int c = 0; c < nc; ++c) {
       GemmProb* p = g.add();
+      o.prob_net[g.L.nprob - 1] = (signed char)c; o.prob_tensor[g.L.nprob - 1] = W2;
       g.flops += fill_dw(e, p, rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab,
                          L0.t[W2].slab_stride);
       if (e->unit_bwd) p->a_row_scale = e->delta[c];
     }
     for (int c = 0; c < nc; ++c) {
       GemmProb* p = g.add();
+      o.prob_net[g.L.nprob - 1] = (signed char)c; o.prob_tensor[g.L.nprob - 1] = W1;
       g.flops += fill_dw(e, p, rows, e->dzc1[c], Hp, H, e->xcs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1],
                          L0.t[W1].nslab, L0.t[W1].slab_stride);
       if (e->unit_bwd) p->a_row_scale = e->delta[c];
+    }
+    if (fuse && dwopt_eligible(&g.L)) {
+      o.mode = vf ? DWOPT_APPLY : DWOPT_GRAD;
+      o.n_net = nc;
+      for (int c = 0; c < nc; ++c) {
+        Net& v = e->net[VAL[c]];
+        const NetLayout L = make_layout(e, VAL[c], 0);
+        for (int t = 0; t < 6; ++t) o.seg[c][t] = L.t[t];
+        if (vf) {
+          if ((rc = fill_apply_args(e, VAL[c], L, true, 1, vf->grad_scale, false, vf->soft ? TVAL[c] : -1, e->hy.soft_tau, &o.a[c]))) return rc;
+        } else {
+          RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+          if ((rc = fill_apply_args(e, VAL[c], L, false, 1, 1.0f, false, -1, 0.f, &o.a[c]))) return rc;
+        }
+        DwVecProb& q = o.v[c];
+        q.rows = rows; q.H = H; q.delta = e->delta[c]; q.h2 = e->cv[c].h2; q.u2 = e->dzc2[c]; q.U = e->dzc1[c]; q.ldh = Hp;
+      }
+      const GatherArgs* pg = vf ? e->pregather : nullptr;
+      if ((rc = slot(e, vf ? (pg ? "dw_adam_critic+gather" : "dw_adam_critic") : "dw_grad_critic", g.flops, s,
+                     [&] { return dwopt_launch(&g.L, o, pg, s); }, !vf)))
+        return rc;
+      if (applied) *applied = vf != nullptr;
+      return 0;
     }
     if (e->unit_bwd) {  // dW3 / db2 / db1 partial sums per 32-row panel ride on this launch
       vec.n = nc;
@@ -1376,6 +1440,31 @@ int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
   return 0;
 }
 
+// Step scalars of every optimizer instance for the `len` steps about to be issued (step i of them is a policy step when
+// pol[i]): one small launch; afterwards fill_apply_args points every optimizer launch at its table entry.
+int opt_table(recnn_engine* e, int len, const bool* pol, hipStream_t s) {
+  OptTableArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_steps = len;
+  a.n_nets = e->td3 ? 3 : 2;
+  a.out = e->opt_tab;
+  const int nets[3] = {RECNN_NET_POLICY, RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+  for (int k = 0; k < a.n_nets; ++k) {
+    const int oi = k == 0 ? 0 : 1;
+    OptTableNet& n = a.net[k];
+    n.t_ptr = e->net[nets[k]].t_ptr;
+    n.opt_kind = e->hy.opt_kind[oi]; n.la_k = e->hy.la_k[oi];
+    n.lr = e->hy.lr[oi]; n.nsma_thr = e->hy.nsma_threshold[oi];
+    n.beta1 = e->hy.beta1[oi]; n.beta2 = e->hy.beta2[oi];
+    int n_pol = 0;
+    for (int i = 0; i < len; ++i) {
+      n.t_add[i] = (unsigned char)(k == 0 ? n_pol : i);
+      if (pol[i]) ++n_pol;
+    }
+  }
+  return slot(e, "opt_scalars", 0, s, [&] { return opt_table_launch(a, s); });
+}
+
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
 // pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
 // optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
@@ -1385,12 +1474,15 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
-    if ((rc = ph_value_backward(e, rows, false, s))) return rc;
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
-    // next step, so on policy steps it is fused into the critic's Adam pass (ddpg.py:95-97).
+    // next step, so on policy steps it is fused into the critic's optimizer pass (ddpg.py:95-97) -- which itself is the
+    // epilogue of the weight-gradient launch on the bf16 unit-backward path (dwopt.hip), a separate Adam launch otherwise.
     GatherArgs ga;
     if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1); e->pregather = &ga; }
-    rc = value_apply(e, policy_step, 1.0f, s, rows);
+    const ValueFuse vf{policy_step, 1.0f};
+    bool applied = false;
+    rc = ph_value_backward(e, rows, false, s, &vf, &applied);
+    if (!rc && !applied) rc = value_apply(e, policy_step, 1.0f, s, rows);
     e->pregather = nullptr;
     if (rc) return rc;
   }
@@ -1534,7 +1626,13 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
     e->prof_on = true;
     e->prof_n = 0;
     e->use_sampler = e->has_sampler;
-    rc = step_impl(e, rows, true, policy_steps != 0, s);
+    {   // as the run graphs do: the step scalars of the optimizers come from the table launch
+      const bool pol1[1] = {policy_steps != 0};
+      rc = opt_table(e, 1, pol1, s);
+      e->scal_on = rc == 0;
+    }
+    if (!rc) rc = step_impl(e, rows, true, policy_steps != 0, s);
+    e->scal_on = false;
     e->use_sampler = false;
     e->prof_on = false;
     if (rc) return rc;
@@ -1582,6 +1680,12 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   e->use_sampler = e->has_sampler;
   int n_pol = 0;
+  if (len <= OPT_TABLE_STEPS) {   // the optimizers' step scalars for the whole run: one small launch at the head of the graph
+    bool polv[OPT_TABLE_STEPS];
+    for (int i = 0; i < len; ++i) polv[i] = phase >= 0 && ((phase + i) % pe) == 0;
+    rc = opt_table(e, len, polv, s);
+    e->scal_on = rc == 0;
+  }
   for (int i = 0; i < len && !rc; ++i) {
     const bool pol = phase >= 0 && ((phase + i) % pe) == 0;
     use_set(e, look ? (i & 1) : 0);
@@ -1599,6 +1703,7 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
   }
   e->run_off = 0;
+  e->scal_on = false;
   use_hist_slot(e, 0);
   e->pending_pc.on = false;
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;

@@ -19,6 +19,7 @@
 // global loads of tile t+1 are in flight while tile t is multiplied.
 #include <type_traits>
 #include "gemm.h"
+#include "dw_tile.h"
 
 template <class TC, int KB> struct LdsCfg {
   static constexpr int VEC = TcTraits<TC>::VEC;
@@ -513,18 +514,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
-// dW[m][n] = sum_b dZ[b][m] * X[b][n]: BOTH operands are k-strided (k = batch row), i.e. stored with the tile
-// dimension contiguous.  The register-staged kernel above transposes them with 16-bit shuffles and 8-byte LDS
-// writes; here the rows go global -> LDS untouched (`global_load_lds_dwordx4`) and the MFMA fragments are read
-// with gfx950's `ds_read_b64_tr_b16`, which hands lane i of a 16-lane group column i of a [4 k][16 cols] block.
-// Tile 64 (m) x 64 (n); a k stage = 128 batch rows x 128 bytes per operand (32 KB for both); two stages, both in
-// flight before the first MFMA (a workgroup's whole k range when rows/splits <= 256).
-// LDS image of a stage: row b of an operand is 8 chunks of 16 bytes; chunk pair p of row b sits at pair position
-// p ^ f(b), f(b) = ((b>>1)&1) | (((b>>3)&1)<<1), so the 8 rows x 32 bytes one half-wave transpose read touches
-// (rows {0..3} and {8..11} of a k step, same 16 columns) fall on 8 different 32-byte bank groups.
-typedef short v4s16 __attribute__((ext_vector_type(4)));
+// dW[m][n] = sum_b dZ[b][m] * X[b][n], batch split into slabs (deterministic): the 64 x 64 tile itself is dw_tile.h; here the
+// split-batch driver that writes one fp32 slab per batch slice (summed later by grad_reduce / the Adam pass).  The fused
+// single-GPU step uses dwopt.hip instead (whole batch per tile, optimizer in the epilogue: no slabs at all).
 constexpr int DW_SCALE_ROWS = 512;    // per-row scales of a workgroup's k range are staged in LDS up to this many rows
-// SUB = batch rows per stage, NS = ring slots (all filled before the first MFMA).
 // one 32-row panel of one critic: per-column sums over the rows of d_r * {h2, u2, U}; thread = column
 __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
   const int m0 = panel * 32;
@@ -546,6 +539,7 @@ __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
   }
 }
 
+// SUB = batch rows per stage, NS = ring slots (all filled before the first MFMA).
 template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch, const DwVec vec, const int nprob) {
   // extra workgroups, first in the launch order (their chain of row loads is the longest single-workgroup path):
   // row-vector partial sums for the bias / last-layer gradients
@@ -557,11 +551,6 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
   }
   (void)nprob;
   const GemmProb& P = batch.p[(int)blockIdx.y - y0];
-  constexpr int DWT_SUB = SUB;
-  constexpr int DWT_OP_BYTES = DWT_SUB * 128;        // one operand of a stage
-  constexpr int DWT_STAGE_BYTES = 2 * DWT_OP_BYTES;
-  constexpr int NI = SUB / 16;                       // DMA instructions per wave and stage
-  constexpr int RG = SUB / 8;                        // 8-row groups per operand and stage
   const int nwg = P.tiles_m * P.tiles_n * P.dw_splits;
   if ((int)blockIdx.x >= nwg) return;
   const int lid = xcd_remap(blockIdx.x, nwg);
@@ -571,9 +560,8 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
   const int m0 = tile_m * 64, n0 = tile_n * 64;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
-  const unsigned lds0 = (unsigned)(size_t)dsmem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
   const int fr = lane & 15, fg = lane >> 4;
 
@@ -583,122 +571,11 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const GemmSeg& G = P.seg[0];
-  const int Kc = G.K;
+  const int Kc = P.seg[0].K;
   const int chunk = (((Kc + P.dw_splits - 1) / P.dw_splits) + 63) / 64 * 64;
   const int kbeg = split * chunk;
   const int kend = min(Kc, kbeg + chunk);
-  const int nt = kend > kbeg ? (kend - kbeg + DWT_SUB - 1) / DWT_SUB : 0;
-
-  // DMA geometry: wave instruction g = wave*8 + i covers rows 8*(g&15) .. +7 of operand g>>4 (64 lanes x 16 bytes)
-  const int d_row = lane >> 3, d_slot = lane & 7;
-  auto issue = [&](int t, int stage) {
-    const int k0 = kbeg + t * DWT_SUB;
-    const unsigned sbase = lds0 + stage * DWT_STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int g = wave * NI + i;
-      const int op = g / RG, rg = g % RG;
-      const int f = ((d_row >> 1) & 1) | ((rg & 1) << 1);
-      const int c = (((d_slot >> 1) ^ f) << 1) | (d_slot & 1);
-      const int row = min(k0 + rg * 8 + d_row, kend - 1);  // clamped rows are masked out of the A fragments below
-      const char* src = op == 0 ? (const char*)G.A + ((int64_t)row * G.lda + m0) * 2 + c * 16
-                                : (const char*)G.B + ((int64_t)row * G.ldb + n0) * 2 + c * 16;
-      dma16(src, sbase + op * DWT_OP_BYTES + rg * 1024);
-    }
-  };
-
-#pragma unroll
-  for (int i = 0; i < NS; ++i)
-    if (i < nt) issue(i, i);
-  // per-row scales of this workgroup's k range -> LDS (read back in the k loop; a global load there would stall every
-  // k step for a memory latency)
-  float* sds = (float*)(dsmem + NS * DWT_STAGE_BYTES);
-  const bool lds_scale = P.a_row_scale && (kend - kbeg) <= DW_SCALE_ROWS;
-  if (lds_scale) {
-    for (int i = tid; i < kend - kbeg; i += 256) sds[i] = P.a_row_scale[kbeg + i];
-    for (int i = kend - kbeg + tid; i < ((kend - kbeg + 63) & ~63); i += 256) sds[i] = 0.f;
-    __syncthreads();
-  }
-  for (int t = 0; t < nt; ++t) {
-    // stages issued so far: the NS of the prologue plus one per iteration 1..t-1
-    const int younger = min(nt - 1, NS - 1 + max(t - 1, 0)) - t;
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // stage t is in LDS; every wave is done reading stage t-1
-    if (t >= 1 && t - 1 + NS < nt) issue(t - 1 + NS, (t - 1) % NS);
-    const unsigned char* sa = dsmem + (t % NS) * DWT_STAGE_BYTES;
-    const unsigned char* sb = sa + DWT_OP_BYTES;
-    const int k0 = kbeg + t * DWT_SUB;
-    const bool tail = k0 + DWT_SUB > kend;
-#pragma unroll
-    for (int ks = 0; ks < DWT_SUB / 32; ++ks) {
-      v4s16 a[2][2], b[2][2];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int row = ks * 32 + fg * 8 + half * 4 + (fr >> 2);
-        const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-        const int rbyte = row * 128 + (fr & 1) * 8;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          const int c = ((wm0 + tm * 16) >> 3) + ((fr & 3) >> 1);  // 16-byte chunk holding the lane's 4 columns
-          const int slot = (((c >> 1) ^ f) << 1) | (c & 1);
-          a[tm][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4s16*)(sa + rbyte + slot * 16));
-        }
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          const int c = ((wn0 + tn * 16) >> 3) + ((fr & 3) >> 1);
-          const int slot = (((c >> 1) ^ f) << 1) | (c & 1);
-          b[tn][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) v4s16*)(sb + rbyte + slot * 16));
-        }
-      }
-      if (tail) {  // batch rows past the end of this split: zero the A side (the B side holds finite, clamped rows)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int kk = k0 + ks * 32 + fg * 8 + half * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kk + j >= kend) { a[0][half][j] = 0; a[1][half][j] = 0; }
-        }
-      }
-      if (P.a_row_scale) {  // uniform: A rows are unit backward tensors, multiply batch row k by its loss seed d_k
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int kk = k0 + ks * 32 + fg * 8 + half * 4;
-          float dv[4];
-          if (lds_scale) {
-            const float4 d4 = *(const float4*)(sds + (kk - kbeg));
-            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-          } else if (kk + 3 < Kc) {   // kk is a multiple of 4 and the scale array is 16-byte aligned
-            const float4 d4 = *(const float4*)(P.a_row_scale + kk);
-            dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dv[j] = P.a_row_scale[min(kk + j, Kc - 1)];
-          }
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) {
-            const uint2 raw = __builtin_bit_cast(uint2, a[tm][half]);
-            const uint2 sc = make_uint2(pack_bf2(bf2f((bf16_t)(raw.x & 0xFFFF)) * dv[0], bf2f((bf16_t)(raw.x >> 16)) * dv[1]),
-                                        pack_bf2(bf2f((bf16_t)(raw.y & 0xFFFF)) * dv[2], bf2f((bf16_t)(raw.y >> 16)) * dv[3]));
-            a[tm][half] = __builtin_bit_cast(v4s16, sc);
-          }
-        }
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          struct { v4s16 lo, hi; } av = {a[tm][0], a[tm][1]}, bv = {b[tn][0], b[tn][1]};
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                                acc[tm][tn], 0, 0, 0);
-        }
-    }
-  }
+  dw_tile_accumulate<SUB, NS, 1>(P, m0, n0, kbeg, kend, dsmem, DW_SCALE_ROWS, acc, [] {});
 
   float* Cs = (float*)P.C + (int64_t)split * P.dw_slab_stride;
 #pragma unroll

@@ -62,6 +62,7 @@ struct ApplyArgs {
   float la_alpha;
   int la_k;
   float nsma_thr;
+  const struct OptScalars* scal;   // optional: this launch's step scalars, precomputed on the device (opt_table_launch)
 };
 
 // The hyper-parameters cross the C ABI as floats; torch computes 1 - beta and beta^t from the Python double the user wrote
@@ -82,7 +83,98 @@ __host__ __device__ inline RadamScalars radam_scalars(int t, double log_beta1, d
   return r;
 }
 
+// ---- the optimizer arithmetic of ONE element, shared by every kernel that applies it (apply_kernel, the dW GEMM's fused
+// epilogue in gemm.hip): floating-point contraction is OFF inside these functions, so the operation sequence is exactly the
+// one written here whatever code surrounds the call -- a fused multiply-add chosen in one kernel and not in the other would
+// make "gradient arena + apply_kernel" (data parallel, external optimizers) and "fused epilogue" (single GPU) drift apart.
+struct OptScalars {
+  int adam, ranger, rect, la_sync;
+  float step_size, bc2_sqrt, sl_lr;
+  int pad;
+};
+// The step scalars are double-precision arithmetic (bias corrections 1 - beta^t = -expm1(t ln beta), sqrt, a division: torch
+// computes them in Python floats) on a DEPENDENT chain of ~500 fp64 instructions: ~13k shader cycles = 6 us per evaluation
+// (in-kernel trace, round 3) -- half of round 2's whole Adam launch, where every thread evaluated them.  They depend on the
+// device-side step counter only, so a one-workgroup kernel evaluates them for every step of a run graph at the graph's start
+// (opt_table_launch) and the optimizer kernels just load their entry; without a table (`scal` NULL) they compute in place.
+__host__ __device__ inline OptScalars opt_scalars_at(int do_adam, int opt_kind, int t, float lr, double log_beta1, double log_beta2,
+                                                     float nsma_thr, int la_k) {
+  OptScalars S;
+  S.adam = do_adam && opt_kind != RECNN_OPT_RANGER;
+  S.ranger = do_adam && opt_kind == RECNN_OPT_RANGER;
+  S.rect = 0; S.la_sync = 0; S.step_size = 0.f; S.bc2_sqrt = 1.f; S.sl_lr = 0.f; S.pad = 0;
+  if (S.ranger) {
+    // RAdam + Lookahead, the published torch_optimizer.Ranger algorithm (recnn/nn/algo.py:84-89 builds it; the package
+    // itself is absent and un-pinned: restated, see recnn_amd/optim.py):
+    //   v = b2 v + (1-b2) g^2;  m = b1 m + (1-b1) g;  N_sma = N_max - 2 t b2^t / (1 - b2^t)
+    //   p -= wd lr p;  N_sma > thr: p -= step lr m / (sqrt(v) + eps)  else  p -= step lr m
+    //   every k-th step: slow += alpha (p - slow); p = slow
+    const RadamScalars rs = radam_scalars(t, log_beta1, log_beta2, exp(log_beta2), (double)nsma_thr);
+    S.rect = rs.rect;
+    S.sl_lr = rs.step * lr;
+    S.la_sync = la_k > 0 && (t % la_k) == 0;
+  } else if (S.adam) {
+    // bias corrections 1 - beta^t = -expm1(t ln beta) in double (torch computes them in Python floats)
+    const double bc1 = -expm1((double)t * log_beta1);
+    const double bc2 = -expm1((double)t * log_beta2);
+    S.step_size = (float)((double)lr / bc1);
+    S.bc2_sqrt = (float)sqrt(bc2);
+  }
+  return S;
+}
+#if defined(__HIPCC__)
+__device__ inline OptScalars opt_scalars(const ApplyArgs& a) {
+  if (a.scal) return *a.scal;
+  const int t = a.do_adam ? *a.t_ptr + 1 + a.t_add : 0;
+  return opt_scalars_at(a.do_adam, a.opt_kind, t, a.lr, a.log_beta1, a.log_beta2, a.nsma_thr, a.la_k);
+}
+// g: raw gradient, gs: gradient scale (1/world, clip coefficient); p, m, v, sl updated in place (sl only on Lookahead syncs)
+__device__ inline void opt_elem(const ApplyArgs& a, const OptScalars& S, float g, float gs, float& p, float& m, float& v, float& sl) {
+#pragma clang fp contract(off)
+  if (S.ranger) {
+    const float gj = g * gs;
+    v = a.beta2 * v + (a.omb2 * gj) * gj;
+    m = a.beta1 * m + a.omb1 * gj;
+    if (a.weight_decay != 0.f) p = p + (-a.weight_decay * a.lr) * p;
+    if (S.rect) p = p + (-S.sl_lr) * (m / (sqrtf(v) + a.eps));
+    else p = p + (-S.sl_lr) * m;
+    if (S.la_sync) { sl = sl + a.la_alpha * (p - sl); p = sl; }
+  } else if (S.adam) {
+    float gj = g * gs;
+    if (a.weight_decay != 0.f) gj = gj + a.weight_decay * p;
+    m = m + a.omb1 * (gj - m);
+    v = a.beta2 * v + (a.omb2 * gj) * gj;
+    const float denom = sqrtf(v) / S.bc2_sqrt + a.eps;
+    p = p - S.step_size * (m / denom);
+  }
+}
+// recnn/utils/misc.py:3-5, that operand order: target * (1 - tau) + param * tau
+__device__ inline float soft_elem(float tp, float p, float tau) {
+#pragma clang fp contract(off)
+  return tp * (1.0f - tau) + p * tau;
+}
+#endif
+
 int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStream_t s);
+// fills the launch-time scalars of an ApplyArgs (log betas in double, 1 - beta as torch rounds them)
+void apply_args_finish(ApplyArgs* a);
+
+// Step scalars of up to 3 optimizer instances for every step of a run: out[step * 3 + net] (see OptScalars).
+constexpr int OPT_TABLE_STEPS = 64;
+struct OptTableNet {
+  const int32_t* t_ptr;            // device: optimizer steps already taken
+  int opt_kind, la_k;
+  float lr, nsma_thr;
+  float beta1, beta2;              // (log betas in double are derived by opt_table_launch, as apply_args_finish does)
+  double log_beta1, log_beta2;
+  unsigned char t_add[OPT_TABLE_STEPS];   // steps taken earlier in the run, per step of the run
+};
+struct OptTableArgs {
+  int n_steps, n_nets;
+  OptTableNet net[3];
+  OptScalars* out;
+};
+int opt_table_launch(const OptTableArgs& a, hipStream_t s);
 struct GatherArgs;
 // pregather != NULL: the sampler + gather of the NEXT step runs as extra workgroups of this launch
 int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s, const GatherArgs* pregather = nullptr);

@@ -204,9 +204,8 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
   float p[4], m[4], v[4], tp[4], g[4], sl[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) p[j] = m[j] = v[j] = tp[j] = g[j] = sl[j] = 0.f;
-  const bool ranger = a.do_adam && a.opt_kind == RECNN_OPT_RANGER;
-  int t = a.do_adam ? *a.t_ptr + 1 + a.t_add : 0;
-  const bool la_sync = ranger && a.la_k > 0 && (t % a.la_k) == 0;   // Lookahead: slow += alpha (p - slow); p = slow
+  const OptScalars S = opt_scalars(a);
+  const bool la_sync = S.la_sync != 0;   // Lookahead: slow += alpha (p - slow); p = slow
   if (o.cnt) {
     load_own(a.p + e, o, p);
     if (a.do_adam) { load_own(a.m + e, o, m); load_own(a.v + e, o, v); }
@@ -228,50 +227,17 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
     gs *= coef;
   }
   if (o.cnt == 0) return;
-  if (ranger) {
-    // RAdam + Lookahead, the published torch_optimizer.Ranger algorithm (recnn/nn/algo.py:84-89 builds it; the package
-    // itself is absent and un-pinned: restated, see recnn_amd/optim.py):
-    //   v = b2 v + (1-b2) g^2;  m = b1 m + (1-b1) g;  N_sma = N_max - 2 t b2^t / (1 - b2^t)
-    //   p -= wd lr p;  N_sma > thr: p -= step lr m / (sqrt(v) + eps)  else  p -= step lr m
-    //   every k-th step: slow += alpha (p - slow); p = slow
-    const RadamScalars rs = radam_scalars(t, a.log_beta1, a.log_beta2, exp(a.log_beta2), (double)a.nsma_thr);
-    const float sl_lr = rs.step * a.lr;
+  if (a.do_adam) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gj = g[j] * gs;
-      v[j] = a.beta2 * v[j] + a.omb2 * gj * gj;
-      m[j] = a.beta1 * m[j] + a.omb1 * gj;
-      if (a.weight_decay != 0.f) p[j] += (-a.weight_decay * a.lr) * p[j];
-      if (rs.rect) p[j] += -sl_lr * (m[j] / (sqrtf(v[j]) + a.eps));
-      else p[j] += -sl_lr * m[j];
-      if (la_sync) { sl[j] += a.la_alpha * (p[j] - sl[j]); p[j] = sl[j]; }
-    }
+    for (int j = 0; j < 4; ++j) opt_elem(a, S, g[j], gs, p[j], m[j], v[j], sl[j]);
     store_own(a.m + e, o, m);
     store_own(a.v + e, o, v);
     store_own(a.p + e, o, p);
     if (la_sync) store_own(a.slow + e, o, sl);
-  } else if (a.do_adam) {
-    // bias corrections 1 - beta^t = -expm1(t ln beta) in double (torch computes them in Python floats)
-    const double bc1 = -expm1((double)t * a.log_beta1);
-    const double bc2 = -expm1((double)t * a.log_beta2);
-    const float step_size = (float)((double)a.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float gj = g[j] * gs;
-      if (a.weight_decay != 0.f) gj += a.weight_decay * p[j];
-      m[j] += a.omb1 * (gj - m[j]);
-      v[j] = a.beta2 * v[j] + a.omb2 * gj * gj;
-      const float denom = sqrtf(v[j]) / bc2_sqrt + a.eps;
-      p[j] -= step_size * (m[j] / denom);
-    }
-    store_own(a.m + e, o, m);
-    store_own(a.v + e, o, v);
-    store_own(a.p + e, o, p);
   }
   if (a.tgt_p) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tp[j] = tp[j] * (1.0f - a.tau) + p[j] * a.tau;  // utils/misc.py:3-5 operand order
+    for (int j = 0; j < 4; ++j) tp[j] = soft_elem(tp[j], p[j], a.tau);
     store_own(a.tgt_p + e, o, tp);
   }
   if (T.sh_off >= 0 && (a.shadow || (a.tgt_p && a.tgt_shadow))) {
@@ -331,12 +297,39 @@ __global__ __launch_bounds__(256) void apply_gather_kernel(const NetLayout L, co
   else apply_body(L, a, (int)blockIdx.x - n_gather, red, sp);
 }
 
+void apply_args_finish(ApplyArgs* a) {
+  a->log_beta1 = log(recnn_snap7(a->beta1));
+  a->log_beta2 = log(recnn_snap7(a->beta2));
+  a->omb1 = (float)(1.0 - recnn_snap7(a->beta1));
+  a->omb2 = (float)(1.0 - recnn_snap7(a->beta2));
+}
+
+// one thread per (step of the run, optimizer instance): 192 independent fp64 chains side by side instead of one per consumer
+__global__ __launch_bounds__(256) void opt_table_kernel(const OptTableArgs a) {
+  const int i = threadIdx.x;
+  if (i >= a.n_steps * 3) return;
+  const int step = i / 3, ni = i % 3;
+  if (ni >= a.n_nets) return;
+  const OptTableNet& n = a.net[ni];
+  const int t = *n.t_ptr + 1 + (int)n.t_add[step];
+  a.out[i] = opt_scalars_at(1, n.opt_kind, t, n.lr, n.log_beta1, n.log_beta2, n.nsma_thr, n.la_k);
+}
+
+int opt_table_launch(const OptTableArgs& a0, hipStream_t s) {
+  OptTableArgs a = a0;
+  RECNN_REQUIRE(a.out && a.n_steps >= 1 && a.n_steps <= OPT_TABLE_STEPS && a.n_nets >= 1 && a.n_nets <= 3, "opt_table: bad arguments");
+  for (int i = 0; i < a.n_nets; ++i) {
+    RECNN_REQUIRE(a.net[i].t_ptr, "opt_table: null step counter");
+    a.net[i].log_beta1 = log(recnn_snap7(a.net[i].beta1));
+    a.net[i].log_beta2 = log(recnn_snap7(a.net[i].beta2));
+  }
+  hipLaunchKernelGGL(opt_table_kernel, dim3(1), dim3(256), 0, s, a);
+  return recnn_check_hip(hipGetLastError(), "opt_table_kernel");
+}
+
 int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s, const GatherArgs* pregather) {
   ApplyArgs a = a0;
-  a.log_beta1 = log(recnn_snap7(a.beta1));
-  a.log_beta2 = log(recnn_snap7(a.beta2));
-  a.omb1 = (float)(1.0 - recnn_snap7(a.beta1));
-  a.omb2 = (float)(1.0 - recnn_snap7(a.beta2));
+  apply_args_finish(&a);
   if (pregather) {
     const GatherArgs& g = *pregather;
     const size_t lds = frame_gather_lds_bytes(g, 4);
