@@ -504,6 +504,9 @@ void recnn_tune_mlp_fault(int mode);
  * their epilogue (csrc/dwopt.hip: no gradient slabs, no separate Adam launch; 2 / 3 = the same with 8 / 4 waves per workgroup
  * instead of 16); 0 (default: faster at 2048 rows, see csrc/engine.hip) = split-batch slabs + reduce / Adam launches. */
 void recnn_tune_dw_fuse(int on);
+/* 1: split forward (csrc/l1gemm.hip + csrc/mlpt.hip: layer 1 as a tiled GEMM, the rest as a row-panel tail launch, frozen
+ * networks first); 0: the fused row-panel kernel (csrc/mlps.hip).  Same results bit for bit. */
+void recnn_tune_split_fwd(int on);
 /* timing experiments on csrc/dwopt.hip (results are garbage): 1 = no per-row scale, 2 = no LDS reads / MFMA, 4 = no DMA */
 void recnn_tune_dw_probe(int bits);
 void recnn_tune_dw_trace(void* device_u64_wg8);   /* shader-clock stamps of dw_opt_kernel, [workgroup][8] uint64, NULL = off */

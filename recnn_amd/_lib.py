@@ -104,6 +104,7 @@ SIGNATURES = {
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_dw_dma": (None, [_I]),
     "recnn_tune_dw_fuse": (None, [_I]),
+    "recnn_tune_split_fwd": (None, [_I]),
     "recnn_tune_dw_probe": (None, [_I]),
     "recnn_tune_dw_trace": (None, [_P]),
     "recnn_tune_chain_target_critic": (None, [_I]),

@@ -34,6 +34,7 @@
 #include "bwd.h"
 #include "optim.h"
 #include "dwopt.h"
+#include "split.h"
 
 constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
 
@@ -108,7 +109,21 @@ struct recnn_engine {
   int run_tick[3] = {1, 1, 1};             // increments applied by the finalize: steps, critic steps, actor steps
   char* gen_action;                        // tc [Bc, Ap] of the current batch buffer set
   char *gen_action0 = nullptr, *gen_action2 = nullptr;
-  struct PendingPc { bool on = false; int set = 0; int run_off = 0; int slot = 0; } pending_pc;  // deferred policy-loss forward
+  // deferred policy-loss forward of the previous step: that step's packed state rows and actor output, its run offset / slot
+  struct PendingPc { bool on = false; const char* xs = nullptr; const char* ga = nullptr; int run_off = 0; int slot = 0; } pending_pc;
+  // ---- cycle mode (round 3, bf16 sampler engines): the batches of up to MSET_MAX consecutive steps live side by side
+  // (batch j = rows j * rows .. of every array), gathered by ONE launch and pushed through the FROZEN networks (target actor,
+  // target critics, actor: they only change at a policy step) by one set of cycle-batched launches; the per-step launches
+  // then carry the learning critics only (capture_run)
+  static constexpr int MSET_MAX = 16;
+  char *m_xs = nullptr, *m_xn = nullptr;           // bf16 [MSET_MAX * Bc, ldx]
+  float *m_reward = nullptr, *m_done = nullptr;    // [MSET_MAX * Bc]
+  char* m_ga = nullptr;                            // actor outputs, bf16 [MSET_MAX * Bc, Ap]
+  float* m_tq[2] = {nullptr, nullptr};             // Q'(s', pi'(s')) per target critic, fp32 [MSET_MAX * Bc]
+  float* m_noise = nullptr;                        // TD3 target-action noise, fp32 [MSET_MAX * Bc, A]
+  char *m_tp_h1 = nullptr, *m_pa_h1 = nullptr, *m_pa_h2 = nullptr, *m_tq_h1[2] = {nullptr, nullptr};   // bf16 [MSET_MAX * Bc, Hp]
+  Acts pa0;                                        // the single-batch buffers the pointers below return to
+  float* tqv0[2] = {nullptr, nullptr};
   float* noise_buf;                        // fp32 [Bc, A]
   float *expected, *target_q, *q[2], *delta[2], *qpi;
   bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
@@ -274,6 +289,15 @@ int64_t carve(recnn_engine* e, char* base) {
     e->reward2 = (float*)c.take(Bc * 4);
     e->done2 = (float*)c.take(Bc * 4);
   }
+  if (e->bf16) {
+    const int64_t MB = (int64_t)recnn_engine::MSET_MAX * Bc;
+    e->m_xs = c.take(MB * e->ldx * 2); e->m_xn = c.take(MB * e->ldx * 2);
+    e->m_reward = (float*)c.take(MB * 4); e->m_done = (float*)c.take(MB * 4);
+    e->m_ga = c.take(MB * Ap * 2);
+    e->m_tp_h1 = c.take(MB * Hp * 2); e->m_pa_h1 = c.take(MB * Hp * 2); e->m_pa_h2 = c.take(MB * Hp * 2);
+    for (int i = 0; i < e->n_critic; ++i) { e->m_tq[i] = (float*)c.take(MB * 4); e->m_tq_h1[i] = c.take(MB * Hp * 2); }
+    if (e->td3) e->m_noise = (float*)c.take(MB * A * 4);
+  }
   e->noise_buf = (float*)c.take(Bc * A * 4);
   e->expected = (float*)c.take(Bc * 4);
   e->target_q = (float*)c.take(Bc * 4);
@@ -319,6 +343,8 @@ int64_t carve(recnn_engine* e, char* base) {
   e->counters = (int32_t*)c.take(64);
   e->l1_scratch = (float*)c.take(4096);
   e->opt_tab = (OptScalars*)c.take((int64_t)OPT_TABLE_STEPS * 3 * sizeof(OptScalars));
+  e->pa0 = e->pa;
+  for (int i = 0; i < 2; ++i) e->tqv0[i] = e->tqv[i];
   return ru(c.off, 256);
 }
 
@@ -372,6 +398,8 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = mlp_init())) { delete e; return rc; }
   if ((rc = bwd_init())) { delete e; return rc; }
   if ((rc = dwopt_init())) { delete e; return rc; }
+  if ((rc = l1gemm_init())) { delete e; return rc; }
+  if ((rc = mlpt_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
@@ -737,6 +765,11 @@ extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic =
 
 int g_policy_chain = 1;
 extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
+// 1: the bf16 forward runs SPLIT (split.h): layer 1 of every network as a full-machine tiled GEMM, the rest (layers 2 / 3,
+// TD head, the critics' layer-2 backward) as a lean row-panel tail launch, the frozen networks first so that the learning
+// critic's own workgroup knows the TD target; 0: the fused row-panel kernel (mlps.hip) with its in-launch hand-offs
+int g_split_fwd = 0;
+extern "C" void recnn_tune_split_fwd(int on) { g_split_fwd = on; }
 // 1: the critic's weight-gradient GEMMs contract the whole batch per tile and finish the optimizer step (single GPU) or the
 // flat gradient arena (phase API / data parallel) in their epilogue (dwopt.hip: no slabs, no Adam launch, results identical
 // to "arena + apply_kernel" bit for bit); 0 (default): split-batch slabs + grad_reduce / slab-summing Adam launches.
@@ -804,6 +837,151 @@ double fill_mlp(const recnn_engine* e, const MlpSpec& f, int rows, MlpProb* p) {
 }
 
 // ------------------------------------------------------------------------------------ phases
+// ---- split forward (split.h): problem builders
+void fill_l1(const recnn_engine* e, L1Prob* p, int ni, int rows, const void* A0, int64_t lda0, int K0, int col0, void* h1, int mask_idx,
+             int step_add) {
+  const Net& n = e->net[ni];
+  memset(p, 0, sizeof(*p));
+  p->A[0] = A0; p->lda[0] = lda0; p->K[0] = K0; p->w1_col[0] = col0; p->nseg = 1;
+  p->W1 = sh_ptr(e, ni, W1); p->ldw1 = n.ld_w1;
+  p->b1 = n.p + n.off[B1];
+  p->rows = rows; p->H = e->H;
+  p->mask_mode = RECNN_MASK_NONE;
+  if (mask_idx >= 0 && e->cfg.mask_mode != RECNN_MASK_NONE) {
+    p->mask_mode = e->cfg.mask_mode;
+    if (e->cfg.mask_mode == RECNN_MASK_EXTERNAL) {
+      p->mask = e->ext_masks + (int64_t)mask_idx * e->cfg.max_rows * e->H; p->ld_mask = e->H;
+    } else {
+      p->seed = e->cfg.seed; p->stream = (uint32_t)mask_idx; p->step_ptr = e->counters; p->step_add = step_add;
+    }
+  }
+  p->h1 = h1; p->ldh = e->Hp;
+}
+void l1_seg1(L1Prob* p, const void* A1, int64_t lda1, int K1, int col1) {
+  p->A[1] = A1; p->lda[1] = lda1; p->K[1] = K1; p->w1_col[1] = col1; p->nseg = 2;
+}
+void fill_tail(const recnn_engine* e, TailProb* p, int kind, int ni, int rows, const void* h1, int mask2_idx, int step_add) {
+  const Net& n = e->net[ni];
+  memset(p, 0, sizeof(*p));
+  p->kind = kind;
+  p->h1 = h1; p->ldh = e->Hp;
+  p->W2 = sh_ptr(e, ni, W2); p->ldw2 = n.ld_w2;
+  if (!n.critic) { p->W3 = sh_ptr(e, ni, W3); p->ldw3 = n.ld_w3; }
+  p->b2 = n.p + n.off[B2]; p->b3 = n.p + n.off[B3];
+  p->w3row = n.critic ? n.p + n.off[W3] : nullptr;
+  p->rows = rows; p->H = e->H; p->out_dim = n.out_dim;
+  p->mask_mode = RECNN_MASK_NONE;
+  if (mask2_idx >= 0 && e->cfg.mask_mode != RECNN_MASK_NONE) {
+    p->mask_mode = e->cfg.mask_mode;
+    if (e->cfg.mask_mode == RECNN_MASK_EXTERNAL) {
+      p->mask2 = e->ext_masks + (int64_t)mask2_idx * e->cfg.max_rows * e->H; p->ld_mask = e->H;
+    } else {
+      p->seed = e->cfg.seed; p->stream2 = (uint32_t)mask2_idx; p->step_ptr = e->counters; p->step_add = step_add;
+    }
+  }
+}
+
+// The forward of one step, split (g_split_fwd): frozen networks first (target actor -> target critics on its action; the
+// actor), then the learning critics with the TD head and their layer-2 backward in their own workgroups.  Six launches here;
+// inside run graphs the frozen half is hoisted out of the step and applied to a whole policy cycle at once (capture_run).
+int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s, bool frozen_done = false) {
+  const int A = e->A, nc = e->n_critic;
+  const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
+  const int actor_m1 = e->td3 ? 4 : 2;
+  const int64_t aoff = (int64_t)A * e->esz;
+  const double l1_fl_a = 2.0 * rows * (double)e->H * e->S, l1_fl_c = 2.0 * rows * (double)e->H * (e->S + A);
+  const double t_fl_a = 2.0 * rows * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * rows * ((double)e->H * e->H + e->H);
+  int rc = 0;
+  if (!frozen_done && value_side && e->td3 && !e->ext_noise) {
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
+  }
+  if (!frozen_done) {  // ---- frozen networks, layer 1: target actor on s', actor on s
+    L1Batch lb;
+    int np = 0;
+    double fl = 0;
+    if (value_side) { fill_l1(e, &lb.p[np++], TPOL, rows, e->xcn + aoff, e->ldx, e->K1a, 0, e->tp.h1, -1, e->run_off); fl += l1_fl_a; }
+    if (actor_side) { fill_l1(e, &lb.p[np++], POL, rows, e->xcs + aoff, e->ldx, e->K1a, 0, e->pa.h1, actor_m1, e->run_off); fl += l1_fl_a; }
+    if (np && (rc = slot(e, "l1_actors", fl, s, [&] { return l1gemm_launch(lb, np, 0, s); }))) return rc;
+    TailBatch tb;
+    np = 0; fl = 0;
+    if (value_side) {   // next_action into the action slot of the packed next rows (+ TD3's clipped noise, td3.py:74-78)
+      TailProb* p = &tb.p[np++];
+      fill_tail(e, p, TAIL_ACTOR, TPOL, rows, e->tp.h1, -1, e->run_off);
+      p->out = e->xcn; p->ldo = e->ldx;
+      if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->noise_buf; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
+      fl += t_fl_a;
+    }
+    if (actor_side) {
+      TailProb* p = &tb.p[np++];
+      fill_tail(e, p, TAIL_ACTOR, POL, rows, e->pa.h1, actor_m1 + 1, e->run_off);
+      p->h2 = e->pa.h2; p->out = e->gen_action; p->ldo = e->Ap;
+      fl += t_fl_a;
+    }
+    if (np && (rc = slot(e, "tail_actors", fl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
+  }
+  e->panel_bwd_done = false;
+  e->unit_bwd = false;
+  if (!value_side) return 0;
+  if (!frozen_done) {  // ---- target critics on [next_state | next_action]: state part first, then the action columns (mlps.hip's chained order)
+    L1Batch lb;
+    TailBatch tb;
+    double fl = 0, tfl = 0;
+    for (int c = 0; c < nc; ++c) {
+      fill_l1(e, &lb.p[c], TVAL[c], rows, e->xcn + aoff, e->ldx, e->K1a, A, e->tq[c].h1, -1, e->run_off);
+      l1_seg1(&lb.p[c], e->xcn, e->ldx, e->Ap, 0);
+      fill_tail(e, &tb.p[c], TAIL_CRITIC_Q, TVAL[c], rows, e->tq[c].h1, -1, e->run_off);
+      tb.p[c].q = e->tqv[c];
+      fl += l1_fl_c; tfl += t_fl_c;
+    }
+    if ((rc = slot(e, "l1_target_critic", fl, s, [&] { return l1gemm_launch(lb, nc, 0, s); }))) return rc;
+    if ((rc = slot(e, "tail_target_critic", tfl, s, [&] { return mlpt_launch(tb, nc, s); }))) return rc;
+  }
+  {  // ---- learning critics (+ the previous step's policy-loss forward riding along: same weights, the previous batch)
+    L1Batch lb;
+    TailBatch tb;
+    int np = 0;
+    double fl = 0, tfl = 0;
+    const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
+    for (int c = 0; c < nc; ++c) {
+      Net& v = e->net[VAL[c]];
+      fill_l1(e, &lb.p[np], VAL[c], rows, e->xcs, e->ldx, e->K1c, 0, e->cv[c].h1, 2 * c, e->run_off);
+      TailProb* p = &tb.p[np++];
+      fill_tail(e, p, TAIL_CRITIC_LEARN, VAL[c], rows, e->cv[c].h1, 2 * c + 1, e->run_off);
+      p->h2 = e->cv[c].h2; p->q = e->q[c];
+      p->n_target = nc;
+      for (int t = 0; t < nc; ++t) p->tq[t] = e->tqv[t];
+      p->reward = e->reward; p->done = e->done; p->gamma = e->hy.gamma;
+      p->lo = e->td3 ? -INFINITY : e->hy.min_value;
+      p->hi = e->td3 ? INFINITY : e->hy.max_value;
+      if (c == 0) { p->expected = e->expected; p->target_q = e->target_q; }
+      p->delta_out = e->delta[c]; p->loss_part = e->loss_part[c];
+      p->scale = train ? 2.0f : 1.0f;
+      p->dz2 = e->dzc2[c]; p->dz1 = e->dzc1[c];
+      if (value_bwd) {
+        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+        p->dw3_part = v.gp[W3]; p->db2_part = v.gp[B2]; p->db1_part = v.gp[B1]; p->db3_part = v.gp[B3];
+      }
+      fl += l1_fl_c; tfl += t_fl_c + 2.0 * rows * (double)e->H * e->H;
+    }
+    if (e->pending_pc.on && np < L1_MAX_GROUP) {
+      const auto& pp = e->pending_pc;
+      const int m0 = e->td3 ? 6 : 4;
+      fill_l1(e, &lb.p[np], RECNN_NET_VALUE1, rows, pp.ga, e->Ap, e->Ap, 0, e->pc.h1, m0, pp.run_off);
+      l1_seg1(&lb.p[np], pp.xs + aoff, e->ldx, e->K1a, A);
+      TailProb* p = &tb.p[np++];
+      fill_tail(e, p, TAIL_CRITIC_Q, RECNN_NET_VALUE1, rows, e->pc.h1, m0 + 1, pp.run_off);
+      p->q = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;   // that step's policy-loss slot: Q per row, b3 included
+      fl += l1_fl_c; tfl += t_fl_c;
+      e->pending_pc.on = false;
+    }
+    if ((rc = slot(e, "l1_critic", fl, s, [&] { return l1gemm_launch(lb, np, 0, s); }))) return rc;
+    if ((rc = slot(e, "tail_critic", tfl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
+  }
+  e->panel_bwd_done = true;     // dz2 / dz1 (already times the per-row loss seed) and the small tensors' panel sums exist
+  return 0;
+}
+
 // Forward of the value side (+ optionally the actor forward, which is independent of it).
 int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
   const int A = e->A, Hp = e->Hp, nc = e->n_critic;
@@ -811,6 +989,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
+  if (g_split_fwd && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
   bool chained = false;  // target critics computed inside the first fused launch
   bool fwd_did_bwd = false;  // ... and the critics' head + layer-2 backward too
   // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
@@ -904,9 +1083,8 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         // batch, weights as that step's optimizer left them = the current ones) rides here as one more problem: nothing
         // of this or later steps depends on it, and the launch has idle CUs once its short workgroups are done
         const auto& pp = e->pending_pc;
-        const char* xs_prev = pp.set ? e->xsh2 : e->xsh;
-        MlpSpec f{RECNN_NET_VALUE1, pp.set ? e->gen_action2 : e->gen_action0, e->Ap, e->Ap, 0};
-        f.A1 = xs_prev + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
+        MlpSpec f{RECNN_NET_VALUE1, pp.ga, e->Ap, e->Ap, 0};
+        f.A1 = pp.xs + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
         f.q = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;   // that step's policy-loss slot: Q per row, b3 included
         f.mask_idx = e->td3 ? 6 : 4;
         MlpProb* pd = &mb.p[np++];
@@ -1440,6 +1618,79 @@ int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
   return 0;
 }
 
+// ---- cycle mode: batch j of the cycle = rows j * rows .. (j + 1) * rows - 1 of the m_* arrays
+void use_mset(recnn_engine* e, int j, int rows) {
+  const int64_t r0 = (int64_t)j * rows;
+  e->xcs = e->m_xs + r0 * e->ldx * 2; e->xcn = e->m_xn + r0 * e->ldx * 2;
+  e->reward = e->m_reward + r0; e->done = e->m_done + r0;
+  e->gen_action = e->m_ga + r0 * e->Ap * 2;
+  e->pa.h1 = e->m_pa_h1 + r0 * e->Hp * 2; e->pa.h2 = e->m_pa_h2 + r0 * e->Hp * 2;
+  for (int c = 0; c < e->n_critic; ++c) e->tqv[c] = e->m_tq[c] + r0;
+}
+void leave_mset(recnn_engine* e) {
+  e->pa = e->pa0;
+  for (int c = 0; c < 2; ++c) e->tqv[c] = e->tqv0[c];
+  use_set(e, 0);
+}
+bool cycle_ok(const recnn_engine* e, int rows) {
+  return g_split_fwd && lookahead_ok(e) && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0 && rows % 32 == 0 && e->m_xs != nullptr &&
+         !e->ext_noise && e->cfg.mask_mode != RECNN_MASK_EXTERNAL;   // (external masks / noise describe ONE batch)
+}
+
+// The batches of run steps run_off0 .. run_off0 + n - 1 (one gather launch) and the FROZEN networks on all n * rows rows:
+// target actor -> next_action (+ TD3 noise) -> target critics -> Q', and the actor -> gen_action (+ its activations for the
+// policy step's backward).  recnn/nn/update/misc.py:28-31, td3.py:73-81 (target side), ddpg.py:66-69 / td3.py:104-110 (actor).
+int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_t s) {
+  const int A = e->A, nc = e->n_critic;
+  const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
+  const int TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
+  const int actor_m1 = e->td3 ? 4 : 2;
+  const int64_t aoff = (int64_t)A * 2;
+  const int M = n * rows;
+  int rc;
+  {
+    GatherArgs g = gather_args(e, rows, 0, run_off0);
+    g.state_h = (bf16_t*)e->m_xs + A; g.next_h = (bf16_t*)e->m_xn + A; g.action_h = (bf16_t*)e->m_xs;
+    g.reward = e->m_reward; g.done = e->m_done;
+    if ((rc = slot(e, "frame_gather_cycle", 0, s, [&] { return frame_gather_multi_launch(g, n, s); }))) return rc;
+  }
+  if (e->td3 && !e->ext_noise)
+    for (int j = 0; j < n; ++j)
+      if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->m_noise + (int64_t)j * rows * A, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, run_off0 + j, s); }))) return rc;
+  const double l1_fl_a = 2.0 * M * (double)e->H * e->S, l1_fl_c = 2.0 * M * (double)e->H * (e->S + A);
+  const double t_fl_a = 2.0 * M * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * M * ((double)e->H * e->H + e->H);
+  {
+    L1Batch lb;
+    fill_l1(e, &lb.p[0], TPOL, M, e->m_xn + aoff, e->ldx, e->K1a, 0, e->m_tp_h1, -1, run_off0);
+    fill_l1(e, &lb.p[1], POL, M, e->m_xs + aoff, e->ldx, e->K1a, 0, e->m_pa_h1, actor_m1, run_off0);
+    lb.p[1].rows_per_set = rows;
+    if ((rc = slot(e, "l1_frozen_actors", 2 * l1_fl_a, s, [&] { return l1gemm_launch(lb, 2, 1, s); }))) return rc;
+    TailBatch tb;
+    TailProb* p = &tb.p[0];
+    fill_tail(e, p, TAIL_ACTOR, TPOL, M, e->m_tp_h1, -1, run_off0);
+    p->out = e->m_xn; p->ldo = e->ldx;
+    if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->m_noise; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
+    p = &tb.p[1];
+    fill_tail(e, p, TAIL_ACTOR, POL, M, e->m_pa_h1, actor_m1 + 1, run_off0);
+    p->rows_per_set = rows;
+    p->h2 = e->m_pa_h2; p->out = e->m_ga; p->ldo = e->Ap;
+    if ((rc = slot(e, "tail_frozen_actors", 2 * t_fl_a, s, [&] { return mlpt_launch(tb, 2, s); }))) return rc;
+  }
+  {
+    L1Batch lb;
+    TailBatch tb;
+    for (int c = 0; c < nc; ++c) {
+      fill_l1(e, &lb.p[c], TVAL[c], M, e->m_xn + aoff, e->ldx, e->K1a, A, e->m_tq_h1[c], -1, run_off0);
+      l1_seg1(&lb.p[c], e->m_xn, e->ldx, e->Ap, 0);
+      fill_tail(e, &tb.p[c], TAIL_CRITIC_Q, TVAL[c], M, e->m_tq_h1[c], -1, run_off0);
+      tb.p[c].q = e->m_tq[c];
+    }
+    if ((rc = slot(e, "l1_frozen_target_critic", nc * l1_fl_c, s, [&] { return l1gemm_launch(lb, nc, 1, s); }))) return rc;
+    if ((rc = slot(e, "tail_frozen_target_critic", nc * t_fl_c, s, [&] { return mlpt_launch(tb, nc, s); }))) return rc;
+  }
+  return 0;
+}
+
 // Step scalars of every optimizer instance for the `len` steps about to be issued (step i of them is a policy step when
 // pol[i]): one small launch; afterwards fill_apply_args points every optimizer launch at its table entry.
 int opt_table(recnn_engine* e, int len, const bool* pol, hipStream_t s) {
@@ -1469,10 +1720,12 @@ int opt_table(recnn_engine* e, int len, const bool* pol, hipStream_t s) {
 // pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
 // optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered = false,
-              bool gather_next = false, bool defer_policy_fwd = false) {
+              bool gather_next = false, bool defer_policy_fwd = false, bool frozen_done = false) {
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
-  if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
+  if (frozen_done) {   // cycle mode: the batch is in place and the frozen networks have been applied to it (ph_frozen_batched)
+    if ((rc = ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
+  } else if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
     // next step, so on policy steps it is fused into the critic's optimizer pass (ddpg.py:95-97) -- which itself is the
@@ -1489,7 +1742,8 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   const bool pol = learn && policy_step;
   if (defer_policy_fwd && !pol && learn) {
     // run graphs: the next step's forward launch carries this step's policy-loss forward (see ph_forward)
-    e->pending_pc.on = true; e->pending_pc.set = e->cur_set; e->pending_pc.run_off = e->run_off; e->pending_pc.slot = e->run_off;
+    e->pending_pc.on = true; e->pending_pc.xs = e->xcs; e->pending_pc.ga = e->gen_action;
+    e->pending_pc.run_off = e->run_off; e->pending_pc.slot = e->run_off;
     e->hist_pol_count[e->run_off] = rows; e->hist_pol_add[e->run_off] = 0;
   } else if ((rc = ph_policy(e, rows, pol, true, s, !learn))) {
     return rc;
@@ -1686,7 +1940,34 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     rc = opt_table(e, len, polv, s);
     e->scal_on = rc == 0;
   }
-  for (int i = 0; i < len && !rc; ++i) {
+  const bool cyc = !rc && len > 1 && cycle_ok(e, rows);
+  auto is_pol = [&](int i) { return phase >= 0 && ((phase + i) % pe) == 0; };
+  for (int i0 = 0; cyc && i0 < len && !rc;) {
+    // segment = the steps up to and including the next policy step (the frozen networks change right after it)
+    int i1 = i0;
+    while (i1 + 1 < len && !is_pol(i1) && i1 - i0 + 1 < recnn_engine::MSET_MAX) ++i1;
+    const int n = i1 - i0 + 1;
+    e->run_off = i0;
+    rc = ph_frozen_batched(e, rows, n, i0, s);
+    for (int i = i0; i <= i1 && !rc; ++i) {
+      const bool pol = is_pol(i);
+      use_mset(e, i - i0, rows);
+      e->run_off = i;
+      use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
+      e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
+      for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
+      e->run_skip_finish = i + 1 < len;
+      if (pol) ++n_pol;
+      e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
+      // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
+      // then: not across a segment boundary, where the next cycle's gather refills the arrays)
+      const bool defer = g_defer_policy_fwd && i < i1;
+      rc = step_impl(e, rows, true, pol, s, true, false, defer, true);
+    }
+    i0 = i1 + 1;
+  }
+  if (cyc) leave_mset(e);
+  for (int i = 0; !cyc && i < len && !rc; ++i) {
     const bool pol = phase >= 0 && ((phase + i) % pe) == 0;
     use_set(e, look ? (i & 1) : 0);
     // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
@@ -1895,7 +2176,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       const bool defer = look && g_defer_policy_fwd && value_chain_ok(e);
       if (!r) {
         if (defer) {
-          e->pending_pc.on = true; e->pending_pc.set = set; e->pending_pc.run_off = 0; e->pending_pc.slot = set;
+          e->pending_pc.on = true; e->pending_pc.xs = e->xcs; e->pending_pc.ga = e->gen_action; e->pending_pc.run_off = 0; e->pending_pc.slot = set;
         } else if (!(r = ph_policy(e, rows, false, false, s, false))) {
           r = ph_finish(e, rows, true, false, s);
         }

@@ -32,4 +32,6 @@ struct GatherArgs {
 
 
 int frame_gather_launch(GatherArgs a, hipStream_t s);
+// batches cursor_add .. cursor_add + n_sets - 1 of the plan; batch j lands j * a.rows rows below the given outputs (bf16 rows only)
+int frame_gather_multi_launch(const GatherArgs& a, int n_sets, hipStream_t s);
 size_t frame_gather_lds_bytes(const GatherArgs& a, int rows_per_wg);

@@ -127,6 +127,29 @@ __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {
   frame_gather_body<R, W>(a, blockIdx.x, smem_raw);
 }
 
+// n consecutive batches of the epoch plan in ONE launch (blockIdx.y = batch j: cursor look-ahead + j, outputs j * rows rows
+// further down): the batches of a whole policy cycle for the cycle-batched frozen-network forwards (engine.hip).  bf16 rows only.
+__global__ __launch_bounds__(256) void frame_gather_multi_kernel(const GatherArgs a0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  GatherArgs a = a0;
+  const int j = blockIdx.y;
+  const int64_t r0 = (int64_t)j * a.rows;
+  a.cursor_add += j;
+  a.state_h += r0 * a.ld_h; a.next_h += r0 * a.ld_h; a.action_h += r0 * a.ld_h;
+  a.reward += r0; a.done += r0;
+  frame_gather_body<4, 4>(a, blockIdx.x, smem_raw);
+}
+
+int frame_gather_multi_launch(const GatherArgs& a, int n_sets, hipStream_t s) {
+  const size_t lds = frame_gather_lds_bytes(a, 4);
+  if (lds > 48 * 1024 || !a.state_h || a.state || (a.emb % 4) || a.rows <= 0 || n_sets <= 0 || n_sets > 65535) {
+    recnn_set_error("frame_gather_multi: needs the bf16-only gather with a tile that fits 48 KB of LDS");
+    return RECNN_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(frame_gather_multi_kernel, dim3((a.rows + 3) / 4, n_sets), dim3(256), lds, s, a);
+  return recnn_check_hip(hipGetLastError(), "frame_gather_multi");
+}
+
 size_t frame_gather_lds_bytes(const GatherArgs& a, int R) {
   const int F1 = a.frame + 1;
   (void)F1;

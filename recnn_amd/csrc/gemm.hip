@@ -529,9 +529,9 @@ __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
       const int m = min(m0 + r, V.rows - 1);
       const float d = m0 + r < V.rows ? V.delta[m] : 0.f;
       const int64_t off = (int64_t)m * V.ldh + k;
-      s3 += d * bf2f(((const bf16_t*)V.h2)[off]);
-      s2 += d * bf2f(((const bf16_t*)V.u2)[off]);
-      s1 += d * bf2f(((const bf16_t*)V.U)[off]);
+      s3 = fmaf(d, bf2f(((const bf16_t*)V.h2)[off]), s3);    // (explicit fma: the same chain as mlpt.hip's panel sums)
+      s2 = fmaf(d, bf2f(((const bf16_t*)V.u2)[off]), s2);
+      s1 = fmaf(d, bf2f(((const bf16_t*)V.U)[off]), s1);
     }
     V.dw3_part[(int64_t)panel * V.H + k] = s3;
     V.db2_part[(int64_t)panel * V.H + k] = s2;

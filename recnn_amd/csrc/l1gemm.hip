@@ -1,0 +1,193 @@
+// l1gemm.hip -- layer 1 of the Actor / Critic MLPs as a tiled bf16 MFMA GEMM over the whole machine (gfx950).
+//
+//   h1 = dropout(relu(cat(segments) W1^T + b1))        recnn/nn/models.py:66-69 (Actor), :207-211 (Critic: cat + linear1)
+//
+// Both operands are k-contiguous (batch rows / weight-shadow rows), so the tile is the plain LDS-DMA pipeline: a k stage is
+// 256 bytes (128 k) of every tile row of A and of W1, copied global -> LDS by `global_load_lds_dwordx4` into an NS-slot ring,
+// NS - 1 stages in flight ahead of the MFMAs, counted vmcnt waits, one raw s_barrier per stage.  The 16-byte chunk c of tile
+// row r sits at chunk position c ^ (r & 15) of its LDS row (XOR applied to the lane's SOURCE address): conflict-free
+// ds_read_b128 fragment reads.  MFMA operands are swapped (weights first) as in mlps.hip: a lane then owns four neighbouring
+// COLUMNS of one row, so the epilogue packs them into ONE 8-byte store and one dropout word serves the lane's 4 x 4 block.
+// Per output element the arithmetic is exactly mlps.hip's (k ascending in steps of 32, segment 0 before segment 1, fp32
+// accumulate, + bias, relu, x2 keep-mask, round to bf16): the two forwards are interchangeable bit for bit
+// (tests/test_gpu_split.py).
+//
+// Two tile shapes: 64 x 64 (8 waves as 2 x 4, 4-slot ring = 128 KB: per-step launches -- at 4096 rows x 256 columns that is
+// 256 workgroups of 393 KB each instead of 128 of 1.0 MB) and 128 x 128 (8 waves as 2 x 4, wave tile 64 x 32, 2-slot ring:
+// the cycle-batched launches of the frozen networks, M >= 16k rows).
+#include "split.h"
+
+namespace {
+
+__device__ __forceinline__ void l1_dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_const() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// TM x TN 16 x 16 MFMA tiles per wave, WM x WN waves per workgroup, NS ring slots
+template <int TM, int TN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch batch) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+  constexpr int KB = 128;                                  // k elements per stage (256-byte rows)
+  constexpr int D = NS - 1;                                // prefetch distance
+  constexpr int STAGE_BYTES = (BM + BN) * 256;
+  constexpr int NA = BM / (4 * NW), NB = BN / (4 * NW);    // DMA instructions per wave and stage (4 rows each)
+  static_assert(BM % (4 * NW) == 0 && BN % (4 * NW) == 0, "tile rows must split over the waves");
+  static_assert(D * (NA + NB) <= 60, "vmcnt is a 6-bit counter");
+  const L1Prob& P = batch.p[blockIdx.y];
+  const int nwg = P.tiles_m * P.tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);              // consecutive tiles of one row panel share an XCD's L2
+  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+  const unsigned lds0 = (unsigned)(size_t)dsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WN) * 16 * TM, wn0 = (wave % WN) * 16 * TN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt0 = P.K[0] / KB;
+  const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
+  const int q_row = lane >> 4, q_pos = lane & 15;          // within the 4 rows one wave instruction covers
+
+  auto issue = [&](int t, int stage) {
+    const int sidx = (t < nt0) ? 0 : 1;
+    const int k0 = (sidx == 0 ? t : t - nt0) * KB;
+    const unsigned sbase = lds0 + stage * STAGE_BYTES;
+    const char* Ab = (const char*)P.A[sidx] + (int64_t)k0 * 2;
+    const int64_t lda = P.lda[sidx];
+    const char* Wb = (const char*)P.W1 + ((int64_t)P.w1_col[sidx] + k0) * 2;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int row = (j * NW + wave) * 4 + q_row;
+      const int c = q_pos ^ (row & 15);
+      const int gr = min(m0 + row, P.rows - 1);
+      l1_dma16(Ab + (int64_t)gr * lda * 2 + c * 16, sbase + (j * NW + wave) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int row = (j * NW + wave) * 4 + q_row;
+      const int c = q_pos ^ (row & 15);
+      l1_dma16(Wb + (int64_t)(n0 + row) * P.ldw1 * 2 + c * 16, sbase + BM * 256 + (j * NW + wave) * 1024);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+    if (i < nt) issue(i, i);
+  // everything the epilogue reads from global memory is requested now, under the first stages' latency (a compiler-visible
+  // load inside the stream would drain the DMA queue with a vmcnt(0))
+  f32x4 bias[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 16 + fg * 4;
+    bias[tn] = (n + 3 < P.H) ? *(const f32x4*)(P.b1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int32_t step0 = (P.mask_mode == RECNN_MASK_HASH) ? (P.step_ptr ? *P.step_ptr : 0) + P.step_add : 0;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(bias[tn]));
+
+  for (int t = 0; t < nt; ++t) {
+    // stage t has landed once at most the loads of the (up to D - 1) younger stages are still outstanding
+    const int younger = min(D - 1, nt - 1 - t);
+    if (younger >= 2 && D >= 3) wait_vm_const<2 * (NA + NB)>();
+    else if (younger == 1 && D >= 2) wait_vm_const<NA + NB>();
+    else wait_vm_const<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's part of stage t is in LDS; every wave is done reading stage t - 1
+    if (t + D < nt) issue(t + D, (t + D) % NS);
+    const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
+    const unsigned char* sb = sa + BM * 256;
+#pragma unroll
+    for (int ks = 0; ks < KB / 32; ++ks) {
+      const int pos = ((ks * 4 + fg) ^ fr) * 16;
+      uint4 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pos);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pos);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]),
+                                                                acc[tm][tn], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[tm][tn][r] = C[row m0 + wm0 + 16 tm + fr][column n0 + wn0 + 16 tn + 4 fg + r]
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + fr;
+    int mrow = m;                    // row inside its batch / mask-key step of the batch
+    uint32_t key = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) {
+      int set = 0;
+      if (P.rows_per_set > 0) { set = m / P.rows_per_set; mrow = m - set * P.rows_per_set; }
+      key = mask_key(P.seed, step0 + set, P.stream);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + wn0 + tn * 16 + fg * 4;
+      uint32_t word = 0;
+      if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mrow >> 2), (uint32_t)(n >> 2));
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = fmaxf(acc[tm][tn][r] + bias[tn][r], 0.f);
+        if (P.mask_mode == RECNN_MASK_EXTERNAL) v[r] = (m < P.rows && n + r < P.H && P.mask[(int64_t)m * P.ld_mask + n + r]) ? v[r] * 2.f : 0.f;
+        else if (P.mask_mode == RECNN_MASK_HASH) v[r] = mask_keep(word, mrow & 3, r) ? v[r] * 2.f : 0.f;
+        if (n + r >= P.H) v[r] = 0.f;
+      }
+      if (m < P.rows) *(uint2*)((bf16_t*)P.h1 + (int64_t)m * P.ldh + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    }
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int NS> constexpr int lds_bytes() { return NS * (16 * TM * WM + 16 * TN * WN) * 256; }
+}  // namespace
+
+int l1gemm_init() {
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<2, 1, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               lds_bytes<2, 1, 2, 4, 4>()), "l1gemm attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<4, 2, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    lds_bytes<4, 2, 2, 4, 2>()), "l1gemm attr");
+  return rc;
+}
+
+int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s) {
+  RECNN_REQUIRE(nprob >= 1 && nprob <= L1_MAX_GROUP, "l1gemm: 1..%d problems per launch", L1_MAX_GROUP);
+  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  int maxwg = 0;
+  for (int i = 0; i < nprob; ++i) {
+    L1Prob& p = b.p[i];
+    RECNN_REQUIRE(p.rows > 0 && p.H > 0 && p.H <= 256 && (p.H & 3) == 0, "l1gemm: bad shape");
+    RECNN_REQUIRE(p.nseg >= 1 && p.nseg <= 2 && p.h1 && p.W1 && p.b1, "l1gemm: bad problem");
+    for (int g = 0; g < p.nseg; ++g)
+      RECNN_REQUIRE(p.K[g] > 0 && p.K[g] % 128 == 0 && p.lda[g] % 8 == 0 && (((uintptr_t)p.A[g]) & 15) == 0 && (p.w1_col[g] & 7) == 0,
+                    "l1gemm: segment %d must be 16-byte aligned with K a multiple of 128", g);
+    RECNN_REQUIRE(p.ldw1 % 8 == 0 && p.ldh % 4 == 0 && (((uintptr_t)p.W1 | (uintptr_t)p.h1) & 15) == 0, "l1gemm: bad pitches");
+    RECNN_REQUIRE(p.rows_per_set == 0 || p.rows_per_set % 16 == 0, "l1gemm: batches must be multiples of 16 rows");
+    p.tiles_m = (p.rows + BM - 1) / BM;
+    p.tiles_n = (256 + BN - 1) / BN;     // the weight shadows are zero-padded to 256 rows
+    const int nwg = p.tiles_m * p.tiles_n;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (big) hipLaunchKernelGGL((l1_gemm_kernel<4, 2, 2, 4, 2>), dim3(maxwg, nprob), dim3(512), (lds_bytes<4, 2, 2, 4, 2>()), s, b);
+  else hipLaunchKernelGGL((l1_gemm_kernel<2, 1, 2, 4, 4>), dim3(maxwg, nprob), dim3(512), (lds_bytes<2, 1, 2, 4, 4>()), s, b);
+  return recnn_check_hip(hipGetLastError(), "l1_gemm_kernel");
+}

@@ -1,0 +1,396 @@
+// mlpt.hip -- the "tail" of an Actor / Critic application on a 32-row panel: layers 2 and 3, the TD head and the learning
+// critic's layer-2 backward, starting from the layer-1 activations a tiled GEMM produced (l1gemm.hip).  bf16, gfx950.
+//
+//   Actor            h2 = drop(relu(h1 W2^T + b2));  out = h2 W3^T + b3 (+ clip(noise))          recnn/nn/models.py:70-73
+//   Critic (Q only)  h2 as above;  q = h2 . w3 + b3                                               recnn/nn/models.py:211-213
+//   Critic (learn)   ... plus  y = clamp(r + (1 - done) gamma min_t Q'_t),  d = 2 (q - y) / B,  sum (q - y)^2
+//                    (recnn/nn/update/misc.py:6-7,33-39, td3.py:83-93) and the backward of linear3 / linear2:
+//                    dz2 = d w3 s [h2 > 0],  dz1 = d ((u2 W2) s [h1 > 0]),  per-panel sums for dw3, db3, db2, db1
+//
+// Same panel layout and arithmetic as mlps.hip's phases after layer 1 (one 16-wave workgroup, 32 rows x 256 hidden columns,
+// activations in a swizzled LDS panel that is the next layer's A operand, weights streamed as 32 KB k-slabs) -- but a
+// workgroup here streams 128 KB (critic) or 192 KB (actor) instead of 1.0-1.2 MB, ALL of its weights are requested in the
+// first instructions (the ring holds four slabs: everything a critic needs), and because the frozen networks were applied
+// before (engine.hip: their Q' arrive as per-row scalars) the TD head needs no cross-workgroup hand-off: the critic's own
+// workgroup evaluates it, so the backward tensors leave already multiplied by the per-row loss seed -- the dW GEMM no longer
+// rescales its A operand in its k loop (that VALU work was 30 % of it, round-3 trace).
+// Rounding matches the path it replaces (unit tensor rounded to bf16, times d, rounded again), so the weight gradients of
+// W1 / W2 are bit-identical to mlps.hip + the scaling dW kernel (tests/test_gpu_split.py).
+#include <cstddef>
+#include "mlp_panel.h"
+#include "split.h"
+
+namespace {
+constexpr int NW = 16;
+constexpr int KB1 = 64;                       // k elements per slab row (128 bytes)
+constexpr int W_BYTES = HP * 128;             // 32 KB: one k-slab of a 256-row matrix
+constexpr int NST = 4;
+constexpr int PANEL_OFF = NST * W_BYTES;      // 128 KB
+constexpr int SCR_OFF = PANEL_OFF + 2 * PANEL_HALF;   // per-row scalars: q[32], d[32] (fp32)
+constexpr int LDS_TOTAL = SCR_OFF + 512;      // 144.5 KB
+constexpr int OW = 8;                         // waves of the actor's 128-column output layer
+constexpr int RW = BM / NW;                   // critic head rows per wave
+
+__device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "m0");
+}
+
+// acc += panel(k quarter q: columns 64 q .. 64 q + 63 of the 32 x 256 activation panel) * W(rows wrow0 + fr, 64 k)^T; operands
+// swapped as in mlps.hip: acc[tm][0][r] = C[row 16 tm + fr][column wrow0 + 4 fg + r]
+__device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, const unsigned char* sb, f32x4 (&acc)[2][1], int wrow0, int fr, int fg) {
+  const int sw = (fr >> 1) & 7;
+  const unsigned char* sa = panel + (q >> 1) * PANEL_HALF;
+#pragma unroll
+  for (int ks = 0; ks < KB1 / 32; ++ks) {
+    const int posa = ((((q & 1) * 8) + ks * 4 + fg) ^ fr) * 16;
+    const int posb = ((ks * 4 + fg) ^ sw) * 16;
+    uint4 a[2], b;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + posa);
+    b = *(const uint4*)(sb + (wrow0 + fr) * 128 + posb);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+      acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a[tm]), acc[tm][0], 0, 0, 0);
+  }
+}
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+// element (row, column n) of the panel image as float
+__device__ __forceinline__ float panel_at(const unsigned char* panel, int row, int n) {
+  const bf16_t v = *(const bf16_t*)(panel + (n >> 7) * PANEL_HALF + row * 256 + ((((n & 127) >> 3) ^ (row & 15)) << 4) + (n & 7) * 2);
+  return bf2f(v);
+}
+}  // namespace
+
+__global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch) {
+  const TailProb& P = batch.p[blockIdx.y];
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= P.rows) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool actor = P.kind == TAIL_ACTOR;
+  const bool learn = P.kind == TAIL_CRITIC_LEARN;
+  unsigned char* panel = lds + PANEL_OFF;
+  float* qs = (float*)(lds + SCR_OFF);          // Q of the panel's rows
+  float* ds = qs + BM;                          // loss seed d of the panel's rows
+
+  // ---- request EVERYTHING the workgroup will multiply, now: the h1 panel (one instruction per wave: 4 rows x 256 bytes of one
+  // k half; LDS position p of row r holds source chunk p ^ (r & 15)) and W2's four k-slabs (ring stages 0..3; rows l_row and
+  // l_row + 128 per lane, chunk c of row r at position c ^ ((r >> 1) & 7)); the actor's two W3 slabs follow into stages 0 / 1
+  // once W2's first two slabs have been multiplied
+  {
+    const int half = wave >> 3, r = (wave & 7) * 4 + (lane >> 4), pos = lane & 15;
+    const int gr = min(m0 + r, P.rows - 1);
+    const unsigned voff = (unsigned)((gr * (int)P.ldh + half * 128) * 2 + ((pos ^ (r & 15)) << 4));
+    dma_s(voff, P.h1, lds0 + PANEL_OFF + half * PANEL_HALF + (wave & 7) * 1024);
+  }
+  const int l_row = wave * 8 + (lane >> 3);
+  const int l_c = ((lane & 7) ^ ((l_row >> 1) & 7)) * 16;
+  const unsigned voff_sq = (unsigned)(l_row * (int)P.ldw2 * 2 + l_c);   // W2 / W3 share the pitch (mlpt_launch)
+  const unsigned wave_kb = wave * 1024;
+  auto issue_w2 = [&](int q) {
+    const char* b0 = (const char*)P.W2 + q * (2 * KB1);
+    const unsigned wb = lds0 + q * W_BYTES + wave_kb;
+    dma_s(voff_sq, b0, wb);
+    dma_s(voff_sq, b0 + 256 * P.ldw2, wb + NW * 1024);
+  };
+  auto issue_w3 = [&](int p) {     // k-slabs 2 p and 2 p + 1 of W3's 128 rows as image rows 0..127 / 128..255 of stage p
+    const char* b0 = (const char*)P.W3 + 2 * p * (2 * KB1);
+    const unsigned wb = lds0 + p * W_BYTES + wave_kb;
+    dma_s(voff_sq, b0, wb);
+    dma_s(voff_sq, b0 + 2 * KB1, wb + NW * 1024);
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w2(q);
+
+  // ---- then everything the epilogues and the head read from global memory (the compiler's vmcnt(0) for these loads also
+  // drains the DMAs above: they have to land anyway before anything can be multiplied)
+  const int n0 = wave * 16 + fg * 4;            // this lane's four hidden columns
+  f32x4 b2v[1];
+  b2v[0] = (n0 + 3 < P.H) ? *(const f32x4*)(P.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int no = (wave & (OW - 1)) * 16 + fg * 4;   // this lane's four output columns (actor, waves 0..7)
+  float v3[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    v3[r] = actor ? (no + r < P.out_dim ? P.b3[no + r] : 0.f) : ((lane * 4 + r < P.H) ? P.w3row[lane * 4 + r] : 0.f);
+  const float b3s = actor ? 0.f : P.b3[0];
+  uint32_t key2 = 0;
+  int mrow0 = m0;                               // first row of the panel inside its batch
+  if (P.mask_mode == RECNN_MASK_HASH) {
+    int set = 0;
+    if (P.rows_per_set > 0) { set = m0 / P.rows_per_set; mrow0 = m0 - set * P.rows_per_set; }
+    key2 = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add + set, P.stream2);
+  }
+  float h_rew = 0.f, h_done = 0.f, h_tq = 0.f;
+  if (learn && wave == 0) {
+    const int mc = min(m0 + (lane & 31), P.rows - 1);
+    h_rew = P.reward[mc];
+    h_done = P.done[mc];
+    h_tq = P.tq[0][mc];
+    if (P.n_target > 1) h_tq = fminf(h_tq, P.tq[1][mc]);
+  }
+  asm volatile("" : "+v"(b2v[0]), "+v"(h_rew), "+v"(h_done), "+v"(h_tq));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v3[r]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // the h1 panel and all four W2 slabs are in LDS for every wave
+
+  // relu/dropout gate of h1 for this lane's accumulator elements (bit tm * 4 + r): the backward's gate of U
+  uint32_t gate1 = 0;
+  if (learn) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int row = tm * 16 + fr;
+      const uint2 hv = *(const uint2*)(panel + (n0 >> 7) * PANEL_HALF + row * 256 + ((((n0 & 127) >> 3) ^ (row & 15)) << 4) + (n0 & 7) * 2);
+      if (hv.x & 0x7FFFu) gate1 |= 1u << (tm * 4 + 0);
+      if (hv.x & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 1);
+      if (hv.y & 0x7FFFu) gate1 |= 1u << (tm * 4 + 2);
+      if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
+    }
+  }
+
+  // ------------------------------------------------------------------ layer 2
+  f32x4 acc[2][1];
+  acc[0][0] = acc[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg);
+    if (actor && q < 2) {                       // W2's k-slab q is done with for every wave after this barrier: W3's slab q takes its stage
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_w3(q);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // everyone is done reading the h1 panel
+  // (hidden_epilogue hashes the dropout word from the row's index INSIDE its batch: m0 -> mrow0)
+  hidden_epilogue<1>(acc, b2v, P.H, P.rows - (m0 - mrow0), mrow0, wave, fr, fg, P.mask_mode,
+                     P.mask2 ? P.mask2 + (int64_t)(m0 - mrow0) * P.ld_mask : nullptr, P.ld_mask, key2, panel);
+
+  if (actor) {
+    // ---------------------------------------------------------------- layer 3 (actor): 32 x 128 outputs on waves 0..7
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // h2 panel complete, both W3 slabs landed
+    f32x4 o[2][1];
+    o[0][0] = o[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < OW) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        mma_panel(panel, 2 * p, lds + p * W_BYTES, o, wave * 16, fr, fg);
+        mma_panel(panel, 2 * p + 1, lds + p * W_BYTES, o, 128 + wave * 16, fr, fg);
+      }
+    }
+    if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
+    if (wave < OW) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int m = m0 + tm * 16 + fr;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ncol = no + r < P.out_dim;
+          v[r] = o[tm][0][r] + v3[r];
+          if (P.addend && ncol && m < P.rows) {
+            const float z = P.addend[(int64_t)m * P.ld_add + no + r];
+            v[r] += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+          }
+          if (!ncol) v[r] = 0.f;
+        }
+        uint2 packed = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if (no + 3 >= P.out_dim) {                             // (padded columns hold bf16 +0, not -0)
+          if (no + 0 >= P.out_dim) packed.x &= 0xFFFF0000u;
+          if (no + 1 >= P.out_dim) packed.x &= 0x0000FFFFu;
+          if (no + 2 >= P.out_dim) packed.y &= 0xFFFF0000u;
+          if (no + 3 >= P.out_dim) packed.y &= 0x0000FFFFu;
+        }
+        if (m < P.rows) {
+          if (no + 3 < P.out_dim) {
+            *(uint2*)((bf16_t*)P.out + (int64_t)m * P.ldo + no) = packed;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (no + r < P.out_dim) ((bf16_t*)P.out)[(int64_t)m * P.ldo + no + r] = (bf16_t)((r < 2 ? packed.x : packed.y) >> ((r & 1) * 16));
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ critic head: q[m] = h2[m, :] . w3 + b3
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // h2 panel complete
+  if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
+  for (int i = 0; i < RW; ++i) {
+    const int row = wave * RW + i;
+    const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
+    const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
+    const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float qv = s + b3s;
+      if (m0 + row < P.rows && P.q) P.q[m0 + row] = qv;
+      qs[row] = qv;
+    }
+  }
+  if (!learn) return;
+
+  // ------------------------------------------------------------------ TD target, TD error, loss (wave 0; lanes 0..31 = rows)
+  __syncthreads();                              // Q of all 32 rows is in LDS
+  if (wave == 0) {
+    const int r = lane & 31, m = m0 + r;
+    const bool valid = lane < 32 && m < P.rows;
+    float y = h_rew + (1.0f - h_done) * P.gamma * h_tq;
+    y = fminf(fmaxf(y, P.lo), P.hi);
+    if (valid) {
+      if (P.expected) P.expected[m] = y;
+      if (P.target_q) P.target_q[m] = h_tq;
+    }
+    const float e = valid ? qs[r] - y : 0.f;
+    const float d = e * (2.0f / (float)P.rows);
+    if (valid && P.delta_out) P.delta_out[m] = d;
+    if (lane < 32) ds[r] = d;
+    const float tot = wave_sum(e * e);
+    const float dsum = wave_sum(d);
+    if (lane == 0) {
+      if (P.loss_part) P.loss_part[blockIdx.x] = tot;
+      if (P.db3_part) P.db3_part[blockIdx.x] = dsum;
+    }
+  }
+  __syncthreads();                              // d of all 32 rows is in LDS; every wave is done reading h2 rows for its q dots
+
+  // ---- dw3 partial sums of this panel: sum_r d_r h2[r][k], thread = column k (h2 is still in the panel)
+  if (P.dw3_part && tid < P.H) {
+    float s3 = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < BM; ++r) s3 = fmaf(ds[r], panel_at(panel, r, tid), s3);
+    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = s3;
+  }
+  __syncthreads();
+
+  // ---- u2 = w3 * scale * [h2 > 0] in place in the panel (the A operand of the next product); dz2 = d * u2 to global
+  {
+    const int row = lane & 31, m = m0 + row;
+    const int n8 = (2 * wave + (lane >> 5)) * 8;
+    const int nb = min(n8, P.H - 8);
+    const float4 w3a = *(const float4*)(P.w3row + nb), w3b = *(const float4*)(P.w3row + nb + 4);
+    const float wsc = n8 < P.H ? P.scale : 0.f;
+    const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
+    unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16);
+    const uint4 raw = *(const uint4*)cell;
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float d = ds[row];
+    float uz[8], dz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
+      uz[j] = hv > 0.f ? w3s[j] : 0.f;
+    }
+    const uint4 packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
+    const uint32_t pu[4] = {packed.x, packed.y, packed.z, packed.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[j] = bf2f((bf16_t)((pu[j >> 1] >> ((j & 1) * 16)) & 0xFFFF)) * d;   // (the ROUNDED unit value times d)
+    *(uint4*)cell = packed;
+    if (m < P.rows)
+      *(uint4*)((bf16_t*)P.dz2 + (int64_t)m * P.ldh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // u2 panel complete
+
+  // ---- db2 partial sums: sum_r d_r u2[r][k]
+  if (P.db2_part && tid < P.H) {
+    float s2 = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < BM; ++r) s2 = fmaf(ds[r], panel_at(panel, r, tid), s2);
+    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = s2;
+  }
+
+  // ---- U = (u2 W2) * scale * gate(h1): W2's four k-slabs are still in stages 0..3: k-slab q holds in-columns 64 q .. 64 q + 63,
+  // rows = out index = the contraction index here, chunk c of row r at c ^ ((r >> 1) & 7); B fragments by transpose reads
+  f32x4 dacc[2];
+  dacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* wslab = lds + (wave >> 2) * W_BYTES;     // in-columns 16 wave .. 16 wave + 15
+    const int cpair = (wave & 3) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const unsigned char* sa = panel + (ks >> 2) * PANEL_HALF;
+      const int pos = ((((ks & 3) * 4) + fg) ^ fr) * 16;
+      uint4 a[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + pos);
+      v4s16 b[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int k = ks * 32 + fg * 8 + half * 4 + (fr >> 2);
+        b[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s16*)(wslab + k * 128 + (((cpair + ((fr & 3) >> 1)) ^ ((k >> 1) & 7)) * 16) + (fr & 1) * 8));
+      }
+      struct { v4s16 lo, hi; } bv = {b[0], b[1]};
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+        dacc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[tm]), dacc[tm], 0, 0, 0);
+    }
+  }
+  // (operands swapped: dacc[tm][r] = U[row 16 tm + fr][column 16 wave + 4 fg + r], the layout of gate1)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // every wave is done with the u2 panel (MFMA A operand, db2 sums): U takes its place
+  {
+    unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
+    const int c = (n0 & 127) >> 3;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int row = tm * 16 + fr, mm = m0 + row;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (((gate1 >> (tm * 4 + r)) & 1u) && n0 + r < P.H) ? dacc[tm][r] * P.scale : 0.f;
+      const uint32_t lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);          // unit U, rounded to bf16
+      *(uint2*)(col + row * 256 + ((c ^ fr) << 4)) = make_uint2(lo, hi);             // panel image (db1 sums)
+      const float d = ds[row];
+      const float z[4] = {bf2f((bf16_t)(lo & 0xFFFFu)) * d, bf2f((bf16_t)(lo >> 16)) * d, bf2f((bf16_t)(hi & 0xFFFFu)) * d, bf2f((bf16_t)(hi >> 16)) * d};
+      if (mm < P.rows) *(uint2*)((bf16_t*)P.dz1 + (int64_t)mm * P.ldh + n0) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
+    }
+  }
+  if (P.db1_part) {
+    __syncthreads();                            // U panel complete
+    if (tid < P.H) {
+      float s1 = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < BM; ++r) s1 = fmaf(ds[r], panel_at(panel, r, tid), s1);
+      P.db1_part[(int64_t)blockIdx.x * P.H + tid] = s1;
+    }
+  }
+}
+
+int mlpt_init() {
+  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlp_tail attr");
+}
+
+int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s) {
+  RECNN_REQUIRE(nprob >= 1 && nprob <= TAIL_MAX_GROUP, "mlp_tail: 1..%d problems per launch", TAIL_MAX_GROUP);
+  int rows = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const TailProb& p = b.p[i];
+    if (p.rows > rows) rows = p.rows;
+    RECNN_REQUIRE(p.rows > 0 && p.H >= 8 && p.H <= HP && (p.H & 7) == 0 && p.out_dim <= 128, "mlp_tail: hidden <= 256 (multiple of 8), out_dim <= 128");
+    RECNN_REQUIRE(p.h1 && p.W2 && p.b2 && p.b3 && p.ldh % 8 == 0 && p.ldw2 % 8 == 0 && (((uintptr_t)p.h1 | (uintptr_t)p.W2) & 15) == 0, "mlp_tail: bad operands");
+    RECNN_REQUIRE(p.rows_per_set == 0 || p.rows_per_set % BM == 0, "mlp_tail: batches must be multiples of %d rows", BM);
+    if (p.kind == TAIL_ACTOR) {
+      RECNN_REQUIRE(p.W3 && p.out && p.ldw3 == p.ldw2 && (((uintptr_t)p.W3) & 15) == 0, "mlp_tail: actor needs W3 (same pitch as W2) and an output");
+    } else {
+      RECNN_REQUIRE(p.w3row && (((uintptr_t)p.w3row) & 15) == 0, "mlp_tail: critic needs its last layer's row");
+      if (p.kind == TAIL_CRITIC_LEARN)
+        RECNN_REQUIRE(p.n_target >= 1 && p.n_target <= 2 && p.tq[0] && (p.n_target < 2 || p.tq[1]) && p.reward && p.done && p.dz2 && p.dz1,
+                      "mlp_tail: the learning critic needs Q', reward, done and its backward buffers");
+    }
+  }
+  hipLaunchKernelGGL(mlp_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b);
+  return recnn_check_hip(hipGetLastError(), "mlp_tail_kernel");
+}

@@ -22,9 +22,10 @@ def cuda():
     import torch
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no GPU is visible")
-    if os.environ.get("RECNN_LD_PAD"):          # run the GPU suite on a different leading-dimension padding (tuning knob)
-        from recnn_amd import _lib as L
-        L.load().recnn_tune_ld_pad(int(os.environ["RECNN_LD_PAD"]))
+    # run the GPU suite under other schedules / tile shapes (tuning knobs never change results): every RECNN_* knob that is
+    # set in the environment (recnn_amd/_tune.py), e.g. RECNN_SPLIT_FWD=0 python -m pytest tests -m gpu
+    from recnn_amd._tune import apply_env_knobs
+    apply_env_knobs()
     return torch.device("cuda")
 
 

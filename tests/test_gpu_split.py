@@ -1,0 +1,65 @@
+"""The split forward (csrc/l1gemm.hip + csrc/mlpt.hip, round 3) against the fused row-panel kernel (csrc/mlps.hip).
+
+Both compute recnn/nn/models.py:66-73 / :207-213 (the three Linear + relu + dropout layers), recnn/nn/update/misc.py:6-7,33-39
+(TD target, MSE) and the backward of the critic's last two layers with the same per-element arithmetic: k ascending in
+MFMA steps of 32, [state | action] contracted state-first for the target critics, unit backward tensors rounded to bf16 and
+THEN multiplied by the per-row loss seed -- so every buffer of a step, the gradients and the parameters after several
+steps (policy steps included) must agree BIT FOR BIT.  What differs is where the work runs (tiled layer-1 GEMMs over the
+whole machine, 128-192 KB tails, frozen networks first so that no workgroup waits for another).
+"""
+import pytest
+import torch
+
+from tests.test_gpu_engine import _engine, _init_nets, _rand_batch
+
+pytestmark = pytest.mark.gpu
+S, A, H = 1290, 128, 256
+BUFS = ("next_action", "gen_action", "expected", "target_q", "q1", "delta1", "critic1_h1", "critic1_h2", "actor_h1", "actor_h2")
+
+
+def _run(algo, B, split, mask_mode, steps, L, learn_last=True):
+    td3 = algo == "td3"
+    actor, critics = _init_nets(8, S, A, H, 2 if td3 else 1)
+    batch = _rand_batch(B, S, A, torch.Generator().manual_seed(31))
+    L.load().recnn_tune_split_fwd(split)
+    eng = _engine(algo, S, A, H, B, "bf16", mask_mode=mask_mode, seed=17)
+    nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
+    if td3:
+        nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
+    for ni, p in nets:
+        eng.load_params(ni, p)
+    eng.set_hyper(policy_opt=dict(lr=1e-3, weight_decay=1e-2), value_opt=dict(lr=1e-3, weight_decay=1e-2), policy_every=2)
+    eng.set_counters()
+    eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+    out = []
+    for t in range(steps):
+        eng.step(B, True, t)
+        torch.cuda.synchronize()
+        rec = dict(loss=eng.losses(), bufs={n: eng.buffer(n, B).clone() for n in BUFS},
+                   g={ni: eng.grads[ni].clone() for ni in eng.value_nets()},
+                   p={ni: eng.params[ni].clone() for ni, _ in nets})
+        if td3:
+            rec["bufs"]["q2"] = eng.buffer("q2", B).clone()
+        out.append(rec)
+    eng.step(B, False, steps)                 # a learn=False evaluation as well
+    out.append(dict(loss=eng.losses(), bufs={n: eng.buffer(n, B).clone() for n in ("expected", "q1", "gen_action")}, g={}, p={}))
+    return out
+
+
+@pytest.mark.parametrize("algo,B,mask_mode", [("ddpg", 2048, "hash"), ("ddpg", 333, "hash"), ("td3", 1024, "hash"), ("ddpg", 77, "none"),
+                                              ("ddpg", 4100, "hash")])
+def test_split_forward_equals_fused_row_panel_forward(cuda, algo, B, mask_mode):
+    from recnn_amd import _lib as L
+    try:
+        ref = _run(algo, B, 0, mask_mode, 3, L)
+        new = _run(algo, B, 1, mask_mode, 3, L)
+    finally:
+        L.load().recnn_tune_split_fwd(0)
+    for t, (a, b) in enumerate(zip(ref, new)):
+        for n in a["bufs"]:
+            assert torch.equal(a["bufs"][n], b["bufs"][n]), (t, n, (a["bufs"][n] - b["bufs"][n]).abs().max().item())
+        assert a["loss"] == b["loss"], (t, a["loss"], b["loss"])
+        for ni in a["g"]:
+            assert torch.equal(a["g"][ni], b["g"][ni]), (t, "grad", ni, (a["g"][ni] - b["g"][ni]).abs().max().item())
+        for ni in a["p"]:
+            assert torch.equal(a["p"][ni], b["p"][ni]), (t, "param", ni, (a["p"][ni] - b["p"][ni]).abs().max().item())
