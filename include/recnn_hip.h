@@ -507,6 +507,10 @@ void recnn_tune_dw_fuse(int on);
 /* 1: split forward (csrc/l1gemm.hip + csrc/mlpt.hip: layer 1 as a tiled GEMM, the rest as a row-panel tail launch, frozen
  * networks first); 0: the fused row-panel kernel (csrc/mlps.hip).  Same results bit for bit. */
 void recnn_tune_split_fwd(int on);
+void recnn_tune_frozen_gemm(int on);   /* cycle mode: layers 2 / 3 of the frozen networks as tiled GEMMs (1, default) or row-panel tails (0) */
+void recnn_tune_l1_big(int shape);   /* tile of the cycle-batched layer-1 GEMMs: 1 = 128 x 128 (default), 2 = 128 x 64 */
+void recnn_tune_tail_trace(void* device_u64_wg16);   /* shader-clock stamps of mlp_tail_kernel / l1_gemm_kernel, [workgroup][16] uint64 */
+void recnn_tune_l1_trace(void* device_u64_wg16);
 /* timing experiments on csrc/dwopt.hip (results are garbage): 1 = no per-row scale, 2 = no LDS reads / MFMA, 4 = no DMA */
 void recnn_tune_dw_probe(int bits);
 void recnn_tune_dw_trace(void* device_u64_wg8);   /* shader-clock stamps of dw_opt_kernel, [workgroup][8] uint64, NULL = off */

@@ -121,7 +121,7 @@ struct recnn_engine {
   char* m_ga = nullptr;                            // actor outputs, bf16 [MSET_MAX * Bc, Ap]
   float* m_tq[2] = {nullptr, nullptr};             // Q'(s', pi'(s')) per target critic, fp32 [MSET_MAX * Bc]
   float* m_noise = nullptr;                        // TD3 target-action noise, fp32 [MSET_MAX * Bc, A]
-  char *m_tp_h1 = nullptr, *m_pa_h1 = nullptr, *m_pa_h2 = nullptr, *m_tq_h1[2] = {nullptr, nullptr};   // bf16 [MSET_MAX * Bc, Hp]
+  char *m_tp_h1 = nullptr, *m_tp_h2 = nullptr, *m_pa_h1 = nullptr, *m_pa_h2 = nullptr, *m_tq_h1[2] = {nullptr, nullptr};   // bf16 [MSET_MAX * Bc, Hp]
   Acts pa0;                                        // the single-batch buffers the pointers below return to
   float* tqv0[2] = {nullptr, nullptr};
   float* noise_buf;                        // fp32 [Bc, A]
@@ -294,7 +294,7 @@ int64_t carve(recnn_engine* e, char* base) {
     e->m_xs = c.take(MB * e->ldx * 2); e->m_xn = c.take(MB * e->ldx * 2);
     e->m_reward = (float*)c.take(MB * 4); e->m_done = (float*)c.take(MB * 4);
     e->m_ga = c.take(MB * Ap * 2);
-    e->m_tp_h1 = c.take(MB * Hp * 2); e->m_pa_h1 = c.take(MB * Hp * 2); e->m_pa_h2 = c.take(MB * Hp * 2);
+    e->m_tp_h1 = c.take(MB * Hp * 2); e->m_tp_h2 = c.take(MB * Hp * 2); e->m_pa_h1 = c.take(MB * Hp * 2); e->m_pa_h2 = c.take(MB * Hp * 2);
     for (int i = 0; i < e->n_critic; ++i) { e->m_tq[i] = (float*)c.take(MB * 4); e->m_tq_h1[i] = c.take(MB * Hp * 2); }
     if (e->td3) e->m_noise = (float*)c.take(MB * A * 4);
   }
@@ -770,6 +770,10 @@ extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
 // critic's own workgroup knows the TD target; 0: the fused row-panel kernel (mlps.hip) with its in-launch hand-offs
 int g_split_fwd = 0;
 extern "C" void recnn_tune_split_fwd(int on) { g_split_fwd = on; }
+// 1 (default): in cycle mode the frozen networks' layers 2 / 3 run as cycle-wide tiled GEMMs (+ a row-dot launch for the target
+// critics' heads); 0: as row-panel tail launches
+int g_frozen_gemm = 1;
+extern "C" void recnn_tune_frozen_gemm(int on) { g_frozen_gemm = on; }
 // 1: the critic's weight-gradient GEMMs contract the whole batch per tile and finish the optimizer step (single GPU) or the
 // flat gradient arena (phase API / data parallel) in their epilogue (dwopt.hip: no slabs, no Adam launch, results identical
 // to "arena + apply_kernel" bit for bit); 0 (default): split-batch slabs + grad_reduce / slab-summing Adam launches.
@@ -1665,28 +1669,69 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
     fill_l1(e, &lb.p[1], POL, M, e->m_xs + aoff, e->ldx, e->K1a, 0, e->m_pa_h1, actor_m1, run_off0);
     lb.p[1].rows_per_set = rows;
     if ((rc = slot(e, "l1_frozen_actors", 2 * l1_fl_a, s, [&] { return l1gemm_launch(lb, 2, 1, s); }))) return rc;
-    TailBatch tb;
-    TailProb* p = &tb.p[0];
-    fill_tail(e, p, TAIL_ACTOR, TPOL, M, e->m_tp_h1, -1, run_off0);
-    p->out = e->m_xn; p->ldo = e->ldx;
-    if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->m_noise; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
-    p = &tb.p[1];
-    fill_tail(e, p, TAIL_ACTOR, POL, M, e->m_pa_h1, actor_m1 + 1, run_off0);
-    p->rows_per_set = rows;
-    p->h2 = e->m_pa_h2; p->out = e->m_ga; p->ldo = e->Ap;
-    if ((rc = slot(e, "tail_frozen_actors", 2 * t_fl_a, s, [&] { return mlpt_launch(tb, 2, s); }))) return rc;
+    if (g_frozen_gemm) {
+      // layers 2 and 3 of both actors as cycle-wide GEMMs through the same tiled kernel (K = 256): per output element the
+      // arithmetic of the row-panel tail kernel (k ascending in steps of 32 from a zero accumulator, + bias, relu, dropout /
+      // + clipped noise, round to bf16), without 1280 workgroups each starting a 192 KB weight stream for 32 rows
+      const Net& tn = e->net[TPOL];
+      const Net& pn = e->net[POL];
+      L1Batch l2;
+      fill_l1(e, &l2.p[0], TPOL, M, e->m_tp_h1, e->Hp, e->Hp, 0, e->m_tp_h2, -1, run_off0);
+      l2.p[0].W1 = sh_ptr(e, TPOL, W2); l2.p[0].ldw1 = tn.ld_w2; l2.p[0].b1 = tn.p + tn.off[B2];
+      fill_l1(e, &l2.p[1], POL, M, e->m_pa_h1, e->Hp, e->Hp, 0, e->m_pa_h2, actor_m1 + 1, run_off0);
+      l2.p[1].W1 = sh_ptr(e, POL, W2); l2.p[1].ldw1 = pn.ld_w2; l2.p[1].b1 = pn.p + pn.off[B2];
+      l2.p[1].rows_per_set = rows;
+      if ((rc = slot(e, "l2_frozen_actors", 4.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, 2, 1, s); }))) return rc;
+      L1Batch l3;
+      fill_l1(e, &l3.p[0], TPOL, M, e->m_tp_h2, e->Hp, e->Hp, 0, e->m_xn, -1, run_off0);
+      l3.p[0].W1 = sh_ptr(e, TPOL, W3); l3.p[0].ldw1 = tn.ld_w3; l3.p[0].b1 = tn.p + tn.off[B3];
+      l3.p[0].H = A; l3.p[0].w_rows = e->Ap; l3.p[0].no_relu = 1; l3.p[0].ldh = e->ldx;
+      if (e->td3) { l3.p[0].addend = e->ext_noise ? e->ext_noise : e->m_noise; l3.p[0].ld_add = A; l3.p[0].add_clip = e->hy.noise_clip; }
+      fill_l1(e, &l3.p[1], POL, M, e->m_pa_h2, e->Hp, e->Hp, 0, e->m_ga, -1, run_off0);
+      l3.p[1].W1 = sh_ptr(e, POL, W3); l3.p[1].ldw1 = pn.ld_w3; l3.p[1].b1 = pn.p + pn.off[B3];
+      l3.p[1].H = A; l3.p[1].w_rows = e->Ap; l3.p[1].no_relu = 1; l3.p[1].ldh = e->Ap;
+      if ((rc = slot(e, "l3_frozen_actors", 4.0 * M * (double)A * e->H, s, [&] { return l1gemm_launch(l3, 2, 1, s); }))) return rc;
+    } else {
+      TailBatch tb;
+      TailProb* p = &tb.p[0];
+      fill_tail(e, p, TAIL_ACTOR, TPOL, M, e->m_tp_h1, -1, run_off0);
+      p->out = e->m_xn; p->ldo = e->ldx;
+      if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->m_noise; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
+      p = &tb.p[1];
+      fill_tail(e, p, TAIL_ACTOR, POL, M, e->m_pa_h1, actor_m1 + 1, run_off0);
+      p->rows_per_set = rows;
+      p->h2 = e->m_pa_h2; p->out = e->m_ga; p->ldo = e->Ap;
+      if ((rc = slot(e, "tail_frozen_actors", 2 * t_fl_a, s, [&] { return mlpt_launch(tb, 2, s); }))) return rc;
+    }
   }
   {
     L1Batch lb;
-    TailBatch tb;
     for (int c = 0; c < nc; ++c) {
       fill_l1(e, &lb.p[c], TVAL[c], M, e->m_xn + aoff, e->ldx, e->K1a, A, e->m_tq_h1[c], -1, run_off0);
       l1_seg1(&lb.p[c], e->m_xn, e->ldx, e->Ap, 0);
-      fill_tail(e, &tb.p[c], TAIL_CRITIC_Q, TVAL[c], M, e->m_tq_h1[c], -1, run_off0);
-      tb.p[c].q = e->m_tq[c];
     }
     if ((rc = slot(e, "l1_frozen_target_critic", nc * l1_fl_c, s, [&] { return l1gemm_launch(lb, nc, 1, s); }))) return rc;
-    if ((rc = slot(e, "tail_frozen_target_critic", nc * t_fl_c, s, [&] { return mlpt_launch(tb, nc, s); }))) return rc;
+    if (g_frozen_gemm) {
+      L1Batch l2;
+      for (int c = 0; c < nc; ++c) {
+        const Net& t = e->net[TVAL[c]];
+        fill_l1(e, &l2.p[c], TVAL[c], M, e->m_tq_h1[c], e->Hp, e->Hp, 0, c == 0 ? e->m_tp_h2 : e->m_tp_h1, -1, run_off0);   // (the target actor's panels are done with)
+        l2.p[c].W1 = sh_ptr(e, TVAL[c], W2); l2.p[c].ldw1 = t.ld_w2; l2.p[c].b1 = t.p + t.off[B2];
+      }
+      if ((rc = slot(e, "l2_frozen_target_critic", nc * 2.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, nc, 1, s); }))) return rc;
+      for (int c = 0; c < nc; ++c) {
+        const Net& t = e->net[TVAL[c]];
+        const void* h2 = c == 0 ? e->m_tp_h2 : e->m_tp_h1;
+        if ((rc = slot(e, "q_frozen_target_critic", 2.0 * M * e->H, s, [&] { return qdot_launch(h2, e->Hp, t.p + t.off[W3], t.p + t.off[B3], e->H, M, e->m_tq[c], s); }))) return rc;
+      }
+    } else {
+      TailBatch tb;
+      for (int c = 0; c < nc; ++c) {
+        fill_tail(e, &tb.p[c], TAIL_CRITIC_Q, TVAL[c], M, e->m_tq_h1[c], -1, run_off0);
+        tb.p[c].q = e->m_tq[c];
+      }
+      if ((rc = slot(e, "tail_frozen_target_critic", nc * t_fl_c, s, [&] { return mlpt_launch(tb, nc, s); }))) return rc;
+    }
   }
   return 0;
 }
@@ -1880,7 +1925,7 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
     e->prof_on = true;
     e->prof_n = 0;
     e->use_sampler = e->has_sampler;
-    {   // as the run graphs do: the step scalars of the optimizers come from the table launch
+    if (g_dw_fuse) {   // as the run graphs do: the step scalars of the optimizers come from the table launch
       const bool pol1[1] = {policy_steps != 0};
       rc = opt_table(e, 1, pol1, s);
       e->scal_on = rc == 0;
@@ -1934,7 +1979,10 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   e->use_sampler = e->has_sampler;
   int n_pol = 0;
-  if (len <= OPT_TABLE_STEPS) {   // the optimizers' step scalars for the whole run: one small launch at the head of the graph
+  // the optimizers' step scalars for the whole run: one small launch at the head of the graph.  Only when the optimizer runs in
+  // the dW epilogue (dwopt.hip, where ONE thread per workgroup would otherwise sit on a 6 us fp64 chain): apply_kernel's
+  // threads all evaluate them side by side under their loads' latency -- measured no gain from the table there
+  if (g_dw_fuse && len <= OPT_TABLE_STEPS) {
     bool polv[OPT_TABLE_STEPS];
     for (int i = 0; i < len; ++i) polv[i] = phase >= 0 && ((phase + i) % pe) == 0;
     rc = opt_table(e, len, polv, s);

@@ -523,16 +523,25 @@ __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
   const int m0 = panel * 32;
   if (m0 >= V.rows) return;
   for (int k = threadIdx.x; k < V.H; k += 256) {
-    float s3 = 0.f, s2 = 0.f, s1 = 0.f;
-#pragma unroll 8   // 24 loads in flight; more would raise the kernel's VGPR count and cost the GEMM tiles occupancy
-    for (int r = 0; r < 32; ++r) {
-      const int m = min(m0 + r, V.rows - 1);
-      const float d = m0 + r < V.rows ? V.delta[m] : 0.f;
-      const int64_t off = (int64_t)m * V.ldh + k;
-      s3 = fmaf(d, bf2f(((const bf16_t*)V.h2)[off]), s3);    // (explicit fma: the same chain as mlpt.hip's panel sums)
-      s2 = fmaf(d, bf2f(((const bf16_t*)V.u2)[off]), s2);
-      s1 = fmaf(d, bf2f(((const bf16_t*)V.U)[off]), s1);
+    // four row chunks of 8, each an fma chain upwards, combined (c0 + c1) + (c2 + c3): the order of mlpt.hip's panel sums
+    // (the chunk loop is NOT unrolled: 24 loads in flight; more would raise the kernel's VGPR count and cost the GEMM tiles
+    // their occupancy -- 96 in flight made the whole dW launch 18 us instead of 10)
+    float c3[4], c2[4], c1[4];
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      float s3 = 0.f, s2 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int r = c * 8; r < c * 8 + 8; ++r) {
+        const int m = min(m0 + r, V.rows - 1);
+        const float d = m0 + r < V.rows ? V.delta[m] : 0.f;
+        const int64_t off = (int64_t)m * V.ldh + k;
+        s3 = fmaf(d, bf2f(((const bf16_t*)V.h2)[off]), s3);
+        s2 = fmaf(d, bf2f(((const bf16_t*)V.u2)[off]), s2);
+        s1 = fmaf(d, bf2f(((const bf16_t*)V.U)[off]), s1);
+      }
+      c3[c] = s3; c2[c] = s2; c1[c] = s1;
     }
+    const float s3 = (c3[0] + c3[1]) + (c3[2] + c3[3]), s2 = (c2[0] + c2[1]) + (c2[2] + c2[3]), s1 = (c1[0] + c1[1]) + (c1[2] + c1[3]);
     V.dw3_part[(int64_t)panel * V.H + k] = s3;
     V.db2_part[(int64_t)panel * V.H + k] = s2;
     V.colsum[(int64_t)panel * V.H + k] = s1;

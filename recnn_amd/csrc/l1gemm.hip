@@ -12,28 +12,40 @@
 // accumulate, + bias, relu, x2 keep-mask, round to bf16): the two forwards are interchangeable bit for bit
 // (tests/test_gpu_split.py).
 //
-// Two tile shapes: 64 x 64 (8 waves as 2 x 4, 4-slot ring = 128 KB: per-step launches -- at 4096 rows x 256 columns that is
-// 256 workgroups of 393 KB each instead of 128 of 1.0 MB) and 128 x 128 (8 waves as 2 x 4, wave tile 64 x 32, 2-slot ring:
-// the cycle-batched launches of the frozen networks, M >= 16k rows).
+// Tile shapes (16 waves as 4 x 4 each): 64 x 64 (4-slot ring = 128 KB: per-step launches -- at 4096 rows x 256 columns that
+// is 256 workgroups of 393 KB each instead of 128 of 1.0 MB) and 128 x 128 / 128 x 64 (2- / 3-slot rings: the cycle-batched
+// launches of the frozen networks, M >= 16k rows).
 #include "split.h"
 
 namespace {
 
-__device__ __forceinline__ void l1_dma16(const void* gsrc, unsigned lds_dst_uniform) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst_uniform)
-      : "memory");
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (uniform base + per-lane 32-bit byte offset) to LDS at lds_dst + 16 lane.
+// M0 is written directly (the kernel has no other M0 consumer); no "memory" clobber: the ordering points are the waits and
+// barriers of the consumer.  (mlps.hip's lean issue: the saddr form keeps a stage's address arithmetic to scalar adds.)
+__device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "m0");
 }
 
 template <int N> __device__ __forceinline__ void wait_vm_const() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // TM x TN 16 x 16 MFMA tiles per wave, WM x WN waves per workgroup, NS ring slots
 template <int TM, int TN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch batch) {
+__global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch batch, unsigned long long* trace) {
   constexpr int NW = WM * WN;
+  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  asm volatile("" : "+v"(trow));
+  if (trow) trow[0] = __builtin_amdgcn_s_memtime();
+  // pull the kernel-argument cache lines of this workgroup's problem into the scalar cache NOW, all in flight together (a first
+  // touch costs a scalar-cache miss of ~0.5 us and the fields are otherwise fetched one dependent batch after the other)
+  unsigned touch = 0;
+  {
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    const char __attribute__((address_space(4)))* pa = ka + blockIdx.y * sizeof(L1Prob);
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(L1Prob) + 63) / 64); ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"((int)sizeof(L1Prob) - 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
+  }
   constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
   constexpr int KB = 128;                                  // k elements per stage (256-byte rows)
   constexpr int D = NS - 1;                                // prefetch distance
@@ -65,31 +77,44 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
   const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
   const int q_row = lane >> 4, q_pos = lane & 15;          // within the 4 rows one wave instruction covers
 
-  auto issue = [&](int t, int stage) {
-    const int sidx = (t < nt0) ? 0 : 1;
-    const int k0 = (sidx == 0 ? t : t - nt0) * KB;
-    const unsigned sbase = lds0 + stage * STAGE_BYTES;
-    const char* Ab = (const char*)P.A[sidx] + (int64_t)k0 * 2;
-    const int64_t lda = P.lda[sidx];
-    const char* Wb = (const char*)P.W1 + ((int64_t)P.w1_col[sidx] + k0) * 2;
+  // per-lane source offsets of this wave's DMA instructions (constant over a contraction segment): instruction j covers tile
+  // rows (j NW + wave) 4 .. + 3, the lane's 16-byte chunk is source chunk q_pos ^ (row & 15) of the stage's 256 bytes
+  unsigned voff_a[NA], voff_w[NB];
+  auto lane_offsets = [&](int sidx) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int row = (j * NW + wave) * 4 + q_row;
-      const int c = q_pos ^ (row & 15);
-      const int gr = min(m0 + row, P.rows - 1);
-      l1_dma16(Ab + (int64_t)gr * lda * 2 + c * 16, sbase + (j * NW + wave) * 1024);
+      voff_a[j] = (unsigned)(min(m0 + row, P.rows - 1) * (int)P.lda[sidx] * 2 + ((q_pos ^ (row & 15)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int row = (j * NW + wave) * 4 + q_row;
-      const int c = q_pos ^ (row & 15);
-      l1_dma16(Wb + (int64_t)(n0 + row) * P.ldw1 * 2 + c * 16, sbase + BM * 256 + (j * NW + wave) * 1024);
+      voff_w[j] = (unsigned)((n0 + row) * (int)P.ldw1 * 2 + ((q_pos ^ (row & 15)) << 4));
     }
+  };
+  lane_offsets(0);
+  const char* sa_ptr = (const char*)P.A[0];                                   // running scalar bases: + 256 bytes per stage
+  const char* sw_ptr = (const char*)P.W1 + (int64_t)P.w1_col[0] * 2;
+  int issued = 0;
+  auto issue = [&](int stage) {
+    if (issued == nt0) {           // second contraction segment
+      lane_offsets(1);
+      sa_ptr = (const char*)P.A[1];
+      sw_ptr = (const char*)P.W1 + (int64_t)P.w1_col[1] * 2;
+    }
+    ++issued;
+    const unsigned sbase = lds0 + stage * STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) dma_s(voff_a[j], sa_ptr, sbase + j * NW * 1024);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dma_s(voff_w[j], sw_ptr, sbase + BM * 256 + j * NW * 1024);
+    sa_ptr += 256;
+    sw_ptr += 256;
   };
 
 #pragma unroll
   for (int i = 0; i < D; ++i)
-    if (i < nt) issue(i, i);
+    if (i < nt) issue(i);
   // everything the epilogue reads from global memory is requested now, under the first stages' latency (a compiler-visible
   // load inside the stream would drain the DMA queue with a vmcnt(0))
   f32x4 bias[TN];
@@ -98,10 +123,11 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
     const int n = n0 + wn0 + tn * 16 + fg * 4;
     bias[tn] = (n + 3 < P.H) ? *(const f32x4*)(P.b1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int32_t step0 = (P.mask_mode == RECNN_MASK_HASH) ? (P.step_ptr ? *P.step_ptr : 0) + P.step_add : 0;
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(bias[tn]));
+  // the device step counter through the SCALAR cache (a plain load of this uniform global becomes a vector load + vmcnt(0))
+  int32_t step_now = 0;
+  if (P.mask_mode == RECNN_MASK_HASH && P.step_ptr) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(step_now) : "s"(P.step_ptr));
 
+  if (trow) trow[1] = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < nt; ++t) {
     // stage t has landed once at most the loads of the (up to D - 1) younger stages are still outstanding
     const int younger = min(D - 1, nt - 1 - t);
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
     else if (younger == 1 && D >= 2) wait_vm_const<NA + NB>();
     else wait_vm_const<0>();
     __builtin_amdgcn_s_barrier();  // every wave's part of stage t is in LDS; every wave is done reading stage t - 1
-    if (t + D < nt) issue(t + D, (t + D) % NS);
+    if (t + D < nt) issue((t + D) % NS);
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
     const unsigned char* sb = sa + BM * 256;
 #pragma unroll
@@ -129,6 +155,9 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
     }
   }
 
+  if (trow) trow[2] = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(step_now));
+  const int32_t step0 = step_now + P.step_add;
   // ---- epilogue: acc[tm][tn][r] = C[row m0 + wm0 + 16 tm + fr][column n0 + wn0 + 16 tn + 4 fg + r]
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -148,7 +177,12 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = fmaxf(acc[tm][tn][r] + bias[tn][r], 0.f);
+        v[r] = acc[tm][tn][r] + bias[tn][r];
+        if (!P.no_relu) v[r] = fmaxf(v[r], 0.f);
+        if (P.addend && m < P.rows && n + r < P.H) {
+          const float z = P.addend[(int64_t)m * P.ld_add + n + r];
+          v[r] += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+        }
         if (P.mask_mode == RECNN_MASK_EXTERNAL) v[r] = (m < P.rows && n + r < P.H && P.mask[(int64_t)m * P.ld_mask + n + r]) ? v[r] * 2.f : 0.f;
         else if (P.mask_mode == RECNN_MASK_HASH) v[r] = mask_keep(word, mrow & 3, r) ? v[r] * 2.f : 0.f;
         if (n + r >= P.H) v[r] = 0.f;
@@ -156,38 +190,55 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
       if (m < P.rows) *(uint2*)((bf16_t*)P.h1 + (int64_t)m * P.ldh + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
     }
   }
+  if (trow) trow[3] = __builtin_amdgcn_s_memtime();
 }
 
 template <int TM, int TN, int WM, int WN, int NS> constexpr int lds_bytes() { return NS * (16 * TM * WM + 16 * TN * WN) * 256; }
 }  // namespace
 
+// 16 waves as 4 x 4 everywhere (the more waves issue the DMAs, the closer a CU gets to its ~45 B/clk: DESIGN.md 5):
+//   SMALL  64 x  64, wave tile 16 x 16, 4-slot ring (128 KB)      per-step launches
+//   BIG   128 x 128, wave tile 32 x 32, 2-slot ring (128 KB)      cycle-batched launches
+//   MID   128 x  64, wave tile 32 x 16, 3-slot ring (144 KB)      cycle-batched launches (recnn_tune_l1_big(2)): no 2.5-round tail
+#define L1_SMALL 1, 1, 4, 4, 4
+#define L1_BIG 2, 2, 4, 4, 2
+#define L1_MID 2, 1, 4, 4, 3
+static int g_l1_big = 1;
+extern "C" void recnn_tune_l1_big(int shape) { g_l1_big = shape == 2 ? 2 : 1; }
+
+static unsigned long long* g_l1_trace = nullptr;
+extern "C" void recnn_tune_l1_trace(void* p) { g_l1_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
+
 int l1gemm_init() {
-  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<2, 1, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               lds_bytes<2, 1, 2, 4, 4>()), "l1gemm attr");
-  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<4, 2, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    lds_bytes<4, 2, 2, 4, 2>()), "l1gemm attr");
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_SMALL>()), "l1gemm attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_BIG>()), "l1gemm attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_MID>()), "l1gemm attr");
   return rc;
 }
 
 int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s) {
   RECNN_REQUIRE(nprob >= 1 && nprob <= L1_MAX_GROUP, "l1gemm: 1..%d problems per launch", L1_MAX_GROUP);
-  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  const int shape = big ? g_l1_big : 0;
+  const int BM = shape ? 128 : 64, BN = shape == 1 ? 128 : 64;
   int maxwg = 0;
   for (int i = 0; i < nprob; ++i) {
     L1Prob& p = b.p[i];
     RECNN_REQUIRE(p.rows > 0 && p.H > 0 && p.H <= 256 && (p.H & 3) == 0, "l1gemm: bad shape");
     RECNN_REQUIRE(p.nseg >= 1 && p.nseg <= 2 && p.h1 && p.W1 && p.b1, "l1gemm: bad problem");
     for (int g = 0; g < p.nseg; ++g)
-      RECNN_REQUIRE(p.K[g] > 0 && p.K[g] % 128 == 0 && p.lda[g] % 8 == 0 && (((uintptr_t)p.A[g]) & 15) == 0 && (p.w1_col[g] & 7) == 0,
-                    "l1gemm: segment %d must be 16-byte aligned with K a multiple of 128", g);
+      RECNN_REQUIRE(p.K[g] > 0 && p.K[g] % 128 == 0 && p.lda[g] % 8 == 0 && (((uintptr_t)p.A[g]) & 15) == 0 && (p.w1_col[g] & 7) == 0 &&
+                        (int64_t)p.rows * p.lda[g] * 2 < (1ll << 31),
+                    "l1gemm: segment %d must be 16-byte aligned with K a multiple of 128 (and < 2 GB)", g);
     RECNN_REQUIRE(p.ldw1 % 8 == 0 && p.ldh % 4 == 0 && (((uintptr_t)p.W1 | (uintptr_t)p.h1) & 15) == 0, "l1gemm: bad pitches");
     RECNN_REQUIRE(p.rows_per_set == 0 || p.rows_per_set % 16 == 0, "l1gemm: batches must be multiples of 16 rows");
     p.tiles_m = (p.rows + BM - 1) / BM;
-    p.tiles_n = (256 + BN - 1) / BN;     // the weight shadows are zero-padded to 256 rows
+    p.tiles_n = ((p.w_rows > 0 ? p.w_rows : 256) + BN - 1) / BN;     // (the hidden layers' weight shadows are zero-padded to 256 rows)
     const int nwg = p.tiles_m * p.tiles_n;
     if (nwg > maxwg) maxwg = nwg;
   }
-  if (big) hipLaunchKernelGGL((l1_gemm_kernel<4, 2, 2, 4, 2>), dim3(maxwg, nprob), dim3(512), (lds_bytes<4, 2, 2, 4, 2>()), s, b);
-  else hipLaunchKernelGGL((l1_gemm_kernel<2, 1, 2, 4, 4>), dim3(maxwg, nprob), dim3(512), (lds_bytes<2, 1, 2, 4, 4>()), s, b);
+  const dim3 grid(maxwg, nprob), block(1024);
+  if (shape == 1) hipLaunchKernelGGL((l1_gemm_kernel<L1_BIG>), grid, block, (lds_bytes<L1_BIG>()), s, b, g_l1_trace);
+  else if (shape == 2) hipLaunchKernelGGL((l1_gemm_kernel<L1_MID>), grid, block, (lds_bytes<L1_MID>()), s, b, g_l1_trace);
+  else hipLaunchKernelGGL((l1_gemm_kernel<L1_SMALL>), grid, block, (lds_bytes<L1_SMALL>()), s, b, g_l1_trace);
   return recnn_check_hip(hipGetLastError(), "l1_gemm_kernel");
 }

@@ -26,8 +26,9 @@ constexpr int KB1 = 64;                       // k elements per slab row (128 by
 constexpr int W_BYTES = HP * 128;             // 32 KB: one k-slab of a 256-row matrix
 constexpr int NST = 4;
 constexpr int PANEL_OFF = NST * W_BYTES;      // 128 KB
-constexpr int SCR_OFF = PANEL_OFF + 2 * PANEL_HALF;   // per-row scalars: q[32], d[32] (fp32)
-constexpr int LDS_TOTAL = SCR_OFF + 512;      // 144.5 KB
+constexpr int SCR_OFF = PANEL_OFF + 2 * PANEL_HALF;   // per-row scalars: q, e, d, y (fp32 [32] each)
+constexpr int COL_OFF = SCR_OFF + 512;        // column-sum partials: fp32 [2][4][256]
+constexpr int LDS_TOTAL = COL_OFF + 8192;     // 152.5 KB
 constexpr int OW = 8;                         // waves of the actor's 128-column output layer
 constexpr int RW = BM / NW;                   // critic head rows per wave
 
@@ -62,10 +63,25 @@ __device__ __forceinline__ float panel_at(const unsigned char* panel, int row, i
 }
 }  // namespace
 
-__global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch) {
+#define MLPT_STAMP(i) do { if (trow) trow[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch, unsigned long long* trace) {
   const TailProb& P = batch.p[blockIdx.y];
   const int m0 = blockIdx.x * BM;
   if (m0 >= P.rows) return;
+  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  asm volatile("" : "+v"(trow));
+  MLPT_STAMP(0);
+  // pull the kernel-argument cache lines of this workgroup's problem into the scalar cache NOW, all in flight together (a first
+  // touch costs a scalar-cache miss of ~0.5 us and the fields are otherwise fetched one dependent batch after the other)
+  unsigned touch = 0;
+  {
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    const char __attribute__((address_space(4)))* pa = ka + blockIdx.y * sizeof(TailProb);
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(TailProb) + 63) / 64); ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"((int)sizeof(TailProb) - 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const unsigned lds0 = (unsigned)(size_t)lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,10 +90,50 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   const bool actor = P.kind == TAIL_ACTOR;
   const bool learn = P.kind == TAIL_CRITIC_LEARN;
   unsigned char* panel = lds + PANEL_OFF;
-  float* qs = (float*)(lds + SCR_OFF);          // Q of the panel's rows
-  float* ds = qs + BM;                          // loss seed d of the panel's rows
+  float* qs = (float*)(lds + SCR_OFF);          // per row: Q, TD error e, loss seed d, TD target y
+  float* es = qs + BM;
+  float* ds = es + BM;
+  float* ys = ds + BM;
+  float* colp = (float*)(lds + COL_OFF);        // column-sum partials [2 sums][4 row chunks][256 columns]
 
-  // ---- request EVERYTHING the workgroup will multiply, now: the h1 panel (one instruction per wave: 4 rows x 256 bytes of one
+  // ---- everything the epilogues and the head read from global memory is requested FIRST: these loads are then the oldest
+  // entries of the wave's vector-memory queue, so the counted waits of the operand stream below cover them too, and their
+  // first uses come after the stream has landed (a compiler-visible load issued AFTER a DMA makes hipcc wait vmcnt(0) --
+  // for every DMA in flight -- at its first use)
+  const int n0 = wave * 16 + fg * 4;            // this lane's four hidden columns
+  f32x4 b2v[1];
+  b2v[0] = (n0 + 3 < P.H) ? *(const f32x4*)(P.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int no = (wave & (OW - 1)) * 16 + fg * 4;   // this lane's four output columns (actor, waves 0..7)
+  float v3[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    v3[r] = actor ? (no + r < P.out_dim ? P.b3[no + r] : 0.f) : ((lane * 4 + r < P.H) ? P.w3row[lane * 4 + r] : 0.f);
+  const float b3s = actor ? 0.f : P.b3[0];
+  // (raw loads only up here: arithmetic on a loaded value would make the compiler wait for it before the stream is issued)
+  float h_rew = 0.f, h_done = 0.f, h_tq0 = 0.f, h_tq1 = 0.f;
+  if (learn && wave == 0) {
+    const int mc = min(m0 + (lane & 31), P.rows - 1);
+    h_rew = P.reward[mc];
+    h_done = P.done[mc];
+    h_tq0 = P.tq[0][mc];
+    h_tq1 = P.n_target > 1 ? P.tq[1][mc] : 0.f;
+  }
+  // the learning critic's w3 for this thread's u2 cell (columns n8 .. n8 + 7 of row lane & 31)
+  const int n8 = (2 * wave + (lane >> 5)) * 8;
+  float4 w3a = make_float4(0.f, 0.f, 0.f, 0.f), w3b = w3a;
+  if (learn) {
+    const int nb = min(n8, P.H - 8);
+    w3a = *(const float4*)(P.w3row + nb);
+    w3b = *(const float4*)(P.w3row + nb + 4);
+  }
+  int mrow0 = m0, mset = 0;                     // first row of the panel inside its batch, the batch's index
+  if (P.rows_per_set > 0) { mset = m0 / P.rows_per_set; mrow0 = m0 - mset * P.rows_per_set; }
+  // the device step counter through the SCALAR cache (hipcc turns a plain load of this uniform global into a vector load + an
+  // immediate vmcnt(0)): requested here, waited for where the dropout key is hashed
+  int32_t step_now = 0;
+  if (P.mask_mode == RECNN_MASK_HASH && P.step_ptr) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(step_now) : "s"(P.step_ptr));
+
+  // ---- request EVERYTHING the workgroup will multiply: the h1 panel (one instruction per wave: 4 rows x 256 bytes of one
   // k half; LDS position p of row r holds source chunk p ^ (r & 15)) and W2's four k-slabs (ring stages 0..3; rows l_row and
   // l_row + 128 per lane, chunk c of row r at position c ^ ((r >> 1) & 7)); the actor's two W3 slabs follow into stages 0 / 1
   // once W2's first two slabs have been multiplied
@@ -106,67 +162,45 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w2(q);
 
-  // ---- then everything the epilogues and the head read from global memory (the compiler's vmcnt(0) for these loads also
-  // drains the DMAs above: they have to land anyway before anything can be multiplied)
-  const int n0 = wave * 16 + fg * 4;            // this lane's four hidden columns
-  f32x4 b2v[1];
-  b2v[0] = (n0 + 3 < P.H) ? *(const f32x4*)(P.b2 + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const int no = (wave & (OW - 1)) * 16 + fg * 4;   // this lane's four output columns (actor, waves 0..7)
-  float v3[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    v3[r] = actor ? (no + r < P.out_dim ? P.b3[no + r] : 0.f) : ((lane * 4 + r < P.H) ? P.w3row[lane * 4 + r] : 0.f);
-  const float b3s = actor ? 0.f : P.b3[0];
-  uint32_t key2 = 0;
-  int mrow0 = m0;                               // first row of the panel inside its batch
-  if (P.mask_mode == RECNN_MASK_HASH) {
-    int set = 0;
-    if (P.rows_per_set > 0) { set = m0 / P.rows_per_set; mrow0 = m0 - set * P.rows_per_set; }
-    key2 = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add + set, P.stream2);
-  }
-  float h_rew = 0.f, h_done = 0.f, h_tq = 0.f;
-  if (learn && wave == 0) {
-    const int mc = min(m0 + (lane & 31), P.rows - 1);
-    h_rew = P.reward[mc];
-    h_done = P.done[mc];
-    h_tq = P.tq[0][mc];
-    if (P.n_target > 1) h_tq = fminf(h_tq, P.tq[1][mc]);
-  }
-  asm volatile("" : "+v"(b2v[0]), "+v"(h_rew), "+v"(h_done), "+v"(h_tq));
-#pragma unroll
-  for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v3[r]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // the h1 panel and all four W2 slabs are in LDS for every wave
-
-  // relu/dropout gate of h1 for this lane's accumulator elements (bit tm * 4 + r): the backward's gate of U
-  uint32_t gate1 = 0;
-  if (learn) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int row = tm * 16 + fr;
-      const uint2 hv = *(const uint2*)(panel + (n0 >> 7) * PANEL_HALF + row * 256 + ((((n0 & 127) >> 3) ^ (row & 15)) << 4) + (n0 & 7) * 2);
-      if (hv.x & 0x7FFFu) gate1 |= 1u << (tm * 4 + 0);
-      if (hv.x & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 1);
-      if (hv.y & 0x7FFFu) gate1 |= 1u << (tm * 4 + 2);
-      if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
-    }
-  }
-
-  // ------------------------------------------------------------------ layer 2
+  // ------------------------------------------------------------------ layer 2, slab by slab as the stream lands
+  // (per wave: 1 panel + 8 slab instructions in flight; slab q has landed once at most the 2 (3 - q) younger ones are outstanding)
   f32x4 acc[2][1];
   acc[0][0] = acc[1][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint32_t gate1 = 0;   // relu/dropout gate of h1 for this lane's accumulator elements (bit tm * 4 + r): the backward's gate of U
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg);
-    if (actor && q < 2) {                       // W2's k-slab q is done with for every wave after this barrier: W3's slab q takes its stage
+    // A critic's whole stream (144 KB) arrives within ~1k cycles of its first slab (every wave issued its nine instructions
+    // back to back), so waiting slab by slab buys nothing and costs three more rendezvous (trace: +0.9k cycles): ONE wait, one
+    // barrier.  The actor keeps the per-slab rendezvous: W3's slabs take over the stages of W2's first two.
+    if (actor || q == 0) {
+      // actor: W3's slab p was issued after W2's slab p + 1 was waited for, so the younger set at slab q is {W2 q+1.., W3 ..}
+      if (!actor) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (q == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue_w3(q);
+      __builtin_amdgcn_s_barrier();             // slab q (and the h1 panel) landed for every wave; everybody is done with slab q - 1
     }
+    if (q == 0) MLPT_STAMP(1);
+    if (actor && q >= 1 && q <= 2) issue_w3(q - 1);   // W2's slab q - 1 is done with: W3's slab q - 1 takes its stage
+    if (q == 0 && learn) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int row = tm * 16 + fr;
+        const uint2 hv = *(const uint2*)(panel + (n0 >> 7) * PANEL_HALF + row * 256 + ((((n0 & 127) >> 3) ^ (row & 15)) << 4) + (n0 & 7) * 2);
+        if (hv.x & 0x7FFFu) gate1 |= 1u << (tm * 4 + 0);
+        if (hv.x & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 1);
+        if (hv.y & 0x7FFFu) gate1 |= 1u << (tm * 4 + 2);
+        if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
+      }
+    }
+    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg);
   }
+  MLPT_STAMP(2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // everyone is done reading the h1 panel
   // (hidden_epilogue hashes the dropout word from the row's index INSIDE its batch: m0 -> mrow0)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(step_now));
+  const uint32_t key2 = P.mask_mode == RECNN_MASK_HASH ? mask_key(P.seed, step_now + P.step_add + mset, P.stream2) : 0u;
   hidden_epilogue<1>(acc, b2v, P.H, P.rows - (m0 - mrow0), mrow0, wave, fr, fg, P.mask_mode,
                      P.mask2 ? P.mask2 + (int64_t)(m0 - mrow0) * P.ld_mask : nullptr, P.ld_mask, key2, panel);
 
@@ -183,6 +217,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
         mma_panel(panel, 2 * p + 1, lds + p * W_BYTES, o, 128 + wave * 16, fr, fg);
       }
     }
+    MLPT_STAMP(3);
     if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
     if (wave < OW) {
 #pragma unroll
@@ -217,45 +252,79 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
         }
       }
     }
+    MLPT_STAMP(10);
     return;
   }
 
   // ------------------------------------------------------------------ critic head: q[m] = h2[m, :] . w3 + b3
+  // The TD target needs nothing this workgroup computes (Q' came with the kernel's inputs): wave 0 evaluates it while the
+  // h2 panel is being completed, so a row's TD error and loss seed are one subtraction away from its q dot.
+  const float h_tq = P.n_target > 1 ? fminf(h_tq0, h_tq1) : h_tq0;
+  if (learn && wave == 0 && lane < BM) {
+    float y = h_rew + (1.0f - h_done) * P.gamma * h_tq;
+    y = fminf(fmaxf(y, P.lo), P.hi);
+    ys[lane] = y;
+  }
+  MLPT_STAMP(3);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // h2 panel complete
+  __builtin_amdgcn_s_barrier();                 // h2 panel complete (and the TD targets are in LDS)
   if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
-  for (int i = 0; i < RW; ++i) {
-    const int row = wave * RW + i;
-    const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
-    const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
-    const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
-    float s = 0.f;
+  {
+    // both rows of the wave side by side (two independent load -> dot -> reduction chains); Q and the loss seed reach global
+    // memory after the rendezvous below, as two 128-byte stores, instead of one 4-byte store per row from here
+    float sdot[RW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
-    s = wave_sum(s);
+    for (int i = 0; i < RW; ++i) {
+      const int row = wave * RW + i;
+      const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
+      const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
+      const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
+      sdot[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) sdot[i] = wave_sum(sdot[i]);
     if (lane == 0) {
-      const float qv = s + b3s;
-      if (m0 + row < P.rows && P.q) P.q[m0 + row] = qv;
-      qs[row] = qv;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int row = wave * RW + i;
+        const float qv = sdot[i] + b3s;
+        const bool valid = m0 + row < P.rows;
+        qs[row] = qv;
+        if (learn) {
+          const float e = valid ? qv - ys[row] : 0.f;
+          es[row] = e;
+          ds[row] = e * (2.0f / (float)P.rows);
+        }
+      }
     }
   }
-  if (!learn) return;
+  if (!learn) {
+    __syncthreads();
+    if (tid < BM && m0 + tid < P.rows && P.q) P.q[m0 + tid] = qs[tid];
+    MLPT_STAMP(4);
+    return;
+  }
+  MLPT_STAMP(4);
+  __syncthreads();                              // e and d of all 32 rows are in LDS; every wave is done with its q dots
+  MLPT_STAMP(5);
+  if (wave == 1 && lane < BM && m0 + lane < P.rows) {       // (wave 0 has the loss sums)
+    if (P.q) P.q[m0 + lane] = qs[lane];
+    if (P.delta_out) P.delta_out[m0 + lane] = ds[lane];
+  }
 
-  // ------------------------------------------------------------------ TD target, TD error, loss (wave 0; lanes 0..31 = rows)
-  __syncthreads();                              // Q of all 32 rows is in LDS
+  // ---- loss partial sums (wave 0, off everybody else's path): sum (q - y)^2 and sum d over the panel, lanes 0..31 = rows
   if (wave == 0) {
     const int r = lane & 31, m = m0 + r;
     const bool valid = lane < 32 && m < P.rows;
-    float y = h_rew + (1.0f - h_done) * P.gamma * h_tq;
-    y = fminf(fmaxf(y, P.lo), P.hi);
+    const float e = lane < 32 ? es[r] : 0.f;
+    const float d = lane < 32 ? ds[r] : 0.f;
     if (valid) {
-      if (P.expected) P.expected[m] = y;
+      if (P.expected) P.expected[m] = ys[r];
       if (P.target_q) P.target_q[m] = h_tq;
     }
-    const float e = valid ? qs[r] - y : 0.f;
-    const float d = e * (2.0f / (float)P.rows);
-    if (valid && P.delta_out) P.delta_out[m] = d;
-    if (lane < 32) ds[r] = d;
     const float tot = wave_sum(e * e);
     const float dsum = wave_sum(d);
     if (lane == 0) {
@@ -263,52 +332,56 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
       if (P.db3_part) P.db3_part[blockIdx.x] = dsum;
     }
   }
-  __syncthreads();                              // d of all 32 rows is in LDS; every wave is done reading h2 rows for its q dots
 
-  // ---- dw3 partial sums of this panel: sum_r d_r h2[r][k], thread = column k (h2 is still in the panel)
-  if (P.dw3_part && tid < P.H) {
-    float s3 = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < BM; ++r) s3 = fmaf(ds[r], panel_at(panel, r, tid), s3);
-    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = s3;
+  // ---- column sums over the panel's rows, four row chunks of 8 per column (thread = (chunk, column)), fma chains upwards:
+  //   dw3[k] = sum_r d_r h2[r][k]         db2[k] = sum_r d_r u2[r][k],  u2 = bf16(w3[k] scale) where h2 > 0
+  const int ck = tid & 255, cc = tid >> 8;
+  if (P.dw3_part && ck < P.H) {
+    const float u = bf2f(f2bf(P.w3row[ck] * P.scale));
+    float s3 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = cc * 8; r < cc * 8 + 8; ++r) {
+      const float h = panel_at(panel, r, ck);
+      s3 = fmaf(ds[r], h, s3);
+      s2 = fmaf(ds[r], h > 0.f ? u : 0.f, s2);
+    }
+    colp[cc * 256 + ck] = s3;
+    colp[1024 + cc * 256 + ck] = s2;
   }
-  __syncthreads();
-
-  // ---- u2 = w3 * scale * [h2 > 0] in place in the panel (the A operand of the next product); dz2 = d * u2 to global
+  // ---- u2 = w3 * scale * [h2 > 0] for this thread's cell (row lane & 31, columns n8 .. n8 + 7), dz2 = d * u2 to global; the
+  // cell goes back into the panel (the A operand of the next product) once every thread has read the h2 it needs
+  uint4 packed;
   {
     const int row = lane & 31, m = m0 + row;
-    const int n8 = (2 * wave + (lane >> 5)) * 8;
-    const int nb = min(n8, P.H - 8);
-    const float4 w3a = *(const float4*)(P.w3row + nb), w3b = *(const float4*)(P.w3row + nb + 4);
-    const float wsc = n8 < P.H ? P.scale : 0.f;
-    const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
     unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16);
     const uint4 raw = *(const uint4*)cell;
     const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
     const float d = ds[row];
+    const float wsc = n8 < P.H ? P.scale : 0.f;
+    const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
     float uz[8], dz[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
       uz[j] = hv > 0.f ? w3s[j] : 0.f;
     }
-    const uint4 packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
+    packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
     const uint32_t pu[4] = {packed.x, packed.y, packed.z, packed.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) dz[j] = bf2f((bf16_t)((pu[j >> 1] >> ((j & 1) * 16)) & 0xFFFF)) * d;   // (the ROUNDED unit value times d)
-    *(uint4*)cell = packed;
     if (m < P.rows)
       *(uint4*)((bf16_t*)P.dz2 + (int64_t)m * P.ldh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // every thread has read its h2 values (column sums, cells)
+    *(uint4*)cell = packed;
   }
+  MLPT_STAMP(6);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // u2 panel complete
-
-  // ---- db2 partial sums: sum_r d_r u2[r][k]
-  if (P.db2_part && tid < P.H) {
-    float s2 = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < BM; ++r) s2 = fmaf(ds[r], panel_at(panel, r, tid), s2);
-    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = s2;
+  __builtin_amdgcn_s_barrier();                 // u2 panel complete, the column partials are in LDS
+  MLPT_STAMP(7);
+  if (P.dw3_part && tid < P.H) {
+    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]);
+    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = (colp[1024 + tid] + colp[1280 + tid]) + (colp[1536 + tid] + colp[1792 + tid]);
   }
 
   // ---- U = (u2 W2) * scale * gate(h1): W2's four k-slabs are still in stages 0..3: k-slab q holds in-columns 64 q .. 64 q + 63,
@@ -340,8 +413,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     }
   }
   // (operands swapped: dacc[tm][r] = U[row 16 tm + fr][column 16 wave + 4 fg + r], the layout of gate1)
+  MLPT_STAMP(8);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // every wave is done with the u2 panel (MFMA A operand, db2 sums): U takes its place
+  __builtin_amdgcn_s_barrier();                 // every wave is done with the u2 panel (MFMA A operand): U takes its place
   {
     unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
     const int c = (n0 & 127) >> 3;
@@ -358,15 +432,48 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
       if (mm < P.rows) *(uint2*)((bf16_t*)P.dz1 + (int64_t)mm * P.ldh + n0) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
     }
   }
-  if (P.db1_part) {
+  MLPT_STAMP(9);
+  if (P.db1_part) {                             // db1[k] = sum_r d_r U[r][k], same four-chunk order
     __syncthreads();                            // U panel complete
-    if (tid < P.H) {
+    if (ck < P.H) {
       float s1 = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < BM; ++r) s1 = fmaf(ds[r], panel_at(panel, r, tid), s1);
-      P.db1_part[(int64_t)blockIdx.x * P.H + tid] = s1;
+#pragma unroll
+      for (int r = cc * 8; r < cc * 8 + 8; ++r) s1 = fmaf(ds[r], panel_at(panel, r, ck), s1);
+      colp[cc * 256 + ck] = s1;
     }
+    __syncthreads();
+    if (tid < P.H) P.db1_part[(int64_t)blockIdx.x * P.H + tid] = (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]);
   }
+  MLPT_STAMP(10);
+}
+
+static unsigned long long* g_mlpt_trace = nullptr;
+extern "C" void recnn_tune_tail_trace(void* p) { g_mlpt_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
+
+// ---- the critic head alone: q[m] = h2[m, :] . w3 + b3, one wave per row -- the q-dot loop of mlp_tail_kernel, same lane ->
+// column map (lane owns columns 4 lane .. 4 lane + 3), same products, same wave_sum tree
+__global__ __launch_bounds__(NW * 64) void qdot_kernel(const bf16_t* __restrict__ h2, int64_t ldh, const float* __restrict__ w3row,
+                                                       const float* __restrict__ b3, int H, int rows, float* __restrict__ q) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * NW + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v3[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v3[r] = (lane * 4 + r < H) ? w3row[lane * 4 + r] : 0.f;
+  const float b3s = b3[0];
+  const uint2 hv = *(const uint2*)(h2 + (int64_t)row * ldh + lane * 4);
+  const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += lane * 4 + j < H ? hf[j] * v3[j] : 0.f;
+  s = wave_sum(s);
+  if (lane == 0) q[row] = s + b3s;
+}
+
+int qdot_launch(const void* h2, int64_t ldh, const float* w3row, const float* b3, int H, int rows, float* q, hipStream_t s) {
+  RECNN_REQUIRE(h2 && w3row && b3 && q && rows > 0 && H > 0 && H <= 256 && ldh >= 256 && ldh % 4 == 0, "qdot: bad arguments");
+  hipLaunchKernelGGL(qdot_kernel, dim3((rows + NW - 1) / NW), dim3(NW * 64), 0, s, (const bf16_t*)h2, ldh, w3row, b3, H, rows, q);
+  return recnn_check_hip(hipGetLastError(), "qdot_kernel");
 }
 
 int mlpt_init() {
@@ -391,6 +498,6 @@ int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s) {
                       "mlp_tail: the learning critic needs Q', reward, done and its backward buffers");
     }
   }
-  hipLaunchKernelGGL(mlp_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b);
+  hipLaunchKernelGGL(mlp_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b, g_mlpt_trace);
   return recnn_check_hip(hipGetLastError(), "mlp_tail_kernel");
 }

@@ -34,6 +34,13 @@ struct L1Prob {
   // (*step_ptr + step_add + j) of the run: mask key step + j, mask row = row inside the batch
   int rows_per_set;
   void* h1; int64_t ldh;
+  // The same tiled kernel also runs the LATER layers of the cycle-batched frozen networks as plain GEMMs (K = 256: h2 = act(h1
+  // W2^T + b2), out = h2 W3^T + b3 + clip(noise)), whose per-panel tail launches were weight-stream startups for 32 rows each:
+  int no_relu;                  // 1: linear output (an actor's last layer)
+  int w_rows;                   // rows of the weight matrix = output columns to cover (0: 256, the padded hidden width)
+  const float* addend;          // optional fp32 [rows, ld_add] added after the bias, clamped to +- add_clip (TD3 target noise)
+  int64_t ld_add;
+  float add_clip;
   // filled by the launcher
   int tiles_m, tiles_n;
 };
@@ -92,3 +99,6 @@ struct TailBatch { TailProb p[TAIL_MAX_GROUP]; };
 
 int mlpt_init();
 int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s);
+// q[m] = h2[m, :] . w3 + b3 for bf16 h2 [rows, ldh]: the critic head of mlp_tail_kernel as its own launch (one wave per row,
+// the same lane -> column map and reduction tree, so the same bits), behind a cycle-batched layer-2 GEMM
+int qdot_launch(const void* h2, int64_t ldh, const float* w3row, const float* b3, int H, int rows, float* q, hipStream_t s);

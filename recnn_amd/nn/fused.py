@@ -49,7 +49,7 @@ def notify_params_changed(module):
     if ctx is not None:
         ctx.dirty.add(id(module))
     from . import functional
-    functional.mark_written(_module_params(module))      # cached derived layouts of the module-level forward are stale too
+    functional.mark_written(module.parameters())         # cached derived layouts of the module-level forward are stale too
 
 
 def _module_params(m):
