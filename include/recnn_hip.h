@@ -504,10 +504,15 @@ void recnn_tune_mlp_fault(int mode);
  * their epilogue (csrc/dwopt.hip: no gradient slabs, no separate Adam launch; 2 / 3 = the same with 8 / 4 waves per workgroup
  * instead of 16); 0 (default: faster at 2048 rows, see csrc/engine.hip) = split-batch slabs + reduce / Adam launches. */
 void recnn_tune_dw_fuse(int on);
-/* 1: split forward (csrc/l1gemm.hip + csrc/mlpt.hip: layer 1 as a tiled GEMM, the rest as a row-panel tail launch, frozen
- * networks first); 0: the fused row-panel kernel (csrc/mlps.hip).  Same results bit for bit. */
+/* Scheduling of the bf16 step (all variants agree bit for bit): 0 = the fused row-panel forward (csrc/mlps.hip) everywhere;
+ * 1 (default) = run graphs of >= recnn_tune_cycle_min_len steps (default 30) run in cycle mode: a policy cycle's batches gathered
+ * at once, the frozen networks (target actor / critics, actor) applied to all of them by csrc/mlpf.hip, the per-step launches =
+ * split forward of the learning critics (csrc/l1gemm.hip + csrc/mlpt.hip); 2 = split forward and cycle mode everywhere. */
 void recnn_tune_split_fwd(int on);
-void recnn_tune_frozen_gemm(int on);   /* cycle mode: layers 2 / 3 of the frozen networks as tiled GEMMs (1, default) or row-panel tails (0) */
+void recnn_tune_cycle_min_len(int steps);
+void recnn_tune_frozen_gemm(int on);
+void recnn_tune_frozen_fused(int on);
+void recnn_tune_cycle_fork(int on);   /* cycle mode: gather the next cycle's batches on a side branch of the run graph (measured slower: off) */   /* cycle mode: each frozen network as one launch of 128-row panels (csrc/mlpf.hip; 1, default) */   /* cycle mode: layers 2 / 3 of the frozen networks as tiled GEMMs (1, default) or row-panel tails (0) */
 void recnn_tune_l1_big(int shape);   /* tile of the cycle-batched layer-1 GEMMs: 1 = 128 x 128 (default), 2 = 128 x 64 */
 void recnn_tune_tail_trace(void* device_u64_wg16);   /* shader-clock stamps of mlp_tail_kernel / l1_gemm_kernel, [workgroup][16] uint64 */
 void recnn_tune_l1_trace(void* device_u64_wg16);

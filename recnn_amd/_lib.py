@@ -105,8 +105,11 @@ SIGNATURES = {
     "recnn_tune_dw_dma": (None, [_I]),
     "recnn_tune_dw_fuse": (None, [_I]),
     "recnn_tune_split_fwd": (None, [_I]),
+    "recnn_tune_cycle_min_len": (None, [_I]),
     "recnn_tune_l1_big": (None, [_I]),
     "recnn_tune_frozen_gemm": (None, [_I]),
+    "recnn_tune_frozen_fused": (None, [_I]),
+    "recnn_tune_cycle_fork": (None, [_I]),
     "recnn_tune_dw_probe": (None, [_I]),
     "recnn_tune_dw_trace": (None, [_P]),
     "recnn_tune_tail_trace": (None, [_P]),

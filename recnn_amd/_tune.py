@@ -27,8 +27,11 @@ KNOBS = {
     "RECNN_DW_SPLITS": "recnn_tune_dw_splits",
     "RECNN_DW_FUSE": "recnn_tune_dw_fuse",
     "RECNN_SPLIT_FWD": "recnn_tune_split_fwd",
+    "RECNN_CYCLE_MIN_LEN": "recnn_tune_cycle_min_len",
     "RECNN_L1_BIG": "recnn_tune_l1_big",
     "RECNN_FROZEN_GEMM": "recnn_tune_frozen_gemm",
+    "RECNN_FROZEN_FUSED": "recnn_tune_frozen_fused",
+    "RECNN_CYCLE_FORK": "recnn_tune_cycle_fork",
     "RECNN_DW_PROBE": "recnn_tune_dw_probe",
     "RECNN_GEMM_TGF": "recnn_tune_gemm_ks_layout",
     "RECNN_LD_PAD": "recnn_tune_ld_pad",

@@ -116,8 +116,14 @@ struct recnn_engine {
   // target critics, actor: they only change at a policy step) by one set of cycle-batched launches; the per-step launches
   // then carry the learning critics only (capture_run)
   static constexpr int MSET_MAX = 16;
-  char *m_xs = nullptr, *m_xn = nullptr;           // bf16 [MSET_MAX * Bc, ldx]
-  float *m_reward = nullptr, *m_done = nullptr;    // [MSET_MAX * Bc]
+  char *m_xs = nullptr, *m_xn = nullptr;           // bf16 [MSET_MAX * Bc, ldx]      (the CURRENT one of two copies: while a cycle
+  float *m_reward = nullptr, *m_done = nullptr;    // [MSET_MAX * Bc]                  steps on one, a side branch of the run graph
+  char *m_xs_b[2] = {nullptr, nullptr}, *m_xn_b[2] = {nullptr, nullptr};            //  gathers the next cycle's batches into the other)
+  float *m_reward_b[2] = {nullptr, nullptr}, *m_done_b[2] = {nullptr, nullptr};
+  hipStream_t side = nullptr;                      // capture-time side branch (gather look-ahead)
+  static constexpr int EV_POOL = 16;
+  hipEvent_t ev_pool[EV_POOL] = {};
+  int ev_next = 0;
   char* m_ga = nullptr;                            // actor outputs, bf16 [MSET_MAX * Bc, Ap]
   float* m_tq[2] = {nullptr, nullptr};             // Q'(s', pi'(s')) per target critic, fp32 [MSET_MAX * Bc]
   float* m_noise = nullptr;                        // TD3 target-action noise, fp32 [MSET_MAX * Bc, A]
@@ -291,8 +297,11 @@ int64_t carve(recnn_engine* e, char* base) {
   }
   if (e->bf16) {
     const int64_t MB = (int64_t)recnn_engine::MSET_MAX * Bc;
-    e->m_xs = c.take(MB * e->ldx * 2); e->m_xn = c.take(MB * e->ldx * 2);
-    e->m_reward = (float*)c.take(MB * 4); e->m_done = (float*)c.take(MB * 4);
+    for (int b = 0; b < 2; ++b) {
+      e->m_xs_b[b] = c.take(MB * e->ldx * 2); e->m_xn_b[b] = c.take(MB * e->ldx * 2);
+      e->m_reward_b[b] = (float*)c.take(MB * 4); e->m_done_b[b] = (float*)c.take(MB * 4);
+    }
+    e->m_xs = e->m_xs_b[0]; e->m_xn = e->m_xn_b[0]; e->m_reward = e->m_reward_b[0]; e->m_done = e->m_done_b[0];
     e->m_ga = c.take(MB * Ap * 2);
     e->m_tp_h1 = c.take(MB * Hp * 2); e->m_tp_h2 = c.take(MB * Hp * 2); e->m_pa_h1 = c.take(MB * Hp * 2); e->m_pa_h2 = c.take(MB * Hp * 2);
     for (int i = 0; i < e->n_critic; ++i) { e->m_tq[i] = (float*)c.take(MB * 4); e->m_tq_h1[i] = c.take(MB * Hp * 2); }
@@ -400,6 +409,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = dwopt_init())) { delete e; return rc; }
   if ((rc = l1gemm_init())) { delete e; return rc; }
   if ((rc = mlpt_init())) { delete e; return rc; }
+  if ((rc = mlpf_init())) { delete e; return rc; }
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
@@ -438,6 +448,9 @@ static void drop_graphs(recnn_engine* e) {
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
   if (!e) return;
   drop_graphs(e);
+  for (int i = 0; i < recnn_engine::EV_POOL; ++i)
+    if (e->ev_pool[i]) (void)hipEventDestroy(e->ev_pool[i]);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 
@@ -768,12 +781,29 @@ extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
 // 1: the bf16 forward runs SPLIT (split.h): layer 1 of every network as a full-machine tiled GEMM, the rest (layers 2 / 3,
 // TD head, the critics' layer-2 backward) as a lean row-panel tail launch, the frozen networks first so that the learning
 // critic's own workgroup knows the TD target; 0: the fused row-panel kernel (mlps.hip) with its in-launch hand-offs
-int g_split_fwd = 0;
+// 0: never.  1 (default): run graphs of at least g_cycle_min_len steps run in CYCLE MODE (capture_run: the batches of a policy
+// cycle gathered at once, the frozen networks applied to all of them by mlpf.hip, per-step launches = split forward of the
+// learning critics); shorter graphs and eager steps keep the fused row-panel kernel -- all paths agree bit for bit, so
+// mixing them is a pure scheduling decision.  2: split forward everywhere, cycle mode in every graph (tests).
+// Measured (round 3, DDPG 2048 rows): sustained 61.2-61.5 us/step in cycle mode vs 62.9-63.2 fused; a 20-step graph
+// (the driver's command) 74.7 vs 69.9 -- three partial cycles and ~30 more graph nodes per launch do not pay there.
+int g_split_fwd = 1;
+int g_cycle_min_len = 30;
 extern "C" void recnn_tune_split_fwd(int on) { g_split_fwd = on; }
+extern "C" void recnn_tune_cycle_min_len(int steps) { g_cycle_min_len = steps < 2 ? 2 : steps; }
 // 1 (default): in cycle mode the frozen networks' layers 2 / 3 run as cycle-wide tiled GEMMs (+ a row-dot launch for the target
 // critics' heads); 0: as row-panel tail launches
 int g_frozen_gemm = 1;
 extern "C" void recnn_tune_frozen_gemm(int on) { g_frozen_gemm = on; }
+// 1 (default): in cycle mode each frozen network runs as ONE launch of 128-row panels that keep all three layers on chip
+// (mlpf.hip); 0: layer 1 as a tiled GEMM + the later layers as GEMMs / tails (the knob above)
+int g_frozen_fused = 1;
+extern "C" void recnn_tune_frozen_fused(int on) { g_frozen_fused = on; }
+// 1: inside a run graph the next cycle's batches are gathered on a side branch while the current cycle steps
+// (measured: 67.5 us/step with the side branch vs 61.5 without -- a graph with parallel branches costs more in
+// cross-queue synchronisation than the 2.8 us/step of gather it hides; off)
+int g_cycle_fork = 0;
+extern "C" void recnn_tune_cycle_fork(int on) { g_cycle_fork = on; }
 // 1: the critic's weight-gradient GEMMs contract the whole batch per tile and finish the optimizer step (single GPU) or the
 // flat gradient arena (phase API / data parallel) in their epilogue (dwopt.hip: no slabs, no Adam launch, results identical
 // to "arena + apply_kernel" bit for bit); 0 (default): split-batch slabs + grad_reduce / slab-summing Adam launches.
@@ -993,7 +1023,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
-  if (g_split_fwd && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
+  if (g_split_fwd >= 2 && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
   bool chained = false;  // target critics computed inside the first fused launch
   bool fwd_did_bwd = false;  // ... and the critics' head + layer-2 backward too
   // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
@@ -1641,9 +1671,20 @@ bool cycle_ok(const recnn_engine* e, int rows) {
          !e->ext_noise && e->cfg.mask_mode != RECNN_MASK_EXTERNAL;   // (external masks / noise describe ONE batch)
 }
 
-// The batches of run steps run_off0 .. run_off0 + n - 1 (one gather launch) and the FROZEN networks on all n * rows rows:
+// The FROZEN networks on all n * rows rows of the cycle's batches (gathered by ph_gather_cycle into the current copy):
 // target actor -> next_action (+ TD3 noise) -> target critics -> Q', and the actor -> gen_action (+ its activations for the
 // policy step's backward).  recnn/nn/update/misc.py:28-31, td3.py:73-81 (target side), ddpg.py:66-69 / td3.py:104-110 (actor).
+void select_mbuf(recnn_engine* e, int b) {
+  e->m_xs = e->m_xs_b[b]; e->m_xn = e->m_xn_b[b]; e->m_reward = e->m_reward_b[b]; e->m_done = e->m_done_b[b];
+}
+// the batches of run steps run_off0 .. run_off0 + n - 1 into copy `b` of the cycle arrays: one launch
+int ph_gather_cycle(recnn_engine* e, int rows, int n, int run_off0, int b, hipStream_t s) {
+  GatherArgs g = gather_args(e, rows, 0, run_off0);
+  g.state_h = (bf16_t*)e->m_xs_b[b] + e->A; g.next_h = (bf16_t*)e->m_xn_b[b] + e->A; g.action_h = (bf16_t*)e->m_xs_b[b];
+  g.reward = e->m_reward_b[b]; g.done = e->m_done_b[b];
+  return slot(e, "frame_gather_cycle", 0, s, [&] { return frame_gather_multi_launch(g, n, s); });
+}
+
 int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_t s) {
   const int A = e->A, nc = e->n_critic;
   const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
@@ -1652,17 +1693,72 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
   const int64_t aoff = (int64_t)A * 2;
   const int M = n * rows;
   int rc;
-  {
-    GatherArgs g = gather_args(e, rows, 0, run_off0);
-    g.state_h = (bf16_t*)e->m_xs + A; g.next_h = (bf16_t*)e->m_xn + A; g.action_h = (bf16_t*)e->m_xs;
-    g.reward = e->m_reward; g.done = e->m_done;
-    if ((rc = slot(e, "frame_gather_cycle", 0, s, [&] { return frame_gather_multi_launch(g, n, s); }))) return rc;
-  }
   if (e->td3 && !e->ext_noise)
     for (int j = 0; j < n; ++j)
       if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->m_noise + (int64_t)j * rows * A, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, run_off0 + j, s); }))) return rc;
   const double l1_fl_a = 2.0 * M * (double)e->H * e->S, l1_fl_c = 2.0 * M * (double)e->H * (e->S + A);
   const double t_fl_a = 2.0 * M * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * M * ((double)e->H * e->H + e->H);
+  if (g_frozen_fused) {
+    auto fill = [&](FrozenProb* p, int ni, const void* A0, int K0, int col0, int mask_idx) {
+      const Net& n = e->net[ni];
+      memset(p, 0, sizeof(*p));
+      p->A[0] = A0; p->lda[0] = e->ldx; p->K[0] = K0; p->w1_col[0] = col0; p->nseg = 1;
+      p->W1 = sh_ptr(e, ni, W1); p->ldw1 = n.ld_w1;
+      p->W2 = sh_ptr(e, ni, W2); p->ldw2 = n.ld_w2;
+      if (!n.critic) { p->W3 = sh_ptr(e, ni, W3); p->ldw3 = n.ld_w3; }
+      p->b1 = n.p + n.off[B1]; p->b2 = n.p + n.off[B2]; p->b3 = n.p + n.off[B3];
+      p->w3row = n.critic ? n.p + n.off[W3] : nullptr;
+      p->rows = M; p->H = e->H; p->out_dim = n.out_dim;
+      p->mask_mode = RECNN_MASK_NONE;
+      if (mask_idx >= 0 && e->cfg.mask_mode == RECNN_MASK_HASH) {
+        p->mask_mode = RECNN_MASK_HASH;
+        p->seed = e->cfg.seed; p->stream1 = (uint32_t)mask_idx; p->stream2 = (uint32_t)mask_idx + 1;
+        p->step_ptr = e->counters; p->step_add = run_off0; p->rows_per_set = rows;
+      }
+      p->ldh = e->Hp;
+    };
+    // Two launches (the target critics need the target actor's output).  A launch is 128-row workgroups at ONE per CU, so what
+    // counts is how many rounds of 256 it takes: {target actor, actor} = 2 x 160 workgroups at 10 x 2048 rows = two rounds
+    // with the second three quarters empty.  The actor depends on nothing here, so its batches are dealt out over both
+    // launches to fill them: as many whole batches next to the target actor as fit the first round, the rest next to the
+    // target critics (DDPG, 10 x 2048 rows: 160 + 96 and 160 + 64 workgroups = two full rounds instead of three).
+    const int wg_set = (rows + 127) / 128;                            // workgroups per batch (batches start on panel boundaries
+    int sets_a = n;                                                   //  when rows is a multiple of 128: else no dealing)
+    if (rows % 128 == 0) {
+      const int cus = 256;
+      const int free1 = ((n * wg_set + cus - 1) / cus) * cus - n * wg_set;   // idle slots of the target actor's last round
+      sets_a = free1 / wg_set;
+      if (sets_a > n) sets_a = n;
+      if (sets_a < 0) sets_a = 0;
+    }
+    auto actor_part = [&](FrozenProb* p, int set0, int nsets) {      // the actor on batches set0 .. set0 + nsets - 1
+      const int64_t r0 = (int64_t)set0 * rows;
+      fill(p, POL, e->m_xs + r0 * e->ldx * 2 + aoff, e->K1a, 0, actor_m1);
+      p->rows = nsets * rows;
+      p->step_add = run_off0 + set0;
+      p->h1 = e->m_pa_h1 + r0 * e->Hp * 2; p->h2 = e->m_pa_h2 + r0 * e->Hp * 2;
+      p->out = e->m_ga + r0 * e->Ap * 2; p->ldo = e->Ap;
+    };
+    FrozenBatch fb;
+    int np = 0;
+    fill(&fb.p[np], TPOL, e->m_xn + aoff, e->K1a, 0, -1);            // target actor on s' -> next_action into the rows' action slot
+    fb.p[np].out = e->m_xn; fb.p[np].ldo = e->ldx;
+    if (e->td3) { fb.p[np].addend = e->m_noise; fb.p[np].ld_add = A; fb.p[np].add_clip = e->hy.noise_clip; }
+    ++np;
+    if (sets_a > 0) actor_part(&fb.p[np++], 0, sets_a);              // actor on s -> gen_action, activations kept for the policy step
+    if ((rc = slot(e, "frozen_actors", l1_fl_a + t_fl_a + (l1_fl_a + t_fl_a) * sets_a / n, s, [&] { return mlpf_launch(fb, np, s); }))) return rc;
+    FrozenBatch fc;
+    int nq = 0;
+    for (int c = 0; c < nc; ++c) {                                  // target critics on [s' | next_action]: state part first
+      fill(&fc.p[nq], TVAL[c], e->m_xn + aoff, e->K1a, A, -1);
+      fc.p[nq].A[1] = e->m_xn; fc.p[nq].lda[1] = e->ldx; fc.p[nq].K[1] = e->Ap; fc.p[nq].w1_col[1] = 0; fc.p[nq].nseg = 2;
+      fc.p[nq].q = e->m_tq[c];
+      ++nq;
+    }
+    if (sets_a < n) actor_part(&fc.p[nq++], sets_a, n - sets_a);
+    return slot(e, "frozen_target_critics", nc * (l1_fl_c + t_fl_c) + (l1_fl_a + t_fl_a) * (n - sets_a) / n, s, [&] { return mlpf_launch(fc, nq, s); });
+  }
+
   {
     L1Batch lb;
     fill_l1(e, &lb.p[0], TPOL, M, e->m_xn + aoff, e->ldx, e->K1a, 0, e->m_tp_h1, -1, run_off0);
@@ -1976,6 +2072,13 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   const bool look = lookahead_ok(e) && len > 1;
   hipGraph_t graph = nullptr;
   int rc = 0;
+  if (!e->side && g_cycle_fork) {   // the side branch of cycle mode (created outside the capture)
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); e->side = nullptr; }
+    for (int i = 0; e->side && i < recnn_engine::EV_POOL; ++i)
+      if (hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipStreamDestroy(e->side); e->side = nullptr;
+      }
+  }
   RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   e->use_sampler = e->has_sampler;
   int n_pol = 0;
@@ -1988,31 +2091,63 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     rc = opt_table(e, len, polv, s);
     e->scal_on = rc == 0;
   }
-  const bool cyc = !rc && len > 1 && cycle_ok(e, rows);
+  const bool cyc = !rc && len > 1 && (g_split_fwd >= 2 || len >= g_cycle_min_len) && cycle_ok(e, rows);
   auto is_pol = [&](int i) { return phase >= 0 && ((phase + i) % pe) == 0; };
-  for (int i0 = 0; cyc && i0 < len && !rc;) {
-    // segment = the steps up to and including the next policy step (the frozen networks change right after it)
-    int i1 = i0;
-    while (i1 + 1 < len && !is_pol(i1) && i1 - i0 + 1 < recnn_engine::MSET_MAX) ++i1;
-    const int n = i1 - i0 + 1;
-    e->run_off = i0;
-    rc = ph_frozen_batched(e, rows, n, i0, s);
-    for (int i = i0; i <= i1 && !rc; ++i) {
-      const bool pol = is_pol(i);
-      use_mset(e, i - i0, rows);
-      e->run_off = i;
-      use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
-      e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
-      for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
-      e->run_skip_finish = i + 1 < len;
-      if (pol) ++n_pol;
-      e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
-      // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
-      // then: not across a segment boundary, where the next cycle's gather refills the arrays)
-      const bool defer = g_defer_policy_fwd && i < i1;
-      rc = step_impl(e, rows, true, pol, s, true, false, defer, true);
+  if (cyc) {
+    // segments = the steps up to and including the next policy step (the frozen networks change right after it)
+    int seg0[OPT_TABLE_STEPS + 1], seg1[OPT_TABLE_STEPS + 1], nseg = 0;
+    for (int i0 = 0; i0 < len;) {
+      int i1 = i0;
+      while (i1 + 1 < len && !is_pol(i1) && i1 - i0 + 1 < recnn_engine::MSET_MAX) ++i1;
+      seg0[nseg] = i0; seg1[nseg] = i1; ++nseg;
+      i0 = i1 + 1;
     }
-    i0 = i1 + 1;
+    // the next segment's batches depend on nothing but the sampler cursor: they are gathered on a side branch of the graph,
+    // into the other copy of the cycle arrays, while this segment steps (the gather is a latency chain with little
+    // bandwidth or ALU demand; the per-step launches leave half of every CU's wave slots free)
+    const bool fork = g_cycle_fork && nseg > 1;
+    const bool side_ok = fork && e->side != nullptr && 2 * (nseg - 1) <= recnn_engine::EV_POOL;
+    int evi = 0;
+    rc = ph_gather_cycle(e, rows, seg1[0] - seg0[0] + 1, seg0[0], 0, s);
+    for (int k = 0; k < nseg && !rc; ++k) {
+      const int i0 = seg0[k], i1 = seg1[k], n = i1 - i0 + 1, buf = k & 1;
+      hipEvent_t joined = nullptr;
+      if (k + 1 < nseg) {
+        const int n_next = seg1[k + 1] - seg0[k + 1] + 1;
+        if (side_ok) {
+          hipEvent_t forked = e->ev_pool[evi++];
+          joined = e->ev_pool[evi++];
+          rc = recnn_check_hip(hipEventRecord(forked, s), "cycle fork");
+          if (!rc) rc = recnn_check_hip(hipStreamWaitEvent(e->side, forked, 0), "cycle fork wait");
+          if (!rc) rc = ph_gather_cycle(e, rows, n_next, seg0[k + 1], buf ^ 1, e->side);
+          if (!rc) rc = recnn_check_hip(hipEventRecord(joined, e->side), "cycle join");
+          if (rc) break;
+        }
+      }
+      select_mbuf(e, buf);
+      e->run_off = i0;
+      rc = ph_frozen_batched(e, rows, n, i0, s);
+      for (int i = i0; i <= i1 && !rc; ++i) {
+        const bool pol = is_pol(i);
+        use_mset(e, i - i0, rows);
+        e->run_off = i;
+        use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
+        e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
+        for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
+        e->run_skip_finish = i + 1 < len;
+        if (pol) ++n_pol;
+        e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
+        // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
+        // then: not across a segment boundary)
+        const bool defer = g_defer_policy_fwd && i < i1;
+        rc = step_impl(e, rows, true, pol, s, true, false, defer, true);
+      }
+      if (!rc && k + 1 < nseg) {
+        if (joined) rc = recnn_check_hip(hipStreamWaitEvent(s, joined, 0), "cycle join wait");
+        else rc = ph_gather_cycle(e, rows, seg1[k + 1] - seg0[k + 1] + 1, seg0[k + 1], buf ^ 1, s);
+      }
+    }
+    select_mbuf(e, 0);
   }
   if (cyc) leave_mset(e);
   for (int i = 0; !cyc && i < len && !rc; ++i) {

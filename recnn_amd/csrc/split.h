@@ -102,3 +102,35 @@ int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s);
 // q[m] = h2[m, :] . w3 + b3 for bf16 h2 [rows, ldh]: the critic head of mlp_tail_kernel as its own launch (one wave per row,
 // the same lane -> column map and reduction tree, so the same bits), behind a cycle-batched layer-2 GEMM
 int qdot_launch(const void* h2, int64_t ldh, const float* w3row, const float* b3, int H, int rows, float* q, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------- frozen networks, cycle-wide
+// One whole network (all three layers) on 128-row panels of M = cycle x rows rows (mlpf.hip): the target actor, the target
+// critics on its output, the actor between its optimizer steps.
+struct FrozenProb {
+  const void* A[2];               // layer-1 input: up to two k-contiguous bf16 segments, contracted in order
+  int64_t lda[2];
+  int K[2];                       // multiples of 64
+  int w1_col[2];
+  int nseg;
+  const void* W1; int64_t ldw1;
+  const void* W2; int64_t ldw2;
+  const void* W3; int64_t ldw3;   // actor (NULL: critic)
+  const float* b1;
+  const float* b2;
+  const float* b3;
+  const float* w3row;             // critic
+  int rows, H, out_dim;
+  int mask_mode;                  // RECNN_MASK_NONE | RECNN_MASK_HASH
+  uint32_t seed, stream1, stream2;
+  const int32_t* step_ptr;
+  int step_add;
+  int rows_per_set;               // batches of this many rows (a multiple of 32): batch j uses mask step + j
+  void* h1; void* h2; int64_t ldh;   // optional bf16 [rows, ldh] (the actor's activations, for the policy step's backward)
+  void* out; int64_t ldo;         // actor output, bf16
+  const float* addend; int64_t ld_add; float add_clip;
+  float* q;                       // critic output, fp32 [rows] (b3 included)
+};
+constexpr int FROZEN_MAX_GROUP = 4;
+struct FrozenBatch { FrozenProb p[FROZEN_MAX_GROUP]; };
+int mlpf_init();
+int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s);

@@ -211,12 +211,17 @@ def test_broken_handoff_is_reported(cuda, fault):
     good = eng.losses()
     assert np.isfinite(good["value"])
     try:
+        # (the hand-offs belong to the fused row-panel forward: a suite run with RECNN_SPLIT_FWD=2 evaluates eager steps with
+        # the split forward, which has none -- this test is about csrc/mlps.hip)
+        L.load().recnn_tune_split_fwd(1)
         L.load().recnn_tune_mlp_fault(fault)
         eng.step(B, False, 1)
         with pytest.raises(L.RecnnHipError, match="hand-off timed out"):
             eng.losses()
     finally:
         L.load().recnn_tune_mlp_fault(0)
+        from recnn_amd._tune import apply_env_knobs
+        apply_env_knobs()
     eng.step(B, False, 1)
     again = eng.losses()                                   # the error word was cleared, flags and slots are at rest
     assert again["value"] == good["value"] and again["policy"] == good["policy"]

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 T=${1:-r03d}
 mkdir -p gpurun_out
-RECNN_SPLIT_FWD=1 timeout 900 python -m pytest tests/test_gpu_bench_shape.py tests/test_gpu_api.py tests/test_gpu_split.py -m gpu -q -x 2>&1 | tail -30 > gpurun_out/${T}_tests.log
+RECNN_SPLIT_FWD=2 timeout 900 python -m pytest tests/test_gpu_bench_shape.py tests/test_gpu_api.py tests/test_gpu_split.py -m gpu -q -x 2>&1 | tail -30 > gpurun_out/${T}_tests.log
 tail -12 gpurun_out/${T}_tests.log
 for v in 1 0 1; do
   RECNN_SPLIT_FWD=$v timeout 300 python bench.py --steps 2000 --warmup 200 --repeats 3 --no-cpu-baseline --no-traffic > gpurun_out/${T}_split$v.json 2>gpurun_out/${T}_split$v.err
@@ -17,7 +17,7 @@ except Exception as ex:
 PY
 done
 cd /tmp
-RECNN_SPLIT_FWD=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2000 --warmup 200 --repeats 1 --no-cpu-baseline --no-traffic > /dev/null 2>&1
+RECNN_SPLIT_FWD=2 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2000 --warmup 200 --repeats 1 --no-cpu-baseline --no-traffic > /dev/null 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/${T}_kernel_stats.csv 2>/dev/null
 python - <<PY

@@ -16,7 +16,7 @@ def mk(inp, out):
     return {"w1": torch.randn(H, inp) * 0.03, "b1": torch.randn(H) * 0.1, "w2": torch.randn(H, H) * 0.06, "b2": torch.randn(H) * 0.1,
             "w3": torch.randn(out, H) * 0.3, "b3": torch.randn(out) * 0.3}
 actor, critic = mk(S, A), mk(S + A, 1)
-L.load().recnn_tune_split_fwd(1)
+L.load().recnn_tune_split_fwd(2)
 eng = StepEngine("ddpg", S, A, H, B, dtype="bf16", mask_mode="hash", seed=1, device=dev)
 for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
     eng.load_params(ni, p)
