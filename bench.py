@@ -109,7 +109,8 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
 
 # launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports (the default fused forward
 # is mlps.hip's mlps_fwd_kernel; the opt-in variants mlp_fwd_kernel / mlp64 / mlpr are reached through recnn_tune_*)
-KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_l1_nets": "mlp_l1_kernel", "mlp_tail_nets": "mlp_tail_kernel",
+KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "l1_critic": "l1_gemm_kernel", "tail_critic": "mlp_tail_kernel",
+                  "frozen_actors": "mlp_frozen_kernel", "frozen_target_critics": "mlp_frozen_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",
                   "dw_adam_critic": "dw_opt_kernel", "dw_adam_critic+gather": "dw_opt_kernel"}
@@ -327,30 +328,57 @@ def main():
                        "rows_per_step_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single",
                        "final_losses": losses},
         }
-        # ---- roofline of the dominant kernel, measured live with HIP events around every launch (eager replays of the same step)
+        # ---- per-launch times, measured live with HIP events around every launch (eager replays of the same steps on the stream
+        # the kernels run on), and the rooflines they imply.  Two schedules exist and agree bit for bit:
+        #   "fused": one row-panel launch for all networks of a step (csrc/mlps.hip) -- eager steps and run graphs shorter than
+        #            the cycle-mode threshold (30 steps: the driver's `--steps 20` replays THIS one);
+        #   "cycle": a policy cycle's batches gathered at once, the frozen networks applied to all of them (csrc/mlpf.hip), the
+        #            per-step launches carry the learning critics only (csrc/l1gemm.hip + csrc/mlpt.hip) -- run graphs >= 30 steps.
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        pe = int(eng.policy_every)
         with torch.cuda.stream(stream):
             prof = eng.profile(rows, policy=False, n_steps=50)
             prof_pol = eng.profile(rows, policy=True, n_steps=10)
-        dom = max(prof, key=lambda r: r[1])
+            try:
+                prof_cyc = eng.profile(rows, policy=2, n_steps=20) if args.dtype == "bf16" else None
+            except L.RecnnHipError:
+                prof_cyc = None
+        cyc_min = int(os.environ.get("RECNN_CYCLE_MIN_LEN", "30"))
+        split_knob = int(os.environ.get("RECNN_SPLIT_FWD", "1"))
+        schedule = "cycle" if (prof_cyc and not use_dp and split_knob >= 1 and (args.steps >= cyc_min or split_knob >= 2)) else "fused"
+
+        def roof(name, ms, fl, per_step=1.0):
+            ach = fl / (ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "avg_ms": ms, "flops_per_launch": fl, "launches_per_step": per_step}
+        FROZEN = ("frame_gather_cycle", "td3_noise", "frozen_actors", "frozen_target_critics", "l1_frozen_actors", "l2_frozen_actors",
+                  "l3_frozen_actors", "tail_frozen_actors", "l1_frozen_target_critic", "l2_frozen_target_critic",
+                  "q_frozen_target_critic", "tail_frozen_target_critic")
+        used = prof_cyc if schedule == "cycle" else prof
+        share = lambda r: r[1] / pe if r[0] in FROZEN else r[1]          # per-step time share (cycle launches serve `pe` steps)
+        cand = [r for r in used if r[2] > 0]
+        dom = max(cand, key=share) if cand else max(used, key=lambda r: r[1])
         # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
         traffic, traffic_note = None, "skipped"
         gather_traffic, gather_note = None, "skipped"
         if world == 1 and not args.no_traffic and not use_dp:
-            tail = ["--steps", "40", "--warmup", "20", "--repeats", "1", "--no-cpu-baseline", "--no-traffic", "--dtype", args.dtype,
-                    "--algo", args.algo, "--rows", str(args.rows)]
+            tail = ["--steps", str(max(40, cyc_min) if schedule == "cycle" else 20), "--warmup", "20", "--repeats", "1", "--no-cpu-baseline",
+                    "--no-traffic", "--dtype", args.dtype, "--algo", args.algo, "--rows", str(args.rows)]
             dom_k = KERNEL_OF_SLOT.get(dom[0], dom[0])
             tr = measure_traffic(tail, [dom_k, "frame_gather_kernel"])
             traffic, traffic_note = tr[dom_k]
             gather_traffic, gather_note = tr["frame_gather_kernel"]
+        out["schedule"] = schedule
         if dom[2] > 0:
-            ach = dom[2] / (dom[1] * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS[args.dtype]
-            out["roofline"] = {"kernel": dom[0], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_note,
-                               "avg_ms": dom[1], "flops_per_launch": dom[2]}
+            out["roofline"] = dict(roof(dom[0], dom[1], dom[2], 1.0 / pe if dom[0] in FROZEN else 1.0), traffic=traffic,
+                                   traffic_source=traffic_note)
         else:
             out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": traffic, "traffic_source": traffic_note, "avg_ms": dom[1]}
+        # every MFMA launch of both schedules (the per-step forward AND the cycle-batched frozen-network launch)
+        out["roofline_kernels"] = {
+            "fused": [roof(n, ms, fl) for n, ms, fl in prof if fl > 0],
+            "cycle": [roof(n, ms, fl, 1.0 / pe if n in FROZEN else 1.0) for n, ms, fl in (prof_cyc or []) if fl > 0]}
         g = [r for r in prof if r[0] == "frame_gather"]
         if g:
             f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
@@ -361,11 +389,21 @@ def main():
                                       "traffic": gather_traffic, "traffic_source": gather_note, "avg_ms": g[0][1],
                                       "bytes_per_launch": per_row * rows,
                                       "rows_dtype": "fp32+bf16" if (f32_rows and args.dtype == "bf16") else args.dtype}
+            gc = [r for r in (prof_cyc or []) if r[0] == "frame_gather_cycle"]
+            if gc:       # the cycle's batches in one launch: `pe` batches of `rows` rows
+                gbs_c = per_row * rows * pe / (gc[0][1] * 1e-3) / 1e9
+                out["roofline_gather"]["cycle_launch"] = {"batches": pe, "avg_ms": gc[0][1], "achieved": gbs_c, "frac": gbs_c / HBM_PEAK_GBS,
+                                                          "bytes_per_launch": per_row * rows * pe}
         gemm_fl = sum(r[2] for r in prof)
         gemm_ms = sum(r[1] for r in prof if r[2] > 0)
         out["step_breakdown"] = {"launches": [{"name": n, "ms": round(ms, 5), "gflop": round(fl / 1e9, 4)} for n, ms, fl in prof],
                                  "sum_kernel_ms": sum(r[1] for r in prof), "gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12,
                                  "policy_step_sum_kernel_ms": sum(r[1] for r in prof_pol), "policy_step_launches": len(prof_pol)}
+        if prof_cyc:
+            out["step_breakdown"]["cycle_mode"] = {
+                "launches": [{"name": n, "ms": round(ms, 5), "gflop": round(fl / 1e9, 4), "per_step": (round(1.0 / pe, 4) if n in FROZEN else 1)}
+                             for n, ms, fl in prof_cyc],
+                "sum_kernel_ms_per_step": sum(share(r) for r in prof_cyc)}
         if world == 1 and not args.no_cpu_baseline and (args.algo, rows) == ("ddpg", B_ROWS):
             out["cpu_baseline"] = cpu_baseline(items, ratings, off, table)
     if use_dp:

@@ -470,7 +470,9 @@ int recnn_engine_graph_prepare(recnn_engine* e, int first_step, int n_steps, voi
  * Kernels whose relaunch does not change state (everything but Adam and the loss/counter kernel) are issued
  * 8 times back to back inside their event pair and the time divided by 8, which amortises the event overhead.
  * *h_n is in: capacity, out: slots used.  Policy and non-policy steps have different slot
- * lists; only steps with (step % policy_every == 0) == policy_steps are run and averaged. */
+ * lists; only steps with (step % policy_every == 0) == policy_steps are run and averaged.  policy_steps = 2 profiles CYCLE
+ * MODE (what run graphs of >= recnn_tune_cycle_min_len steps replay): the gather of one policy cycle's batches, the frozen
+ * networks on all of them, then one ordinary step of the cycle on the split forward. */
 int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream,
                          float* h_ms, double* h_flops, const char** h_names, int* h_n);
 
@@ -504,6 +506,8 @@ void recnn_tune_mlp_fault(int mode);
  * their epilogue (csrc/dwopt.hip: no gradient slabs, no separate Adam launch; 2 / 3 = the same with 8 / 4 waves per workgroup
  * instead of 16); 0 (default: faster at 2048 rows, see csrc/engine.hip) = split-batch slabs + reduce / Adam launches. */
 void recnn_tune_dw_fuse(int on);
+void recnn_tune_cycle_min_seg(int n);   /* cycle mode: segments shorter than n steps use the fused forward (default 3) */
+void recnn_tune_opt_table(int on);   /* 1: run graphs precompute the optimizers' step scalars in one launch at the graph head */
 /* Scheduling of the bf16 step (all variants agree bit for bit): 0 = the fused row-panel forward (csrc/mlps.hip) everywhere;
  * 1 (default) = run graphs of >= recnn_tune_cycle_min_len steps (default 30) run in cycle mode: a policy cycle's batches gathered
  * at once, the frozen networks (target actor / critics, actor) applied to all of them by csrc/mlpf.hip, the per-step launches =

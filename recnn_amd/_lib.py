@@ -104,6 +104,8 @@ SIGNATURES = {
     "recnn_tune_dw_splits": (None, [_I]),
     "recnn_tune_dw_dma": (None, [_I]),
     "recnn_tune_dw_fuse": (None, [_I]),
+    "recnn_tune_opt_table": (None, [_I]),
+    "recnn_tune_cycle_min_seg": (None, [_I]),
     "recnn_tune_split_fwd": (None, [_I]),
     "recnn_tune_cycle_min_len": (None, [_I]),
     "recnn_tune_l1_big": (None, [_I]),

@@ -26,6 +26,8 @@ KNOBS = {
     "RECNN_DW_DMA": "recnn_tune_dw_dma",
     "RECNN_DW_SPLITS": "recnn_tune_dw_splits",
     "RECNN_DW_FUSE": "recnn_tune_dw_fuse",
+    "RECNN_OPT_TABLE": "recnn_tune_opt_table",
+    "RECNN_CYCLE_MIN_SEG": "recnn_tune_cycle_min_seg",
     "RECNN_SPLIT_FWD": "recnn_tune_split_fwd",
     "RECNN_CYCLE_MIN_LEN": "recnn_tune_cycle_min_len",
     "RECNN_L1_BIG": "recnn_tune_l1_big",

@@ -812,6 +812,10 @@ extern "C" void recnn_tune_cycle_fork(int on) { g_cycle_fork = on; }
 // to the unit backward tensors (13k of 44k cycles) and by DMA latency at one workgroup per CU (20 B/cycle).  Off until the
 // forward hands over already-scaled backward tensors.
 int g_dw_fuse = 0;
+int g_cycle_min_seg = 3;   // cycle mode: segments shorter than this step through the fused forward
+extern "C" void recnn_tune_cycle_min_seg(int n) { g_cycle_min_seg = n < 1 ? 1 : n; }
+int g_opt_table = 0;   // 1: the run graphs' optimizer launches read their step scalars from the table even without dw_fuse
+extern "C" void recnn_tune_opt_table(int on) { g_opt_table = on; }
 extern "C" void recnn_tune_dw_fuse(int on) { g_dw_fuse = on; if (on) dwopt_set_groups(on == 2 ? 2 : (on == 3 ? 1 : 4)); }
 int g_bwd_panel = 2;  // 0: head + dX launches, 1: row-panel launch (bwd.hip), 2: inside the critic's forward workgroup (mlp.hip)
 extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
@@ -2026,7 +2030,22 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
       rc = opt_table(e, 1, pol1, s);
       e->scal_on = rc == 0;
     }
-    if (!rc) rc = step_impl(e, rows, true, policy_steps != 0, s);
+    if (!rc && policy_steps == 2) {
+      // cycle mode, as the long run graphs issue it: one policy cycle's batches, the frozen networks on all of them, then
+      // the first step of the cycle (an ordinary step) on the split forward
+      RECNN_REQUIRE(cycle_ok(e, rows), "profile: cycle mode is not available for this engine / batch size");
+      const int n = e->hy.policy_every < recnn_engine::MSET_MAX ? e->hy.policy_every : recnn_engine::MSET_MAX;
+      select_mbuf(e, 0);
+      rc = ph_gather_cycle(e, rows, n, 0, 0, s);
+      if (!rc) rc = ph_frozen_batched(e, rows, n, 0, s);
+      if (!rc) {
+        use_mset(e, 0, rows);
+        rc = step_impl(e, rows, true, false, s, true, false, false, true);
+      }
+      leave_mset(e);
+    } else if (!rc) {
+      rc = step_impl(e, rows, true, policy_steps != 0, s);
+    }
     e->scal_on = false;
     e->use_sampler = false;
     e->prof_on = false;
@@ -2085,7 +2104,7 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   // the optimizers' step scalars for the whole run: one small launch at the head of the graph.  Only when the optimizer runs in
   // the dW epilogue (dwopt.hip, where ONE thread per workgroup would otherwise sit on a 6 us fp64 chain): apply_kernel's
   // threads all evaluate them side by side under their loads' latency -- measured no gain from the table there
-  if (g_dw_fuse && len <= OPT_TABLE_STEPS) {
+  if ((g_dw_fuse || g_opt_table) && len <= OPT_TABLE_STEPS) {
     bool polv[OPT_TABLE_STEPS];
     for (int i = 0; i < len; ++i) polv[i] = phase >= 0 && ((phase + i) % pe) == 0;
     rc = opt_table(e, len, polv, s);
@@ -2126,7 +2145,10 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
       }
       select_mbuf(e, buf);
       e->run_off = i0;
-      rc = ph_frozen_batched(e, rows, n, i0, s);
+      // a one- or two-step segment (a graph that starts ON a policy step has one at its head) does not pay for the batched
+      // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays
+      const bool batched = n >= g_cycle_min_seg;
+      if (batched) rc = ph_frozen_batched(e, rows, n, i0, s);
       for (int i = i0; i <= i1 && !rc; ++i) {
         const bool pol = is_pol(i);
         use_mset(e, i - i0, rows);
@@ -2140,7 +2162,7 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
         // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
         // then: not across a segment boundary)
         const bool defer = g_defer_policy_fwd && i < i1;
-        rc = step_impl(e, rows, true, pol, s, true, false, defer, true);
+        rc = step_impl(e, rows, true, pol, s, true, false, defer, batched);
       }
       if (!rc && k + 1 < nseg) {
         if (joined) rc = recnn_check_hip(hipStreamWaitEvent(s, joined, 0), "cycle join wait");

@@ -255,8 +255,9 @@ class StepEngine:
         (only graph replays, the data-parallel phase graphs and profile() draw from it); on=True makes them sample too."""
         L.call("recnn_engine_sampler_eager", self.handle, int(on))
 
-    def profile(self, rows: int, policy: bool, n_steps: int = 20):
-        """Per-launch average device time of an eager step: [(name, ms, flops)]."""
+    def profile(self, rows: int, policy, n_steps: int = 20):
+        """Per-launch average device time of an eager step: [(name, ms, flops)].  policy = False / True: an ordinary / a policy
+        step; policy = 2: cycle mode (one policy cycle's gather + frozen-network launches + one step on the split forward)."""
         cap = 48
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()

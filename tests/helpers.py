@@ -29,3 +29,55 @@ def fro_err(a, b):
     a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a), dtype=torch.float64)
     b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(np.asarray(b), dtype=torch.float64)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---- measured-vs-asserted bookkeeping for the bf16 parity bounds ("bounds 30x looser than measured").  Every bf16
+# tolerance check goes through `within`: it asserts value <= bound AND records the largest value ever seen under that name in
+# gpurun_out/measured_bounds.json.  The bound of a bf16 quantity comes from BF16_BOUNDS below: 2.5x the value measured on an
+# MI355X (profiles/r03_measured_bounds.json is the recorder's file from that run), never above the round-2 constant;
+# tests/test_bounds_table.py checks table against file (every bound <= 3x its measured value).
+import json as _json
+import os as _os
+
+_BOUNDS_FILE = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gpurun_out", "measured_bounds.json")
+
+BF16_BOUNDS = {
+    "bench_shape/bf16/loss_curve_policy": 4.1e-03,   # measured 1.63e-03
+    "bench_shape/bf16/loss_curve_value": 5.7e-04,   # measured 2.27e-04
+    "ddpg_vs_oracle/bf16/clip_coef": 2.9e-04,   # measured 1.14e-04
+    "ddpg_vs_oracle/bf16/dact": 9.2e-03,   # measured 3.66e-03
+    "ddpg_vs_oracle/bf16/dz1": 6.8e-03,   # measured 2.71e-03
+    "ddpg_vs_oracle/bf16/dz2": 3.9e-03,   # measured 1.54e-03
+    "ddpg_vs_oracle/bf16/fwd/expected": 3.1e-03,   # measured 1.22e-03
+    "ddpg_vs_oracle/bf16/fwd/gen_action": 1.1e-02,   # measured 4.03e-03
+    "ddpg_vs_oracle/bf16/fwd/next_action": 1.2e-02,   # measured 4.47e-03
+    "ddpg_vs_oracle/bf16/fwd/q1": 1.0e-02,   # measured 3.98e-03
+    "ddpg_vs_oracle/bf16/fwd/target_q": 8.9e-03,   # measured 3.55e-03
+    "ddpg_vs_oracle/bf16/loss": 2.4e-02,   # measured 9.30e-03
+    "ddpg_vs_oracle/bf16/params/policy": 1.8e-02,   # measured 6.85e-03
+    "ddpg_vs_oracle/bf16/params/target_policy": 1.7e-05,   # measured 6.49e-06
+    "ddpg_vs_oracle/bf16/params/target_value": 4.5e-05,   # measured 1.77e-05
+    "ddpg_vs_oracle/bf16/params/value": 5.0e-02,   # measured 2.41e-02
+    "ddpg_vs_oracle/bf16/policy_grad": 1.3e-02,   # measured 5.15e-03
+    "ddpg_vs_oracle/bf16/value_grad": 9.0e-03,   # measured 3.57e-03
+    "td3_vs_oracle/bf16/loss": 6.7e-03,   # measured 2.64e-03
+    "td3_vs_oracle/bf16/params/policy": 5.0e-02,   # measured 2.62e-02
+    "td3_vs_oracle/bf16/params/target_policy": 1.0e-06,   # measured 0.00e+00
+    "td3_vs_oracle/bf16/params/target_value1": 4.5e-05,   # measured 1.79e-05
+    "td3_vs_oracle/bf16/params/value1": 5.0e-02,   # measured 2.15e-02
+    "td3_vs_oracle/bf16/params/value2": 5.0e-02,   # measured 2.15e-02
+}
+
+
+def within(name, value, bound=None):
+    value = float(value)
+    bound = float(BF16_BOUNDS.get(name, bound))
+    try:
+        _os.makedirs(_os.path.dirname(_BOUNDS_FILE), exist_ok=True)
+        rec = _json.load(open(_BOUNDS_FILE)) if _os.path.exists(_BOUNDS_FILE) else {}
+        old = rec.get(name, {"measured": 0.0})
+        rec[name] = {"measured": max(float(old["measured"]), value), "bound": bound}
+        _json.dump(rec, open(_BOUNDS_FILE, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert value <= bound, (name, value, bound)

@@ -17,22 +17,26 @@ import pytest
 import torch
 
 from oracle import recnn_oracle as O
+from tests.helpers import within
 
 pytestmark = pytest.mark.gpu
 
 ROWS, UPB, PE = 2048, 256, 10
 SEED = 4242
+# bf16 loss curve against the fp32 oracle over 65 steps: ceilings; the asserted bounds are tests.helpers.BF16_BOUNDS (2.5x measured)
+BF16_CURVE_VALUE = 8e-4
+BF16_CURVE_POLICY = 3e-3
 
 
-def _bench_env(recnn_amd, cuda, n_users, seed=3):
+def _bench_env(recnn_amd, cuda, n_users, seed=3, n_items=3000):
     rng = np.random.default_rng(seed)
     lens = rng.integers(20, 61, size=n_users).astype(np.int64)          # every user has >= 10 windows
     off = np.zeros(n_users + 1, dtype=np.int64)
     off[1:] = np.cumsum(lens)
     total = int(off[-1])
-    items = rng.integers(0, 3000, size=total, dtype=np.int32)
+    items = rng.integers(0, n_items, size=total, dtype=np.int32)
     ratings = (2.0 * (rng.integers(1, 11, size=total) * 0.5 - 2.5)).astype(np.float32)
-    table = torch.randn(3000, 128, generator=torch.Generator().manual_seed(seed))
+    table = torch.randn(n_items, 128, generator=torch.Generator().manual_seed(seed))
     env = recnn_amd.data.env.FrameEnv.from_store(table, items, ratings, off, frame_size=10, batch_size=25, device=cuda,
                                                  test_fraction=0.0, rows_per_batch=ROWS)
     return env, table
@@ -68,7 +72,8 @@ def _hash_masks(L, step, cuda):
 def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
     import recnn_amd
     from recnn_amd import _lib as L
-    env, table = _bench_env(recnn_amd, cuda, n_users=(n + 2) * UPB)
+    # bf16 (the benchmarked dtype) on a table of ML20M's size (26,744 items: bench.py's), fp32 on a 3,000-item one
+    env, table = _bench_env(recnn_amd, cuda, n_users=(n + 2) * UPB, n_items=26744 if dtype == "bf16" else 3000)
     results = {}
     for mode in ("one_call", "pieces", "prepared", "loop"):
         ddpg = _make_algo(recnn_amd, cuda, env, dtype)
@@ -158,7 +163,8 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
                 assert float((got - ref).norm() / ref.norm()) <= 1e-5, (net, k)      # tau = 1e-3 times the deviations above
     else:
         # bf16 compute (fp32 master weights / accumulation): measured, bounded, NOT claimed as 1e-4
-        assert worst["value"] <= 3e-2 and worst["policy"] <= 3e-2, worst
+        within("bench_shape/bf16/loss_curve_value", worst["value"], BF16_CURVE_VALUE)
+        within("bench_shape/bf16/loss_curve_policy", worst["policy"], BF16_CURVE_POLICY)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"bench_shape_parity_{dtype}.json"), "w") as f:
@@ -228,7 +234,7 @@ def test_td3_b4096_run_graphs_equal_pieces_and_update_loop(cuda):
     losses (value1, value2, policy) to summation order."""
     import recnn_amd
     from recnn_amd.nn import fused
-    rows, upb, n = 4096, 512, 45
+    rows, upb, n = 4096, 512, 65          # run(65) = a 60-step multi-cycle graph (cycle mode: frozen networks hoisted) + 5 steps
     env, _ = _bench_env(recnn_amd, cuda, n_users=(n + 2) * upb, seed=5)
     env.rows_per_batch = rows                  # (the helper builds a 2048-row env)
     names = ("policy_net", "value_net1", "value_net2", "target_policy_net", "target_value_net1", "target_value_net2")
@@ -272,6 +278,99 @@ def test_td3_b4096_run_graphs_equal_pieces_and_update_loop(cuda):
             for k in ("value1", "value2", "policy"):
                 assert abs(a[k] - b[k]) <= 1e-5 * max(abs(b[k]), 1.0), (other, k, a, b)
     assert all(np.isfinite(h[k]) for h in results["one_call"][0] for k in ("value1", "value2", "policy"))
+
+
+def test_td3_b4096_loss_curve_and_parameters_vs_oracle(cuda):
+    """BASELINE configs[2] against the CPU oracle (it was pinned for 2 steps only): TD3, 4096 rows, fp32, 200
+    steps of the reference-shaped loop `update(batch); step()` with hash dropout masks and on-device target noise, the oracle
+    (recnn/nn/update/td3.py:66-150 restated, pinned to the real reference by oracle/make_golden.py) driven with the same
+    batches, the dumped masks and the dumped noise draw of every step.  Every step's three losses within north_star's 1e-4;
+    final parameters of all six networks element-wise at rtol 1e-4 (Adam eps-regime elements excluded and counted, as in the
+    DDPG test above), nothing further than 20 lr, Frobenius <= 1e-4."""
+    import recnn_amd
+    from recnn_amd import _lib as L
+    from recnn_amd.nn import fused
+    rows, upb, n = 4096, 512, 200
+    env, _ = _bench_env(recnn_amd, cuda, n_users=(n + 2) * upb, seed=7)
+    env.rows_per_batch = rows
+    fused.set_defaults(dtype="fp32", mask_mode="hash", seed=SEED)
+    torch.manual_seed(23)
+    td3 = recnn_amd.nn.TD3(recnn_amd.nn.Actor(1290, 128, 256, 6e-1), recnn_amd.nn.Critic(1290, 128, 256, 54e-2),
+                           recnn_amd.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+    torch.manual_seed(78)
+    td3.attach_env(env, rows_per_batch=rows, users_per_batch=upb)
+    ctx = td3._fused_ctx
+    eng = ctx.engine
+    assert eng.dtype == "fp32" and ctx.sampler["n_batches"] >= n
+    lr, wd = 1e-5, 1e-2
+    for k in ("policy_optimizer", "value_optimizer1", "value_optimizer2"):
+        g = td3.optimizers[k].param_groups[0]
+        assert abs(g["lr"] - lr) < 1e-12 and abs(g["weight_decay"] - wd) < 1e-12
+    ost = O.TD3State.create(O.params_from_module(td3.nets["policy_net"]), O.params_from_module(td3.nets["value_net1"]),
+                            O.params_from_module(td3.nets["value_net2"]), O.AdamState(lr=lr, weight_decay=wd),
+                            O.AdamState(lr=lr, weight_decay=wd), O.AdamState(lr=lr, weight_decay=wd))
+    for k in ("gamma", "noise_std", "noise_clip", "soft_tau", "policy_update"):
+        ost.params[k] = td3.params[k]
+
+    def masks_of(step):
+        out = []
+        for stream in range(8):
+            m = torch.zeros(rows, 256, dtype=torch.uint8, device=cuda)
+            L.call("recnn_hash_mask_dump", SEED, int(step), stream, rows, 256, L.ptr(m), L.current_stream())
+            out.append(m)
+        torch.cuda.synchronize()
+        return [m.cpu() for m in out]
+
+    perm = ctx.perm.cpu().numpy()
+    worst = {"value1": 0.0, "value2": 0.0, "policy": 0.0}
+    for i in range(n):
+        batch = env.collate_users([int(u) for u in perm[i * upb:(i + 1) * upb]])
+        assert batch["state"].shape[0] == rows
+        got = td3.update(batch, learn=True)
+        noise = eng.buffer("noise", rows).cpu()                # this step's unclipped N(0, noise_std) draw (on-device generator)
+        ref = O.td3_step(ost, {k: batch[k].float().cpu() for k in ("state", "action", "reward", "next_state", "done")}, noise,
+                         masks_of(i), step=i, learn=True)
+        for k in worst:
+            worst[k] = max(worst[k], abs(got[k] - ref[k]) / (abs(ref[k]) + 1e-6))
+        td3.step()
+    assert float(noise.std()) > 0.3 and float(noise.abs().max()) < 6.0         # a real Gaussian draw went through the oracle
+    report = {"algo": "td3", "rows": rows, "dtype": "fp32", "steps": n, "worst_rel_loss_dev": worst}
+    for k in worst:
+        assert worst[k] <= 1e-4, worst
+    excluded = failed = total = 0
+    max_dev = fro = 0.0
+    names = ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "linear3.weight", "linear3.bias")
+    for net, refp, opt in (("policy_net", ost.policy, ost.policy_opt), ("value_net1", ost.value1, ost.value_opt1),
+                           ("value_net2", ost.value2, ost.value_opt2)):
+        sd = td3.nets[net].state_dict()
+        for k, name in zip(O.PARAM_ORDER, names):
+            gotp, refk = sd[name].float().cpu(), refp[k]
+            vhat = (opt.v[k] / (1.0 - opt.beta2 ** opt.t)).sqrt()
+            eps_regime = vhat < 1e3 * opt.eps
+            dev = (gotp - refk).abs()
+            bad = dev > 1e-4 * refk.abs() + 1e-4 * refk.pow(2).mean().sqrt()
+            excluded += int(eps_regime.sum())
+            failed += int((bad & ~eps_regime).sum())
+            total += refk.numel()
+            max_dev = max(max_dev, float(dev.max()))
+            fro = max(fro, float((gotp - refk).norm() / refk.norm()))
+    report.update(param_elements=total, eps_regime_excluded=excluded, outside_rtol_1e4=failed, max_abs_dev=max_dev,
+                  max_abs_dev_in_lr=max_dev / lr, worst_frobenius=fro)
+    assert failed <= 0.01 * total, report
+    assert excluded <= 0.05 * total, report
+    assert max_dev <= 20 * lr, report
+    assert fro <= 1e-4, report
+    for net, refp in (("target_policy_net", ost.target_policy), ("target_value_net1", ost.target_value1),
+                      ("target_value_net2", ost.target_value2)):
+        sd = td3.nets[net].state_dict()
+        for k, name in zip(O.PARAM_ORDER, names):
+            gotp, refk = sd[name].float().cpu(), refp[k]
+            assert float((gotp - refk).norm() / refk.norm()) <= 1e-5, (net, k)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "bench_shape_parity_td3_fp32.json"), "w") as f:
+        json.dump(report, f)
+    print("TD3 bench-shape parity:", json.dumps(report))
 
 
 def test_run_on_a_caller_owned_stream_equals_run_from_the_default_stream(cuda):

@@ -24,10 +24,18 @@ import pytest
 import torch
 
 from oracle import recnn_oracle as O
-from tests.helpers import fro_err, rel_err
+from tests.helpers import fro_err, rel_err, within
 
 pytestmark = pytest.mark.gpu
 FP32_RTOL = 1e-4
+# bf16 compute (fp32 master weights and accumulation) against the fp32 oracle.  The constants below are ceilings only: the bound
+# that is asserted comes per quantity from tests.helpers.BF16_BOUNDS (2.5x the value measured on MI355X,
+# profiles/r03_measured_bounds.json) -- a 3x regression fails, which these round-2 constants would have passed
+BF16_FWD = 3e-2
+BF16_LOSS = 3e-2
+BF16_GRAD = 4e-2
+BF16_COEF = 2e-2
+BF16_PARAM = 5e-2
 
 
 def _engine(algo, S, A, H, B, dtype, mask_mode="external", seed=0):
@@ -183,7 +191,7 @@ def test_ddpg_vs_oracle(cuda, dtype, B):
     eng.set_hyper(policy_opt=dict(lr=1e-3, weight_decay=1e-2), value_opt=dict(lr=1e-3))
     eng.set_counters()
     fp32 = dtype == "fp32"
-    tol = FP32_RTOL if fp32 else 3e-2
+    tol = FP32_RTOL if fp32 else BF16_FWD
     for t in range(steps):
         masks = [(torch.rand(B, H, generator=gen) < 0.5).to(torch.uint8) for _ in range(6)]
         b = batches[t % 2]
@@ -200,33 +208,34 @@ def test_ddpg_vs_oracle(cuda, dtype, B):
             # ---- forward, kernel by kernel
             for name, key in (("next_action", "next_action"), ("target_q", "target_value"), ("expected", "expected"),
                               ("q1", "value"), ("gen_action", "gen_action")):
-                assert rel_err(eng.buffer(name, B), trace[key]) < tol, name
+                within(f"ddpg_vs_oracle/{dtype}/fwd/{name}", rel_err(eng.buffer(name, B), trace[key]), tol)
             # ---- critic backward on the GPU's own activations (same relu/dropout gates)
             x = torch.cat([b["state"], b["action"]], 1)
             cache = (x, eng.buffer("critic1_h1", B).cpu(), eng.buffer("critic1_h2", B).cpu())
             dq = (eng.buffer("q1", B).cpu() - eng.buffer("expected", B).cpu()) * (2.0 / B)
             gv, _, inter = O.mlp_backward(critic, cache, dq, train=True)
-            gtol = FP32_RTOL if fp32 else 4e-2
-            assert (rel_err if fp32 else fro_err)(eng.buffer("critic1_dz2", B), inter["dz2"]) < gtol
-            assert (rel_err if fp32 else fro_err)(eng.buffer("critic1_dz1", B), inter["dz1"]) < gtol
+            gtol = FP32_RTOL if fp32 else BF16_GRAD
+            err = rel_err if fp32 else fro_err
+            within(f"ddpg_vs_oracle/{dtype}/dz2", err(eng.buffer("critic1_dz2", B), inter["dz2"]), gtol)
+            within(f"ddpg_vs_oracle/{dtype}/dz1", err(eng.buffer("critic1_dz1", B), inter["dz1"]), gtol)
             got = _grads(eng, L.NET_VALUE1)
             for k in O.PARAM_ORDER:
-                assert (rel_err if fp32 else fro_err)(got[k], gv[k]) < gtol, ("value grad", k)
+                within(f"ddpg_vs_oracle/{dtype}/value_grad", err(got[k], gv[k]), gtol)
             # ---- policy backward through the UPDATED critic, again on the GPU's activations
             vnew = {k: v.cpu().clone() for k, v in eng.param_views(L.NET_VALUE1).items()}
             qc = (torch.cat([b["state"], eng.buffer("gen_action", B).cpu()], 1), eng.buffer("pc_h1", B).cpu(),
                   eng.buffer("pc_h2", B).cpu())
             _, dxa, _ = O.mlp_backward(vnew, qc, torch.full((B, 1), -1.0 / B), train=True, need_dx=True, need_dw=False)
             dact = dxa[:, S:]
-            assert (rel_err if fp32 else fro_err)(eng.buffer("dact", B), dact) < gtol
+            within(f"ddpg_vs_oracle/{dtype}/dact", err(eng.buffer("dact", B), dact), gtol)
             pcache = (b["state"], eng.buffer("actor_h1", B).cpu(), eng.buffer("actor_h2", B).cpu())
             gp, _, _ = O.mlp_backward(actor, pcache, dact, train=True)
             got = _grads(eng, L.NET_POLICY)
             for k in O.PARAM_ORDER:
-                assert (rel_err if fp32 else fro_err)(got[k], gp[k]) < gtol, ("policy grad", k)
+                within(f"ddpg_vs_oracle/{dtype}/policy_grad", err(got[k], gp[k]), gtol)
             coef = eng.buffer("clip_coef").item()
             want = O.clip_grad_quirk_scale(gp)
-            assert abs(coef - want) <= (1e-4 if fp32 else 2e-2) * abs(want)
+            within(f"ddpg_vs_oracle/{dtype}/clip_coef", abs(coef - want) / abs(want), 1e-4 if fp32 else BF16_COEF)
             if fp32:
                 # ---- UNCONDITIONED: the GPU's gradients against the oracle's own backward (its own relu / dropout gates).
                 # The two differ only where a pre-activation sits within fp32 round-off of zero (the gate of that unit
@@ -243,13 +252,15 @@ def test_ddpg_vs_oracle(cuda, dtype, B):
                 print(f"unconditioned gradients B={B}: worst max-norm rel err {worst_max:.2e}, worst Frobenius {worst_fro:.2e}, "
                       f"critic relu gates that differ from the oracle's: {flips}")
                 assert worst_fro < 1e-4 and worst_max < 1e-4, (worst_max, worst_fro, flips)      # measured 1e-6 / 6e-7, no gate flips
-        assert abs(lo["value"] - ref["value"]) <= tol * abs(ref["value"]) + 1e-6, (t, lo, ref)
-        assert abs(lo["policy"] - ref["policy"]) <= tol * abs(ref["policy"]) + 1e-6, (t, lo, ref)
-    ptol = 3e-3 if fp32 else 5e-2   # relative Frobenius; see the module docstring for why not max-norm 1e-4
+        for k in ("value", "policy"):
+            within(f"ddpg_vs_oracle/{dtype}/loss", abs(lo[k] - ref[k]) / (abs(ref[k]) + 1e-6), tol if fp32 else BF16_LOSS)
+    ptol = 3e-3 if fp32 else BF16_PARAM   # relative Frobenius; see the module docstring for why not max-norm 1e-4
     for tag, ni, refp in (("policy", L.NET_POLICY, ost.policy), ("value", L.NET_VALUE1, ost.value),
                           ("target_policy", L.NET_TARGET_POLICY, ost.target_policy),
                           ("target_value", L.NET_TARGET_VALUE1, ost.target_value)):
-        _params_close(eng, ni, refp, ptol, tag, metric=fro_err)
+        got = eng.param_views(ni)
+        for k in O.PARAM_ORDER:
+            within(f"ddpg_vs_oracle/{dtype}/params/{tag}", fro_err(got[k], refp[k]), ptol)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -269,7 +280,7 @@ def test_td3_vs_oracle_b4096(cuda, dtype):
         eng.load_params(ni, p)
     eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3))
     eng.set_counters()
-    tol = FP32_RTOL if dtype == "fp32" else 3e-2
+    tol = FP32_RTOL if dtype == "fp32" else BF16_LOSS
     for t in range(steps):
         masks = [(torch.rand(B, H, generator=gen) < 0.5).to(torch.uint8) for _ in range(8)]
         noise = torch.randn(B, A, generator=gen) * 0.5
@@ -279,12 +290,14 @@ def test_td3_vs_oracle_b4096(cuda, dtype):
         eng.step(B, True, t)
         lo = eng.losses()
         for k in ("value1", "value2", "policy"):
-            assert abs(lo[k] - ref[k]) <= tol * abs(ref[k]) + 1e-6, (t, k, lo, ref)
-    ptol = 3e-3 if dtype == "fp32" else 5e-2
+            within(f"td3_vs_oracle/{dtype}/loss", abs(lo[k] - ref[k]) / (abs(ref[k]) + 1e-6), tol)
+    ptol = 3e-3 if dtype == "fp32" else BF16_PARAM
     for tag, ni, refp in (("policy", L.NET_POLICY, ost.policy), ("value1", L.NET_VALUE1, ost.value1),
                           ("value2", L.NET_VALUE2, ost.value2), ("target_value1", L.NET_TARGET_VALUE1, ost.target_value1),
                           ("target_policy", L.NET_TARGET_POLICY, ost.target_policy)):
-        _params_close(eng, ni, refp, ptol, tag, metric=fro_err)
+        got = eng.param_views(ni)
+        for k in O.PARAM_ORDER:
+            within(f"td3_vs_oracle/{dtype}/params/{tag}", fro_err(got[k], refp[k]), ptol)
 
 
 @pytest.mark.parametrize("first,pe", [(0, 3), (1, 3), (0, 40)])

@@ -205,9 +205,9 @@ def test_critic_gathers_columns_for_onehot_actions(cuda):
     assert F_hip.onehot_index_of(touched) is None
 
 
-def _run_fixture(name, golden_dir, optimizer, tagged=False):
+def _run_fixture(name, golden_dir, optimizer, tagged=False, fx=None):
     import recnn_amd
-    fx = RR.load(os.path.join(golden_dir, name + ".npz"))
+    fx = RR.load(os.path.join(golden_dir, name + ".npz")) if fx is None else fx
     g = fx["g"]
     dev = torch.device("cuda")
     value = recnn_amd.nn.Critic(fx["S"], fx["N"], fx["H"], 54e-2)
@@ -280,6 +280,69 @@ def test_reinforce_replays_reference_run(cuda, golden_dir, name):
                            ("target_value", "target_value_net", O.params_from_module)):
         for k, v in snap(algo.nets[net]).items():
             assert rel_err(v, fx["g"][f"final.{tag}.{k}"]) < 1e-4, (tag, k)
+
+
+def _synthetic_fixture(S, N, H, B, steps, method, pi_source, K, seed):
+    """A fixture of the tests/golden/reinforce_*.npz layout made in memory (too large to commit at a 100k catalogue): initial
+    parameters from the modules' own init, two batches, every random draw of the run (actions of pi and beta, dropout masks)."""
+    import recnn_amd
+    from oracle import recnn_oracle as O
+    from oracle import reinforce_oracle as R
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    value = recnn_amd.nn.Critic(S, N, H, 54e-2)
+    policy = recnn_amd.nn.DiscreteActor(S, N, H)
+    g = {f"policy.{k}": v.numpy() for k, v in R.policy_params_from_module(policy).items()}
+    g.update({f"value.{k}": v.numpy() for k, v in O.params_from_module(value).items()})
+    for i in range(2):
+        onehot = np.zeros((B, N), np.float32)
+        onehot[np.arange(B), rng.integers(0, N, B)] = 1
+        g.update({f"batch{i}.state": rng.standard_normal((B, S)).astype(np.float32), f"batch{i}.action": onehot,
+                  f"batch{i}.reward": (rng.standard_normal(B) * 3).astype(np.float32),
+                  f"batch{i}.next_state": rng.standard_normal((B, S)).astype(np.float32),
+                  f"batch{i}.done": (rng.random(B) < 0.1).astype(np.float32)})
+    g["beta_w"] = (rng.standard_normal((S, N)) * 0.3).astype(np.float32)
+    g["pi_draws"] = rng.integers(0, N, (steps, B))
+    g["beta_draws"] = rng.integers(0, N, (steps, B))
+    g["masks"] = (rng.random((steps, 4, B, H)) < 0.5).astype(np.uint8)
+    return dict(g=g, S=S, N=N, H=H, B=B, steps=steps, K=K, lr_v=1e-3, lr_p=1e-3, wd_v=1e-2, wd_p=1e-2, method=method,
+                pi_source=pi_source)
+
+
+@pytest.mark.parametrize("method,pi_source", [("topk", "beta"), ("corr", "pi")])
+def test_reinforce_full_cycle_at_100k_catalogue_vs_oracle(cuda, method, pi_source):
+    """the sparse / fused REINFORCE path (softmax + log-prob over N, one-hot column gather in the critic,
+    vocab-sized Adam passes, soft updates) at N = 100,000 through 22 updates -- two whole policy cycles (oracle
+    reinforce_oracle.py:201: steps 10 and 20) -- against oracle/reinforce_oracle.py on the same batches, draws and masks: fp32,
+    losses and all four networks at 1e-4 relative.  Hidden width 128 and 16 rows keep the CPU oracle at seconds."""
+    from oracle import recnn_oracle as O
+    from oracle import reinforce_oracle as R
+    fx = _synthetic_fixture(S=64, N=100_000, H=128, B=16, steps=22, method=method, pi_source=pi_source, K=10, seed=31)
+    want_losses, want = RR.replay_oracle(fx)
+    _, losses, algo = _run_fixture(None, None, torch.optim.Adam, tagged=True, fx=fx)
+    assert losses.shape == want_losses.shape == (2, 3) and np.array_equal(losses[:, 0], want_losses[:, 0])
+    e_loss = rel_err(losses[:, 1:], want_losses[:, 1:])
+    assert e_loss < 1e-4, (losses, want_losses)
+    # Parameters: every element within 1e-4 of the tensor's max, EXCEPT a bounded number of Adam sign flips.  An Adam update is
+    # lr * m / (sqrt(v) + eps) ~ +- lr whatever |g| is, so the few of the 12.8 M elements of policy.w2 (100 k of b2) whose
+    # gradient -- a sum of 16 signed terms -- cancels to below fp32 rounding step in opposite directions in two equally exact
+    # fp32 evaluations.  Such elements must be rarer than 1e-5 (at least 2 allowed) and off by no more than the two policy
+    # updates' worth of steps, 2 * 2 lr (+ 10 %).
+    worst, n_flip = 0.0, 0
+    for tag, net, snap in (("policy", "policy_net", R.policy_params_from_module), ("value", "value_net", O.params_from_module),
+                           ("target_policy", "target_policy_net", R.policy_params_from_module),
+                           ("target_value", "target_value_net", O.params_from_module)):
+        for k, v in snap(algo.nets[net]).items():
+            w = want[tag][k].double()
+            d = (v.double() - w).abs()
+            flip = d > 1e-4 * w.abs().max()
+            n = int(flip.sum())
+            assert n <= max(2, 1e-5 * w.numel()), (tag, k, n)
+            if n:
+                assert tag.endswith("policy") and float(d[flip].max()) <= 1.1 * 4 * fx["lr_p"], (tag, k, n, float(d.max()))
+            n_flip += n
+            worst = max(worst, float(d[~flip].max() / w.abs().max()))
+    print(f"reinforce N=100k {method}: loss {e_loss:.2e}, params {worst:.2e} (+ {n_flip} Adam sign flips)")
 
 
 def F_hip_mod():
