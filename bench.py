@@ -198,6 +198,9 @@ def main():
                     help="weak: every rank steps on its own --rows rows (headline); strong: the GLOBAL batch is --rows rows, "
                          "each rank takes rows/N of it")
     ap.add_argument("--overlap", action="store_true", help="data parallel: overlap the critic all-reduce with the actor forward")
+    ap.add_argument("--collective", default="peer", choices=["peer", "rccl"],
+                    help="data parallel: in-graph two-shot all-reduce over peer-mapped buffers (default; falls back to rccl when "
+                         "the peers cannot be mapped) or host-issued RCCL all-reduces")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of `--steps` steps each; value = their median")
     args = ap.parse_args()
@@ -212,6 +215,8 @@ def main():
     if os.environ.get("RECNN_BENCH_SINGLE_DEVICE"):      # functional test of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
         os.environ.setdefault("RECNN_BENCH_BACKEND", "gloo")
+        os.environ.setdefault("RECNN_COMM_WORKGROUPS", "32")   # the ranks' collective launches wait for each other: all resident at once
+        os.environ.setdefault("RECNN_COMM_FUSED", "0")         # (... which the 420-workgroup optimizer launches of two ranks are not)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rows = args.rows
@@ -267,12 +272,27 @@ def main():
         def run(first, n):
             algo.run(n)                                   # hipGraph replays; ends with one loss read-back
     else:
-        from recnn_amd.parallel import DataParallelStepper
+        from recnn_amd.parallel import DataParallelStepper, PeerComm
         with torch.cuda.stream(stream):
-            dp = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=args.overlap)
+            # the gradient exchange: recnn_dp_allreduce_flat launches inside the run graphs (peer buffers over hipIpc / xGMI,
+            # csrc/comm.hip) when every rank can map its peers, else RCCL all-reduces issued by the host between phase graphs
+            comm = None
+            if args.collective == "peer" and not args.overlap:
+                comm = PeerComm.create(PeerComm.floats_for(eng))
+            collective = "peer" if comm is not None else "rccl"
+            dp = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=args.overlap, comm=comm)
 
-        def run(first, n):
-            dp.run(first, n)
+        if os.environ.get("RECNN_BENCH_SINGLE_DEVICE") and comm is not None:
+            # ranks sharing ONE GPU are time-sliced, not co-scheduled: a collective launch that waits for its peer inside a
+            # long run graph only proceeds when the slice ends (seconds per step, measured).  One-step graphs with a host
+            # sync in between let the queues go idle and alternate: a functional check of the N > 1 path, not a measurement.
+            def run(first, n):
+                for t in range(first, first + n):
+                    dp.step(t)
+                    torch.cuda.synchronize(dev)
+        else:
+            def run(first, n):
+                dp.run(first, n)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -286,6 +306,9 @@ def main():
     reps = max(1, args.repeats)
     samples = []
     with torch.cuda.stream(stream):
+        if use_dp and comm is not None and 2 <= args.steps <= 64:
+            for r in range(reps):
+                eng.graph_prepare(args.warmup + r * args.steps, args.steps)
         if not use_dp and 2 <= args.steps <= 64:
             # setup, like the rest of the graph family: every timed `run(steps)` call gets a run graph made to order for
             # (first step mod policy_step, steps), i.e. ONE graph launch instead of [ordinary stretch][cycles][policy + tail]
@@ -325,7 +348,7 @@ def main():
                                    + f", {rows} transition rows/step/GPU ({args.scaling} scaling), frame_size 10, emb_dim 128, "
                                    "Actor/Critic hidden 256, Adam, policy+soft update every 10th step, synthetic ML20M-shaped "
                                    "replay store (138,493 users, 26,744 items, ~20M ratings)",
-                       "rows_per_step_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "rows_per_step_per_gpu": rows, "parallelism": (f"dp{world}" if world > 1 else "single") + (f" ({collective} collective)" if use_dp else ""),
                        "final_losses": losses},
         }
         # ---- per-launch times, measured live with HIP events around every launch (eager replays of the same steps on the stream

@@ -496,6 +496,39 @@ int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int
 int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream);
 int recnn_engine_dp_sets(recnn_engine* e);
 
+/* ---- device-side gradient exchange (csrc/comm.hip; SURVEY.md 8(b) `dp_allreduce_flat`, 5 "two-shot P2P all-reduce").
+ * New functionality (the reference is single-process); what it preserves is the gradient of the GLOBAL batch mean that
+ * recnn/nn/update/ddpg.py:74-87 / td3.py:95-123 compute on one concatenated batch: sum over ranks x 1 / world.
+ *
+ * Every rank (one process per GPU, up to 8 = one node) creates a communicator able to carry `max_floats` floats, exports its
+ * peer buffer as an opaque handle of recnn_comm_handle_bytes() bytes (a hipIpcMemHandle_t), exchanges the handles out of band
+ * (torch.distributed all_gather_object, MPI, a file: anything) and connects with the `world` handles in rank order.  After
+ * that recnn_dp_allreduce_flat sums data[0 .. n) over the ranks IN PLACE with ONE kernel launch on `stream`: reduce-scatter by
+ * direct peer reads, all-gather by direct peer writes over xGMI, ranks added in the order 0 .. world-1 (every rank gets the
+ * same bits; world 2 == any other order).  The launch can be captured: epochs are advanced on the device.  Every rank must
+ * issue the same sequence of collectives.  A peer that does not arrive within 4 s sets an error word instead of hanging the
+ * GPU: recnn_comm_status then returns RECNN_E_STATE and names the rank(s).
+ *
+ * recnn_engine_set_comm attaches a connected communicator to an engine: from then on every step -- eager or inside the run
+ * graphs (rebuild them) -- all-reduces the critics' flat gradient arenas each step and the actor's on policy steps in-stream
+ * and the optimizers step on grad * grad_scale (1 / world); the L1 clip quirk acts on the reduced actor gradient.  A
+ * data-parallel run is then recnn_engine_graph_run on every rank: no host code between the phases of a step.  NULL detaches. */
+typedef struct recnn_comm recnn_comm;
+int recnn_comm_create(int world, int rank, int64_t max_floats, recnn_comm** out);
+int64_t recnn_comm_handle_bytes(void);
+int recnn_comm_export(recnn_comm* c, void* handle_out, int64_t bytes);
+int recnn_comm_connect(recnn_comm* c, const void* handles, int64_t bytes_each);
+int recnn_dp_allreduce_flat(recnn_comm* c, float* data, int64_t n, void* stream);
+int recnn_comm_status(recnn_comm* c, int32_t* timed_out_ranks, int32_t* epoch);
+void recnn_comm_destroy(recnn_comm* c);
+int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
+/* tuning knob: memory kind of the peer buffers created afterwards: 0 fine-grained (default), 1 uncached, 2 ordinary */
+void recnn_tune_comm_memory(int kind);
+/* tuning knob: 1 (default) the critics' gradient exchange runs inside their optimizer launch, 0 as launches of its own */
+void recnn_tune_comm_fused(int on);
+/* tuning knob: workgroups per collective launch (default 128) */
+void recnn_tune_comm_workgroups(int n);
+
 /* In-launch hand-offs (the fused forward chains dependent networks through producer / consumer workgroups) wait with
  * a bound; a wait that runs out sets a device error word and both readers below then return RECNN_E_STATE (and clear
  * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off

@@ -180,6 +180,17 @@ SIGNATURES = {
     "recnn_engine_graph_prepare": (_I, [_P, _I, _I, _P]),
     "recnn_engine_dp_graph_build": (_I, [_P, _I, _F, _I, _P]),
     "recnn_engine_dp_graph_launch": (_I, [_P, _I, _P]),
+    "recnn_comm_create": (_I, [_I, _I, _L, C.POINTER(_P)]),
+    "recnn_comm_handle_bytes": (_L, []),
+    "recnn_comm_export": (_I, [_P, _P, _L]),
+    "recnn_comm_connect": (_I, [_P, _P, _L]),
+    "recnn_dp_allreduce_flat": (_I, [_P, _P, _L, _P]),
+    "recnn_comm_status": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "recnn_comm_destroy": (None, [_P]),
+    "recnn_engine_set_comm": (_I, [_P, _P, _F]),
+    "recnn_tune_comm_memory": (None, [_I]),
+    "recnn_tune_comm_fused": (None, [_I]),
+    "recnn_tune_comm_workgroups": (None, [_I]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),
     "recnn_topk_item_aux": (_I, [_P, _I, _I, _I, _P, _P]),
     "recnn_topk_workspace_bytes": (_I, [_I, _I, C.POINTER(_L)]),

@@ -27,6 +27,9 @@ KNOBS = {
     "RECNN_DW_SPLITS": "recnn_tune_dw_splits",
     "RECNN_DW_FUSE": "recnn_tune_dw_fuse",
     "RECNN_OPT_TABLE": "recnn_tune_opt_table",
+    "RECNN_COMM_MEMORY": "recnn_tune_comm_memory",
+    "RECNN_COMM_FUSED": "recnn_tune_comm_fused",
+    "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",
     "RECNN_CYCLE_MIN_SEG": "recnn_tune_cycle_min_seg",
     "RECNN_SPLIT_FWD": "recnn_tune_split_fwd",
     "RECNN_CYCLE_MIN_LEN": "recnn_tune_cycle_min_len",

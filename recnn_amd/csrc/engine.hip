@@ -33,6 +33,7 @@
 #include "mlp.h"
 #include "bwd.h"
 #include "optim.h"
+#include "comm.h"
 #include "dwopt.h"
 #include "split.h"
 
@@ -153,6 +154,10 @@ struct recnn_engine {
   float* l1_scratch;
   // step scalars of the optimizers (bias corrections ...: fp64 chains, optim.h) for every step of the run being issued:
   // [RUN_MAX][3] = {policy, value1, value2}; filled by one small launch at the start of a run graph / an eager step
+  recnn_comm* comm = nullptr;              // data parallel: the gradient arenas are all-reduced in-stream (comm.hip)
+  float comm_scale = 1.0f;                 // 1 / world
+  bool comm_region = false;                // the arenas have regions of their own inside the communicator's buffers:
+  int64_t comm_off[RECNN_NET_COUNT] = {};  //   gradients are produced into in[] and the optimizers read out[] (no copies)
   OptScalars* opt_tab = nullptr;
   bool scal_on = false;                    // the table holds the step being issued
   // device-resident sampler (optional)
@@ -523,6 +528,31 @@ extern "C" int recnn_engine_set_mask_mode(recnn_engine* e, int mask_mode) {
   return 0;
 }
 
+// Data parallel without the host: with a connected communicator attached, every step (eager, run graphs) sums the flat gradient
+// arenas over the ranks in-stream -- critics each step, actor on policy steps -- and the optimizers step on grad * grad_scale
+// (1 / world).  comm == NULL detaches.  Run graphs must be (re)built afterwards.
+extern "C" int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale) {
+  RECNN_REQUIRE(e, "set_comm: null engine");
+  RECNN_REQUIRE(!comm || grad_scale > 0.f, "set_comm: grad_scale must be positive");
+  drop_graphs(e);
+  e->comm = comm;
+  e->comm_scale = comm ? grad_scale : 1.0f;
+  e->comm_region = false;
+  if (comm) {
+    // a region per trained network when the communicator is large enough for all of them (else every collective copies its
+    // arena in and out of the one shared region)
+    int64_t off = 0;
+    const int nets[3] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2, RECNN_NET_POLICY};
+    for (int k = 0; k < 3; ++k) {
+      if (!net_used(e, nets[k])) continue;
+      e->comm_off[nets[k]] = off;
+      off += (e->net[nets[k]].n_params + 63) & ~(int64_t)63;
+    }
+    e->comm_region = off <= comm_capacity(comm);
+  }
+  return 0;
+}
+
 extern "C" int recnn_engine_set_counters(recnn_engine* e, int policy_t, int value1_t, int value2_t, int step) {
   RECNN_REQUIRE(e, "set_counters: null engine");
   int32_t h[4] = {step, policy_t, value1_t, value2_t};
@@ -593,13 +623,24 @@ inline char* sh_ptr(const recnn_engine* e, int ni, int which) {
   return n.shadow + n.sh_off[which] * e->esz;
 }
 
+// Where network ni's finished gradient is written: the bound arena, or -- data parallel with a region of its own in the
+// communicator (recnn_engine_set_comm) -- straight into this rank's in[] of the peer buffer (no copy in; the collective launch
+// delivers the sums to the arena, where the optimizer reads them).
+inline float* g_produce(const recnn_engine* e, int ni) { return e->comm && e->comm_region ? comm_in(e->comm, e->comm_off[ni]) : e->net[ni].g; }
+// where its optimizer reads the gradient: a critic's, in region mode, straight from the collective's out[] (system-scope loads,
+// ApplyArgs.g_sys); everything else from the bound arena, where the collective launch delivers the sums
+inline bool g_direct(const recnn_engine* e, int ni) { return e->comm && e->comm_region && e->net[ni].critic; }
+inline float* g_consume(const recnn_engine* e, int ni) { return g_direct(e, ni) ? comm_out(e->comm, e->comm_off[ni]) : e->net[ni].g; }
+int net_allreduce(recnn_engine* e, int ni, const char* name, hipStream_t s);
+
 // The optimizer / soft-update description of network `ni` (shared by apply_kernel launches and the fused dW epilogue).
 int fill_apply_args(recnn_engine* e, int ni, const NetLayout& L, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni,
                     float tau, ApplyArgs* out) {
   Net& n = e->net[ni];
   ApplyArgs& a = *out;
   memset(&a, 0, sizeof(a));
-  a.p = n.p; a.g = n.g; a.m = n.m; a.v = n.v;
+  a.p = n.p; a.g = g_consume(e, ni); a.m = n.m; a.v = n.v;
+  a.g_sys = g_direct(e, ni);
   a.shadow = n.shadow;
   a.tc_bf16 = e->bf16;
   a.do_adam = do_adam;
@@ -638,6 +679,11 @@ int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, floa
   int rc = fill_apply_args(e, ni, L, do_adam, opt_idx, grad_scale, clip, target_ni, tau, &a);
   if (rc) return rc;
   a.from_slabs = from_slabs && do_adam && rows > 0;
+  if (e->comm && a.from_slabs) {   // data parallel: the exchange runs inside this launch (comm_fused_ok checked by the caller)
+    if ((rc = comm_port(e->comm, e->comm_off[ni], &a.comm))) return rc;
+    a.comm_nwg = L.nblk;
+    a.g = n.g; a.g_sys = 0;
+  }
   const GatherArgs* pg = (do_adam && ni == RECNN_NET_VALUE1) ? e->pregather : nullptr;
   return slot(e, do_adam ? (n.critic ? (pg ? "adam_critic+gather" : "adam_critic") : "adam_actor") : "shadow_refresh", 0, s,
               [&] { return apply_launch(L, a, s, pg); }, !do_adam && target_ni < 0);
@@ -814,6 +860,8 @@ extern "C" void recnn_tune_cycle_fork(int on) { g_cycle_fork = on; }
 int g_dw_fuse = 0;
 int g_cycle_min_seg = 3;   // cycle mode: segments shorter than this step through the fused forward
 extern "C" void recnn_tune_cycle_min_seg(int n) { g_cycle_min_seg = n < 1 ? 1 : n; }
+int g_comm_fused = 1;   // data parallel: 1 = the critics' gradient exchange runs inside their optimizer launch, 0 = launches of its own
+extern "C" void recnn_tune_comm_fused(int on) { g_comm_fused = on; }
 int g_opt_table = 0;   // 1: the run graphs' optimizer launches read their step scalars from the table even without dw_fuse
 extern "C" void recnn_tune_opt_table(int on) { g_opt_table = on; }
 extern "C" void recnn_tune_dw_fuse(int on) { g_dw_fuse = on; if (on) dwopt_set_groups(on == 2 ? 2 : (on == 3 ? 1 : 4)); }
@@ -1378,7 +1426,7 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, con
   }
   for (int c = 0; c < nc && reduce; ++c) {
     NetLayout L = make_layout(e, VAL[c], rows);
-    if ((rc = slot(e, "grad_reduce_critic", 0, s, [&] { return grad_reduce_launch(L, e->net[VAL[c]].g, nullptr, s); }))) return rc;
+    if ((rc = slot(e, "grad_reduce_critic", 0, s, [&] { return grad_reduce_launch(L, g_produce(e, VAL[c]), nullptr, s); }))) return rc;
   }
   return 0;
 }
@@ -1502,7 +1550,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
                        L.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_actor"))) return rc;
   }
-  return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, pn.g, with_l1 ? pn.l1part : nullptr, s); });
+  return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, g_produce(e, RECNN_NET_POLICY), with_l1 ? pn.l1part : nullptr, s); });
 }
 
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
@@ -1560,7 +1608,7 @@ int ph_policy_l1(recnn_engine* e, hipStream_t s) {
   Net& pn = e->net[RECNN_NET_POLICY];
   NetLayout L = make_layout(e, RECNN_NET_POLICY, 0);
   return slot(e, "l1_norm_actor", 0, s, [&] {
-    return l1_blocks_launch(L, pn.g, pn.l1part, s);
+    return l1_blocks_launch(L, g_consume(e, RECNN_NET_POLICY), pn.l1part, s);
   });
 }
 
@@ -1861,6 +1909,30 @@ int opt_table(recnn_engine* e, int len, const bool* pol, hipStream_t s) {
   return slot(e, "opt_scalars", 0, s, [&] { return opt_table_launch(a, s); });
 }
 
+// The critics' exchange can run inside their optimizer launch when every workgroup's element range is made of whole float4
+// groups of the arena (all tensor offsets and all but the last tensor's sizes multiples of 4) and there is a flag slot per
+// workgroup.
+bool comm_fused_ok(recnn_engine* e, int rows) {
+  if (!e->comm || !e->comm_region || !g_comm_fused) return false;
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+  for (int c = 0; c < e->n_critic; ++c) {
+    const NetLayout L = make_layout(e, VAL[c], rows);
+    if (L.nblk > COMM_MAX_WG || !L.t[W1].nslab) return false;
+    for (int t = 0; t < 6; ++t) {
+      if (L.t[t].p_off & 3) return false;
+      if (t < 5 && (((int64_t)L.t[t].rows * L.t[t].cols) & 3)) return false;
+    }
+  }
+  return true;
+}
+
+int net_allreduce(recnn_engine* e, int ni, const char* name, hipStream_t s) {
+  Net& n = e->net[ni];
+  return slot(e, name, 0, s, [&] {
+    return e->comm_region ? comm_allreduce_region(e->comm, e->comm_off[ni], g_direct(e, ni) ? nullptr : n.g, n.n_params, s) : comm_allreduce_launch(e->comm, n.g, n.n_params, s);
+  });
+}
+
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
 // pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
 // optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
@@ -1877,10 +1949,26 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     // epilogue of the weight-gradient launch on the bf16 unit-backward path (dwopt.hip), a separate Adam launch otherwise.
     GatherArgs ga;
     if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1); e->pregather = &ga; }
-    const ValueFuse vf{policy_step, 1.0f};
-    bool applied = false;
-    rc = ph_value_backward(e, rows, false, s, &vf, &applied);
-    if (!rc && !applied) rc = value_apply(e, policy_step, 1.0f, s, rows);
+    if (e->comm) {
+      // data parallel: finished gradients into the flat arenas, summed over the ranks by one launch per arena, then the
+      // replicated optimizer step on grad / world (recnn_amd/parallel.py; the arithmetic of the global batch mean)
+      const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+      if (comm_fused_ok(e, rows)) {
+        // ... with the exchange inside the critics' optimizer launches (optim.hip exchange_grads): the launches of the
+        // single-GPU step
+        rc = ph_value_backward(e, rows, false, s);
+        if (!rc) rc = value_apply(e, policy_step, e->comm_scale, s, rows);
+      } else {
+        rc = ph_value_backward(e, rows, true, s);
+        for (int c = 0; c < e->n_critic && !rc; ++c) rc = net_allreduce(e, VAL[c], "allreduce_critic", s);
+        if (!rc) rc = value_apply(e, policy_step, e->comm_scale, s);
+      }
+    } else {
+      const ValueFuse vf{policy_step, 1.0f};
+      bool applied = false;
+      rc = ph_value_backward(e, rows, false, s, &vf, &applied);
+      if (!rc && !applied) rc = value_apply(e, policy_step, 1.0f, s, rows);
+    }
     e->pregather = nullptr;
     if (rc) return rc;
   }
@@ -1890,10 +1978,15 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     e->pending_pc.on = true; e->pending_pc.xs = e->xcs; e->pending_pc.ga = e->gen_action;
     e->pending_pc.run_off = e->run_off; e->pending_pc.slot = e->run_off;
     e->hist_pol_count[e->run_off] = rows; e->hist_pol_add[e->run_off] = 0;
-  } else if ((rc = ph_policy(e, rows, pol, true, s, !learn))) {
+  } else if ((rc = ph_policy(e, rows, pol, !e->comm, s, !learn))) {
     return rc;
   }
-  if (pol && (rc = policy_apply(e, true, 1.0f, s, true))) return rc;
+  if (pol && e->comm) {   // the L1 clip quirk acts on the REDUCED actor gradient
+    if ((rc = net_allreduce(e, RECNN_NET_POLICY, "allreduce_actor", s))) return rc;
+    if ((rc = policy_apply(e, true, e->comm_scale, s, false))) return rc;
+  } else if (pol && (rc = policy_apply(e, true, 1.0f, s, true))) {
+    return rc;
+  }
   return ph_finish(e, rows, learn, pol, s);
 }
 }  // namespace

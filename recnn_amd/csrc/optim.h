@@ -1,6 +1,7 @@
 // optim.h -- flat-arena optimizer kernels (optim.hip).
 #pragma once
 #include "common.h"
+#include "comm_dev.h"
 
 // One parameter tensor of a network inside the flat canonical arena [w1|b1|w2|b2|w3|b3].
 struct TensorSeg {
@@ -63,6 +64,13 @@ struct ApplyArgs {
   int la_k;
   float nsma_thr;
   const struct OptScalars* scal;   // optional: this launch's step scalars, precomputed on the device (opt_table_launch)
+  // Data parallel, from_slabs only (comm.world > 0): the exchange of the slab-summed gradient runs INSIDE this launch, workgroup by
+  // workgroup -- workgroup b publishes ITS elements into the peer buffer, meets workgroup b of every other rank (flags, no
+  // grid-wide counter), reduces its 1 / world share of those elements over the ranks, and reads its elements' sums back
+  // (optim.hip exchange_grads; protocol: comm.hip).  A data-parallel critic step then has the launches of the single-GPU step.
+  CommPort comm;
+  int comm_nwg;         // workgroups of the optimizer role (= the layout's nblk <= COMM_MAX_WG)
+  int g_sys;            // g lives in peer-written memory (the all-reduce's out[] buffer, comm.hip): read it with system-scope loads
 };
 
 // The hyper-parameters cross the C ABI as floats; torch computes 1 - beta and beta^t from the Python double the user wrote

@@ -9,6 +9,7 @@
 // "shadow" copy of the weights (zero-padded, 16-byte aligned rows; critic W1 columns rotated to the
 // packed [action | state] batch layout) that the MFMA GEMMs read, and optionally the soft-updated target.
 #include "optim.h"
+#include "comm_dev.h"
 #include "gather_dev.h"
 
 double recnn_snap7(float x) {
@@ -192,6 +193,52 @@ __device__ inline float clip_coef(const float* l1part, int n, float grad_scale, 
   return fminf(-1.0f / (total + 1e-6f), 1.0f);
 }
 
+// Data parallel: this thread's slab-summed gradient elements g[0 .. o.cnt) at flat offset e = e0 + ... of the workgroup's range
+// [e0, e0 + n_blk) (a multiple of 4 floats from a multiple of 4) -> the sums over the ranks.  All threads of the workgroup call.
+__device__ inline void exchange_grads(const ApplyArgs& a, int64_t e, int64_t e0, int n_blk, const Own& o, float g[4], int b) {
+  const CommPort& c = a.comm;
+  const uint32_t ep = comm_epoch(c);
+  char* own = c.peer[c.rank];
+  if (o.cnt) {
+    float* in = comm_in_of(own) + c.off;
+    if (o.vec) comm_st4(comm_rsrc(in), e >> 2, f32x4{g[0], g[1], g[2], g[3]});
+    else
+      for (int j = 0; j < o.cnt; ++j) comm_st1(in + e + j, g[j]);
+  }
+  comm_raise(c, false, b, ep);
+  comm_wait(c, false, b, ep);
+  {  // this rank's share of the workgroup's float4 groups: summed over the ranks in rank order, scattered to every out[]
+    const int groups = (n_blk + 3) >> 2, piece = (groups + c.world - 1) / c.world;
+    const int lo = piece * c.rank, hi = lo + piece < groups ? lo + piece : groups;
+    const int64_t g0 = (c.off + e0) >> 2;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      f32x4 v[COMM_MAX_WORLD];
+#pragma unroll
+      for (int p = 0; p < COMM_MAX_WORLD; ++p)
+        if (p < c.world) v[p] = comm_ld4(comm_rsrc(comm_in_of(c.peer[p])), g0 + i);
+      f32x4 s = v[0];
+#pragma unroll
+      for (int p = 1; p < COMM_MAX_WORLD; ++p)
+        if (p < c.world) s += v[p];
+#pragma unroll
+      for (int p = 0; p < COMM_MAX_WORLD; ++p)
+        if (p < c.world) comm_st4(comm_rsrc(comm_out_of(c.peer[p], c.cap)), g0 + i, s);
+    }
+  }
+  comm_raise(c, true, b, ep);
+  comm_wait(c, true, b, ep);
+  if (o.cnt) {
+    float* out = comm_out_of(own, c.cap) + c.off;
+    if (o.vec) {
+      const f32x4 v = comm_ld4(comm_rsrc(out), e >> 2);
+      g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3];
+    } else {
+      for (int j = 0; j < o.cnt; ++j) g[j] = comm_ld1(out + e + j);
+    }
+  }
+  if (threadIdx.x == 0) comm_leave(c, ep, a.comm_nwg);
+}
+
 // Adam (+ clip quirk) + shadow refresh + soft target update: one pass, each element touched by exactly one thread,
 // every load of the thread issued before the first use.
 __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& a, const int b, float* red,
@@ -215,7 +262,22 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
   if (a.do_adam) {
     if (a.from_slabs) {
       slab_grads(T, bt, o, g, sp);
+      if (a.comm.world) {
+        const int64_t nT = (int64_t)T.rows * T.cols, per = T.small ? OPT_SMALL_ELEMS : OPT_BLOCK_ELEMS;
+        const int64_t left = nT - (int64_t)bt * per;
+        exchange_grads(a, e, T.p_off + (int64_t)bt * per, (int)(left < per ? left : per), o, g, b);
+      }
       if (o.cnt && a.g_out) store_own(a.g_out + e, o, g);
+    } else if (o.cnt && a.g_sys) {
+      // data parallel: the summed gradient is read where the collective's peers wrote it, bypassing the caches (a plain load
+      // could hit a line cached from the previous step's sums); the bound arena gets a copy
+      if (o.vec) {
+        const f32x4 x = comm_ld4(comm_rsrc(a.g), e >> 2);
+        g[0] = x[0]; g[1] = x[1]; g[2] = x[2]; g[3] = x[3];
+      } else {
+        for (int j = 0; j < o.cnt; ++j) g[j] = comm_ld1(a.g + e + j);
+      }
+      if (a.g_out) store_own(a.g_out + e, o, g);
     } else if (o.cnt) {
       load_own(a.g + e, o, g);
     }

@@ -296,6 +296,13 @@ class StepEngine:
     def grad_arena(self, ni: int) -> torch.Tensor:
         return self.grads[ni]
 
+    def set_comm(self, comm, grad_scale: float = None):
+        """Attach a connected recnn_amd.parallel.PeerComm (None detaches): every step -- eager or inside the run graphs, which
+        must be rebuilt -- then all-reduces the flat gradient arenas in-stream and steps the optimizers on grad / world."""
+        self._comm = comm     # keeps the communicator alive as long as the engine points at it
+        L.call("recnn_engine_set_comm", self.handle, comm.handle if comm is not None else None,
+               float(grad_scale if grad_scale is not None else (1.0 / comm.world if comm is not None else 1.0)))
+
     def dp_graph_build(self, rows: int, grad_scale: float, overlap_actor: bool = False):
         L.call("recnn_engine_dp_graph_build", self.handle, rows, float(grad_scale), int(overlap_actor), self._stream())
         self._dp_graphs = True

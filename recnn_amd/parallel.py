@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 
-__all__ = ["DataParallelStepper", "shard_users"]
+__all__ = ["DataParallelStepper", "PeerComm", "shard_users"]
 
 
 def shard_users(perm: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -24,12 +24,81 @@ def shard_users(perm: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return perm[rank::world].contiguous()
 
 
+class PeerComm:
+    """The device-side gradient exchange `recnn_dp_allreduce_flat` (csrc/comm.hip): one peer-mapped buffer per rank (hipIpc;
+    one process per GPU of ONE node, world <= 8), a two-shot all-reduce as a single kernel launch -- a graph node.
+
+    The handles travel over the given torch.distributed group once, at construction (`all_gather_object`); afterwards the
+    group is not used again.  `PeerComm.create` returns None on every rank when any rank cannot map its peers (another node,
+    IPC unavailable): the caller then stays on RCCL (`dist.all_reduce`)."""
+
+    def __init__(self, max_floats: int, group=None):
+        import ctypes as C
+        self.lib = L.load()
+        self.group = group
+        ready = dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
+        h = C.c_void_p()
+        L.call("recnn_comm_create", self.world, self.rank, int(max_floats), C.byref(h))
+        self.handle = h
+        self.max_floats = int(max_floats)
+        if self.world > 1:
+            nb = int(self.lib.recnn_comm_handle_bytes())
+            mine = C.create_string_buffer(nb)
+            L.call("recnn_comm_export", self.handle, mine, nb)
+            every = [None] * self.world
+            dist.all_gather_object(every, bytes(mine.raw), group=group)
+            blob = C.create_string_buffer(b"".join(every), nb * self.world)
+            L.call("recnn_comm_connect", self.handle, blob, nb)
+
+    @staticmethod
+    def floats_for(engine) -> int:
+        """Capacity that gives every trained network of `engine` a region of its own (the engine then produces its gradients
+        straight into the peer buffer and the optimizers read the sums from it: no copy in, no copy out)."""
+        return sum((int(g.numel()) + 63) // 64 * 64 for g in engine.grads.values())
+
+    @classmethod
+    def create(cls, max_floats: int, group=None):
+        """A connected communicator, or None on EVERY rank if any rank failed (agreement over the group)."""
+        comm, ok = None, 1
+        try:
+            comm = cls(max_floats, group)
+        except L.RecnnHipError:
+            ok = 0
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            votes = [None] * dist.get_world_size(group)
+            dist.all_gather_object(votes, ok, group=group)
+            ok = min(votes)
+        if not ok:
+            if comm is not None:
+                comm.close()
+            return None
+        return comm
+
+    def all_reduce(self, t: torch.Tensor):
+        """In-place sum over the ranks of a contiguous fp32 CUDA tensor, on the current stream (same bits on every rank)."""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("PeerComm.all_reduce needs a contiguous fp32 CUDA tensor")
+        L.call("recnn_dp_allreduce_flat", self.handle, L.ptr(t), t.numel(), L.current_stream())
+        return t
+
+    def check(self):
+        """Raises if a wait for a peer ran out since the last check (synchronises the device)."""
+        L.call("recnn_comm_status", self.handle, None, None)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.recnn_comm_destroy(self.handle)
+            self.handle = None
+
+
 class DataParallelStepper:
     """Drives any engine exposing the phase API of recnn_amd.nn.engine.StepEngine
     (value_grads / value_apply / policy_grads / policy_apply / finish / grad_arena / value_nets / policy_every)."""
 
     def __init__(self, engine, rows: int, group=None, use_graphs: bool = True, always_reduce: bool = False,
-                 overlap: bool = False):
+                 overlap: bool = False, comm: "PeerComm | None" = None):
         if not dist.is_initialized():
             raise RuntimeError("DataParallelStepper needs an initialised torch.distributed process group "
                                "(backend 'nccl' = RCCL on ROCm)")
@@ -39,6 +108,19 @@ class DataParallelStepper:
         self.world = dist.get_world_size(group)
         self.scale = 1.0 / self.world
         self.always_reduce = always_reduce
+        # With a PeerComm the collectives are launches INSIDE the engine's steps (csrc/comm.hip): a data-parallel run is the
+        # single-GPU run graph with collective nodes -- `run` is one call per stretch, no Python between the phases of a step.
+        self.comm = comm
+        if comm is not None:
+            if comm.world != self.world:
+                raise ValueError(f"PeerComm spans {comm.world} ranks, the process group {self.world}")
+            engine.set_comm(comm, self.scale)
+            self.graphs = bool(use_graphs and hasattr(engine, "graph_build"))
+            self.overlap = False
+            self._eager_sampler = (not self.graphs) and bool(getattr(engine, "has_sampler", False))
+            if self.graphs:
+                engine.graph_build(rows)
+            return
         # the phases between the all-reduces replay as hipGraphs when the engine offers them (StepEngine does)
         self.graphs = bool(use_graphs and hasattr(engine, "dp_graph_build"))
         # overlap (optional): the actor forward does not depend on the critic update, so it can be launched while the
@@ -54,11 +136,25 @@ class DataParallelStepper:
         self._eager_sampler = (not self.graphs) and bool(getattr(engine, "has_sampler", False))
 
     def _allreduce(self, t: torch.Tensor):
-        if self.world > 1 or self.always_reduce:
+        if self.comm is not None:
+            self.comm.all_reduce(t)
+        elif self.world > 1 or self.always_reduce:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, t: int, learn: bool = True):
         e = self.engine
+        if self.comm is not None:
+            if self.graphs and learn:
+                e.graph_run(t, 1)
+                return
+            if self._eager_sampler:
+                e.sampler_eager(True)
+            try:
+                e.step(self.rows, learn, t)
+            finally:
+                if self._eager_sampler:
+                    e.sampler_eager(False)
+            return
         policy = learn and (t % e.policy_every == 0)
         if self.graphs and learn:
             e.dp_graph_launch(0)
@@ -101,6 +197,9 @@ class DataParallelStepper:
         bf16 batches, the gather of step t+1 rides on step t's critic optimizer launch (two batch buffer sets)."""
         e = self.engine
         if n <= 0:
+            return
+        if self.comm is not None and self.graphs and learn:
+            e.graph_run(first, n)
             return
         if not (self.graphs and learn) or self.overlap:
             for t in range(first, first + n):
