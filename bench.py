@@ -327,6 +327,13 @@ def main():
         samples = [float(x) for x in t.tolist()]
     elapsed = float(np.median(samples))
     losses = eng.losses()
+    if use_dp and comm is not None:
+        # the per-launch profile below replays steps on rank 0 ONLY: with the communicator attached its collectives would wait
+        # (4 s each, then report) for peers that are not stepping
+        torch.cuda.synchronize(dev)
+        comm.check()
+        dist.barrier()
+        eng.set_comm(None)
     assert os.environ.get("RECNN_MLP_PROBE") or all(np.isfinite(v) for v in losses.values()), losses
 
     if rank == 0:

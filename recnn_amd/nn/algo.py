@@ -49,6 +49,73 @@ def _hard_sync(net, target):
                 tp.data.copy_(p.data)
 
 
+class PlannedBatch:
+    """Handle of the fixed-size batch the engine's sampler draws for update step `index` (Algo.batches)."""
+    __slots__ = ("algo", "index")
+
+    def __init__(self, algo, index):
+        self.algo, self.index = algo, index
+
+    def __getitem__(self, key):
+        raise TypeError("a planned batch is a handle of rows that only exist on the device while its step runs; build an "
+                        "inspectable batch with env.collate_users(users) / the environment's data loaders")
+
+    def __repr__(self):
+        return f"PlannedBatch(step={self.index})"
+
+
+class LazyScalar:
+    """A loss value of a queued / replayed step: behaves like the float it becomes when first looked at."""
+    __slots__ = ("_src", "_key", "_val")
+
+    def __init__(self, src, key):
+        self._src, self._key, self._val = src, key, None
+
+    def item(self):
+        if self._val is None:
+            self._val = float(self._src._values()[self._key])
+        return self._val
+
+    __float__ = item
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __repr__(self):
+        return repr(self.item())
+
+    def __bool__(self):
+        return bool(self.item())
+
+    def _bin(op):
+        return lambda self, other: op(self.item(), float(other))
+
+    def _rbin(op):
+        return lambda self, other: op(float(other), self.item())
+
+    import operator as _o
+    __add__, __sub__, __mul__, __truediv__ = _bin(_o.add), _bin(_o.sub), _bin(_o.mul), _bin(_o.truediv)
+    __radd__, __rsub__, __rmul__, __rtruediv__ = _rbin(_o.add), _rbin(_o.sub), _rbin(_o.mul), _rbin(_o.truediv)
+    __lt__, __le__, __gt__, __ge__, __eq__, __ne__ = _bin(_o.lt), _bin(_o.le), _bin(_o.gt), _bin(_o.ge), _bin(_o.eq), _bin(_o.ne)
+    __neg__ = lambda self: -self.item()
+    __abs__ = lambda self: abs(self.item())
+    __hash__ = object.__hash__
+    del _bin, _rbin, _o
+
+
+class LazyLosses(dict):
+    """The dict `update()` returns ({'value': .., 'policy': .., 'step': ..}, the reference's losses) for a queued step: the
+    values are LazyScalars, resolved -- queue flushed, the device's loss history read once -- when one is looked at."""
+
+    def __init__(self, algo, step, keys):
+        super().__init__({k: LazyScalar(self, k) for k in keys})
+        self["step"] = step
+        self._algo, self._step = algo, step
+
+    def _values(self):
+        return self._algo._loss_of(self._step)
+
+
 class Algo:
     def __init__(self):
         self.nets = {"value_net": None, "policy_net": None}
@@ -63,6 +130,11 @@ class Algo:
         self.algorithm = None
 
     def update(self, batch, learn=True):
+        if isinstance(batch, PlannedBatch):
+            return self._update_planned(batch, learn)
+        if getattr(self, "_queue", (0, 0))[1] or getattr(self, "_since_ring_read", 0):
+            self.flush()
+            self._bank_losses()     # (step-by-step updates that follow move the device's loss history on)
         return self.algorithm(batch, self.params, self.nets, self.optimizers, device=self.device, debug=self.debug,
                               writer=self.writer, learn=learn, step=self._step)
 
@@ -127,15 +199,74 @@ class Algo:
         ctx.apply_external(ctx.sampler["rows"])
         ctx.run_steps(self._step if first_step is None else first_step, n_steps, every=every, prepare=True)
 
-    def run(self, n_steps: int, history: bool = False):
-        """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync).
-        history=True: returns (last losses, [losses of each of the n_steps steps]) -- what the reference's loop would
-        have collected from `update()` step by step (kept on the device, up to 1024 steps back)."""
-        ctx = getattr(self, "_fused_ctx", None)
-        if ctx is None:
+    # ---- the reference's loop shape on the fused path -------------------------------------------------------------
+    def batches(self, n: int = None):
+        """`for batch in algo.batches(): loss = algo.update(batch); algo.step()` -- the reference's training loop
+        (examples: `for batch in tqdm(env.train_dataloader): loss = ddpg.update(batch, learn=True); ddpg.step()`) at the speed
+        of `run`: the handles yielded here stand for the fixed-size batches the engine's sampler draws (see attach_env),
+        `update` only QUEUES the step and returns lazy losses, and the queue is executed as run graphs of up to 60 steps --
+        when it is full, when a loss value is read (float(), format, comparison ...) or at `flush()`.  Handles must be consumed
+        in order, one `update` + `step` each."""
+        if getattr(self, "_fused_ctx", None) is None:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
+        i = 0
+        while n is None or i < n:
+            yield PlannedBatch(self, self._step)
+            i += 1
+
+    def _update_planned(self, batch, learn):
+        if not learn:
+            raise ValueError("planned batches are training steps (learn=True); evaluate test batches with env.collate_users / the test loader")
+        first, queued = getattr(self, "_queue", (self._step, 0))
+        if queued == 0:
+            first = self._step
+        if batch.algo is not self or batch.index != self._step or self._step != first + queued:
+            self.flush()
+            raise RuntimeError(f"planned batch {batch.index} used out of order (the next step is {self._step}): each handle of "
+                               "algo.batches() takes exactly one update() followed by one step()")
+        self._queue = (first, queued + 1)
+        lazy = LazyLosses(self, self._step, ("value1", "value2", "policy") if "value_net1" in self.nets else ("value", "policy"))
+        if queued + 1 >= self.queue_limit:
+            self.flush()
+        return lazy
+
+    queue_limit = 60      # steps per flush: whole policy cycles, one run graph
+
+    def flush(self):
+        """Execute the queued update steps now (asynchronously: graph launches, no host sync)."""
+        first, queued = getattr(self, "_queue", (0, 0))
+        if queued:
+            self._queue = (first + queued, 0)
+            self._execute(first, queued)
+            done = self.__dict__.setdefault("_since_ring_read", 0) + queued
+            self._since_ring_read = done
+            if done > 900:          # the device keeps the last 1024 steps' losses: bank them before they are overwritten
+                self._bank_losses()
+
+    def _bank_losses(self):
+        eng = self._fused_ctx.engine
+        end = eng.counters()[0]
+        n = min(1024, getattr(self, "_since_ring_read", 0), end)
+        bank = self.__dict__.setdefault("_loss_bank", {})
+        last = getattr(self, "_last_exec_step", end - 1)      # Algo step number of the engine's most recent step
+        for i, h in enumerate(eng.loss_history(n)):
+            bank[last - (n - 1 - i)] = h
+        self._since_ring_read = 0
+        while len(bank) > 65536:     # bounded: the oldest banked steps go first
+            bank.pop(next(iter(bank)))
+
+    def _loss_of(self, step):
+        bank = self.__dict__.setdefault("_loss_bank", {})
+        if step not in bank:
+            self.flush()
+            self._bank_losses()
+        if step not in bank:
+            raise KeyError(f"the losses of step {step} are no longer kept (read them within 65536 steps)")
+        return bank[step]
+
+    def _execute(self, first: int, n_steps: int):
+        ctx = self._fused_ctx
         every = self.params["policy_update" if "value_net1" in self.nets else "policy_step"]
-        first = self._step
         # hyper-parameters and optimizer settings are frozen into the graphs: re-read them (lr schedules, edits of
         # self.params) -- a change rebuilds the graphs
         cfgs = self._fused_adam_cfgs(self._fused_keys)
@@ -143,12 +274,24 @@ class Algo:
         ctx.set_hyper(self.params, cfgs[0], cfgs[1])
         ctx.apply_external(ctx.sampler["rows"])
         ctx.run_steps(first, n_steps, every=every)
-        self._step += n_steps
+        self._last_exec_step = first + n_steps - 1
         n_policy = len(range(first + (-first) % every, first + n_steps, every))
         from . import fused
         for k, ni in zip(self._fused_keys, (fused.L.NET_POLICY, fused.L.NET_VALUE1, fused.L.NET_VALUE2)):
             ctx.bump(self.optimizers[k], ni, n_policy if ni == fused.L.NET_POLICY else n_steps)
         ctx.mark_stepped(list(ctx.modules))     # the graphs wrote every network's parameters in place
+
+    def run(self, n_steps: int, history: bool = False):
+        """n_steps fused update steps (see attach_env); returns the losses of the last one (one device sync).
+        history=True: returns (last losses, [losses of each of the n_steps steps]) -- what the reference's loop would
+        have collected from `update()` step by step (kept on the device, up to 1024 steps back)."""
+        ctx = getattr(self, "_fused_ctx", None)
+        if ctx is None:
+            raise RuntimeError("call attach_env(env, rows_per_batch) first")
+        self.flush()
+        self._execute(self._step, n_steps)
+        self._step += n_steps
+        self._since_ring_read = getattr(self, "_since_ring_read", 0) + n_steps
         losses = ctx.engine.losses()
         losses["step"] = self._step - 1
         if history:

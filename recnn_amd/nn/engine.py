@@ -332,11 +332,10 @@ class StepEngine:
         """Losses of the last `n_steps` (<= 1024) steps, oldest first -- also of steps replayed inside run graphs."""
         end = self.counters()[0]
         ring = self.buffer("loss_ring", 1024)
-        out = []
-        for st in range(end - n_steps, end):
-            v = ring[st % 1024].tolist()
-            out.append({"value1": v[0], "value2": v[1], "policy": v[2]} if self.td3 else {"value": v[0], "policy": v[1]})
-        return out
+        rows = ring[torch.arange(end - n_steps, end) % 1024].tolist()       # one conversion, not one per step
+        if self.td3:
+            return [{"value1": v[0], "value2": v[1], "policy": v[2]} for v in rows]
+        return [{"value": v[0], "policy": v[1]} for v in rows]
 
     def losses(self):
         """Synchronises the stream and returns the last step's losses as python floats."""

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 
-__all__ = ["DataParallelStepper", "PeerComm", "shard_users"]
+__all__ = ["DataParallelStepper", "PeerComm", "VocabParallelDiscreteActor", "shard_users"]
 
 
 def shard_users(perm: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -229,3 +229,173 @@ class DataParallelStepper:
             self._allreduce(ref)
             worst = max(worst, float((ref * self.scale - t).abs().max()))
         return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Item-dimension (vocabulary) parallel REINFORCE policy head (new functionality; SURVEY.md 8(f)1, BASELINE configs[4]: a
+# 100k-item catalogue "on 8 x MI355X").  The reference's DiscreteActor (recnn/nn/models.py:76-99) is
+#     probs = softmax(linear2(relu(linear1(state))))          linear2: [n_items, hidden]
+# and its log-prob is torch.distributions.Categorical(probs).log_prob(action) = log(clamp(p_a, eps, 1 - eps))
+# (models.py:103-111).  Here rank r holds rows [n0, n1) of linear2 (weights, Adam state and the [B, n_items / W] activations
+# are 1 / W of the whole); linear1 is replicated.  Per forward: all-reduce(MAX) of the row maxima and all-reduce(SUM) of the
+# row sums of exp (the softmax denominator), all-reduce(SUM) of the chosen action's probability (one rank owns it); per
+# backward one all-reduce(SUM) of the [B, hidden] gradient that flows back into the replicated layer 1.  The catalogue-sized
+# products (logits, dW2, dlogits W2) run on the HIP GEMM kernels; `ops` is swappable so the gloo tests on CPU can stand torch
+# matmuls in for them.
+class _HipOps:
+    """The three products of the head on librecnn_hip's GEMM kernels (fp32)."""
+
+    @staticmethod
+    def linear(x, w, b, relu):
+        from .nn import functional as Fh
+        B, K = x.shape
+        N = w.shape[0]
+        Kp, ldn = Fh._r64(K), Fh._r64(N)
+        xp, wp = Fh._pad(x, B, Kp), Fh._pad(w, Fh._r4(N), Kp)
+        out = torch.empty(B, ldn, device=x.device)
+        if ldn != N:
+            out[:, N:].zero_()
+        Fh._fwd(xp, Kp, wp, b.detach().float().contiguous(), out, ldn, N, relu, None)
+        return out[:, :N]
+
+    @staticmethod
+    def grad_w(dz, x):          # dz^T x : [N, K]
+        from .nn import functional as Fh
+        B, N = dz.shape
+        K = x.shape[1]
+        dzp, xp = Fh._pad(dz, B, Fh._r64(N)), Fh._pad(x, B, Fh._r64(K))
+        out = torch.empty(N, K, device=dz.device)
+        Fh._dw(dzp, N, xp, K, out)
+        return out
+
+    @staticmethod
+    def grad_x(dz, w):          # dz w : [B, K], contraction over the (sharded) item axis: w^T puts it on the contiguous axis
+        from .nn import functional as Fh
+        B, N = dz.shape
+        K = w.shape[1]
+        ldn, Kp = Fh._r64(N), Fh._r64(K)
+
+        def transposed(t):
+            o = torch.zeros(K, ldn, device=t.device)
+            o[:, :N] = t.t()
+            return o
+        wt = Fh._derived_of(w, "transposed", transposed) if isinstance(w, torch.nn.Parameter) else transposed(w)
+        out = torch.zeros(B, Kp, device=dz.device)
+        Fh._fwd(Fh._pad(dz, B, ldn), ldn, wt, None, out, Kp, K, False, None)
+        return out[:, :K]
+
+
+class _TorchOps:
+    linear = staticmethod(lambda x, w, b, relu: torch.relu(x @ w.t() + b) if relu else x @ w.t() + b)
+    grad_w = staticmethod(lambda dz, x: dz.t() @ x)
+    grad_x = staticmethod(lambda dz, w: dz @ w)
+
+
+class VocabParallelPolicyFunction(torch.autograd.Function):
+    """(log_prob [B], probs_shard [B, n1 - n0]) of actions under softmax over the WHOLE catalogue; see the section header."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2s, b2s, actions, n0, group, ops):
+        h = ops.linear(x, w1, b1, True)
+        logits = ops.linear(h, w2s, b2s, False)
+        m = logits.amax(1)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+        e = (logits - m[:, None]).exp_()
+        ssum = e.sum(1)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=group)
+        probs = e.div_(ssum[:, None])
+        ns = w2s.shape[0]
+        local = actions.to(torch.int64) - n0
+        own = (local >= 0) & (local < ns)
+        pa = torch.where(own, probs.gather(1, local.clamp(0, ns - 1)[:, None])[:, 0], torch.zeros_like(ssum))
+        dist.all_reduce(pa, op=dist.ReduceOp.SUM, group=group)
+        eps = torch.finfo(torch.float32).eps
+        lp = pa.clamp(eps, 1 - eps).log()
+        inside = ((pa >= eps) & (pa <= 1 - eps)).float()
+        ctx.save_for_backward(x, h, w1, w2s, probs, local, own, inside)
+        ctx.group, ctx.ops = group, ops
+        ctx.mark_non_differentiable(probs)
+        return lp, probs
+
+    @staticmethod
+    def backward(ctx, dlp, _dprobs):
+        x, h, w1, w2s, probs, local, own, inside = ctx.saved_tensors
+        ops = ctx.ops
+        g = dlp.float() * inside                                  # d log(clamp(p_a)) / d logit_j = [p_a inside] (delta_ja - p_j)
+        dlog = probs * (-g)[:, None]
+        rows = own.nonzero()[:, 0]
+        dlog[rows, local[rows]] += g[rows]
+        gw2 = ops.grad_w(dlog, h)
+        gb2 = dlog.sum(0)
+        dh = ops.grad_x(dlog, w2s).contiguous()
+        dist.all_reduce(dh, op=dist.ReduceOp.SUM, group=ctx.group)   # the other shards' share of d loss / d h
+        dz1 = dh * (h > 0)
+        gw1 = ops.grad_w(dz1, x)
+        gb1 = dz1.sum(0)
+        gx = ops.grad_x(dz1, w1) if ctx.needs_input_grad[0] else None
+        return gx, gw1, gb1, gw2, gb2, None, None, None, None
+
+
+class VocabParallelDiscreteActor(torch.nn.Module):
+    """DiscreteActor (recnn/nn/models.py:76-99) with linear2 sharded over the ranks of `group` along the catalogue.
+
+    `from_full(actor)` takes this rank's rows of a replicated DiscreteActor (same init on every rank); `log_prob(state,
+    actions)` scores given actions (the corrected / top-K REINFORCE path scores logged actions); `sample(state, seed)` draws
+    from the full softmax by inverse CDF with the same uniforms on every rank.  `linear1`'s gradients come out replicated (no
+    reduction needed), `linear2`'s are this rank's rows."""
+
+    def __init__(self, input_dim, action_dim, hidden_size, group=None, ops=None):
+        super().__init__()
+        ready = dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
+        per = -(-action_dim // self.world)
+        self.n_items = action_dim
+        self.n0, self.n1 = min(per * self.rank, action_dim), min(per * (self.rank + 1), action_dim)
+        self.linear1 = torch.nn.Linear(input_dim, hidden_size)
+        self.linear2 = torch.nn.Linear(hidden_size, self.n1 - self.n0)
+        self.ops = ops
+
+    @classmethod
+    def from_full(cls, actor, group=None, ops=None):
+        m = cls(actor.linear1.in_features, actor.linear2.out_features, actor.linear1.out_features, group, ops)
+        with torch.no_grad():
+            m.linear1.weight.copy_(actor.linear1.weight)
+            m.linear1.bias.copy_(actor.linear1.bias)
+            m.linear2.weight.copy_(actor.linear2.weight[m.n0:m.n1])
+            m.linear2.bias.copy_(actor.linear2.bias[m.n0:m.n1])
+        return m.to(actor.linear1.weight.device)
+
+    def _ops(self, x):
+        if self.ops is not None:
+            return self.ops
+        if not x.is_cuda:
+            raise L.RecnnHipError("VocabParallelDiscreteActor runs on the GPU only (no CPU fallback); tests pass ops= explicitly")
+        return _HipOps
+
+    def log_prob(self, state, actions):
+        """(log_prob [B], this rank's columns [n0, n1) of the probabilities)."""
+        return VocabParallelPolicyFunction.apply(state.float(), self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                                 self.linear2.bias, actions, self.n0, self.group, self._ops(state))
+
+    @torch.no_grad()
+    def sample(self, state, seed: int):
+        """Actions ~ softmax over the whole catalogue: u ~ U[0, 1) per row (the same on every rank: generator seeded with
+        `seed`), the rank whose cumulative mass interval contains u finds the item inside its shard."""
+        B = state.shape[0]
+        _, probs = self.log_prob(state, torch.zeros(B, dtype=torch.int64, device=state.device))
+        u = torch.rand(B, generator=torch.Generator().manual_seed(int(seed))).to(state.device)
+        mass = torch.zeros(B, self.world, device=state.device)
+        mass[:, self.rank] = probs.sum(1)
+        dist.all_reduce(mass, op=dist.ReduceOp.SUM, group=self.group)
+        upper = mass.cumsum(1)
+        lower = upper - mass
+        lo, hi = lower[:, self.rank], upper[:, self.rank]
+        last = self.rank == self.world - 1
+        mine = (u >= lo) & ((u < hi) | last)                     # (rounding may leave u above the last upper bound)
+        idx = torch.searchsorted(probs.cumsum(1).contiguous(), (u - lo)[:, None].contiguous(), right=True)[:, 0]
+        idx = idx.clamp(max=probs.shape[1] - 1) + self.n0
+        out = torch.where(mine, idx + 1, torch.zeros_like(idx))
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out - 1

@@ -397,3 +397,42 @@ def test_run_on_a_caller_owned_stream_equals_run_from_the_default_stream(cuda):
     for net, sd in snaps[0].items():
         for k, v in sd.items():
             assert torch.equal(v, snaps[1][net][k]), (net, k)
+
+
+def test_reference_shaped_loop_on_planned_batches_equals_run(cuda):
+    """`for batch in algo.batches(n): loss = algo.update(batch); algo.step()` (the reference's loop: update returns the losses
+    dict, here with lazy values, steps are queued and replayed 60 at a time) == `algo.run(n)`: all four networks bit for bit,
+    every step's losses equal to run's history; reading a loss mid-way flushes the queue; handles out of order are refused."""
+    import recnn_amd
+    n = 147
+    env, _ = _bench_env(recnn_amd, cuda, n_users=UPB * 40)
+    a = _make_algo(recnn_amd, cuda, env, "bf16")
+    _, hist = a.run(n, history=True)
+    want = _snapshot(a)
+    b = _make_algo(recnn_amd, cuda, env, "bf16")
+    got = []
+    for i, batch in enumerate(b.batches(n)):
+        loss = b.update(batch, learn=True)
+        b.step()
+        got.append(loss)
+        if i == 70:
+            assert float(loss["value"]) == hist[70]["value"]           # resolves now: flushes the 11 queued steps
+    b.flush()
+    torch.cuda.synchronize()
+    snap = _snapshot(b)
+    for net in want:
+        for k in want[net]:
+            assert torch.equal(want[net][k], snap[net][k]), (net, k)
+    assert b._step == a._step == n
+    for i, (l, h) in enumerate(zip(got, hist)):
+        # (the policy loss of a step is a sum over rows whose grouping depends on the step's place in its run graph -- per-row
+        # Q of a deferred forward vs per-workgroup partial dots --: equal to fp32 summation order, like the reference's .mean())
+        assert l["step"] == i and float(l["value"]) == h["value"] and abs(float(l["policy"]) - h["policy"]) <= 1e-6 * abs(h["policy"]), (i, h)
+    assert f"{got[3]['value']:.4f}" == f"{hist[3]['value']:.4f}" and got[5]["policy"] + 1.0 == hist[5]["policy"] + 1.0
+    it = b.batches()
+    first = next(it)
+    b.update(first); b.step()
+    with pytest.raises(RuntimeError, match="out of order"):
+        b.update(first)                                    # a handle is good for one update
+    with pytest.raises(TypeError):
+        first["state"]

@@ -36,3 +36,33 @@ for i in range(n):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"collate + update() loop, {dtype}:                        {n / dt:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step")
+
+# the same loop shape on planned batches (Algo.batches): update() queues, the queue replays as 60-step run graphs
+torch.manual_seed(1)
+algo.attach_env(env, rows_per_batch=2048, users_per_batch=256)
+for name, n in (("warm-up", 600), ("timed", 6000)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    log = []
+    t_flush, orig_flush = [0.0], algo.flush
+    def timed_flush():
+        a = time.perf_counter(); orig_flush(); t_flush[0] += time.perf_counter() - a
+    algo.flush = timed_flush
+    for batch in algo.batches(n):
+        loss = algo.update(batch, learn=True); algo.step()
+        log.append(loss)
+    algo.flush()
+    algo.flush = orig_flush
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+loop_rate = n / dt
+print(f"   host time of the loop {t_host / n * 1e6:.1f} us/step, of which inside flush() {t_flush[0] / n * 1e6:.1f} us/step")
+print(f"planned-batch update() loop, {dtype}:                    {loop_rate:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step   (last value loss {float(log[-1]['value']):.4f})")
+algo.run(600)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+algo.run(n)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"algo.run({n}), {dtype}:                                 {n / dt:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step   loop / run = {loop_rate / (n / dt):.3f}")
