@@ -1,5 +1,6 @@
 """Actor / Critic / DiscreteActor / bcqPerturbator / bcqGenerator
-(reference: recnn/nn/models.py:41-73, :187-213, :76-184, :216-242, :245-295).
+(reference: recnn/nn/models.py:41-73, :187-213, :76-184, :216-242, :245-295) and the Soft Actor-Critic networks of the
+reference's `examples/1. Vanilla RL/4. SAC.ipynb` (StateCritic, SoftQ, StochasticActor: code cells 5-7).
 
 Real nn.Modules with the reference's sub-module names (linear1/2/3, drop_layer), state_dict keys and
 constructor RNG consumption (nn.Linear default init for linear1, linear2, linear3 in that order, then
@@ -12,7 +13,7 @@ import torch.nn as nn
 
 from . import functional as F_hip
 
-__all__ = ["Actor", "Critic", "DiscreteActor", "bcqPerturbator", "bcqGenerator"]
+__all__ = ["Actor", "Critic", "DiscreteActor", "bcqPerturbator", "bcqGenerator", "StateCritic", "SoftQ", "StochasticActor"]
 
 
 class Actor(nn.Module):
@@ -224,3 +225,78 @@ class bcqGenerator(nn.Module):
         z = self._noise(state.shape[0] * n, state.device).clamp(-0.5, 0.5)
         return F_hip.mlp_candidates(state, z, n, self.d1.weight, self.d1.bias, self.d2.weight, self.d2.bias,
                                     self.d3.weight, self.d3.bias)
+
+
+# ---- Soft Actor-Critic (examples/1. Vanilla RL/4. SAC.ipynb, code cells 5-7) ------------------------
+class StateCritic(nn.Module):
+    """state -> V(state): relu(L1) -> relu(L2) -> L3, no dropout (SAC.ipynb cell 5)."""
+
+    def __init__(self, state_dim, hidden_dim, init_w=3e-3):
+        super().__init__()
+        self.linear1 = nn.Linear(state_dim, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear3 = nn.Linear(hidden_dim, 1)
+        self.linear3.weight.data.uniform_(-init_w, init_w)
+        self.linear3.bias.data.uniform_(-init_w, init_w)
+
+    def forward(self, state):
+        return F_hip.mlp(state, self, False)
+
+
+class SoftQ(nn.Module):
+    """(state, action) -> Q: the same stack over cat([state, action], 1), no dropout (SAC.ipynb cell 6)."""
+
+    def __init__(self, input_dim, action_dim, hidden_dim, init_w=3e-3):
+        super().__init__()
+        self.linear1 = nn.Linear(input_dim + action_dim, hidden_dim)
+        self.linear2 = nn.Linear(hidden_dim, hidden_dim)
+        self.linear3 = nn.Linear(hidden_dim, 1)
+        self.linear3.weight.data.uniform_(-init_w, init_w)
+        self.linear3.bias.data.uniform_(-init_w, init_w)
+
+    def forward(self, state, action):
+        return F_hip.mlp(torch.cat([state, action], 1), self, False)
+
+
+class StochasticActor(nn.Module):
+    """state -> (mean, log_std) of a tanh-squashed Gaussian policy (SAC.ipynb cell 7): relu(L1) -> dropout -> relu(L2) ->
+    dropout -> {mean_linear, clamp(log_std_linear)}.  The trunk and BOTH heads run as one three-layer HIP MLP (the heads'
+    weights concatenated to a [2 * action_dim, hidden] last layer; autograd splits the gradient back).
+
+    Kept from the notebook: `evaluate` draws ONE standard-normal scalar `z` per call (`Normal(0, 1).sample()` has no batch
+    shape) shared by every row and action dimension, evaluates `Normal(mean, std).log_prob` at the SQUASHED action, and does
+    not sum the log-prob over the action dimension ([B, action_dim]).  `forced_z` (a list, consumed first-in first-out)
+    replaces the next draws: replays and parity tests."""
+
+    def __init__(self, input_dim, action_dim, hidden_size, params):
+        super().__init__()
+        self.log_std_min = params["log_std_min"]
+        self.log_std_max = params["log_std_max"]
+        self.drop_layer = nn.Dropout(p=0.5)
+        self.linear1 = nn.Linear(input_dim, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, hidden_size)
+        self.mean_linear = nn.Linear(hidden_size, action_dim)
+        self.mean_linear.weight.data.uniform_(-params["mean_initw"], params["mean_initw"])
+        self.mean_linear.bias.data.uniform_(-params["mean_initw"], params["mean_initw"])
+        self.log_std_linear = nn.Linear(hidden_size, action_dim)
+        self.log_std_linear.weight.data.uniform_(-params["std_initw"], params["std_initw"])
+        self.log_std_linear.bias.data.uniform_(-params["std_initw"], params["std_initw"])
+        self.forced_z = []
+
+    def forward(self, state):
+        w3 = torch.cat([self.mean_linear.weight, self.log_std_linear.weight], 0)
+        b3 = torch.cat([self.mean_linear.bias, self.log_std_linear.bias], 0)
+        out = F_hip.MLPFunction.apply(state.float(), self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                      w3, b3, self.training, torch.initial_seed(), F_hip._take_forced_masks(self, self.training), None)
+        a = self.mean_linear.out_features
+        return out[:, :a], torch.clamp(out[:, a:], self.log_std_min, self.log_std_max)
+
+    def evaluate(self, state, epsilon=1e-6):
+        mean, log_std = self.forward(state)
+        std = log_std.exp()
+        z = self.forced_z.pop(0) if self.forced_z else torch.randn(())
+        z = torch.as_tensor(z, dtype=torch.float32).to(mean.device)
+        action = torch.tanh(mean + z * std)
+        log_prob = torch.distributions.Normal(mean, std).log_prob(action)
+        log_prob = log_prob - torch.log(1 - action.pow(2) + epsilon)
+        return action, log_prob, z, mean, log_std
