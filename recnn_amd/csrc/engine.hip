@@ -154,6 +154,7 @@ struct recnn_engine {
   float* l1_scratch;
   // step scalars of the optimizers (bias corrections ...: fp64 chains, optim.h) for every step of the run being issued:
   // [RUN_MAX][3] = {policy, value1, value2}; filled by one small launch at the start of a run graph / an eager step
+  float* h_stage = nullptr;                // pinned host words for the read-backs (a pageable destination is staged by the runtime: +30 us)
   recnn_comm* comm = nullptr;              // data parallel: the gradient arenas are all-reduced in-stream (comm.hip)
   float comm_scale = 1.0f;                 // 1 / world
   bool comm_region = false;                // the arenas have regions of their own inside the communicator's buffers:
@@ -456,6 +457,7 @@ extern "C" void recnn_engine_destroy(recnn_engine* e) {
   for (int i = 0; i < recnn_engine::EV_POOL; ++i)
     if (e->ev_pool[i]) (void)hipEventDestroy(e->ev_pool[i]);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
   delete e;
 }
 
@@ -2089,7 +2091,8 @@ extern "C" int recnn_engine_read_counters(recnn_engine* e, int32_t* h_out, void*
 
 extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream) {
   RECNN_REQUIRE(e && h_out, "read_losses: null pointer");
-  float h[5];
+  if (!e->h_stage) RECNN_HIP(hipHostMalloc((void**)&e->h_stage, 16 * sizeof(float), hipHostMallocDefault));
+  float* h = e->h_stage;
   RECNN_HIP(hipMemcpyAsync(h, e->losses, 5 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
   memcpy(h_out, h, 4 * sizeof(float));
