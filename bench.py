@@ -375,7 +375,10 @@ def main():
                 prof_cyc = None
         cyc_min = int(os.environ.get("RECNN_CYCLE_MIN_LEN", "30"))
         split_knob = int(os.environ.get("RECNN_SPLIT_FWD", "1"))
-        schedule = "cycle" if (prof_cyc and not use_dp and split_knob >= 1 and (args.steps >= cyc_min or split_knob >= 2)) else "fused"
+        # (data parallel with the device collective replays the same run graphs; the host-collective path steps phase graphs on
+        # the fused forward)
+        run_graphs = not use_dp or comm is not None
+        schedule = "cycle" if (prof_cyc and run_graphs and split_knob >= 1 and (args.steps >= cyc_min or split_knob >= 2)) else "fused"
 
         def roof(name, ms, fl, per_step=1.0):
             ach = fl / (ms * 1e-3) / 1e12
