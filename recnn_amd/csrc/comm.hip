@@ -56,8 +56,7 @@ __global__ __launch_bounds__(COMM_THREADS) void allreduce_kernel(const CommArgs 
   const int64_t mine = slice * c.world;                     // groups this workgroup moves in A and in C
   const int tail = (int)(a.n & 3);
   char* own = c.peer[c.rank];
-  // ---- A: gradient -> in[] (a partial last group is padded with zeros); region mode: the producer launch did that, and the
-  // kernel boundary behind it wrote its stores back to memory
+  // ---- A: gradient -> in[] with system-scope stores (a partial last group is padded with zeros)
   if (a.src) {
     const __amdgpu_buffer_rsrc_t rin = comm_rsrc(comm_in_of(own) + c.off);
     for (int64_t k0 = threadIdx.x; k0 < mine; k0 += 4 * COMM_THREADS) {
@@ -187,14 +186,13 @@ int comm_allreduce_launch(recnn_comm* c, float* data, int64_t n, hipStream_t s) 
 }
 
 int64_t comm_capacity(const recnn_comm* c) { return c ? c->cap : 0; }
-float* comm_in(const recnn_comm* c, int64_t off) { return (float*)(c->base + COMM_HDR) + off; }
 float* comm_out(const recnn_comm* c, int64_t off) { return (float*)(c->base + COMM_HDR) + c->cap + off; }
-int comm_allreduce_region(recnn_comm* c, int64_t off, float* dst, int64_t n, hipStream_t s) {
+int comm_allreduce_region(recnn_comm* c, int64_t off, const float* src, float* dst, int64_t n, hipStream_t s) {
   RECNN_REQUIRE(c && c->connected, "dp_allreduce_flat: the communicator is not connected (recnn_comm_connect)");
-  RECNN_REQUIRE(((uintptr_t)dst & 15) == 0 && n > 0 && off >= 0 && (off & 3) == 0 && off + n <= c->cap,
-                "dp_allreduce_flat: region [%lld, +%lld) outside the communicator's %lld floats, or a misaligned destination",
+  RECNN_REQUIRE(src && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && n > 0 && off >= 0 && (off & 3) == 0 && off + n <= c->cap,
+                "dp_allreduce_flat: region [%lld, +%lld) outside the communicator's %lld floats, or a misaligned buffer",
                 (long long)off, (long long)n, (long long)c->cap);
-  return launch(c, nullptr, dst, off, n, s);
+  return launch(c, src, dst, off, n, s);
 }
 
 extern "C" int recnn_comm_create(int world, int rank, int64_t max_floats, recnn_comm** out) {

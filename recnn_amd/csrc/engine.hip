@@ -625,10 +625,9 @@ inline char* sh_ptr(const recnn_engine* e, int ni, int which) {
   return n.shadow + n.sh_off[which] * e->esz;
 }
 
-// Where network ni's finished gradient is written: the bound arena, or -- data parallel with a region of its own in the
-// communicator (recnn_engine_set_comm) -- straight into this rank's in[] of the peer buffer (no copy in; the collective launch
-// delivers the sums to the arena, where the optimizer reads them).
-inline float* g_produce(const recnn_engine* e, int ni) { return e->comm && e->comm_region ? comm_in(e->comm, e->comm_off[ni]) : e->net[ni].g; }
+// (the finished per-rank gradient always goes to the bound arena; a collective copies it into the peer buffer itself, with
+// system-scope stores)
+inline float* g_produce(const recnn_engine* e, int ni) { return e->net[ni].g; }
 // where its optimizer reads the gradient: a critic's, in region mode, straight from the collective's out[] (system-scope loads,
 // ApplyArgs.g_sys); everything else from the bound arena, where the collective launch delivers the sums
 inline bool g_direct(const recnn_engine* e, int ni) { return e->comm && e->comm_region && e->net[ni].critic; }
@@ -1931,7 +1930,7 @@ bool comm_fused_ok(recnn_engine* e, int rows) {
 int net_allreduce(recnn_engine* e, int ni, const char* name, hipStream_t s) {
   Net& n = e->net[ni];
   return slot(e, name, 0, s, [&] {
-    return e->comm_region ? comm_allreduce_region(e->comm, e->comm_off[ni], g_direct(e, ni) ? nullptr : n.g, n.n_params, s) : comm_allreduce_launch(e->comm, n.g, n.n_params, s);
+    return e->comm_region ? comm_allreduce_region(e->comm, e->comm_off[ni], n.g, g_direct(e, ni) ? nullptr : n.g, n.n_params, s) : comm_allreduce_launch(e->comm, n.g, n.n_params, s);
   });
 }
 
@@ -2242,7 +2241,9 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
       select_mbuf(e, buf);
       e->run_off = i0;
       // a one- or two-step segment (a graph that starts ON a policy step has one at its head) does not pay for the batched
-      // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays
+      // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays.
+      // (The driver's 20-step request in cycle mode, segments 6 + 10 + 4, with this threshold at 3 / 5 / 8: 67.7 / 67.1 / 67.6
+      // us/step against 67.8-68.3 all-fused -- inside the noise, so short graphs stay on the fused schedule: cycle_min_len 30.)
       const bool batched = n >= g_cycle_min_seg;
       if (batched) rc = ph_frozen_batched(e, rows, n, i0, s);
       for (int i = i0; i <= i1 && !rc; ++i) {

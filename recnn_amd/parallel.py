@@ -64,6 +64,7 @@ class PeerComm:
         comm, ok = None, 1
         try:
             comm = cls(max_floats, group)
+            ok = int(comm.self_test())
         except L.RecnnHipError:
             ok = 0
         if dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -75,6 +76,25 @@ class PeerComm:
                 comm.close()
             return None
         return comm
+
+    def self_test(self) -> bool:
+        """Three collectives on known vectors (exact in fp32), checked on this rank: a protocol that does not work on this
+        machine's fabric (flags or data not visible across GPUs, a peer that never arrives: the waits are bounded) shows up here
+        as a wrong sum or a reported time-out instead of inside a training run."""
+        n = min(4099, self.max_floats)
+        base = (torch.arange(n, dtype=torch.float32) % 7 + 1).cuda()
+        want = base * (self.world * (self.world + 1) / 2)
+        try:
+            for rep in range(3):
+                x = base * float(self.rank + 1)
+                self.all_reduce(x)
+                torch.cuda.synchronize()
+                if not torch.equal(x, want):
+                    return False
+            self.check()
+        except L.RecnnHipError:
+            return False
+        return True
 
     def all_reduce(self, t: torch.Tensor):
         """In-place sum over the ranks of a contiguous fp32 CUDA tensor, on the current stream (same bits on every rank)."""

@@ -21,7 +21,8 @@ def run_allreduce(out):
     from recnn_amd.parallel import PeerComm
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", 0)
-    comm = PeerComm(500_000)
+    comm = PeerComm.create(500_000)          # connects, then checks itself on known vectors; None on every rank if any failed
+    assert comm is not None
     gen = torch.Generator().manual_seed(100 + rank)
     worst, reps = 0.0, 0
     for n in (1, 3, 4, 5, 255, 1024, 4099, 430_337, 500_000):
