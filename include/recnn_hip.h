@@ -206,6 +206,9 @@ int recnn_gemm_dw(const recnn_gemm_args* h_args, void* stream);
  * into out[M, N] (uint8).  Lets tests feed the in-kernel masks to the CPU oracle. */
 int recnn_hash_mask_dump(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N,
                          uint8_t* out, void* stream);
+/* ... with the step in device memory (step = *step_dev + step_add): a captured graph draws fresh masks on every replay */
+int recnn_hash_mask_dump_at(uint32_t seed, const int32_t* step_dev, int step_add, uint32_t stream_id, int M, int N, uint8_t* out,
+                            void* stream);
 
 /* =====================================================================================
  * 3. Flat-arena optimizer / soft-update kernels
@@ -222,6 +225,11 @@ int recnn_soft_update_flat(float* target, const float* net, int64_t n, float tau
  * step_t is the 1-based step count (bias correction). */
 int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step_t, float grad_scale, void* stream);
+
+/* The same step with the 1-based step count taken from device memory: t = *step_dev + step_add.  For captured graphs
+ * (recnn_amd.optim.Adam(capturable=True)): the graph advances *step_dev itself, every replay steps with the right count. */
+int recnn_adam_flat_at(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, const int32_t* step_dev, int step_add, float grad_scale, void* stream);
 
 /* out[0] = sum |g| over n floats (deterministic two-pass reduction; scratch >= 1024 floats). */
 int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, float* out, void* stream);

@@ -140,8 +140,10 @@ SIGNATURES = {
     "recnn_gemm_dx": (_I, [C.POINTER(GemmArgs), _P]),
     "recnn_gemm_dw": (_I, [C.POINTER(GemmArgs), _P]),
     "recnn_hash_mask_dump": (_I, [_U, C.c_int32, _U, _I, _I, _P, _P]),
+    "recnn_hash_mask_dump_at": (_I, [_U, _P, _I, _U, _I, _I, _P, _P]),
     "recnn_soft_update_flat": (_I, [_P, _P, _L, _F, _P]),
     "recnn_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "recnn_adam_flat_at": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _I, _F, _P]),
     "recnn_l1_norm_flat": (_I, [_P, _L, _P, _P, _P]),
     "recnn_engine_query": (_I, [C.POINTER(EngineConfig), C.POINTER(EngineSizes)]),
     "recnn_engine_create": (_I, [C.POINTER(EngineConfig), _P, C.POINTER(_P)]),

@@ -922,6 +922,22 @@ __global__ void hash_mask_dump_kernel(uint32_t seed, int32_t step, uint32_t stre
   int m = (int)(i / N), n = (int)(i % N);
   out[i] = mask_keep(mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n >> 2)), m & 3, n & 3) ? 1 : 0;
 }
+// ... with the step on the device (step = *step_ptr + step_add): what a captured graph needs to draw fresh masks per replay
+__global__ void hash_mask_dump_at_kernel(uint32_t seed, const int32_t* step_ptr, int step_add, uint32_t stream_id, int M, int N, uint8_t* out) {
+  const uint32_t key = mask_key(seed, *step_ptr + step_add, stream_id);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  int m = (int)(i / N), n = (int)(i % N);
+  out[i] = mask_keep(mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n >> 2)), m & 3, n & 3) ? 1 : 0;
+}
+extern "C" int recnn_hash_mask_dump_at(uint32_t seed, const int32_t* step_dev, int step_add, uint32_t stream_id, int M, int N, uint8_t* out,
+                                       void* stream) {
+  RECNN_REQUIRE(out && step_dev && M > 0 && N > 0, "hash_mask_dump_at: bad args");
+  int64_t n = (int64_t)M * N;
+  hipLaunchKernelGGL(hash_mask_dump_at_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, step_dev,
+                     step_add, stream_id, M, N, out);
+  return recnn_check_hip(hipGetLastError(), "hash_mask_dump_at");
+}
 extern "C" int recnn_hash_mask_dump(uint32_t seed, int32_t step, uint32_t stream_id, int M, int N, uint8_t* out, void* stream) {
   RECNN_REQUIRE(out && M > 0 && N > 0, "hash_mask_dump: bad args");
   int64_t n = (int64_t)M * N;

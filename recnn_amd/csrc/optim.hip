@@ -473,6 +473,39 @@ extern "C" int recnn_adam_flat(float* p, const float* g, float* m, float* v, int
   return recnn_check_hip(hipGetLastError(), "adam_flat");
 }
 
+// The same step with the step count on the DEVICE (t = *t_ptr + t_add): a captured graph replays it with the count the graph
+// itself advances (recnn_amd.optim.Adam(capturable=True)); the bias corrections are evaluated per thread, in double like the host.
+__global__ __launch_bounds__(256) void adam_flat_at_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, int64_t n, float lr, float beta2, float eps, float wd,
+                                                           double b1, double b2, const int32_t* __restrict__ t_ptr, int t_add, float gs,
+                                                           float omb1, float omb2) {
+  const double t = (double)(*t_ptr + t_add);
+  const float step_size = (float)((double)lr / (1.0 - pow(b1, t)));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, t));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i];
+    float gi = g[i] * gs;
+    if (wd != 0.f) gi += wd * pi;
+    float mi = m[i], vi = v[i];
+    mi += omb1 * (gi - mi);
+    vi = beta2 * vi + omb2 * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+extern "C" int recnn_adam_flat_at(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, const int32_t* step_dev, int step_add, float grad_scale, void* stream) {
+  RECNN_REQUIRE(p && g && m && v && n >= 0 && step_dev, "adam_flat_at: bad arguments");
+  if (n == 0) return 0;
+  const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(adam_flat_at_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta2, eps, weight_decay, b1,
+                     b2, step_dev, step_add, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2));
+  return recnn_check_hip(hipGetLastError(), "adam_flat_at");
+}
+
 __global__ __launch_bounds__(256) void l1_part_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   __shared__ float red[4];
   float s = 0.f;

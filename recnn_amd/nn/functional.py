@@ -16,6 +16,33 @@ from .. import _lib as L
 
 _call_counter = itertools.count(1)
 
+# Dropout-mask keys on the device (captured updates, recnn_amd/nn/graphed.py): while a key scope is open, every train-mode MLP call
+# keys its two hash masks with `*dev + add` (add = calls so far in the scope) instead of the host-side call counter, so that a
+# captured graph draws fresh masks on every replay; the scope's owner advances *dev by the calls consumed.
+_key_scope = {"dev": None, "add": 0}
+
+
+def open_key_scope(dev_counter):
+    _key_scope["dev"], _key_scope["add"] = dev_counter, 0
+
+
+def close_key_scope() -> int:
+    used = _key_scope["add"]
+    _key_scope["dev"], _key_scope["add"] = None, 0
+    return used
+
+
+def _dump_masks(seed, B, H, m1, m2, s):
+    if _key_scope["dev"] is not None:
+        add = _key_scope["add"]
+        _key_scope["add"] = add + 1
+        for stream_id, m in ((0, m1), (1, m2)):
+            L.call("recnn_hash_mask_dump_at", seed & 0xFFFFFFFF, L.ptr(_key_scope["dev"]), add, stream_id, B, H, L.ptr(m), s)
+        return
+    key = next(_call_counter)
+    L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 0, B, H, L.ptr(m1), s)
+    L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
+
 
 def _r64(x):
     return (x + 63) // 64 * 64
@@ -52,6 +79,10 @@ def _derived_of(w, kind, build):
     writers (optim.Adam / Ranger, utils.soft_update call torch.autograd.graph.increment_version) -- plus the engine's
     write count (`mark_written`) for the kernels that update adopted parameters without any torch op."""
     import weakref
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        # a captured update (recnn_amd/nn/graphed.py) must rebuild the layout on every replay: a cache hit here would leave the
+        # build out of the graph, and the graph would keep reading the copy made at capture time after `w` moved on
+        return build(w.detach())
     key = (id(w), kind)
     tag = (w._version, w.data_ptr(), tuple(w.shape), _written.get(id(w), 0))
     hit = _derived.get(key)
@@ -168,12 +199,9 @@ class MLPFunction(torch.autograd.Function):
         if train and masks is not None:
             m1, m2 = (m.to(device=dev, dtype=torch.uint8).contiguous() for m in masks)
         elif train:
-            key = next(_call_counter)
             m1 = torch.empty(B, H, dtype=torch.uint8, device=dev)
             m2 = torch.empty(B, H, dtype=torch.uint8, device=dev)
-            s = L.current_stream()
-            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 0, B, H, L.ptr(m1), s)
-            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
+            _dump_masks(seed, B, H, m1, m2, L.current_stream())
         b1c, b2c, b3c = b1.detach().float().contiguous(), b2.detach().float().contiguous(), b3.detach().float().contiguous()
         add1 = None if addend1 is None else addend1.detach().float().contiguous()
         if big16:
@@ -219,12 +247,9 @@ class MLPFunction(torch.autograd.Function):
         if train and masks is not None:
             m1, m2 = (m.to(device=dev, dtype=torch.uint8).contiguous() for m in masks)
         elif train:
-            key = next(_call_counter)
             m1 = torch.empty(B, H, dtype=torch.uint8, device=dev)
             m2 = torch.empty(B, H, dtype=torch.uint8, device=dev)
-            s = L.current_stream()
-            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 0, B, H, L.ptr(m1), s)
-            L.call("recnn_hash_mask_dump", seed & 0xFFFFFFFF, key & 0x7FFFFFFF, 1, B, H, L.ptr(m2), s)
+            _dump_masks(seed, B, H, m1, m2, L.current_stream())
         f = lambda t: t.detach().float().contiguous()
         add1 = None if addend1 is None else f(addend1)
         h1 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)

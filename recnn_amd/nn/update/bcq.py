@@ -136,7 +136,8 @@ def bcq_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug
             writer.add_figure("sampled_actions", utils.pairwise_distances_fig(sampled_actions[:50]), step)
             writer.add_figure("perturbed_actions", utils.pairwise_distances_fig(perturbed_actions[:50]), step)
 
-    losses = {"value": value_loss.item(), "perturbator": perturbator_loss.item(), "generator": generator_loss.item(),
-              "step": step}
+    # (inside a stream capture -- recnn_amd.nn.graphed.GraphedUpdate -- the losses stay device scalars: .item() would sync)
+    val = (lambda t: t.detach()) if (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()) else (lambda t: t.item())
+    losses = {"value": val(value_loss), "perturbator": val(perturbator_loss), "generator": val(generator_loss), "step": step}
     utils.write_losses(writer, losses, kind="train" if learn else "test")
     return losses

@@ -23,10 +23,20 @@ __all__ = ["Adam", "Ranger", "adam_config", "fused_config"]
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam's arithmetic on the HIP kernel `recnn_adam_flat`.  capturable=True keeps the step count in device memory
+    (one int32 per optimizer, advanced by a torch op after the parameters' launches): `step()` then has no host-side state that a
+    captured graph would freeze (recnn_amd/nn/graphed.py); `state[p]['step']` still counts the host's calls."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+        self._step_dev = None
+
+    def device_steps(self) -> int:
+        """Optimizer steps taken as the device counts them (capturable mode; synchronises)."""
+        return 0 if self._step_dev is None else int(self._step_dev.item())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -35,6 +45,7 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         stream = None
+        stepped = False
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -52,10 +63,20 @@ class Adam(torch.optim.Optimizer):
                 st["step"] = int(st["step"]) + 1
                 g = p.grad.data if p.grad.data.is_contiguous() else p.grad.data.contiguous()
                 stream = stream or L.current_stream()
-                L.call("recnn_adam_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
-                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                       int(st["step"]), 1.0, stream)
+                if self.capturable:
+                    if self._step_dev is None:
+                        self._step_dev = torch.zeros(1, dtype=torch.int32, device=p.device)
+                    stepped = True
+                    L.call("recnn_adam_flat_at", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                           float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                           L.ptr(self._step_dev), 1, 1.0, stream)
+                else:
+                    L.call("recnn_adam_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                           float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                           int(st["step"]), 1.0, stream)
                 torch.autograd.graph.increment_version(p)    # the kernel wrote p behind autograd's back
+        if stepped:
+            self._step_dev.add_(1)
         return loss
 
 

@@ -362,3 +362,58 @@ def test_bcq_update_in_bf16_mode_follows_the_oracle(cuda):
         F_hip.set_mlp_dtype("fp32")
     print(f"bcq bf16 mode: worst relative loss deviation from the fp32 oracle over {steps} steps: {worst:.2e}")
     assert worst < 3e-2, worst
+
+
+def test_graphed_bcq_update_equals_the_eager_update(cuda):
+    """recnn_amd.nn.GraphedUpdate(bcq_update): the step captured once per kind (ordinary / perturbator step) and replayed == the same
+    steps issued eagerly through the same device counters (capturable HIP Adam, device-keyed dropout masks): all seven networks and
+    the losses bit for bit over 8 steps after 2 warm-up steps; the replayed step is one graph launch for the host."""
+    import copy
+    import time
+    from recnn_amd import optim
+    from recnn_amd.nn import GraphedUpdate, bcq_update
+    from recnn_amd.nn import models as M
+    S, A, L, H, B, n, steps = 1290, 128, 256, 256, 256, 10, 10
+    params = {"gamma": 0.99, "soft_tau": 0.01, "n_generator_samples": n, "perturbator_step": 3}
+    gcpu = torch.Generator().manual_seed(11)
+    batches = [{"state": torch.randn(B, S, generator=gcpu).cuda(), "action": (torch.randn(B, A, generator=gcpu) * 0.5).cuda(),
+                "reward": (torch.randn(B, generator=gcpu) * 2.0).cuda(), "next_state": torch.randn(B, S, generator=gcpu).cuda(),
+                "done": (torch.rand(B, generator=gcpu) < 0.1).float().cuda()} for _ in range(steps)]
+    noise = [[torch.randn(B, L, generator=gcpu).cuda(), torch.randn(B * n, L, generator=gcpu).cuda(), torch.randn(B, L, generator=gcpu).cuda()]
+             for _ in range(steps)]
+
+    def build(graphs):
+        torch.manual_seed(5)
+        gen, pert, v1, v2 = M.bcqGenerator(S, A, L), M.bcqPerturbator(S, A, H), M.Critic(S, A, H, 2e-1), M.Critic(S, A, H, 2e-1)
+        tpert, tv1, tv2 = copy.deepcopy(pert).eval(), copy.deepcopy(v1).eval(), copy.deepcopy(v2).eval()
+        for m in (gen, pert, tpert, v1, v2, tv1, tv2):
+            m.cuda()
+        nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+                "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+        opt = {k: optim.Adam(m.parameters(), lr=1e-4, capturable=True)
+               for k, m in (("generator_optimizer", gen), ("value_optimizer1", v1), ("value_optimizer2", v2), ("perturbator_optimizer", pert))}
+        static_noise = [torch.empty_like(z) for z in noise[0]]
+        # two warm-up steps run inside the constructor, both on batches[0]: their noise goes in up front
+        gen.forced_noise = [z.clone() for z in noise[0]] + [z.clone() for z in noise[1]]
+        gu = GraphedUpdate(bcq_update, batches[0], params, nets, opt, period_key="perturbator_step", warmup=2, graphs=graphs)
+        losses, t_host = [], 0.0
+        for t in range(2, steps):
+            for s_, z in zip(static_noise, noise[t]):
+                s_.copy_(z)
+            gen.forced_noise[:] = static_noise          # a replay reads the tensors its capture consumed: the same three
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = gu(batches[t])
+            t_host += time.perf_counter() - t0
+            losses.append([float(out[k]) for k in ("value", "perturbator", "generator")])
+        torch.cuda.synchronize()
+        assert opt["value_optimizer1"].device_steps() == steps and opt["perturbator_optimizer"].device_steps() == 4   # steps 0, 3, 6, 9
+        return _snapshot(gen, pert, tpert, v1, tv1, v2, tv2), losses, t_host / (steps - 2)
+
+    eager, eager_losses, t_eager = build(False)
+    graphed, graphed_losses, t_graph = build(True)
+    assert eager_losses == graphed_losses, (eager_losses, graphed_losses)
+    for net in eager:
+        for k in eager[net]:
+            assert torch.equal(eager[net][k], graphed[net][k]), (net, k)
+    print(f"bcq step, host time until the call returns: eager {t_eager * 1e3:.2f} ms, graphed {t_graph * 1e3:.2f} ms (incl. 2 captures)")

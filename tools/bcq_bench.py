@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--candidates", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="compute type of the GEMMs (functional.set_mlp_dtype)")
+    ap.add_argument("--graphed", action="store_true", help="replay the step from hipGraphs (recnn_amd.nn.GraphedUpdate): one graph launch per step")
     ap.add_argument("--no-split", action="store_true", help="score candidates on materialised repeated states (the reference's formulation)")
     args = ap.parse_args()
     from recnn_amd import optim
@@ -84,24 +85,37 @@ def main():
                  "value_optimizer2": optim.Adam(v2.parameters(), lr=1e-5), "perturbator_optimizer": optim.Adam(pert.parameters(), lr=1e-5)}
     gb = [{k: v.cuda() for k, v in b.items()} for b in batches]
     step = 0
-    for _ in range(args.warmup):
-        bcq_update(gb[step % 2], params, nets, optimizer, learn=True, step=step)
-        step += 1
+    if args.graphed:
+        from recnn_amd.nn import GraphedUpdate
+        optimizer = {k: optim.Adam(o.param_groups[0]["params"], lr=1e-5, capturable=True) for k, o in optimizer.items()}
+        gu = GraphedUpdate(bcq_update, gb[0], params, nets, optimizer, period_key="perturbator_step", warmup=2)
+        step = 2
+        for _ in range(max(args.warmup, 32)):          # both step kinds get captured here (perturbator_step = 30)
+            gu(gb[step % 2]); step += 1
+    else:
+        for _ in range(args.warmup):
+            bcq_update(gb[step % 2], params, nets, optimizer, learn=True, step=step)
+            step += 1
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
-        out = bcq_update(gb[step % 2], params, nets, optimizer, learn=True, step=step)
+        if args.graphed:
+            out = gu(gb[step % 2])
+        else:
+            out = bcq_update(gb[step % 2], params, nets, optimizer, learn=True, step=step)
         step += 1
     e1.record()
     torch.cuda.synchronize()
+    if args.graphed:
+        out = {k: (float(v) if k != "step" else v) for k, v in out.items()}
     wall = time.perf_counter() - t0
     ms = e0.elapsed_time(e1) / args.steps
     f_ref, f_split = flops_per_step(B, S, A, L, 256, 750, n, 30)
     line = {"metric": "BCQ update steps/sec (batch %d, %d candidates/state, latent %d)" % (B, n, L), "value": 1000.0 / ms,
             "unit": "steps/s", "ms_per_step": ms, "wall_ms_per_step": 1000.0 * wall / args.steps, "steps": args.steps,
-            "dtype": "f32 (exact-fp32 MFMA)" if args.dtype == "fp32" else "bf16 MFMA (fp32 accumulation, master weights, optimizer)", "candidate_path": "materialised" if args.no_split else "shared state part",
+            "dtype": "f32 (exact-fp32 MFMA)" if args.dtype == "fp32" else "bf16 MFMA (fp32 accumulation, master weights, optimizer)", "candidate_path": "materialised" if args.no_split else "shared state part", "issue": "hipGraph replay" if args.graphed else "eager",
             "gflop_per_step_reference_formulation": f_ref / 1e9, "gflop_per_step_executed": (f_ref if args.no_split else f_split) / 1e9,
             "tflops_executed": (f_ref if args.no_split else f_split) / (ms * 1e-3) / 1e12, "final_losses": out, "cpu_baseline": cpu}
     print(json.dumps(line))
