@@ -8,6 +8,8 @@ linear3.weight/bias ~ U(-init_w, init_w)), so equal seeds give equal initial wei
 run the HIP GEMM kernels through `recnn_amd.nn.functional`; inside `ddpg_update` / `td3_update` their
 parameters are adopted by the fused step engine (the parameter tensors become views into its flat arenas).
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -294,9 +296,12 @@ class StochasticActor(nn.Module):
     def evaluate(self, state, epsilon=1e-6):
         mean, log_std = self.forward(state)
         std = log_std.exp()
-        z = self.forced_z.pop(0) if self.forced_z else torch.randn(())
+        # (drawn on the device: no host value enters the step, so it can be captured -- recnn_amd.nn.GraphedUpdate)
+        z = self.forced_z.pop(0) if self.forced_z else torch.randn((), device=mean.device)
         z = torch.as_tensor(z, dtype=torch.float32).to(mean.device)
         action = torch.tanh(mean + z * std)
-        log_prob = torch.distributions.Normal(mean, std).log_prob(action)
+        # torch.distributions.Normal(mean, std).log_prob(action), its formula written out (the class validates its arguments with
+        # a host sync, which a captured step cannot have)
+        log_prob = -((action - mean) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))
         log_prob = log_prob - torch.log(1 - action.pow(2) + epsilon)
         return action, log_prob, z, mean, log_std

@@ -91,5 +91,7 @@ def soft_q_update(batch, params, nets, optimizer, device=torch.device("cpu"), de
                 writer.add_histogram(name, t, step)
         writer.close()
 
-    losses = {"value": value_loss.item(), "softq": q_value_loss.item(), "policy": policy_loss.item(), "step": step}
+    # (inside a stream capture -- recnn_amd.nn.graphed.GraphedUpdate -- the losses stay device scalars: .item() would sync)
+    val = (lambda t: t.detach()) if (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()) else (lambda t: t.item())
+    losses = {"value": val(value_loss), "softq": val(q_value_loss), "policy": val(policy_loss), "step": step}
     return losses

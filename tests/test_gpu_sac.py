@@ -90,3 +90,48 @@ def test_soft_q_update_at_the_notebook_shape_and_eval_mode(cuda):
     assert "test next_action" in debug and debug["test next_action"].shape == (B, 128)
     for n, m in nets.items():
         assert all(torch.equal(a, b) for a, b in zip(snap[n], m.parameters())), n
+
+
+def test_graphed_soft_q_update_equals_the_eager_update(cuda):
+    """GraphedUpdate(soft_q_update) at the notebook's shape: the captured step replayed == the step issued eagerly through the same
+    device counters, bit for bit (all four networks, losses) over 8 steps."""
+    import time
+    import recnn_amd
+    from recnn_amd.nn import GraphedUpdate, soft_q_update
+    dev = torch.device("cuda")
+    B, steps = 1024, 10
+    gcpu = torch.Generator().manual_seed(4)
+    batches = [{"state": torch.randn(B, 1290, generator=gcpu).to(dev), "action": (torch.randn(B, 128, generator=gcpu) * 0.3).to(dev),
+                "reward": torch.randn(B, generator=gcpu).to(dev), "next_state": torch.randn(B, 1290, generator=gcpu).to(dev),
+                "done": (torch.rand(B, generator=gcpu) < 0.1).float().to(dev)} for _ in range(steps)]
+    zs = torch.randn(steps, generator=gcpu)
+
+    def build(graphs):
+        torch.manual_seed(3)
+        nets = {"value_net": recnn_amd.nn.StateCritic(1290, 256, 1e-1).to(dev), "target_value_net": recnn_amd.nn.StateCritic(1290, 256).to(dev),
+                "soft_q_net": recnn_amd.nn.SoftQ(1290, 128, 256, 2e-1).to(dev), "policy_net": recnn_amd.nn.StochasticActor(1290, 128, 256, SR.ACTOR).to(dev)}
+        recnn_amd.utils.soft_update(nets["value_net"], nets["target_value_net"], soft_tau=1.0)
+        opt = {k + "_optimizer": recnn_amd.optim.Adam(nets[n].parameters(), lr=1e-4, capturable=True)
+               for k, n in (("value", "value_net"), ("soft_q", "soft_q_net"), ("policy", "policy_net"))}
+        policy = nets["policy_net"]
+        z_static = torch.zeros((), device=dev)
+        policy.forced_z = [zs[0].to(dev), zs[1].to(dev)]            # the two warm-up steps inside the constructor
+        gu = GraphedUpdate(soft_q_update, batches[0], SR.PARAMS, nets, opt, warmup=2, graphs=graphs)
+        losses, t_host = [], 0.0
+        for t in range(2, steps):
+            z_static.copy_(zs[t])
+            policy.forced_z[:] = [z_static]                        # a replay reads the tensor its capture consumed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = gu(batches[t])
+            t_host += time.perf_counter() - t0
+            losses.append([float(out[k]) for k in ("value", "softq", "policy")])
+        torch.cuda.synchronize()
+        return {n: [p.detach().clone() for p in m.parameters()] for n, m in nets.items()}, losses, t_host / (steps - 2)
+
+    eager, eager_losses, t_eager = build(False)
+    graphed, graphed_losses, t_graph = build(True)
+    assert eager_losses == graphed_losses, (eager_losses, graphed_losses)
+    for n in eager:
+        assert all(torch.equal(a, b) for a, b in zip(eager[n], graphed[n])), n
+    print(f"sac step, host time until the call returns: eager {t_eager * 1e3:.2f} ms, graphed {t_graph * 1e3:.2f} ms (incl. the capture)")
