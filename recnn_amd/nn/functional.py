@@ -61,6 +61,17 @@ _derived = {}
 _written = {}     # id(parameter) -> number of writes the HIP engine made behind autograd's back (mark_written)
 
 
+_capture_cache = {"d": None}
+
+
+def open_capture_cache():
+    _capture_cache["d"] = {}
+
+
+def close_capture_cache():
+    _capture_cache["d"] = None
+
+
 def mark_written(params):
     """The fused engine (ddpg_update / td3_update / value_update / Algo.run) writes adopted parameters in place from its
     kernels: no torch op runs, so their autograd version counters do not move.  Every caller that lets the engine step a
@@ -80,9 +91,20 @@ def _derived_of(w, kind, build):
     write count (`mark_written`) for the kernels that update adopted parameters without any torch op."""
     import weakref
     if w.is_cuda and torch.cuda.is_current_stream_capturing():
-        # a captured update (recnn_amd/nn/graphed.py) must rebuild the layout on every replay: a cache hit here would leave the
-        # build out of the graph, and the graph would keep reading the copy made at capture time after `w` moved on
-        return build(w.detach())
+        # a captured update (recnn_amd/nn/graphed.py) must rebuild the layout on every replay: a hit in the long-lived cache would
+        # leave the build out of the graph, and the graph would keep reading the copy made before the capture after `w` moved on.
+        # Inside ONE capture the same version of `w` is built once (a cache that lives as long as the capture: every replay
+        # rebuilds at the same points of the step).
+        tag = (w._version, w.data_ptr(), tuple(w.shape), _written.get(id(w), 0))
+        scoped = _capture_cache.get("d")
+        if scoped is None:
+            return build(w.detach())
+        hit = scoped.get((id(w), kind))
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        out = build(w.detach())
+        scoped[(id(w), kind)] = (tag, out, w)      # (w kept alive: its id must not be reused while the capture runs)
+        return out
     key = (id(w), kind)
     tag = (w._version, w.data_ptr(), tuple(w.shape), _written.get(id(w), 0))
     hit = _derived.get(key)
@@ -235,12 +257,21 @@ class MLPFunction(torch.autograd.Function):
         return _derived_of(w, f"bf16_{rows}x{cols}", build) if w.is_leaf else build(w.detach())
 
     @staticmethod
+    def _buf16(rows, cols, valid, dev):
+        """bf16 [rows, cols] whose columns >= valid are zero and whose first `valid` columns the caller's kernel writes: only the
+        padding is filled (whole-buffer torch.zeros calls were 17 % of the BCQ step's kernel time, profiles/r03_bcq_*)."""
+        t = torch.empty(rows, cols, dtype=torch.bfloat16, device=dev)
+        if cols != valid:
+            t[:, valid:].zero_()
+        return t
+
+    @staticmethod
     def _forward_bf16(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks, addend1):
         B, K = x.shape
         H, O = w1.shape[0], w3.shape[0]
         Kp, Hp, Op = _r128(K), _r128(H), _r64(O)
         dev = x.device
-        x16 = torch.zeros(B, Kp, dtype=torch.bfloat16, device=dev)
+        x16 = MLPFunction._buf16(B, Kp, K, dev)
         x16[:, :K] = x.detach()
         w1s, w2s, w3s = MLPFunction._shadow16(w1, Hp, Kp), MLPFunction._shadow16(w2, Hp, Hp), MLPFunction._shadow16(w3, Op, Hp)
         m1 = m2 = None
@@ -252,8 +283,8 @@ class MLPFunction(torch.autograd.Function):
             _dump_masks(seed, B, H, m1, m2, L.current_stream())
         f = lambda t: t.detach().float().contiguous()
         add1 = None if addend1 is None else f(addend1)
-        h1 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
-        h2 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        h1 = MLPFunction._buf16(B, Hp, H, dev)
+        h2 = MLPFunction._buf16(B, Hp, H, dev)
         out = torch.empty(B, O, device=dev)
         _fwd(x16, Kp, w1s, f(b1), h1, Hp, H, True, m1, addend=add1, dtype=L.BF16, c_f32=0)
         _fwd(h1, Hp, w2s, f(b2), h2, Hp, H, True, m2, dtype=L.BF16, c_f32=0)
@@ -280,13 +311,13 @@ class MLPFunction(torch.autograd.Function):
             _dw(d16, O, h2, H, gw3, dtype=L.BF16)
         if need[6]:
             gb3 = dout.float().sum(0)
-        dz2 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        dz2 = MLPFunction._buf16(B, Hp, H, dev)
         cs2 = torch.empty(tiles, H, device=dev)
         _dx(d16, Op, w3s, H, dz2, h2, scale, cs2, dtype=L.BF16, c_f32=0)
         if need[3]:
             gw2 = torch.empty(H, H, device=dev)
             _dw(dz2, H, h1, H, gw2, dtype=L.BF16)
-        dz1 = torch.zeros(B, Hp, dtype=torch.bfloat16, device=dev)
+        dz1 = MLPFunction._buf16(B, Hp, H, dev)
         cs1 = torch.empty(tiles, H, device=dev)
         _dx(dz2, Hp, w2s, H, dz1, h1, scale, cs1, dtype=L.BF16, c_f32=0)
         if need[1]:

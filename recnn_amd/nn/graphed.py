@@ -99,8 +99,12 @@ class GraphedUpdate:
             self._load(batch)
             if kind not in self.graphs:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream):
-                    out = self._run(self.step)
+                F_hip.open_capture_cache()
+                try:
+                    with torch.cuda.graph(g, stream=self.stream):
+                        out = self._run(self.step)
+                finally:
+                    F_hip.close_capture_cache()
                 self.graphs[kind] = g
                 self._outs[kind] = out
                 # (capture does not execute: the replay below runs this very step)
