@@ -532,6 +532,9 @@ void recnn_comm_destroy(recnn_comm* c);
 int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
 /* tuning knob: memory kind of the peer buffers created afterwards: 0 fine-grained (default), 1 uncached, 2 ordinary */
 void recnn_tune_comm_memory(int kind);
+/* tuning knob: XCD-affine workgroup map of the fused forward (csrc/mlp.h MlpBatch.xcd_map) for launches of up to max_problems
+ * networks: a network's weights are fetched into two L2s instead of eight */
+void recnn_tune_mlp_xcd(int max_problems);   /* 0 = off (default) */
 /* tuning knob: 1 (default) the critics' gradient exchange runs inside their optimizer launch, 0 as launches of its own */
 void recnn_tune_comm_fused(int on);
 /* tuning knob: workgroups per collective launch (default 128) */

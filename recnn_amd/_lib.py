@@ -191,6 +191,7 @@ SIGNATURES = {
     "recnn_comm_destroy": (None, [_P]),
     "recnn_engine_set_comm": (_I, [_P, _P, _F]),
     "recnn_tune_comm_memory": (None, [_I]),
+    "recnn_tune_mlp_xcd": (None, [_I]),
     "recnn_tune_comm_fused": (None, [_I]),
     "recnn_tune_comm_workgroups": (None, [_I]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),

@@ -98,8 +98,20 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 // PROBE (timing experiments, recnn_tune_mlp_fault bits 0x100 / 0x200 = bench.py RECNN_MLP_PROBE 1 / 2): 1 = no MFMA work, 2 = no DMA
 template <int PROBE>
 __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch, unsigned long long* trace) {
-  const MlpProb& P = batch.p[blockIdx.y];
-  const int m0 = blockIdx.x * BM;
+  int by, bx, panels;
+  if (batch.xcd_map > 0) {   // XCD-affine map (mlp.h): id = slot * 8 + xcd
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, half = batch.xcd_map >> 1;
+    by = (slot / half) * 4 + (xcd >> 1);
+    bx = (slot % half) * 2 + (xcd & 1);
+    panels = batch.xcd_map;
+    if (by >= batch.nprob) return;
+  } else {
+    by = blockIdx.y; bx = blockIdx.x; panels = gridDim.x;
+  }
+  by = __builtin_amdgcn_readfirstlane(by);
+  bx = __builtin_amdgcn_readfirstlane(bx);
+  const MlpProb& P = batch.p[by];
+  const int m0 = bx * BM;
   if (m0 >= P.rows) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const unsigned lds0 = (unsigned)(size_t)lds;
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int row_max = P.rows - 1;
-  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)by * panels + bx) * 32 : nullptr;
   asm volatile("" : "+v"(trow));
   MLPS_STAMP(0);
 
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   {
     // (through the kernarg segment pointer: taking the address of the by-value argument would make the compiler copy it to scratch)
     const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    const char __attribute__((address_space(4)))* pa = ka + blockIdx.y * sizeof(MlpProb);       // batch.p[blockIdx.y]
+    const char __attribute__((address_space(4)))* pa = ka + by * sizeof(MlpProb);       // batch.p[by]
     const char __attribute__((address_space(4)))* pb = ka + offsetof(MlpBatch, tail);            // tails, head, critic tails, err
 #pragma unroll
     for (int i = 0; i < 5; ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
@@ -187,10 +199,10 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
       const int limit = batch.spin_limit > 0 ? batch.spin_limit : (1 << 22);
       int spins = 0;
       bool ok;
-      while (!(ok = __hip_atomic_load(batch.tail[ti].flag + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) && ++spins < limit)
+      while (!(ok = __hip_atomic_load(batch.tail[ti].flag + bx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) && ++spins < limit)
         __builtin_amdgcn_s_sleep(2);
       if (!ok && batch.err) __hip_atomic_fetch_or(batch.err, MLP_ERR_PART_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(batch.tail[ti].flag + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(batch.tail[ti].flag + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_barrier();  // (raw: the other waves keep their DMAs in flight; only wave 0 paid the acquire's drain)
   };
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) *(f32x4*)(P.part_out + (int64_t)(m0 + tm * 16 + fr) * HP + n0) = acc[tm][0];
     __syncthreads();  // every thread's stores have completed (the barrier is preceded by s_waitcnt vmcnt(0))
-    if (tid == 0 && (batch.fault & 3) != 1) __hip_atomic_store(P.part_flag + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && (batch.fault & 3) != 1) __hip_atomic_store(P.part_flag + bx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     MLPS_STAMP(9);
     return;
   }
@@ -495,8 +507,8 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
             const float tot = wave_sum(e * e);
             const float dsum = wave_sum(d);
             if (lane == 0) {
-              if (Hd.loss_part[c]) Hd.loss_part[c][blockIdx.x] = tot;
-              if (Hd.db3_part[c]) Hd.db3_part[c][blockIdx.x] = dsum;
+              if (Hd.loss_part[c]) Hd.loss_part[c][bx] = tot;
+              if (Hd.db3_part[c]) Hd.db3_part[c][bx] = dsum;
             }
           }
         }
@@ -613,6 +625,9 @@ int mlp_waves() { return NW; }
 // mlpr.hip (weights straight into MFMA registers) were measured slower at every shape the engine produces (47 and 70 us vs
 // 26 at DDPG / 2048 rows) and are gone; their bit-for-bit agreement with this kernel was tested up to their removal
 // (tests/test_gpu_kernels.py history, profiles/r02_gpu_tests_v7.log).
+static int g_mlp_xcd_max_prob = 0;   // 0: off; n: launches of up to n problems take the XCD-affine map
+extern "C" void recnn_tune_mlp_xcd(int max_problems) { g_mlp_xcd_max_prob = max_problems < 0 ? 0 : max_problems; }
+
 int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   MlpBatch b = b_in;
   b.fault = g_mlp_fault;
@@ -639,7 +654,20 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
       if (p.K[g] % KB1 || (p.lda[g] % 8) || ((uintptr_t)p.A[g] & 15)) { recnn_set_error("mlp_fwd: bad segment"); return RECNN_E_INVALID; }
   }
   if (rows <= 0 || nprob <= 0) return 0;
-  const dim3 grid((rows + BM - 1) / BM, nprob), block(NW * 64);
+  const int panels = (rows + BM - 1) / BM;
+  dim3 grid(panels, nprob);
+  const dim3 block(NW * 64);
+  b.nprob = nprob;
+  b.xcd_map = 0;
+  // the XCD-affine map needs equal-sized problems with an even panel count, and is a gain only while the problems of the second
+  // round land behind SHORT first-round problems (DDPG: the deferred policy-loss forward behind the target critic's layer-1
+  // producer; TD3's seven problems would queue the target actor behind a producer)
+  bool same = true;
+  for (int i = 0; i < nprob; ++i) same = same && b.p[i].rows == rows;
+  if (same && panels >= 2 && !(panels & 1) && nprob <= g_mlp_xcd_max_prob) {
+    b.xcd_map = panels;
+    grid = dim3(8 * (panels / 2) * ((nprob + 3) / 4), 1);
+  }
   switch ((b.fault >> 8) & 3) {
     case 1: hipLaunchKernelGGL(mlps_fwd_kernel<1>, grid, block, LDS_TOTAL, s, b, g_mlps_trace); break;
     case 2: hipLaunchKernelGGL(mlps_fwd_kernel<2>, grid, block, LDS_TOTAL, s, b, g_mlps_trace); break;
