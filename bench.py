@@ -315,6 +315,26 @@ def main():
             for r in range(reps):
                 algo.prepare_run(args.steps, first_step=args.warmup + r * args.steps)
         run(0, args.warmup)
+        if use_dp and comm is not None:
+            # the warm-up steps were the first to run the exchange INSIDE the optimizer launches (PeerComm's own self-test covers the
+            # stand-alone collective): if any rank saw a wait run out, every rank goes back to RCCL issued by the host
+            torch.cuda.synchronize(dev)
+            ok = 1
+            try:
+                comm.check()
+            except L.RecnnHipError:
+                ok = 0
+            votes = [None] * world
+            dist.all_gather_object(votes, ok)
+            if not min(votes):
+                eng.set_comm(None)
+                comm = None
+                collective = "rccl (the peer collective timed out in the warm-up)"
+                dp = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=args.overlap)
+
+                def run(first, n):
+                    dp.run(first, n)
+                run(args.warmup, 2)
         for r in range(reps):
             barrier()
             t0 = time.perf_counter()
