@@ -109,7 +109,7 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
 
 # launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports (the default fused forward
 # is mlps.hip's mlps_fwd_kernel; the opt-in variants mlp_fwd_kernel / mlp64 / mlpr are reached through recnn_tune_*)
-KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "l1_critic": "l1_gemm_kernel", "tail_critic": "mlp_tail_kernel",
+KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_fwd_critic": "mlps_fwd_kernel", "l1_critic": "l1_gemm_kernel", "tail_critic": "mlp_tail_kernel",
                   "frozen_actors": "mlp_frozen_kernel", "frozen_target_critics": "mlp_frozen_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",

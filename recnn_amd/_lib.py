@@ -192,6 +192,7 @@ SIGNATURES = {
     "recnn_engine_set_comm": (_I, [_P, _P, _F]),
     "recnn_tune_comm_memory": (None, [_I]),
     "recnn_tune_mlp_xcd": (None, [_I]),
+    "recnn_tune_cycle_fused_critic": (None, [_I]),
     "recnn_tune_comm_fused": (None, [_I]),
     "recnn_tune_comm_workgroups": (None, [_I]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),

@@ -28,6 +28,7 @@ KNOBS = {
     "RECNN_DW_FUSE": "recnn_tune_dw_fuse",
     "RECNN_OPT_TABLE": "recnn_tune_opt_table",
     "RECNN_MLP_XCD": "recnn_tune_mlp_xcd",
+    "RECNN_CYCLE_FUSED_CRITIC": "recnn_tune_cycle_fused_critic",
     "RECNN_COMM_MEMORY": "recnn_tune_comm_memory",
     "RECNN_COMM_FUSED": "recnn_tune_comm_fused",
     "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",

@@ -1069,6 +1069,67 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
   return 0;
 }
 
+// Cycle mode, per step: the learning critic(s) on the batch -- whole network, TD head (Q' of the rows was computed for the whole
+// cycle by ph_frozen_batched) and UNIT layer-2 backward -- plus the previous step's policy-loss forward, as ONE fused row-panel
+// launch (mlps.hip; 64-128 workgroups: a single round of CUs).  Against the split form (l1gemm + mlpt) a workgroup streams all of
+// W1 again, but starts once and never writes h1 out for somebody else to read.  MEASURED (tools/fused_critic_ab.sh): the launch
+// takes 21.8 us (23.3 in run graphs with the policy-loss forward) against 8.9 + 12.7 for the two split launches, and the dW
+// launch behind it is the unit-tensor form (13.2 vs 9.8 us): 67.4 vs 65.1 us/step -- bit-identical, slower, so a knob (off).
+int g_cycle_fused_critic = 0;
+extern "C" void recnn_tune_cycle_fused_critic(int on) { g_cycle_fused_critic = on; }
+int ph_forward_cycle_fused(recnn_engine* e, int rows, bool value_bwd, hipStream_t s) {
+  const int A = e->A, nc = e->n_critic;
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+  const int64_t aoff = (int64_t)A * e->esz;
+  const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
+  MlpBatch mb;
+  memset(&mb, 0, sizeof(mb));
+  int np = 0, rc;
+  double fl = 0;
+  for (int c = 0; c < nc; ++c) {
+    MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
+    fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
+    fc.q = e->q[c];
+    MlpProb* pc = &mb.p[np];
+    fl += fill_mlp(e, fc, rows, &mb.p[np++]);
+    MlpCriticBwd& B = mb.cbwd[c];
+    pc->cbwd_idx = c;
+    B.enabled = 1;
+    B.q_slot = nullptr;          // Q(s, a) stays inside the workgroup: it evaluates the head itself
+    B.scale = train ? 2.0f : 1.0f;
+    B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];   // UNIT tensors: the dW launch applies the per-row seed e->delta[c]
+    if (value_bwd) RECNN_REQUIRE(e->net[VAL[c]].g, "value backward: network %d has no gradient arena bound", VAL[c]);
+    fl += 2.0 * rows * (double)e->H * e->H;
+  }
+  MlpHead& Hd = mb.head;
+  Hd.n_critic = nc; Hd.n_target = nc;
+  for (int c = 0; c < nc; ++c) {
+    Hd.self_tq[c] = e->tqv[c];
+    Hd.delta_out[c] = e->delta[c]; Hd.loss_part[c] = e->loss_part[c];
+    Hd.db3_part[c] = value_bwd ? e->net[VAL[c]].gp[B3] : nullptr;
+  }
+  Hd.reward = e->reward; Hd.done = e->done; Hd.gamma = e->hy.gamma;
+  Hd.lo = e->td3 ? -INFINITY : e->hy.min_value;
+  Hd.hi = e->td3 ? INFINITY : e->hy.max_value;
+  Hd.expected = e->expected; Hd.target_q = e->target_q;
+  if (e->pending_pc.on && np < MLP_MAX_GROUP) {   // the previous step's policy-loss forward (see ph_forward)
+    const auto& pp = e->pending_pc;
+    MlpSpec f{RECNN_NET_VALUE1, pp.ga, e->Ap, e->Ap, 0};
+    f.A1 = pp.xs + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
+    f.q = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;
+    f.mask_idx = e->td3 ? 6 : 4;
+    MlpProb* pd = &mb.p[np++];
+    fl += fill_mlp(e, f, rows, pd);
+    pd->step_add = pp.run_off;
+    e->pending_pc.on = false;
+  }
+  mb.err = (int32_t*)(e->losses + 4);
+  if ((rc = slot(e, "mlp_fwd_critic", fl, s, [&] { return mlp_launch(mb, np, s); }))) return rc;
+  e->panel_bwd_done = true;     // losses, the per-row seed and the UNIT dz2 / dz1 came out of the forward launch
+  e->unit_bwd = true;
+  return 0;
+}
+
 // Forward of the value side (+ optionally the actor forward, which is independent of it).
 int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
   const int A = e->A, Hp = e->Hp, nc = e->n_critic;
@@ -1942,7 +2003,8 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if (frozen_done) {   // cycle mode: the batch is in place and the frozen networks have been applied to it (ph_frozen_batched)
-    if ((rc = ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
+    const bool fused = g_cycle_fused_critic && value_chain_ok(e) && g_bwd_panel >= 2 && mlp_waves() == 16;
+    if ((rc = fused ? ph_forward_cycle_fused(e, rows, learn, s) : ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
   } else if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
     // The critic's soft update reads the just-updated weights and nothing reads the target before the

@@ -55,6 +55,11 @@ struct MlpHead {
   float* delta_out[2];       // d = 2 (q - y) / rows, per critic
   float* loss_part[2];       // [panels] sum (q - y)^2
   float* db3_part[2];        // [panels] sum d  (NULL: not wanted)
+  // Cycle mode (engine.hip): Q' of the rows was computed for the whole policy cycle beforehand (mlpf.hip), so no workgroup of
+  // THIS launch owns it -- a learning critic's own workgroup evaluates the head for its rows from self_tq (min over n_target of
+  // them), its Q(s, a) never leaves the workgroup.  Same arithmetic, same reduction tree: the same bits.
+  int n_target;
+  const float* self_tq[2];   // fp32 [rows] each; self_tq[0] != NULL selects this mode (n_critic then counts the critics as usual)
 };
 
 struct MlpProb {

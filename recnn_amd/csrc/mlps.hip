@@ -300,14 +300,19 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
     key2 = mask_key(P.seed, st, P.stream2);
   }
   // head inputs of rows m0 .. m0 + 31 (wave 0 evaluates the head)
-  float h_rew = 0.f, h_done = 0.f;
-  if (batch.head.n_critic > 0 && n_tail > 0 && wave == 0) {
+  float h_rew = 0.f, h_done = 0.f, h_tq = 0.f;
+  const bool self_head = batch.head.self_tq[0] != nullptr && P.cbwd_idx >= 0 && !P.W3;   // this critic evaluates its own head
+  if (batch.head.n_critic > 0 && (n_tail > 0 || self_head) && wave == 0) {
     const int mc = min(m0 + (lane & 31), P.rows - 1);
     h_rew = batch.head.reward[mc];
     h_done = batch.head.done[mc];
+    if (self_head) {
+      h_tq = batch.head.self_tq[0][mc];
+      if (batch.head.n_target > 1) h_tq = fminf(h_tq, batch.head.self_tq[1][mc]);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
-  asm volatile("" : "+v"(b1v[0]), "+v"(b2v[0]), "+v"(h_rew), "+v"(h_done));
+  asm volatile("" : "+v"(b1v[0]), "+v"(b2v[0]), "+v"(h_rew), "+v"(h_done), "+v"(h_tq));
 #pragma unroll
   for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v3[r]));
   MLPS_STAMP(1);
@@ -528,6 +533,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
       s = wave_sum(s);
+      if (lane == 0 && self_head) ((float*)(lds + ps0 * STAGE1 + 3072))[row] = s + b3s;   // (an A part: idle since layer 1)
       if (lane == 0 && m0 + row < P.rows) {
         const float qv = s + b3s;
         P.q[m0 + row] = qv;
@@ -546,6 +552,7 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
         const float4 w3a = *(const float4*)(P.w3row + nb), w3b = *(const float4*)(P.w3row + nb + 4);
         const float wsc = n8 < P.H ? B.scale : 0.f;
         const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the Q values of a self-evaluated head are in LDS behind this barrier)
         __builtin_amdgcn_s_barrier();   // every wave is done reading h2 rows for its q dots
         unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16);
         const uint4 raw = *(const uint4*)cell;
@@ -597,6 +604,30 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (((gate1 >> (tm * 4 + r)) & 1u) && n0 + r < P.H) ? dacc[tm][r] * B.scale : 0.f;
         if (mm < P.rows) *(uint2*)((bf16_t*)B.dz1 + (int64_t)mm * P.ldh + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+      // ---- the head of THIS critic on its own rows (cycle mode: Q' given), last so that wave 0 never holds a barrier up:
+      // the arithmetic and the reduction tree of the head above (recnn/nn/update/misc.py:6-7,33-39, td3.py:83-93)
+      if (self_head && wave == 0) {
+        const MlpHead& Hd = batch.head;
+        const int c = P.cbwd_idx;
+        const int r = lane & 31, m = m0 + r;
+        const bool valid = lane < 32 && m < P.rows;
+        float y = h_rew + (1.0f - h_done) * Hd.gamma * h_tq;
+        y = fminf(fmaxf(y, Hd.lo), Hd.hi);
+        if (valid && c == 0) {
+          if (Hd.expected) Hd.expected[m] = y;
+          if (Hd.target_q) Hd.target_q[m] = h_tq;
+        }
+        const float q = ((const float*)(lds + ps0 * STAGE1 + 3072))[r];
+        const float e = valid ? q - y : 0.f;
+        const float d = e * (2.0f / (float)P.rows);
+        if (valid && Hd.delta_out[c]) Hd.delta_out[c][m] = d;
+        const float tot = wave_sum(e * e);
+        const float dsum = wave_sum(d);
+        if (lane == 0) {
+          if (Hd.loss_part[c]) Hd.loss_part[c][bx] = tot;
+          if (Hd.db3_part[c]) Hd.db3_part[c][bx] = dsum;
+        }
       }
     }
   }
