@@ -121,6 +121,12 @@ class FrameLoader:
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
+        planner = getattr(self, "planner", None)
+        if planner is not None:
+            # an Algo drives this loader (Algo.attach_env(..., drive_loader=True)): one epoch of handles of the fixed-size
+            # batches its engine draws -- `algo.update(batch)` queues them, `batch["state"]` materialises one on demand
+            yield from planner.batches(planner.batches_left_in_epoch())
+            return
         n = len(self.dataset)
         order = torch.randperm(n).numpy() if self.shuffle else np.arange(n)
         users = self.dataset.users
@@ -212,11 +218,18 @@ class FrameEnv(Env):
     # ------------------------------------------------------------------ batches
     def collate_users(self, user_ids):
         """Batch of the given users, windows concatenated in the given order (prepare_batch_static_size)."""
+        return self.collate_slots(self.store.slots(user_ids), user_ids)
+
+    def collate_slots(self, slots, user_ids=None, rows_per_batch="env"):
+        """The same for users given by their slots in the replay store (what the engine's sampler permutes)."""
         st = self.store
-        slots = st.slots(user_ids)
+        slots = np.asarray(slots, dtype=np.int32)          # (the gather kernels read 32-bit slots)
+        if user_ids is None:
+            user_ids = slots
         sizes = st.lengths[slots]
         total = int(np.maximum(sizes - self.frame_size, 0).sum())
-        rows = total if self.rows_per_batch is None else min(self.rows_per_batch, total)
+        cut = self.rows_per_batch if rows_per_batch == "env" else rows_per_batch
+        rows = total if cut is None else min(cut, total)
         meta = {"users": torch.as_tensor(np.asarray(list(user_ids))), "sizes": torch.from_numpy(sizes.copy())}
         if self.embed_batch is utils.batch_tensor_embeddings:
             users_d = torch.from_numpy(slots).to(self.device)

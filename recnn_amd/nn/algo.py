@@ -50,15 +50,36 @@ def _hard_sync(net, target):
 
 
 class PlannedBatch:
-    """Handle of the fixed-size batch the engine's sampler draws for update step `index` (Algo.batches)."""
-    __slots__ = ("algo", "index")
+    """Handle of the fixed-size batch the engine's sampler draws for update step `index` (Algo.batches): `algo.update(batch)`
+    queues it without ever building it on the host side; reading it like the reference's batch dict (`batch["state"]`,
+    `.keys()`, `data.get_base_batch(batch)`) materialises the same rows through the gather kernel, once."""
+    __slots__ = ("algo", "index", "pos", "_rows")
+    KEYS = ("state", "action", "reward", "next_state", "done", "meta")
 
-    def __init__(self, algo, index):
-        self.algo, self.index = algo, index
+    def __init__(self, algo, index, pos=None):
+        self.algo, self.index, self.pos, self._rows = algo, index, pos, None
+
+    def _materialise(self):
+        if self._rows is None:
+            if self.pos is None:
+                raise TypeError("this planned batch carries no sampler position: it cannot be materialised")
+            self._rows = self.algo._planned_rows(self.pos)
+        return self._rows
 
     def __getitem__(self, key):
-        raise TypeError("a planned batch is a handle of rows that only exist on the device while its step runs; build an "
-                        "inspectable batch with env.collate_users(users) / the environment's data loaders")
+        return self._materialise()[key]
+
+    def keys(self):
+        return self.KEYS
+
+    def __contains__(self, key):
+        return key in self.KEYS
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def items(self):
+        return self._materialise().items()
 
     def __repr__(self):
         return f"PlannedBatch(step={self.index})"
@@ -147,7 +168,8 @@ class Algo:
         self._step += 1
 
     # ---- extension: fused training on a device-resident FrameEnv (no reference counterpart) --------------------
-    def attach_env(self, env, rows_per_batch: int, users_per_batch: int = None, shard=(0, 1), dtype: str = None):
+    def attach_env(self, env, rows_per_batch: int, users_per_batch: int = None, shard=(0, 1), dtype: str = None,
+                   drive_loader: bool = False):
         """Let the engine sample its own batches from `env`'s TRAIN users: `run(n)` then executes n update steps
         (sampler, gather, update, step()) as hipGraph replays with no Python or host work per step.  Equivalent to
         `for batch in env.train_dataloader: self.update(batch); self.step()` with fixed `rows_per_batch`-row batches.
@@ -175,6 +197,10 @@ class Algo:
             ctx.mirror_optimizer_state(self.optimizers[k], ni)
         ctx.attach_sampler(env, rows_per_batch, users_per_batch, shard)
         self._fused_ctx, self._fused_keys = ctx, keys
+        if drive_loader:
+            # `for batch in env.train_dataloader: algo.update(batch); algo.step()` -- the reference's loop, verbatim -- then
+            # iterates handles of the engine's own batches (FrameLoader.__iter__) and runs at the speed of `run`
+            env.train_dataloader.planner = self
         return self
 
     def _fused_adam_cfgs(self, keys):
@@ -211,8 +237,29 @@ class Algo:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
         i = 0
         while n is None or i < n:
-            yield PlannedBatch(self, self._step)
+            sm = self._fused_ctx.sampler
+            yield PlannedBatch(self, self._step, pos=sm["pos"] + getattr(self, "_queue", (0, 0))[1])
             i += 1
+
+    def batches_left_in_epoch(self) -> int:
+        """Planned batches until the engine's sampler finishes its current epoch permutation (queued steps counted)."""
+        sm = self._fused_ctx.sampler
+        left = sm["n_batches"] - (sm["cursor"] + getattr(self, "_queue", (0, 0))[1]) % sm["n_batches"]
+        return left
+
+    def _planned_rows(self, pos):
+        """The batch at sampler position `pos` as the reference's dict (for inspection): every earlier step is executed first,
+        so that the epoch permutation the position falls into has been drawn."""
+        self.flush()
+        sm = self._fused_ctx.sampler
+        epoch, idx = divmod(pos, sm["n_batches"])
+        if pos > sm["pos"] and epoch > sm["epoch"]:
+            raise RuntimeError("this batch belongs to an epoch whose permutation is drawn when the previous epoch's last step runs")
+        perm = sm["perms"].get(epoch)
+        if perm is None:
+            raise KeyError("the permutation of that epoch is no longer kept (planned batches can be read up to two epochs back)")
+        slots = perm[idx * sm["upb"]:(idx + 1) * sm["upb"]]
+        return sm["env"].collate_slots(slots, rows_per_batch=sm["rows"])
 
     def _update_planned(self, batch, learn):
         if not learn:

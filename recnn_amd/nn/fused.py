@@ -275,7 +275,7 @@ class FusedContext:
             users_per_batch = int(np.searchsorted(np.cumsum(k), rows) + 1)
         users_per_batch = min(users_per_batch, len(train))
         self.sampler = dict(env=env, rows=rows, upb=users_per_batch, train=torch.from_numpy(train).to(eng.device),
-                            n_batches=len(train) // users_per_batch, cursor=0)
+                            train_host=train, n_batches=len(train) // users_per_batch, cursor=0, pos=0, epoch=-1, perms={})
         self.perm = torch.empty(self.sampler["n_batches"] * users_per_batch, dtype=torch.int32, device=eng.device)
         self._reshuffle()
         eng.bind_sampler(st.items, st.ratings, st.user_off, self.perm, users_per_batch, env.frame_size, self.A, env.table,
@@ -284,7 +284,12 @@ class FusedContext:
 
     def _reshuffle(self):
         sm = self.sampler
-        order = torch.randperm(sm["train"].numel())[: self.perm.numel()].to(sm["train"].device)   # CPU generator, as RandomSampler
+        order = torch.randperm(sm["train"].numel())[: self.perm.numel()]                            # CPU generator, as RandomSampler
+        # the host keeps the last epochs' permutations (store slots): a planned batch can be materialised for inspection
+        sm["epoch"] += 1
+        sm["perms"][sm["epoch"]] = sm["train_host"][order.numpy()]
+        sm["perms"].pop(sm["epoch"] - 3, None)
+        order = order.to(sm["train"].device)
         self.perm.copy_(sm["train"][order].to(torch.int32))
         if getattr(self.engine, "has_sampler", False):
             self.engine.plan_sampler()          # the plan table follows the permutation (same stream as the copy)
@@ -325,6 +330,7 @@ class FusedContext:
                 eng.graph_run(first_step + done, chunk)
                 done += chunk
                 sm["cursor"] += chunk
+                sm["pos"] += chunk
                 if sm["cursor"] >= sm["n_batches"]:      # epoch finished (the device cursor wrapped to 0 by itself)
                     sm["cursor"] = 0
                     self._reshuffle()

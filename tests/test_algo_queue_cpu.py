@@ -25,7 +25,7 @@ class _Engine:
 class _Ctx:
     def __init__(self):
         self.engine = _Engine()
-        self.sampler = {"rows": 8}
+        self.sampler = {"rows": 8, "pos": 0, "cursor": 0, "n_batches": 1000, "epoch": 0, "perms": {}, "upb": 2}
         self.modules = {}
         self.runs = []
 
@@ -38,6 +38,8 @@ class _Ctx:
     def run_steps(self, first, n, every=None, prepare=False):
         self.runs.append((first, n))
         self.engine.steps += n
+        self.sampler["pos"] += n
+        self.sampler["cursor"] = (self.sampler["cursor"] + n) % self.sampler["n_batches"]
 
 
 def _algo():
@@ -97,3 +99,14 @@ def test_handles_must_be_used_in_order_once():
         a.update(PlannedBatch(_algo(), a._step))                             # a handle of another Algo
     with pytest.raises(ValueError):
         a.update(next(a.batches()), learn=False)
+
+
+def test_handles_carry_their_sampler_position():
+    a = _algo()
+    it = a.batches()
+    h0 = next(it); a.update(h0); a.step()
+    h1 = next(it)
+    assert (h0.pos, h1.pos) == (0, 1) and a.batches_left_in_epoch() == 999          # one queued, none executed
+    a.run(10)
+    assert next(a.batches()).pos == 11 and a.batches_left_in_epoch() == 989
+    assert set(h1.keys()) >= {"state", "action", "reward", "next_state", "done"} and "state" in h1

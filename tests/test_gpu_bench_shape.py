@@ -434,5 +434,39 @@ def test_reference_shaped_loop_on_planned_batches_equals_run(cuda):
     b.update(first); b.step()
     with pytest.raises(RuntimeError, match="out of order"):
         b.update(first)                                    # a handle is good for one update
-    with pytest.raises(TypeError):
-        first["state"]
+    assert first["state"].shape == (ROWS, 1290) and first["reward"].shape == (ROWS,)     # a handle materialises on demand
+
+
+def test_train_dataloader_driven_by_the_algo_is_the_reference_loop(cuda):
+    """`algo.attach_env(env, ..., drive_loader=True)`, then the reference's loop VERBATIM -- `for batch in env.train_dataloader:
+    loss = algo.update(batch, learn=True); algo.step()` -- iterates handles of the engine's own batches: an epoch is as long as
+    the sampler's, and a twin DDPG fed the MATERIALISED handles (`batch["state"]` ...: the rows the engine gathers, rebuilt through
+    env.collate_slots) step by step ends with the same four networks bit for bit."""
+    import recnn_amd
+    n = 23
+    env, _ = _bench_env(recnn_amd, cuda, n_users=UPB * 6)
+    a = _make_algo(recnn_amd, cuda, env, "bf16")
+    env.train_dataloader.planner = a
+    assert len(list(zip(range(10 ** 6), env.train_dataloader))) == 6          # one epoch of the sampler: 6 batches of UPB users
+    a2 = _make_algo(recnn_amd, cuda, env, "bf16")                             # (same seeds: the same permutations)
+    env.train_dataloader.planner = a2
+    from recnn_amd.nn import fused
+    fused.set_defaults(dtype="bf16", mask_mode="hash", seed=SEED)
+    torch.manual_seed(12)
+    b = recnn_amd.nn.DDPG(recnn_amd.nn.Actor(1290, 128, 256, 6e-1), recnn_amd.nn.Critic(1290, 128, 256, 54e-2)).to(cuda)
+    done = 0
+    while done < n:                                                           # epochs of 6 batches, the reference's outer loop
+        for batch in env.train_dataloader:
+            rows = {k: batch[k] for k in ("state", "action", "reward", "next_state", "done")}   # materialised BEFORE its step runs
+            assert rows["state"].shape == (ROWS, 1290)
+            a2.update(batch, learn=True); a2.step()
+            b.update(rows, learn=True); b.step()
+            done += 1
+            if done == n:
+                break
+    a2.flush()
+    torch.cuda.synchronize()
+    want, got = _snapshot(a2), _snapshot(b)
+    for net in want:
+        for k in want[net]:
+            assert torch.equal(want[net][k], got[net][k]), (net, k)

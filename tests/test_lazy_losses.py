@@ -28,8 +28,8 @@ def test_lazy_losses_resolve_once_and_behave_like_floats():
     assert sum([lz["value"], lz["policy"]]) == 8.25             # what a plotter's running mean does
 
 
-def test_planned_batch_is_an_opaque_handle():
+def test_planned_batch_without_a_position_cannot_be_materialised():
     b = PlannedBatch(object(), 3)
-    assert "3" in repr(b)
-    with pytest.raises(TypeError, match="handle"):
+    assert "3" in repr(b) and "state" in b
+    with pytest.raises(TypeError, match="position"):
         b["state"]

@@ -59,6 +59,24 @@ for name, n in (("warm-up", 600), ("timed", 6000)):
 loop_rate = n / dt
 print(f"   host time of the loop {t_host / n * 1e6:.1f} us/step, of which inside flush() {t_flush[0] / n * 1e6:.1f} us/step")
 print(f"planned-batch update() loop, {dtype}:                    {loop_rate:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step   (last value loss {float(log[-1]['value']):.4f})")
+# ... and the reference's loop VERBATIM over env.train_dataloader, driven by the algo (attach_env(..., drive_loader=True))
+env.train_dataloader.planner = algo
+done, t0 = 0, None
+for epoch in range(100):
+    for batch in env.train_dataloader:
+        loss = algo.update(batch, learn=True); algo.step()
+        done += 1
+        if done == 600:
+            algo.flush(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        if done == 600 + n:
+            break
+    if done == 600 + n:
+        break
+algo.flush()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"for batch in env.train_dataloader (driven), {dtype}:       {n / dt:8.0f} steps/s, {dt / n * 1e6:7.1f} us/step")
+env.train_dataloader.planner = None
 algo.run(600)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
