@@ -102,7 +102,9 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s and n >= 3:
             break
-    return {"value": n / el, "unit": "steps/s", "cores": ncpu, "threads": torch.get_num_threads(), "kind": "port",
+    # cores = the threads actually used (the contract's definition); host_cpu_count = what the box has
+    return {"value": n / el, "unit": "steps/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "host_cpu_count": ncpu, "kind": "port",
             "sample": f"{n} DDPG steps of B={B_ROWS} (collate + update, fp32, Adam) in {el:.1f}s with {torch.get_num_threads()} "
                       f"intra-op threads (fastest of 8/16/32/64 on this {ncpu}-core host)"}
 
