@@ -533,9 +533,11 @@ int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
 /* tuning knob: memory kind of the peer buffers created afterwards: 0 fine-grained (default), 1 uncached, 2 ordinary */
 void recnn_tune_comm_memory(int kind);
 /* tuning knob: XCD-affine workgroup map of the fused forward (csrc/mlp.h MlpBatch.xcd_map) for launches of up to max_problems
- * networks: a network's weights are fetched into two L2s instead of eight */
-void recnn_tune_cycle_fused_critic(int on);   /* cycle mode: 1 = the learning critic's step forward is one fused row-panel launch, 0 (default) = layer-1 GEMM + tail */
-void recnn_tune_mlp_xcd(int max_problems);   /* 0 = off (default) */
+ * networks: a network's weights are fetched into two L2s instead of eight.  0 = off (default: measured slower) */
+void recnn_tune_mlp_xcd(int max_problems);
+/* tuning knob, cycle mode: 1 = the learning critic's step forward is ONE fused row-panel launch that evaluates the TD head in
+ * the critic's own workgroups, 0 (default: measured faster) = layer-1 GEMM + tail launches */
+void recnn_tune_cycle_fused_critic(int on);
 /* tuning knob: 1 (default) the critics' gradient exchange runs inside their optimizer launch, 0 as launches of its own */
 void recnn_tune_comm_fused(int on);
 /* tuning knob: workgroups per collective launch (default 128) */
