@@ -27,9 +27,12 @@ STATE = FRAME * EMB + FRAME
 N_USERS, N_ITEMS = 138_493, 26_744           # ML20M as processed by the reference
 USERS_PER_BATCH = 256                        # >= 2048 rows guaranteed (every user has >= 10 windows)
 GATHER_BYTES_PER_ROW = {"fp32": 16_604,       # 5,632 + 132 read, 10,840 written (fp32 rows)
-                        "bf16": 11_192}       # same reads, 5,428 written (bf16 rows): what the bf16 engine materialises
+                        "bf16": 11_192,       # same reads, 5,428 written (bf16 rows): what the bf16 engine materialises
+                        "bf16x3": 16_620}     # split-bf16 rows (hi + lo = 4 bytes per value: 10,856 written incl. the reward / done floats)
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+# dense MFMA peaks the ALGORITHMIC flops are priced against; "bf16x3" (split bf16: three bf16 MFMAs per product, fp32-grade
+# results) executes 3x its algorithmic flops on the bf16 pipe, so its ceiling is a third of the bf16 peak
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 
 
 def synthetic_store(seed=0):
@@ -191,7 +194,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3"], help="td3 --rows 4096 = BASELINE.json configs[2]")
     ap.add_argument("--rows", type=int, default=B_ROWS, help="transition rows per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -437,7 +440,7 @@ def main():
         g = [r for r in prof if r[0] == "frame_gather"]
         if g:
             f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
-            per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else "bf16"]
+            per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else args.dtype]
             gbs = per_row * rows / (g[0][1] * 1e-3) / 1e9
             out["roofline_gather"] = {"kernel": "frame_gather", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

@@ -39,7 +39,12 @@ enum {
   RECNN_E_UNSUPPORTED = -3
 };
 
-enum { RECNN_F32 = 0, RECNN_BF16 = 1 };
+/* Compute types.  RECNN_BF16X3 ("split bf16"): every value is held as hi = bf16(x), lo = bf16(x - hi) and every product is
+ * evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores into an fp32 accumulator: fp32-grade results (the 1e-4 loss-curve
+ * parity of the fp32 path) at bf16 MFMA rates.  Tensors of this type are bfloat16 arrays with TWICE the logical columns: logical
+ * column c lives at physical column x = 2 (c & ~31) + (c & 31) (hi) and x + 32 (lo); leading dimensions and contraction lengths
+ * passed for such tensors are PHYSICAL, output extents / bias / mask indices logical (csrc/x3.h). */
+enum { RECNN_F32 = 0, RECNN_BF16 = 1, RECNN_BF16X3 = 2 };
 
 /* dropout mask source for the train-mode networks */
 enum {
@@ -201,6 +206,11 @@ int recnn_gemm_fwd(const recnn_gemm_args* h_args, void* stream);
 int recnn_gemm_dx(const recnn_gemm_args* h_args, void* stream);
 /* C[M,N] = A[Kc,M]^T * B[Kc,N], split over Kc  (dW = dZ^T * X) */
 int recnn_gemm_dw(const recnn_gemm_args* h_args, void* stream);
+
+/* fp32 [rows, cols] (row stride ld) <-> split-bf16 rows (RECNN_BF16X3; row stride ldx >= 2 * roundup(cols, 32) bfloat16, padding
+ * columns of the split rows are left untouched by pack). */
+int recnn_x3_pack(const float* src, int64_t ld, int rows, int cols, void* dst, int64_t ldx, void* stream);
+int recnn_x3_unpack(const void* src, int64_t ldx, int rows, int cols, float* dst, int64_t ld, void* stream);
 
 /* Writes the keep-mask the RECNN_MASK_HASH generator produces for (seed, step, stream_id)
  * into out[M, N] (uint8).  Lets tests feed the in-kernel masks to the CPU oracle. */

@@ -12,7 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RECNN_HIP_LIB") or os.path.join(_HERE, "csrc", "librecnn_hip.so")   # override: A/B of builds
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2      # BF16X3: split bf16 (hi + lo, three MFMAs per product), include/recnn_hip.h
+DTYPES = {"fp32": F32, "bf16": BF16, "bf16x3": BF16X3}
 MASK_NONE, MASK_HASH, MASK_EXTERNAL = 0, 1, 2
 ALGO_DDPG, ALGO_TD3 = 0, 1
 OPT_ADAM, OPT_RANGER = 0, 1
@@ -139,6 +140,8 @@ SIGNATURES = {
     "recnn_gemm_fwd": (_I, [C.POINTER(GemmArgs), _P]),
     "recnn_gemm_dx": (_I, [C.POINTER(GemmArgs), _P]),
     "recnn_gemm_dw": (_I, [C.POINTER(GemmArgs), _P]),
+    "recnn_x3_pack": (_I, [_P, _L, _I, _I, _P, _L, _P]),
+    "recnn_x3_unpack": (_I, [_P, _L, _I, _I, _P, _L, _P]),
     "recnn_hash_mask_dump": (_I, [_U, C.c_int32, _U, _I, _I, _P, _P]),
     "recnn_hash_mask_dump_at": (_I, [_U, _P, _I, _U, _I, _I, _P, _P]),
     "recnn_soft_update_flat": (_I, [_P, _P, _L, _F, _P]),

@@ -36,6 +36,7 @@
 #include "comm.h"
 #include "dwopt.h"
 #include "split.h"
+#include "x3.h"
 
 constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
 
@@ -79,8 +80,13 @@ struct Acts {  // tc activations of one network application, [Bc, Hp]
 struct recnn_engine {
   recnn_engine_config cfg;
   recnn_hyper hy;
+  // Hp / Ap / K1a / K1c / ldx are extents of compute-type rows in ELEMENTS: for the split-bf16 type (x3.h) twice the logical
+  // padded extents Hl / Al (weight-shadow row counts stay logical); ldx32 = row stride of the caller's fp32 packed rows
   int S, A, H, Hp, Ap, K1a, K1c, ldx, Bc, esz;
+  int Hl, Al, ldx32;
   bool bf16, td3;
+  bool x3 = false;     // compute type RECNN_BF16X3: split-bf16 rows through the layer-by-layer launches (gemm.hip / x3.hip)
+  bool twins = false;  // the compute type differs from the bound fp32 rows: the step reads twins of the packed rows (workspace)
   int n_critic;
   char* ws = nullptr;
   int64_t ws_bytes = 0;
@@ -249,11 +255,11 @@ void net_dims(recnn_engine* e, int ni) {
   n.ld_w2 = e->Hp + ld_pad();
   n.ld_w3 = e->Hp + ld_pad();
   n.sh_off[W1] = 0;
-  n.sh_off[W2] = (int64_t)e->Hp * n.ld_w1;
-  int64_t tot = n.sh_off[W2] + (int64_t)e->Hp * n.ld_w2;
+  n.sh_off[W2] = (int64_t)e->Hl * n.ld_w1;
+  int64_t tot = n.sh_off[W2] + (int64_t)e->Hl * n.ld_w2;
   if (!n.critic) {
     n.sh_off[W3] = tot;
-    tot += (int64_t)e->Ap * n.ld_w3;
+    tot += (int64_t)e->Al * n.ld_w3;
   }
   n.shadow_elems = tot;
   {
@@ -293,9 +299,11 @@ int64_t carve(recnn_engine* e, char* base) {
   e->gen_action0 = c.take(Bc * Ap * es);
   e->gen_action2 = c.take(Bc * Ap * es);
   e->gen_action = e->gen_action0;
-  if (e->bf16) {
+  if (e->twins) {
     e->xsh = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh = c.take(Bc * (int64_t)e->ldx * 2);
+  }
+  if (e->bf16) {
     e->xsh2 = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh2 = c.take(Bc * (int64_t)e->ldx * 2);
     e->reward2 = (float*)c.take(Bc * 4);
@@ -366,7 +374,9 @@ int64_t carve(recnn_engine* e, char* base) {
 int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   RECNN_REQUIRE(cfg, "engine: null config");
   RECNN_REQUIRE(cfg->algo == RECNN_ALGO_DDPG || cfg->algo == RECNN_ALGO_TD3, "engine: bad algo");
-  RECNN_REQUIRE(cfg->dtype == RECNN_F32 || cfg->dtype == RECNN_BF16, "engine: bad dtype");
+  RECNN_REQUIRE(cfg->dtype == RECNN_F32 || cfg->dtype == RECNN_BF16 || cfg->dtype == RECNN_BF16X3, "engine: bad dtype");
+  RECNN_REQUIRE(cfg->dtype != RECNN_BF16X3 || (cfg->action_dim % 32 == 0 && cfg->hidden % 32 == 0),
+                "engine: the split-bf16 compute type needs action_dim and hidden to be multiples of 32");
   RECNN_REQUIRE(cfg->state_dim > 0 && cfg->action_dim > 0 && cfg->hidden > 0 && cfg->max_rows > 0, "engine: bad dims");
   RECNN_REQUIRE(cfg->action_dim % 8 == 0 && cfg->hidden % 8 == 0, "engine: action_dim must be a multiple of 8, hidden of 8");
   e->cfg = *cfg;
@@ -380,7 +390,11 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   e->ldx += ld_pad();
   e->Bc = (int)ru(cfg->max_rows, 64);
   e->bf16 = cfg->dtype == RECNN_BF16;
-  e->esz = e->bf16 ? 2 : 4;
+  e->x3 = cfg->dtype == RECNN_BF16X3;
+  e->twins = e->bf16 || e->x3;
+  e->esz = e->twins ? 2 : 4;
+  e->Hl = e->Hp; e->Al = e->Ap; e->ldx32 = e->ldx;
+  if (e->x3) { e->Hp *= 2; e->Ap *= 2; e->K1a *= 2; e->K1c *= 2; e->ldx *= 2; }
   e->td3 = cfg->algo == RECNN_ALGO_TD3;
   e->n_critic = e->td3 ? 2 : 1;
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) net_dims(e, ni);
@@ -397,7 +411,7 @@ extern "C" int recnn_engine_query(const recnn_engine_config* cfg, recnn_engine_s
   out->master_floats_actor = tmp.net[RECNN_NET_POLICY].n_params;
   out->master_floats_critic = tmp.net[RECNN_NET_VALUE1].n_params;
   out->workspace_bytes = carve(&tmp, nullptr);
-  out->ld_x = tmp.ldx;
+  out->ld_x = tmp.ldx32;
   out->x_rows = tmp.Bc;
   return 0;
 }
@@ -484,8 +498,8 @@ extern "C" int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, fl
   RECNN_REQUIRE((((uintptr_t)xs | (uintptr_t)xn) & 15) == 0, "bind_batch: packed rows must be 16-byte aligned");
   e->xs = xs; e->xn = xn; e->reward = reward; e->done = done;
   e->reward0 = reward; e->done0 = done;
-  e->xcs = e->bf16 ? e->xsh : (char*)xs;
-  e->xcn = e->bf16 ? e->xnh : (char*)xn;
+  e->xcs = e->twins ? e->xsh : (char*)xs;
+  e->xcn = e->twins ? e->xnh : (char*)xn;
   e->cur_set = 0;
   drop_graphs(e);
   return 0;
@@ -620,6 +634,8 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
   return L;
 }
 
+// byte offset of logical column `col` (a multiple of 32 for split rows) inside a compute-type row
+inline int64_t tc_off(const recnn_engine* e, int col) { return (int64_t)(e->x3 ? 2 * col : col) * e->esz; }
 inline char* sh_ptr(const recnn_engine* e, int ni, int which) {
   const Net& n = e->net[ni];
   return n.shadow + n.sh_off[which] * e->esz;
@@ -643,7 +659,7 @@ int fill_apply_args(recnn_engine* e, int ni, const NetLayout& L, bool do_adam, i
   a.p = n.p; a.g = g_consume(e, ni); a.m = n.m; a.v = n.v;
   a.g_sys = g_direct(e, ni);
   a.shadow = n.shadow;
-  a.tc_bf16 = e->bf16;
+  a.tc_bf16 = e->cfg.dtype;
   a.do_adam = do_adam;
   a.t_ptr = n.t_ptr;
   a.t_add = e->run_t_off[ni];
@@ -712,11 +728,11 @@ double fill_fwd(const recnn_engine* e, const FwdSpec& f, int rows, GemmProb* p) 
   const int ldw = f.layer == 1 ? n.ld_w1 : (f.layer == 2 ? n.ld_w2 : n.ld_w3);
   char* w = sh_ptr(e, f.ni, wi);
   p->seg[0].A = f.A; p->seg[0].lda = f.lda; p->seg[0].K = f.K;
-  p->seg[0].B = w + (int64_t)f.b_col * e->esz; p->seg[0].ldb = ldw;
+  p->seg[0].B = w + tc_off(e, f.b_col); p->seg[0].ldb = ldw;
   p->nseg = 1;
   if (f.A2) {
     p->seg[1].A = f.A2; p->seg[1].lda = f.lda2; p->seg[1].K = f.K2;
-    p->seg[1].B = w + (int64_t)f.b2_col * e->esz; p->seg[1].ldb = ldw;
+    p->seg[1].B = w + tc_off(e, f.b2_col); p->seg[1].ldb = ldw;
     p->nseg = 2;
   }
   p->M = rows;
@@ -767,7 +783,7 @@ double fill_dx(const recnn_engine* e, GemmProb* p, int rows, const void* A, int6
   gemm_prob_init(p);
   const int ldw = which == W1 ? n.ld_w1 : (which == W2 ? n.ld_w2 : n.ld_w3);
   p->seg[0].A = A; p->seg[0].lda = lda; p->seg[0].K = Kc;
-  p->seg[0].B = sh_ptr(e, ni, which) + (int64_t)col0 * e->esz; p->seg[0].ldb = ldw;
+  p->seg[0].B = sh_ptr(e, ni, which) + tc_off(e, col0); p->seg[0].ldb = ldw;
   p->M = rows; p->N = N;
   p->C = C; p->ldc = ldc; p->c_f32 = 0;
   p->yref = yref; p->ldy = ldy;
@@ -976,7 +992,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
   const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;
-  const int64_t aoff = (int64_t)A * e->esz;
+  const int64_t aoff = tc_off(e, A);
   const double l1_fl_a = 2.0 * rows * (double)e->H * e->S, l1_fl_c = 2.0 * rows * (double)e->H * (e->S + A);
   const double t_fl_a = 2.0 * rows * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * rows * ((double)e->H * e->H + e->H);
   int rc = 0;
@@ -1080,7 +1096,7 @@ extern "C" void recnn_tune_cycle_fused_critic(int on) { g_cycle_fused_critic = o
 int ph_forward_cycle_fused(recnn_engine* e, int rows, bool value_bwd, hipStream_t s) {
   const int A = e->A, nc = e->n_critic;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
-  const int64_t aoff = (int64_t)A * e->esz;
+  const int64_t aoff = tc_off(e, A);
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   MlpBatch mb;
   memset(&mb, 0, sizeof(mb));
@@ -1148,7 +1164,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     if (value_side && e->td3 && !e->ext_noise) {
       if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
     }
-    const int64_t aoff = (int64_t)A * e->esz;
+    const int64_t aoff = tc_off(e, A);
     {
       MlpBatch mb;
       memset(&mb, 0, sizeof(mb));
@@ -1247,7 +1263,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   {  // layer 1: packed rows (compute type) in, tc hidden out
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
-      FwdSpec f{TPOL, 1, e->xcn + (int64_t)A * e->esz, e->ldx, 0, e->K1a};
+      FwdSpec f{TPOL, 1, e->xcn + tc_off(e, A), e->ldx, 0, e->K1a};
       f.C = e->tp.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
       g.flops += fill_fwd(e, f, rows, g.add());
       for (int c = 0; c < nc; ++c) {
@@ -1257,7 +1273,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       }
     }
     if (actor_side) {
-      FwdSpec f{POL, 1, e->xcs + (int64_t)A * e->esz, e->ldx, 0, e->K1a};
+      FwdSpec f{POL, 1, e->xcs + tc_off(e, A), e->ldx, 0, e->K1a};
       f.C = e->pa.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1;
       g.flops += fill_fwd(e, f, rows, g.add());
     }
@@ -1379,7 +1395,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     // heads: TD target, Q, dQ, loss partials
     HeadArgs h;
     memset(&h, 0, sizeof(h));
-    h.rows = rows; h.H = e->H; h.tc_bf16 = e->bf16; h.ld_h = Hp;
+    h.rows = rows; h.H = e->H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
     h.n_target = nc;
     for (int c = 0; c < nc; ++c) {
       const Net& t = e->net[TVAL[c]];
@@ -1510,7 +1526,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     MlpBatch mb;
     memset(&mb, 0, sizeof(mb));
     MlpSpec f{V1, e->gen_action, Ap, Ap, 0};
-    f.A1 = e->xcs + (int64_t)A * e->esz; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
+    f.A1 = e->xcs + tc_off(e, A); f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
     f.h1 = e->pc.h1; f.h2 = e->pc.h2; f.mask_idx = m0;
     const double fl = fill_mlp(e, f, rows, &mb.p[0]);
     if ((rc = slot(e, "mlp_fwd_pcritic", fl, s, [&] { return mlp_launch(mb, 1, s); }))) return rc;
@@ -1519,7 +1535,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     Group g(e, GEMM_FWD, 0, 0);
     FwdSpec f{V1, 1, e->gen_action, Ap, 0, Ap};
     f.b_col = 0;
-    f.A2 = e->xcs + (int64_t)A * e->esz; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
+    f.A2 = e->xcs + tc_off(e, A); f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
     f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
     // gen_action is zero padded to Ap columns, so segment 0 may run over the padded width: the W1
     // shadow columns it meets there (the first state columns) are multiplied by zeros.
@@ -1576,7 +1592,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     HeadArgs h;
     memset(&h, 0, sizeof(h));
     const Net& v = e->net[V1];
-    h.rows = rows; h.H = H; h.tc_bf16 = e->bf16; h.ld_h = Hp;
+    h.rows = rows; h.H = H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
     h.n_target = 0; h.n_critic = 1; h.policy_mode = 1;
     h.ch2[0] = e->pc.h2; h.cw3[0] = v.p + v.off[W3]; h.cb3[0] = v.p + v.off[B3];
     h.q[0] = e->qpi; h.loss_part[0] = e->loss_part[2];
@@ -1608,7 +1624,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     Group g(e, GEMM_DW, 0, 0);
     g.flops += fill_dw(e, g.add(), rows, e->dag, Ap, A, e->pa.h2, Hp, H, 0, pn.gp[W3], L.t[W3].nslab, L.t[W3].slab_stride);
     g.flops += fill_dw(e, g.add(), rows, e->dzp2, Hp, H, e->pa.h1, Hp, H, 0, pn.gp[W2], L.t[W2].nslab, L.t[W2].slab_stride);
-    g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xcs + (int64_t)A * e->esz, e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab,
+    g.flops += fill_dw(e, g.add(), rows, e->dzp1, Hp, H, e->xcs + tc_off(e, A), e->ldx, e->S, 0, pn.gp[W1], L.t[W1].nslab,
                        L.t[W1].slab_stride);
     if ((rc = g.run(s, "dw_actor"))) return rc;
   }
@@ -1702,8 +1718,8 @@ void use_hist_slot(recnn_engine* e, int i) {
 void use_set(recnn_engine* e, int k) {
   e->cur_set = k;
   if (k == 0) {
-    e->xcs = e->bf16 ? e->xsh : (char*)e->xs;
-    e->xcn = e->bf16 ? e->xnh : (char*)e->xn;
+    e->xcs = e->twins ? e->xsh : (char*)e->xs;
+    e->xcn = e->twins ? e->xnh : (char*)e->xn;
     e->reward = e->reward0; e->done = e->done0;
     e->gen_action = e->gen_action0;
   } else {
@@ -1724,19 +1740,21 @@ GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add)
   g.items = m.items; g.ratings = m.ratings; g.user_off = m.user_off; g.users = m.perm;
   g.row_off = inl ? nullptr : m.row_off;
   g.n_users = m.users_per_batch; g.rows = rows; g.frame = m.frame; g.emb = m.emb_dim; g.table = m.table;
-  g.state = e->xs + e->A; g.ld_state = e->ldx;
-  g.next_state = e->xn + e->A; g.ld_next = e->ldx;
-  g.action = e->xs; g.ld_action = e->ldx;
+  g.state = e->xs + e->A; g.ld_state = e->ldx32;
+  g.next_state = e->xn + e->A; g.ld_next = e->ldx32;
+  g.action = e->xs; g.ld_action = e->ldx32;
   g.reward = set ? e->reward2 : e->reward0; g.done = set ? e->done2 : e->done0;
   g.cursor = m.cursor; g.cursor_stride = m.users_per_batch;
   g.cursor_add = cursor_add; g.cursor_mod = m.n_batches;
   g.inline_plan = inl;
   if (m.plan && rows <= m.plan_rows) { g.plan = m.plan; g.plan_stride = m.plan_rows; }
-  if (e->bf16) {  // the compute-type twins of the packed rows are written by the same kernel
+  if (e->twins) {  // the compute-type twins of the packed rows are written by the same kernel
     char* hs = set ? e->xsh2 : e->xsh;
     char* hn = set ? e->xnh2 : e->xnh;
-    g.state_h = (bf16_t*)hs + e->A; g.next_h = (bf16_t*)hn + e->A; g.action_h = (bf16_t*)hs;
+    const int acol = e->x3 ? 2 * e->A : e->A;   // (split rows: the state columns start at physical column 2 A)
+    g.state_h = (bf16_t*)hs + acol; g.next_h = (bf16_t*)hn + acol; g.action_h = (bf16_t*)hs;
     g.ld_h = e->ldx;
+    g.x3 = e->x3;
     // Nothing reads the fp32 rows when the engine samples its own batches in bf16: materialise the batch in
     // the compute type only (recnn_tune_sampler_f32_rows(1) restores the fp32 copies, e.g. for inspection).
     if (!g_sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
@@ -1762,6 +1780,10 @@ int stage_batch(recnn_engine* e, int rows, hipStream_t s) {
   if (e->bf16)
     return slot(e, "rows_to_bf16", 0, s, [&] {
       return rows_to_bf16_launch(e->xs, e->xn, (bf16_t*)e->xsh, (bf16_t*)e->xnh, rows, e->ldx, s);
+    });
+  if (e->x3)   // (padding columns of the split rows rest at zero: the workspace is zero-initialised and nothing writes them)
+    return slot(e, "rows_to_x3", 0, s, [&] {
+      return rows_to_x3_launch(e->xs, e->xn, (bf16_t*)e->xsh, (bf16_t*)e->xnh, rows, e->S + e->A, e->ldx32, e->ldx, s);
     });
   return 0;
 }
@@ -2599,7 +2621,7 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
   struct Ent { const char* n; const void* p; int64_t c, l; int f; };
   const int64_t Hp = e->Hp;
   const Ent tab[] = {
-      {"next_action", e->xcn, e->A, e->ldx, e->bf16 ? 0 : 1}, {"gen_action", e->gen_action, e->A, e->Ap, 0},
+      {"next_action", e->xcn, e->A, e->ldx, e->twins ? 0 : 1}, {"gen_action", e->gen_action, e->A, e->Ap, 0},
       {"expected", e->expected, 1, 1, 1},          {"target_q", e->target_q, 1, 1, 1},
       {"q1", e->q[0], 1, 1, 1},                    {"q2", e->q[1], 1, 1, 1},
       {"delta1", e->delta[0], 1, 1, 1},            {"delta2", e->delta[1], 1, 1, 1},

@@ -28,6 +28,7 @@ struct GatherArgs {
   bf16_t* next_h;
   bf16_t* action_h;
   int64_t ld_h;
+  int x3;   // the twins are split-bf16 rows (x3.h): ld_h physical, every value stored as hi (mapped column) + lo (32 further)
 };
 
 

@@ -2,6 +2,7 @@
 // shared by frame_gather_kernel (gather.hip) and apply_gather_kernel (optim.hip).
 #pragma once
 #include "gather.h"
+#include "x3.h"
 
 template <int W> struct VecT;
 template <> struct VecT<4> { using type = float4; };
@@ -164,7 +165,10 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
         if (jj < F) a.state[row * a.ld_state + FE + jj] = v;
         if (jj >= 1) a.next_state[row * a.ld_next + FE + jj - 1] = v;
       }
-      if (a.state_h) {
+      if (a.state_h && a.x3) {
+        if (jj < F) x3_store(a.state_h + row * a.ld_h, FE + jj, v);
+        if (jj >= 1) x3_store(a.next_h + row * a.ld_h, FE + jj - 1, v);
+      } else if (a.state_h) {
         if (jj < F) a.state_h[row * a.ld_h + FE + jj] = f2bf(v);
         if (jj >= 1) a.next_h[row * a.ld_h + FE + jj - 1] = f2bf(v);
       }
@@ -199,7 +203,11 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (rr0[u] < 0) continue;
-      const uint2 h = make_uint2(pack_bf2(v[u].x, v[u].y), pack_bf2(v[u].z, v[u].w));
+      uint2 h = make_uint2(pack_bf2(v[u].x, v[u].y), pack_bf2(v[u].z, v[u].w)), hl = make_uint2(0, 0);
+      if (a.x3) {
+        const float v4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        x3_split4(v4, h, hl);
+      }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         const int rr = rr0[u] + k, jj = jj0[u] - k;
@@ -211,7 +219,11 @@ __device__ __forceinline__ void frame_gather_body(const GatherArgs& a, const int
           if (jj == F) store_f4<W>(a.action + row * a.ld_action + ee[u], v[u]);
         }
         if constexpr (W == 4) {
-          if (a.state_h) {
+          if (a.state_h && a.x3) {
+            if (jj < F) { bf16_t* d = a.state_h + row * a.ld_h + x3_col(jj * E + ee[u]); *(uint2*)d = h; *(uint2*)(d + 32) = hl; }
+            if (jj >= 1) { bf16_t* d = a.next_h + row * a.ld_h + x3_col((jj - 1) * E + ee[u]); *(uint2*)d = h; *(uint2*)(d + 32) = hl; }
+            if (jj == F) { bf16_t* d = a.action_h + row * a.ld_h + x3_col(ee[u]); *(uint2*)d = h; *(uint2*)(d + 32) = hl; }
+          } else if (a.state_h) {
             if (jj < F) *(uint2*)(a.state_h + row * a.ld_h + jj * E + ee[u]) = h;
             if (jj >= 1) *(uint2*)(a.next_h + row * a.ld_h + (jj - 1) * E + ee[u]) = h;
             if (jj == F) *(uint2*)(a.action_h + row * a.ld_h + ee[u]) = h;

@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "gemm.h"
 #include "dw_tile.h"
+#include "x3.h"
 
 template <class TC, int KB> struct LdsCfg {
   static constexpr int VEC = TcTraits<TC>::VEC;
@@ -183,7 +184,7 @@ __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN
 }
 
 // ------------------------------------------------------------------ forward epilogue (shared by both fwd kernels)
-template <class TC, int TM, int TN>
+template <class TC, int TM, int TN, bool X3 = false>
 __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
                                     int part_idx) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -214,13 +215,22 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
               }
               if (P.relu) v = fmaxf(v, 0.f);
               if (P.yref) {  // gate of a backward pass run as a forward-layout GEMM (transposed weights): [yref > 0] * scale
-                const float y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
+                float y;
+                if constexpr (X3) y = bf2f(((const bf16_t*)P.yref)[(int64_t)m * P.ldy + x3_col(n)]);   // (sign test: the hi half decides)
+                else y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
                 v = y > 0.f ? v * P.dx_scale : 0.f;
               }
               if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
               else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r, n & 3) ? v * 2.f : 0.f;
               if (P.c_f32) {
                 ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
+              } else if constexpr (X3) {
+                bf16_t hi, lo;
+                x3_split(v, hi, lo);
+                bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(n);
+                dst[0] = hi;
+                dst[32] = lo;
+                v = bf2f(hi) + bf2f(lo);   // the value a consumer of C would read
               } else {
                 TC* dst = (TC*)P.C + (int64_t)m * P.ldc + n;
                 tc_store(dst, v);
@@ -409,7 +419,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
       : "memory");
 }
 
-template <class TC, int TM, int TN, int NS, int NW>
+// X3 (x3.h): the operands are split-bf16 rows; a 256-byte stage row is two logical 32-k groups [hi 32 | lo 32 | hi 32 | lo 32], each
+// contracted with three MFMAs (hi hi + hi lo + lo hi); K / lda / ldb are physical, the epilogue writes split columns.
+template <class TC, int TM, int TN, int NS, int NW, bool X3 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch batch) {
   // NW waves arranged (NW/2) x 2 ... 4 waves: 2x2 wave tiles of (16 TM) x (16 TN); 8 waves: 2x4 wave tiles
   constexpr int WCOLS = NW / 2;
@@ -483,6 +495,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
     if (t + D < nt) issue(t + D, (t + D) % NS);
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
     const unsigned char* sb = sa + BM * 256;
+    if constexpr (X3) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
+        uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + ph);
+          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pl);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + ph);
+          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pl);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, al[tm]), __builtin_bit_cast(bf16x8, bh[tn]),
+                                  __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn]);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < KB / KSTEP; ++ks) {
       const int pos = ((ks * 4 + fg) ^ fr) * 16;
@@ -510,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
       }
     }
   }
-  epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
+  epilogue_fwd<TC, TM, TN, X3>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
@@ -736,6 +771,43 @@ template <class TC, int NS, int NW> static int launch_dma_nw(GemmLaunch* L, hipS
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel launch");
 }
 
+// split-bf16 forward (x3.h): 8 waves, 32 x 64 logical tile; ring depth by launch size as below
+template <int NS> static int launch_dma_x3(GemmLaunch* L, hipStream_t stream) {
+  constexpr int NW = 8, TM = 1, TN = 1, BM = 32, BN = 64;
+  constexpr int LDS = NS * (BM + BN) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 dma attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.dot_parts = nwg * NW;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3) launch");
+}
+int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
+  for (int i = 0; i < L->nprob; ++i) {
+    const GemmProb& p = L->batch.p[i];
+    for (int s = 0; s < p.nseg; ++s)
+      if (p.seg[s].K % 128) { recnn_set_error("gemm fwd (bf16x3): physical K=%d is not a multiple of 128", p.seg[s].K); return RECNN_E_UNSUPPORTED; }
+    if (!p.c_f32 && p.ldc < x3_ld(p.N)) { recnn_set_error("gemm fwd (bf16x3): ldc=%lld below the split row width %lld", (long long)p.ldc, (long long)x3_ld(p.N)); return RECNN_E_INVALID; }
+  }
+  long wg = 0;
+  for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
+  if (L->nprob == 0 || wg <= 320) return launch_dma_x3<5>(L, stream);
+  return launch_dma_x3<3>(L, stream);
+}
+
 template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
   if (g_dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
   return launch_dma_nw<TC, NS, 4>(L, stream);
@@ -777,6 +849,9 @@ int gemm_init() {
   if ((rc = launch_dma_nw<float, 3, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 5, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 3, 8>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_x3<3>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_x3<5>(&L, nullptr))) return rc;
+  if ((rc = x3_init())) return rc;
   return launch_dma_nw<bf16_t, 5, 8>(&L, nullptr);
 }
 
@@ -833,6 +908,7 @@ int gemm_launch(GemmLaunch* L, hipStream_t stream) {
   if (L->nprob > GEMM_MAX_GROUP) { recnn_set_error("gemm group too large"); return RECNN_E_INVALID; }
   // k-contiguous operands are read in 16-byte chunks of the compute type; a chunk never straddles the end of K (the tail of
   // the last LDS stage is zero filled by the loaders).  The LDS-DMA kernels want whole stages and are only chosen for such K.
+  if (L->dtype == RECNN_BF16X3) return x3_gemm_launch(L, stream);
   const int BK = L->dtype == RECNN_F32 ? 4 : 8;
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];

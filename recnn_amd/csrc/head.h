@@ -6,7 +6,7 @@ constexpr int HEAD_MAX_CRITIC = 2;
 constexpr int HEAD_ROWS_PER_BLOCK = 16;
 
 struct HeadArgs {
-  int rows, H, tc_bf16;
+  int rows, H, tc_bf16;   // tc_bf16: RECNN_F32 / RECNN_BF16 / RECNN_BF16X3 (compute type of the h2 / dz2 rows; split rows: ld_h physical)
   int64_t ld_h;
   // TD target side (n_target = 0: none, 1: DDPG, 2: TD3 min of twins)
   int n_target;

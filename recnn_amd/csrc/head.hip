@@ -7,11 +7,27 @@
 //   recnn/nn/update/td3.py:83-93   min of twin targets, MSELoss x2
 //   recnn/nn/update/ddpg.py:79,87 / td3.py:117-127   policy_loss = -Q.mean()
 // and the first step of autograd's backward through linear3 of the critic.
+#include <type_traits>
 #include "head.h"
+#include "x3.h"
+
+// compute-type tags of the templates below: float, bf16_t, or x3_t = split-bf16 rows (x3.h: the column index is mapped, a value is hi + lo)
+struct x3_t { bf16_t v; };
+template <class TC> struct HeadStore { using type = TC; };
+template <> struct HeadStore<x3_t> { using type = bf16_t; };
 
 // ---------------------------------------------------------------- row dots: one wave per row
-template <class TC> __device__ inline float dot4(const TC* __restrict__ h, const float4 wv) {
+// h: start of the row, k: first of four consecutive logical columns (k % 4 == 0)
+template <class TC> __device__ inline float dot4(const typename HeadStore<TC>::type* __restrict__ hrow, int k, const float4 wv) {
   float x0, x1, x2, x3;
+  if constexpr (std::is_same<TC, x3_t>::value) {
+    const bf16_t* h = hrow + x3_col(k);
+    const uint2 hv = *(const uint2*)h, lv = *(const uint2*)(h + 32);
+    x0 = bf2f((bf16_t)(hv.x & 0xFFFF)) + bf2f((bf16_t)(lv.x & 0xFFFF)); x1 = bf2f((bf16_t)(hv.x >> 16)) + bf2f((bf16_t)(lv.x >> 16));
+    x2 = bf2f((bf16_t)(hv.y & 0xFFFF)) + bf2f((bf16_t)(lv.y & 0xFFFF)); x3 = bf2f((bf16_t)(hv.y >> 16)) + bf2f((bf16_t)(lv.y >> 16));
+    return x0 * wv.x + x1 * wv.y + x2 * wv.z + x3 * wv.w;
+  }
+  const typename HeadStore<TC>::type* h = hrow + k;
   if constexpr (sizeof(TC) == 4) {
     const float4 hv = *(const float4*)h;
     x0 = hv.x; x1 = hv.y; x2 = hv.z; x3 = hv.w;
@@ -28,6 +44,8 @@ template <class TC> __device__ inline float dot4(const TC* __restrict__ h, const
 // is a chain of memory latencies, not bandwidth.  TD target, Q, dQ, loss partial.  Phase 2 (do_bwd): dz2 and the
 // partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
 template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+  using ST = typename HeadStore<TC>::type;
+  constexpr bool X3 = std::is_same<TC, x3_t>::value;
   __shared__ float part[4][HEAD_MAX_CRITIC];
   __shared__ float sdelta[HEAD_MAX_CRITIC][HEAD_ROWS_PER_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -63,9 +81,9 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int t = 0; t < ND; ++t) st[t][i] += dot4<TC>((const TC*)a.th2[t] + roff[i] + k, wt[t]);
+      for (int t = 0; t < ND; ++t) st[t][i] += dot4<TC>((const ST*)a.th2[t] + roff[i], k, wt[t]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) sc[c][i] += dot4<TC>((const TC*)a.ch2[c] + roff[i] + k, wc[c]);
+      for (int c = 0; c < NC; ++c) sc[c][i] += dot4<TC>((const ST*)a.ch2[c] + roff[i], k, wc[c]);
     }
   }
   float tq[4], qv[HEAD_MAX_CRITIC][4];
@@ -128,8 +146,8 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
   __shared__ float red_b[8][256 + 8];
   const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
   for (int c = 0; c < a.n_critic; ++c) {
-    const TC* h2 = (const TC*)a.ch2[c];
-    TC* dz2 = (TC*)a.dz2[c];
+    const ST* h2 = (const ST*)a.ch2[c];
+    ST* dz2 = (ST*)a.dz2[c];
     for (int n0 = 0; n0 < a.H; n0 += 256) {
       const int n = n0 + cg * 8;
       float w[8], sw[8], sb[8];
@@ -144,9 +162,17 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
         for (int half = 0; half < 2; ++half) {
           const int i = rg + half * 8;
           if (i < nr) {
-            const int64_t off = (int64_t)(r0 + i) * a.ld_h + n;
+            const int64_t off = (int64_t)(r0 + i) * a.ld_h + (X3 ? x3_col(n) : n);
             float hv[8];
-            if constexpr (sizeof(TC) == 2) {
+            if constexpr (X3) {   // 8 logical columns: one 16-byte load of the hi halves, one of the lo halves
+              const uint4 rh = *(const uint4*)(h2 + off), rl = *(const uint4*)(h2 + off + 32);
+              const uint32_t uh[4] = {rh.x, rh.y, rh.z, rh.w}, ul[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                hv[2 * j] = bf2f((bf16_t)(uh[j] & 0xFFFF)) + bf2f((bf16_t)(ul[j] & 0xFFFF));
+                hv[2 * j + 1] = bf2f((bf16_t)(uh[j] >> 16)) + bf2f((bf16_t)(ul[j] >> 16));
+              }
+            } else if constexpr (sizeof(TC) == 2) {
               const uint4 raw = *(const uint4*)(h2 + off);
               const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
@@ -166,7 +192,14 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
               sw[j] += d * hv[j];
               sb[j] += dz[j];
             }
-            if constexpr (sizeof(TC) == 2) {
+            if constexpr (X3) {
+              uint2 h0, l0, h1, l1;
+              const float d0[4] = {dz[0], dz[1], dz[2], dz[3]}, d1[4] = {dz[4], dz[5], dz[6], dz[7]};
+              x3_split4(d0, h0, l0);
+              x3_split4(d1, h1, l1);
+              *(uint4*)(dz2 + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+              *(uint4*)(dz2 + off + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            } else if constexpr (sizeof(TC) == 2) {
               *(uint4*)(dz2 + off) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]),
                                                 pack_bf2(dz[6], dz[7]));
             } else {
@@ -205,6 +238,7 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
 int head_launch(const HeadArgs& a, hipStream_t s) {
   if (a.rows <= 0) return 0;
   if (a.H % 8 || a.ld_h % 8) { recnn_set_error("head: hidden size and pitch must be multiples of 8"); return RECNN_E_INVALID; }
+  if (a.tc_bf16 == 2 && a.ld_h < x3_ld(a.H)) { recnn_set_error("head (bf16x3): pitch below the split row width"); return RECNN_E_INVALID; }
   dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK), block(256);
   if (a.n_target < 0 || a.n_target > 2 || a.n_critic < 1 || a.n_critic > HEAD_MAX_CRITIC) {
     recnn_set_error("head: n_target must be 0..2 and n_critic 1..2");
@@ -214,7 +248,7 @@ int head_launch(const HeadArgs& a, hipStream_t s) {
   if (pre && a.n_target > 1 && !a.tq_in[1]) { recnn_set_error("head: tq_in[1] missing"); return RECNN_E_INVALID; }
 #define HEAD_GO(TC, NT, NC) do { if (pre) hipLaunchKernelGGL((head_kernel<TC, NT, NC, true>), grid, block, 0, s, a); \
                                  else hipLaunchKernelGGL((head_kernel<TC, NT, NC, false>), grid, block, 0, s, a); } while (0)
-#define HEAD_TC(NT, NC) do { if (a.tc_bf16) HEAD_GO(bf16_t, NT, NC); else HEAD_GO(float, NT, NC); } while (0)
+#define HEAD_TC(NT, NC) do { if (a.tc_bf16 == 2) HEAD_GO(x3_t, NT, NC); else if (a.tc_bf16) HEAD_GO(bf16_t, NT, NC); else HEAD_GO(float, NT, NC); } while (0)
   switch (a.n_target * 2 + (a.n_critic - 1)) {
     case 0: HEAD_TC(0, 1); break;
     case 1: HEAD_TC(0, 2); break;

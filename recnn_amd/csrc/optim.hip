@@ -9,6 +9,7 @@
 // "shadow" copy of the weights (zero-padded, 16-byte aligned rows; critic W1 columns rotated to the
 // packed [action | state] batch layout) that the MFMA GEMMs read, and optionally the soft-updated target.
 #include "optim.h"
+#include "x3.h"
 #include "comm_dev.h"
 #include "gather_dev.h"
 
@@ -305,6 +306,20 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
   if (T.sh_off >= 0 && (a.shadow || (a.tgt_p && a.tgt_shadow))) {
     int row = (int)(o.e / T.cols);
     int col = (int)(o.e - (int64_t)row * T.cols);
+    if (a.tc_bf16 == RECNN_BF16X3) {   // split-bf16 shadow (x3.h): hi at the mapped column, lo 32 elements further
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < o.cnt) {
+          int cc = col + T.col_rot;
+          if (cc >= T.cols) cc -= T.cols;
+          const int64_t se = T.sh_off + (int64_t)row * T.sh_ld;
+          if (a.shadow) x3_store((bf16_t*)a.shadow + se, cc, p[j]);
+          if (a.tgt_p && a.tgt_shadow) x3_store((bf16_t*)a.tgt_shadow + se, cc, tp[j]);
+        }
+        if (++col == T.cols) { col = 0; ++row; }
+      }
+      return;
+    }
     const bool pairs = a.tc_bf16 && o.vec && !((T.cols | T.col_rot | T.sh_ld) & 1) && !(T.sh_off & 1);
     if (pairs) {  // two 4-byte stores instead of four 2-byte ones: a pair never straddles a row end or the rotation wrap
 #pragma unroll

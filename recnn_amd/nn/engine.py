@@ -44,7 +44,7 @@ class StepEngine:
         self.max_rows = max_rows
         self.dtype = dtype
         self.mask_mode = {"none": L.MASK_NONE, "hash": L.MASK_HASH, "external": L.MASK_EXTERNAL}[mask_mode]
-        cfg = L.EngineConfig(L.ALGO_TD3 if self.td3 else L.ALGO_DDPG, {"fp32": L.F32, "bf16": L.BF16}[dtype],
+        cfg = L.EngineConfig(L.ALGO_TD3 if self.td3 else L.ALGO_DDPG, L.DTYPES[dtype],
                              state_dim, action_dim, hidden, max_rows, self.mask_mode, seed & 0xFFFFFFFF,
                              device.index or 0)
         self.cfg = cfg
@@ -352,7 +352,7 @@ class StepEngine:
         if not p:
             raise KeyError(name)
         rows = int(r.value) if rows is None else rows
-        esz = 4 if f.value else (2 if self.dtype == "bf16" else 4)
+        esz = 4 if f.value else (4 if self.dtype == "fp32" else 2)
         nbytes = rows * ld.value * esz
         raw = None
         for owner in (self.workspace, self.xn, self.xs) + tuple(getattr(self, "_bound", ())[:2]):
@@ -363,8 +363,14 @@ class StepEngine:
         if raw is None:
             raise KeyError(name)
         dt = torch.float32 if esz == 4 else torch.bfloat16
-        t = raw.view(dt).view(rows, ld.value)[:, :c.value]
-        t = t.float().clone()
+        t = raw.view(dt).view(rows, ld.value)
+        if esz == 2 and self.dtype == "bf16x3":
+            # split-bf16 rows (csrc/x3.h): logical column c = hi at 2 (c & ~31) + (c & 31), lo 32 elements further
+            col = torch.arange(c.value, device=t.device)
+            col = (col // 32) * 64 + (col % 32)
+            t = t[:, col].float() + t[:, col + 32].float()
+        else:
+            t = t[:, :c.value].float().clone()
         if name in ("critic1_dz2", "critic1_dz1") and self.lib.recnn_engine_unit_backward(self.handle):
             # the fused bf16 path stores dz / d (unit backward tensors); the per-row seed d is applied inside the dW launch
             t *= self.buffer("delta1", rows).reshape(rows, 1)

@@ -81,3 +81,35 @@ def within(name, value, bound=None):
     except OSError:
         pass
     assert value <= bound, (name, value, bound)
+
+
+# ---- split-bf16 rows (RECNN_BF16X3, recnn_amd/csrc/x3.h) restated in torch for the tests: logical column c of a row lives at
+# physical column 2 (c & ~31) + (c & 31) (hi = bf16(x)) and 32 elements further (lo = bf16(x - hi))
+def x3_cols(n):
+    c = torch.arange(n)
+    return (c // 32) * 64 + (c % 32)
+
+
+def x3_pack_ref(x, ld=None):
+    """fp32 [R, C] -> bfloat16 [R, ld] in the split layout (padding columns zero)."""
+    x = x.float()
+    R, Cc = x.shape
+    ldp = 2 * ((Cc + 31) // 32 * 32) if ld is None else ld
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    out = torch.zeros(R, ldp, dtype=torch.bfloat16)
+    col = x3_cols(Cc)
+    out[:, col] = hi
+    out[:, col + 32] = lo
+    return out
+
+
+def x3_unpack_ref(xp, cols):
+    col = x3_cols(cols).to(xp.device)
+    return xp[:, col].float() + xp[:, col + 32].float()
+
+
+def x3_value(x):
+    """what a split row holds for x: hi + lo (fp32)"""
+    hi = x.float().bfloat16().float()
+    return hi + (x.float() - hi).bfloat16().float()

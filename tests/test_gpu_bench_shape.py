@@ -26,6 +26,7 @@ SEED = 4242
 # bf16 loss curve against the fp32 oracle over 65 steps: ceilings; the asserted bounds are tests.helpers.BF16_BOUNDS (2.5x measured)
 BF16_CURVE_VALUE = 8e-4
 BF16_CURVE_POLICY = 3e-3
+X3_AUDIT_MAX = 0.01     # bf16x3: fraction of parameter elements outside rtol 1e-4 after 200 steps: 0.0042 measured (fp32: 0.0058), same bound
 
 
 def _bench_env(recnn_amd, cuda, n_users, seed=3, n_items=3000):
@@ -68,7 +69,7 @@ def _hash_masks(L, step, cuda):
     return [m.cpu() for m in out]
 
 
-@pytest.mark.parametrize("dtype,n", [("bf16", 65), ("fp32", 200)])
+@pytest.mark.parametrize("dtype,n", [("bf16", 65), ("fp32", 200), ("bf16x3", 200)])
 def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
     import recnn_amd
     from recnn_amd import _lib as L
@@ -123,7 +124,7 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
         for k in worst:
             worst[k] = max(worst[k], abs(got[k] - ref[k]) / (abs(ref[k]) + 1e-6))
     report = {"dtype": dtype, "steps": n, "worst_rel_loss_dev": worst}
-    if dtype == "fp32":
+    if dtype != "bf16":          # fp32 and split bf16 ("bf16x3"): north_star's 1e-4 on every step of the loss curve
         assert worst["value"] <= 1e-4 and worst["policy"] <= 1e-4, worst
         # final parameters, element-wise: |got - ref| <= 1e-4 |ref| + 1e-4 rms(ref).  Elements whose gradient scale
         # sqrt(v_hat) sits in Adam's eps regime (< 1e3 eps: the update lr*m/(sqrt(v)+eps) amplifies round-off by up to
@@ -151,7 +152,9 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
                 fro = max(fro, float((got - ref).norm() / ref.norm()))
         report.update(param_elements=total, eps_regime_excluded=excluded, outside_rtol_1e4=failed, max_abs_dev=max_dev,
                       max_abs_dev_in_lr=max_dev / 1e-5, worst_frobenius=fro)
-        assert failed <= 0.01 * total, report
+        # (split bf16 carries 16-17 significand bits per operand: more Adam sign flips than fp32's 24, same mechanism; measured
+        # on MI355X: see X3_AUDIT_MAX)
+        assert failed <= (0.01 if dtype == "fp32" else X3_AUDIT_MAX) * total, report
         assert excluded <= 0.05 * total, report
         assert max_dev <= 20 * 1e-5, report
         assert fro <= 1e-4, report

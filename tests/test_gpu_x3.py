@@ -1,0 +1,156 @@
+"""GPU tests of the split-bf16 compute type (RECNN_BF16X3, recnn_amd/csrc/x3.h): every value is hi = bf16(x) + lo = bf16(x - hi),
+every product hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation.
+
+  * the fp32 <-> split-row conversions against their torch restatement, bit for bit;
+  * the three GEMM forms (forward: LDS-DMA kernel with the x3 fragment pairing; dX / dW: transpose-read kernels of x3.hip)
+    against a float64 product of the SAME split operands (what the kernels are asked to compute: <= 2e-6) and against the
+    float64 product of the unsplit fp32 operands (the format's own error: <= 3e-5, bf16 sits at 1e-2);
+  * the engine's step in this type against the CPU oracle at the fp32 criteria (tests/test_gpu_engine.py parametrises its
+    DDPG / TD3 oracle tests with "bf16x3"; tests/test_gpu_bench_shape.py the 200-step loss curve).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from tests.helpers import rel_err, x3_cols, x3_pack_ref, x3_unpack_ref, x3_value
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from recnn_amd import _lib as L
+    L.load()
+    return L
+
+
+def _args(L, M, N):
+    a = L.GemmArgs()
+    C.memset(C.byref(a), 0, C.sizeof(a))
+    a.dtype, a.M, a.N = L.BF16X3, M, N
+    a.dx_scale = 1.0
+    a.dw_splits = 1
+    return a
+
+
+@pytest.mark.parametrize("R,Cc", [(7, 5), (64, 1418), (33, 256), (5, 32)])
+def test_pack_unpack_match_the_torch_restatement(cuda, R, Cc):
+    L = _lib()
+    g = torch.Generator().manual_seed(R * 1000 + Cc)
+    x = torch.randn(R, Cc + 4, generator=g) * torch.logspace(-6, 3, Cc + 4)     # wide exponent range
+    xd = x.to(cuda)
+    ldp = 2 * ((Cc + 31) // 32 * 32) + 64
+    out = torch.zeros(R, ldp, dtype=torch.bfloat16, device=cuda)
+    L.call("recnn_x3_pack", L.ptr(xd), Cc + 4, R, Cc, L.ptr(out), ldp, L.current_stream())
+    back = torch.full((R, Cc), float("nan"), device=cuda)
+    L.call("recnn_x3_unpack", L.ptr(out), ldp, R, Cc, L.ptr(back), Cc, L.current_stream())
+    torch.cuda.synchronize()
+    ref = x3_pack_ref(x[:, :Cc], ldp)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(back.cpu(), x3_unpack_ref(ref, Cc))
+    # the format itself: 16-17 significant bits
+    assert float(((back.cpu() - x[:, :Cc]).abs() / x[:, :Cc].abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 1536), (100, 128, 256), (33, 16, 128), (4096, 256, 256)])
+def test_gemm_fwd(cuda, M, N, K):
+    """C = dropout(relu(X W^T + b)) with split operands and a split output."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    mask = (torch.rand(M, N, generator=g) < 0.5).to(torch.uint8)
+    X, W = x3_pack_ref(x).to(cuda), x3_pack_ref(w).to(cuda)
+    ldc = 2 * ((N + 31) // 32 * 32)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=cuda)
+    out32 = torch.zeros(M, N, device=cuda)
+    bd, md = b.to(cuda), mask.to(cuda)
+    for c_f32 in (0, 1):
+        a = _args(L, M, N)
+        a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), 2 * K, 2 * K, 2 * K
+        a.C, a.ldc, a.c_f32 = (out32.data_ptr(), N, 1) if c_f32 else (out.data_ptr(), ldc, 0)
+        a.bias, a.relu, a.mask_mode, a.mask, a.ld_mask = bd.data_ptr(), 1, L.MASK_EXTERNAL, md.data_ptr(), N
+        L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+    torch.cuda.synchronize()
+    xs, ws = x3_value(x).double(), x3_value(w).double()
+    ref_split = torch.relu(xs @ ws.t() + b.double()) * mask.double() * 2.0
+    ref_full = torch.relu(x.double() @ w.double().t() + b.double()) * mask.double() * 2.0
+    assert rel_err(out32, ref_split) < 5e-6       # fp32 accumulation over K (+ the dropped lo*lo products, <= 2^-16 each)
+    assert rel_err(out32, ref_full) < 3e-5
+    got = x3_unpack_ref(out.cpu(), N)
+    assert rel_err(got, ref_full) < 3e-5
+    assert torch.equal(got, x3_value(out32.cpu()))                  # the split store of the same accumulators
+
+
+def test_gemm_fwd_two_segments(cuda):
+    """critic layer 1 on [gen_action | state]: two contraction segments into one accumulator."""
+    L = _lib()
+    M, N, K0, K1 = 300, 256, 128, 1408
+    g = torch.Generator().manual_seed(7)
+    x0, x1 = torch.randn(M, K0, generator=g), torch.randn(M, K1, generator=g)
+    w = torch.randn(N, K0 + K1, generator=g) * 0.03
+    X0, X1, W = x3_pack_ref(x0).to(cuda), x3_pack_ref(x1).to(cuda), x3_pack_ref(w).to(cuda)
+    out = torch.zeros(M, N, device=cuda)
+    a = _args(L, M, N)
+    a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X0.data_ptr(), W.data_ptr(), 2 * K0, 2 * (K0 + K1), 2 * K0
+    a.A[1], a.B[1], a.lda[1], a.ldb[1], a.K[1] = X1.data_ptr(), W.data_ptr() + 2 * K0 * 2, 2 * K1, 2 * (K0 + K1), 2 * K1
+    a.C, a.ldc, a.c_f32 = out.data_ptr(), N, 1
+    L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+    torch.cuda.synchronize()
+    ref = torch.cat([x0, x1], 1).double() @ w.double().t()
+    assert rel_err(out, ref) < 3e-5
+
+
+@pytest.mark.parametrize("M,Kc,N", [(2048, 256, 256), (70, 64, 128), (2048, 128, 256), (2048, 256, 128)])
+def test_gemm_dx(cuda, M, Kc, N):
+    """dX = (dZ W) * scale * [yref > 0] + 32-row column sums; W's split columns run along the TILE dimension."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + Kc)
+    dz = torch.randn(M, Kc, generator=g)
+    w = torch.randn(Kc, N, generator=g) * 0.1
+    y = torch.randn(M, N, generator=g)
+    DZ, W, Y = x3_pack_ref(dz).to(cuda), x3_pack_ref(w).to(cuda), x3_pack_ref(y).to(cuda)
+    ldc = 2 * ((N + 31) // 32 * 32)
+    out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=cuda)
+    tiles_m = (M + 31) // 32
+    colsum = torch.zeros(tiles_m, N, device=cuda)
+    a = _args(L, M, N)
+    a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = DZ.data_ptr(), W.data_ptr(), DZ.shape[1], W.shape[1], 2 * Kc
+    a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 0
+    a.yref, a.ldy, a.dx_scale, a.colsum = Y.data_ptr(), Y.shape[1], 2.0, colsum.data_ptr()
+    L.call("recnn_gemm_dx", C.byref(a), L.current_stream())
+    torch.cuda.synchronize()
+    ref = (dz.double() @ w.double()) * 2.0 * (y.double() > 0)
+    got = x3_unpack_ref(out.cpu(), N)
+    assert rel_err(got, ref) < 3e-5
+    ref_slab = ref.view(-1, 32, N).sum(1) if M % 32 == 0 else None
+    if ref_slab is not None:
+        assert rel_err(colsum, ref_slab) < 3e-5
+    assert rel_err(colsum.sum(0), ref.sum(0)) < 3e-5
+
+
+@pytest.mark.parametrize("rows,M,N,splits", [(2048, 256, 1418, 4), (2048, 256, 256, 16), (333, 128, 256, 2), (50, 32, 27, 1)])
+def test_gemm_dw(cuda, rows, M, N, splits):
+    """dW slabs = dZ^T X with both operands' split columns along the tile dimensions."""
+    L = _lib()
+    g = torch.Generator().manual_seed(rows + N)
+    dz = torch.randn(rows, M, generator=g) * 1e-3
+    x = torch.randn(rows, N, generator=g)
+    ldz = 2 * ((M + 63) // 64 * 64)
+    ldx = 2 * ((N + 63) // 64 * 64) + 128
+    DZ, X = x3_pack_ref(dz, ldz).to(cuda), x3_pack_ref(x, ldx).to(cuda)
+    rot = 5 if N > 64 else 0
+    slabs = torch.full((splits, M, N), float("nan"), device=cuda)
+    a = _args(L, M, N)
+    a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = DZ.data_ptr(), X.data_ptr(), ldz, ldx, rows
+    a.C, a.ldc = slabs.data_ptr(), N
+    a.dw_splits, a.dw_slab_stride, a.dw_valid_cols, a.dw_col_rot = splits, M * N, N, rot
+    L.call("recnn_gemm_dw", C.byref(a), L.current_stream())
+    torch.cuda.synchronize()
+    got = slabs.sum(0).cpu()
+    assert not torch.isnan(got).any()
+    ref = torch.roll(dz.double().t() @ x.double(), rot, dims=1)
+    assert rel_err(got, ref) < 3e-5
+    ref_split = torch.roll(x3_value(dz).double().t() @ x3_value(x).double(), rot, dims=1)
+    assert rel_err(got, ref_split) < 6e-6
