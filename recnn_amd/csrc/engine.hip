@@ -303,7 +303,7 @@ int64_t carve(recnn_engine* e, char* base) {
     e->xsh = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh = c.take(Bc * (int64_t)e->ldx * 2);
   }
-  if (e->bf16) {
+  if (e->twins) {
     e->xsh2 = c.take(Bc * (int64_t)e->ldx * 2);
     e->xnh2 = c.take(Bc * (int64_t)e->ldx * 2);
     e->reward2 = (float*)c.take(Bc * 4);
@@ -330,7 +330,7 @@ int64_t carve(recnn_engine* e, char* base) {
   e->pl_part = e->pl_part_base;
   e->loss_ring = (float*)c.take((int64_t)LOSS_RING * 4 * 4);
   for (int i = 0; i < e->n_critic; ++i) {
-    e->tc_part[i] = (float*)c.take(Bc * 256 * 4);
+    e->tc_part[i] = (float*)c.take(Bc * (int64_t)(e->Hl > 256 ? e->Hl : 256) * 4);
     e->tc_flag[i] = (int32_t*)c.take((Bc / 32 + 1) * 4);
     e->tqv[i] = (float*)c.take(Bc * 4);
     e->q_slot[i] = (float*)c.take(Bc * 4);
@@ -375,8 +375,8 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   RECNN_REQUIRE(cfg, "engine: null config");
   RECNN_REQUIRE(cfg->algo == RECNN_ALGO_DDPG || cfg->algo == RECNN_ALGO_TD3, "engine: bad algo");
   RECNN_REQUIRE(cfg->dtype == RECNN_F32 || cfg->dtype == RECNN_BF16 || cfg->dtype == RECNN_BF16X3, "engine: bad dtype");
-  RECNN_REQUIRE(cfg->dtype != RECNN_BF16X3 || (cfg->action_dim % 32 == 0 && cfg->hidden % 32 == 0),
-                "engine: the split-bf16 compute type needs action_dim and hidden to be multiples of 32");
+  RECNN_REQUIRE(cfg->dtype != RECNN_BF16X3 || (cfg->action_dim % 32 == 0 && cfg->hidden % 32 == 0 && cfg->action_dim <= 256 && cfg->hidden <= 256),
+                "engine: the split-bf16 compute type needs action_dim and hidden to be multiples of 32, at most 256");
   RECNN_REQUIRE(cfg->state_dim > 0 && cfg->action_dim > 0 && cfg->hidden > 0 && cfg->max_rows > 0, "engine: bad dims");
   RECNN_REQUIRE(cfg->action_dim % 8 == 0 && cfg->hidden % 8 == 0, "engine: action_dim must be a multiple of 8, hidden of 8");
   e->cfg = *cfg;
@@ -1146,6 +1146,176 @@ int ph_forward_cycle_fused(recnn_engine* e, int rows, bool value_bwd, hipStream_
   return 0;
 }
 
+// The forward of one step in the split-bf16 type (x3.h): layer-by-layer GEMM launches like the fp32 path, arranged so that every
+// launch is as full as the data dependencies allow (each launch streams its tiles at one CU's L2 -> LDS rate: time = bytes / CUs):
+//   L1  {target actor(s'), critic(s, a), actor(s), target critic STATE part (raw fp32, 1290 of its 1418 k: it does not depend on
+//        the target actor), [the previous step's policy-loss critic on [pi(s) | s]: deferred, run graphs]}
+//   L2  {target actor, critic, actor, [deferred policy-loss critic, the loss summed in the epilogue]}
+//   L3  {target actor -> next_action (+ TD3 noise), actor -> gen_action}
+//   L1' target critic: relu(state part + next_action W1[:, action columns]^T + b1)      (k = 128)
+//   L2' target critic        then the head launch (TD target, Q dots, loss partials, dz2).
+// recnn/nn/update/misc.py:27-39, td3.py:73-93, ddpg.py:78-79 (deferred), same arithmetic as ph_forward's generic branch up to the
+// summation order of the target critic's layer 1.
+int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
+  const int A = e->A, Hp = e->Hp, nc = e->n_critic;
+  const int POL = RECNN_NET_POLICY, TPOL = RECNN_NET_TARGET_POLICY;
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
+  const int actor_m1 = e->td3 ? 4 : 2;
+  const int64_t aoff = tc_off(e, A);
+  const int ldp = e->Hl > 256 ? e->Hl : 256;     // row pitch of the fp32 layer-1 parts
+  int rc;
+  const bool pend = e->pending_pc.on;
+  const recnn_engine::PendingPc pp = e->pending_pc;
+  e->pending_pc.on = false;
+  const int m0 = e->td3 ? 6 : 4;
+  {  // ---- L1
+    Group g(e, GEMM_FWD, 0, 0);
+    if (value_side) {
+      FwdSpec f{TPOL, 1, e->xcn + aoff, e->ldx, 0, e->K1a};
+      f.C = e->tp.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+      for (int c = 0; c < nc; ++c) {
+        FwdSpec fc{VAL[c], 1, e->xcs, e->ldx, 0, e->K1c};
+        fc.C = e->cv[c].h1; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c;
+        g.flops += fill_fwd(e, fc, rows, g.add());
+      }
+    }
+    if (actor_side) {
+      FwdSpec f{POL, 1, e->xcs + aoff, e->ldx, 0, e->K1a};
+      f.C = e->pa.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+    }
+    if (value_side) {
+      for (int c = 0; c < nc; ++c) {   // state columns of the target critic's W1 shadow ([action | state] order): raw fp32, no bias
+        FwdSpec f{TVAL[c], 1, e->xcn + aoff, e->ldx, 0, e->K1a};
+        f.b_col = A;
+        f.C = e->tc_part[c]; f.ldc = ldp; f.c_f32 = 1; f.relu = 0; f.mask_idx = -1;
+        GemmProb* p = g.add();
+        fill_fwd(e, f, rows, p);
+        p->bias = nullptr;
+        g.flops += 2.0 * rows * (double)e->H * e->S;
+      }
+    }
+    if (pend && g.L.nprob < GEMM_MAX_GROUP) {
+      FwdSpec f{RECNN_NET_VALUE1, 1, pp.ga, e->Ap, 0, e->Ap};
+      f.b_col = 0;
+      f.A2 = pp.xs + aoff; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
+      f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
+      GemmProb* p = g.add();
+      g.flops += fill_fwd(e, f, rows, p);
+      p->step_add = pp.run_off;
+    }
+    if ((rc = g.run(s, "fwd_l1"))) return rc;
+  }
+  {  // ---- L2
+    Group g(e, GEMM_FWD, 0, 0);
+    if (value_side) {
+      FwdSpec f{TPOL, 2, e->tp.h1, Hp, 0, Hp};
+      f.C = e->tp.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+      for (int c = 0; c < nc; ++c) {
+        FwdSpec fc{VAL[c], 2, e->cv[c].h1, Hp, 0, Hp};
+        fc.C = e->cv[c].h2; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c + 1;
+        g.flops += fill_fwd(e, fc, rows, g.add());
+      }
+    }
+    if (actor_side) {
+      FwdSpec f{POL, 2, e->pa.h1, Hp, 0, Hp};
+      f.C = e->pa.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1 + 1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+    }
+    int pend_idx = -1;
+    if (pend && g.L.nprob < GEMM_MAX_GROUP) {   // the deferred policy-loss critic: -mean Q from the epilogue's partial dots (b3 included)
+      const Net& v = e->net[RECNN_NET_VALUE1];
+      FwdSpec f{RECNN_NET_VALUE1, 2, e->pc.h1, Hp, 0, Hp};
+      f.C = e->pc.h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0 + 1;
+      f.dot_w = v.p + v.off[W3]; f.dot_bias = v.p + v.off[B3]; f.dot_part = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;
+      pend_idx = g.L.nprob;
+      GemmProb* p = g.add();
+      g.flops += fill_fwd(e, f, rows, p);
+      p->step_add = pp.run_off;
+    }
+    if ((rc = g.run(s, "fwd_l2"))) return rc;
+    if (pend_idx >= 0) {
+      const int parts = g.L.batch.p[pend_idx].dot_parts;
+      RECNN_REQUIRE(parts > 0 && parts <= e->pl_cap, "policy loss: %d partial sums do not fit %d", parts, e->pl_cap);
+      if (pp.slot < LOSS_HIST_MAX) { e->hist_pol_count[pp.slot] = parts; e->hist_pol_add[pp.slot] = 0; }
+    }
+  }
+  if (value_side && e->td3 && !e->ext_noise) {
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
+  }
+  {  // ---- L3 of the actors: next_action into the action slot of the packed next rows, gen_action
+    Group g(e, GEMM_FWD, 0, 0);
+    if (value_side) {
+      FwdSpec f{TPOL, 3, e->tp.h2, Hp, 0, Hp};
+      f.C = e->xcn; f.ldc = e->ldx; f.c_f32 = 0; f.relu = 0; f.mask_idx = -1;
+      if (e->td3) { f.addend = e->ext_noise ? e->ext_noise : e->noise_buf; f.ld_add = A; f.add_clip = e->hy.noise_clip; }
+      g.flops += fill_fwd(e, f, rows, g.add());
+    }
+    if (actor_side) {
+      FwdSpec f{POL, 3, e->pa.h2, Hp, 0, Hp};
+      f.C = e->gen_action; f.ldc = e->Ap; f.c_f32 = 0; f.relu = 0; f.mask_idx = -1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+    }
+    if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
+  }
+  e->panel_bwd_done = false;
+  e->unit_bwd = false;
+  if (!value_side) return 0;
+  {  // ---- target critics: the action part on top of the state part
+    Group g(e, GEMM_FWD, 0, 0);
+    for (int c = 0; c < nc; ++c) {
+      FwdSpec f{TVAL[c], 1, e->xcn, e->ldx, 0, e->Ap};
+      f.C = e->tq[c].h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
+      f.addend = e->tc_part[c]; f.ld_add = ldp; f.add_clip = INFINITY;
+      g.flops += 2.0 * rows * (double)e->H * A;
+      fill_fwd(e, f, rows, g.add());
+    }
+    if ((rc = g.run(s, "fwd_l1_target_critic"))) return rc;
+  }
+  {
+    Group g(e, GEMM_FWD, 0, 0);
+    for (int c = 0; c < nc; ++c) {
+      FwdSpec f{TVAL[c], 2, e->tq[c].h1, Hp, 0, Hp};
+      f.C = e->tq[c].h2; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
+      g.flops += fill_fwd(e, f, rows, g.add());
+    }
+    if ((rc = g.run(s, "fwd_l2_target_critic"))) return rc;
+  }
+  {  // heads: TD target, Q, dQ, loss partials (+ dz2 and the last layer's gradient partials)
+    HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.rows = rows; h.H = e->H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
+    h.n_target = nc;
+    for (int c = 0; c < nc; ++c) {
+      const Net& t = e->net[TVAL[c]];
+      h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
+      const Net& v = e->net[VAL[c]];
+      h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
+      h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];
+    }
+    h.reward = e->reward; h.done = e->done;
+    h.gamma = e->hy.gamma;
+    h.lo = e->td3 ? -INFINITY : e->hy.min_value;
+    h.hi = e->td3 ? INFINITY : e->hy.max_value;
+    h.expected = e->expected; h.target_q = e->target_q;
+    h.n_critic = nc;
+    h.policy_mode = 0;
+    h.do_bwd = value_bwd;
+    h.train = e->cfg.mask_mode != RECNN_MASK_NONE;
+    if (value_bwd) {
+      for (int c = 0; c < nc; ++c) {
+        Net& v = e->net[VAL[c]];
+        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+        h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
+      }
+    }
+    if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
+  }
+  return 0;
+}
+
 // Forward of the value side (+ optionally the actor forward, which is independent of it).
 int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s) {
   const int A = e->A, Hp = e->Hp, nc = e->n_critic;
@@ -1153,6 +1323,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
+  if (e->x3) return ph_forward_x3(e, rows, value_side, actor_side, value_bwd, s);
   if (g_split_fwd >= 2 && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
   bool chained = false;  // target critics computed inside the first fused launch
   bool fwd_did_bwd = false;  // ... and the critics' head + layer-2 backward too
@@ -1518,7 +1689,10 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   const int m0 = e->td3 ? 6 : 4;
   const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
   int rc;
-  const bool use_dot = !need_rows && value_panel_ok(e) && !fused_mlp_ok(e, 1);
+  // (split bf16: the loss of a step without backward comes from the layer-2 epilogue's partial dots; with backward the head kernel
+  // produces the seed dz_e2 as well -- either way the step's partial sums land in its pl_part slot)
+  const bool x3_dot = e->x3 && !need_rows && !backward;
+  const bool use_dot = (!need_rows && value_panel_ok(e) && !fused_mlp_ok(e, 1)) || x3_dot;
   bool chain_done = false;
   e->pl_dot_parts = 0;
   if (fused_mlp_ok(e, 1)) {
@@ -1596,6 +1770,12 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     h.n_target = 0; h.n_critic = 1; h.policy_mode = 1;
     h.ch2[0] = e->pc.h2; h.cw3[0] = v.p + v.off[W3]; h.cb3[0] = v.p + v.off[B3];
     h.q[0] = e->qpi; h.loss_part[0] = e->loss_part[2];
+    if (e->x3 && !need_rows) {    // the step's policy-loss partial sums (sum of Q incl. b3 per block) in its pl_part slot
+      const int nblk = (rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
+      h.loss_part[0] = e->pl_part;
+      e->pl_dot_parts = nblk;
+      if (e->run_off < LOSS_HIST_MAX) { e->hist_pol_count[e->run_off] = nblk; e->hist_pol_add[e->run_off] = 0; }
+    }
     h.do_bwd = backward;          // d(policy_loss)/dQ = -1/B for every row; no critic parameter gradients
     h.train = train;
     h.delta_const = -1.0f / (float)rows;
@@ -1664,7 +1844,7 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
     h.n_steps = e->run_off; h.n = nc + 1;
     for (int c = 0; c < nc; ++c) { h.part[c] = e->loss_part_base[c]; h.stride[c] = e->loss_part_stride; h.n_part[c] = nval; h.scale[c] = 1.0f / (float)rows; }
     h.scale[nc] = -1.0f / (float)rows;
-    if (value_panel_ok(e)) {   // policy loss from the layer-2 epilogue's partial dots / the deferred forward's per-row Q
+    if (value_panel_ok(e) || e->x3) {   // policy loss from the layer-2 epilogue's partial dots / the deferred forward's per-row Q
       h.part[nc] = e->pl_part_base; h.stride[nc] = e->pl_cap;
       for (int i = 0; i < e->run_off; ++i) { h.pol_count[i] = e->hist_pol_count[i]; h.pol_add[i] = e->hist_pol_add[i]; }
     } else {                   // ... from the head kernel's per-block partial sums (fp32 / generic path)
@@ -1728,7 +1908,7 @@ void use_set(recnn_engine* e, int k) {
   }
 }
 bool lookahead_ok(const recnn_engine* e) {
-  return e->has_sampler && e->bf16 && !g_sampler_f32_rows && (e->smp.users_per_batch <= 1024 || e->smp.plan) && g_pregather;
+  return e->has_sampler && e->twins && !g_sampler_f32_rows && (e->smp.users_per_batch <= 1024 || e->smp.plan) && g_pregather;
 }
 
 // gather of the batch `cursor_add` steps ahead of the device cursor into buffer set `set`
@@ -2366,7 +2546,7 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
     // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
     // buffer set)
-    const bool defer = look && g_defer_policy_fwd && value_chain_ok(e) && i + 1 < len;
+    const bool defer = look && g_defer_policy_fwd && (value_chain_ok(e) || e->x3) && i + 1 < len;
     rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
   }
   e->run_off = 0;

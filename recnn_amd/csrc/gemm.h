@@ -56,7 +56,7 @@ struct GemmProb {
   int tiles_m, tiles_n;
 };
 
-constexpr int GEMM_MAX_GROUP = 6;
+constexpr int GEMM_MAX_GROUP = 8;   // (TD3's split-bf16 layer-1 launch: 6 networks / parts + the deferred policy-loss critic)
 struct GemmBatch {
   GemmProb p[GEMM_MAX_GROUP];
 };

@@ -184,7 +184,7 @@ __device__ inline void mma_stage(const TC* As, const TC* Bs, f32x4 (&acc)[TM][TN
 }
 
 // ------------------------------------------------------------------ forward epilogue (shared by both fwd kernels)
-template <class TC, int TM, int TN, bool X3 = false>
+template <class TC, int TM, int TN>
 __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
                                     int part_idx) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -215,22 +215,13 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
               }
               if (P.relu) v = fmaxf(v, 0.f);
               if (P.yref) {  // gate of a backward pass run as a forward-layout GEMM (transposed weights): [yref > 0] * scale
-                float y;
-                if constexpr (X3) y = bf2f(((const bf16_t*)P.yref)[(int64_t)m * P.ldy + x3_col(n)]);   // (sign test: the hi half decides)
-                else y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
+                const float y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
                 v = y > 0.f ? v * P.dx_scale : 0.f;
               }
               if (P.mask_mode == RECNN_MASK_EXTERNAL) v = P.mask[(int64_t)m * P.ld_mask + n] ? v * 2.f : 0.f;
               else if (P.mask_mode == RECNN_MASK_HASH) v = mask_keep(word, r, n & 3) ? v * 2.f : 0.f;
               if (P.c_f32) {
                 ((float*)P.C)[(int64_t)m * P.ldc + n] = v;
-              } else if constexpr (X3) {
-                bf16_t hi, lo;
-                x3_split(v, hi, lo);
-                bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(n);
-                dst[0] = hi;
-                dst[32] = lo;
-                v = bf2f(hi) + bf2f(lo);   // the value a consumer of C would read
               } else {
                 TC* dst = (TC*)P.C + (int64_t)m * P.ldc + n;
                 tc_store(dst, v);
@@ -242,6 +233,98 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
           }
         }
       }
+  }
+  if (P.dot_part) {  // uniform
+    sdot = wave_sum(sdot);
+    if (lane == 0) P.dot_part[part_idx] = sdot;
+  }
+}
+
+// ------------------------------------------------------------------ forward epilogue, split-bf16 output (x3.h)
+// The x3 kernels multiply with the operands swapped (weights first): acc[tm][tn][r] = C[row 16 tm + fr][column 16 tn + 4 fg + r],
+// i.e. a lane owns FOUR NEIGHBOURING COLUMNS of one row -- one 8-byte store for their hi halves and one for the lo halves (the
+// generic layout, four rows of one column, would take eight 2-byte stores), one 16-byte load of the bias / addend, one dropout
+// word per 4 x 4 block.  Same arithmetic, element by element, as epilogue_fwd.
+template <int TM, int TN>
+__device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane, int part_idx) {
+  const int fr = lane & 15, fg = lane >> 4;
+  float sdot = 0.f;
+  uint32_t key = 0;
+  if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + fr;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int nb = n0 + wn0 + tn * 16 + fg * 4;
+      if (m >= P.M || nb >= P.N) continue;
+      const bool full = nb + 3 < P.N;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, dw[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t mk = 0x01010101u;
+      uint2 yh = make_uint2(0x3F803F80u, 0x3F803F80u);   // (bf16 1.0: gate open)
+      // every load of the block before the first use
+      if (P.bias) {
+        if (full) { const float4 t = *(const float4*)(P.bias + nb); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+        else for (int r = 0; r < 4; ++r) if (nb + r < P.N) bv[r] = P.bias[nb + r];
+      }
+      if (P.dot_w) {
+        if (full) { const float4 t = *(const float4*)(P.dot_w + nb); dw[0] = t.x; dw[1] = t.y; dw[2] = t.z; dw[3] = t.w; }
+        else for (int r = 0; r < 4; ++r) if (nb + r < P.N) dw[r] = P.dot_w[nb + r];
+      }
+      if (P.addend) {
+        const int ma = P.add_row_div > 1 ? m / P.add_row_div : m;
+        const float* ap = P.addend + (int64_t)ma * P.ld_add + nb;
+        if (full && !(P.ld_add & 3) && !((uintptr_t)P.addend & 15)) { const float4 t = *(const float4*)ap; ad[0] = t.x; ad[1] = t.y; ad[2] = t.z; ad[3] = t.w; }
+        else for (int r = 0; r < 4; ++r) if (nb + r < P.N) ad[r] = ap[r];
+      }
+      if (P.yref) yh = *(const uint2*)((const bf16_t*)P.yref + (int64_t)m * P.ldy + x3_col(nb));
+      if (P.mask_mode == RECNN_MASK_EXTERNAL) {
+        const uint8_t* mp = P.mask + (int64_t)m * P.ld_mask + nb;
+        if (full && !(P.ld_mask & 3) && !((uintptr_t)P.mask & 3)) mk = *(const uint32_t*)mp;
+        else { mk = 0; for (int r = 0; r < 4; ++r) if (nb + r < P.N) mk |= (uint32_t)(mp[r] ? 1u : 0u) << (8 * r); }
+      }
+      uint32_t word = 0;
+      if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(nb >> 2));
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[tm][tn][r] + bv[r];
+        if (P.addend) x += fminf(fmaxf(ad[r], -P.add_clip), P.add_clip);
+        if (P.relu) x = fmaxf(x, 0.f);
+        if (P.yref) {
+          const float y = bf2f((bf16_t)((r < 2 ? yh.x : yh.y) >> ((r & 1) * 16)));
+          x = y > 0.f ? x * P.dx_scale : 0.f;
+        }
+        if (P.mask_mode == RECNN_MASK_EXTERNAL) x = ((mk >> (8 * r)) & 0xFFu) ? x * 2.f : 0.f;
+        else if (P.mask_mode == RECNN_MASK_HASH) x = mask_keep(word, m & 3, r) ? x * 2.f : 0.f;
+        v[r] = x;
+      }
+      if (P.c_f32) {
+        float* dst = (float*)P.C + (int64_t)m * P.ldc + nb;
+        if (full && !(P.ldc & 3) && !((uintptr_t)P.C & 15)) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int r = 0; r < 4; ++r) if (nb + r < P.N) dst[r] = v[r];
+      } else {
+        uint2 hi, lo;
+        x3_split4(v, hi, lo);
+        bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(nb);
+        if (full) {
+          *(uint2*)dst = hi;
+          *(uint2*)(dst + 32) = lo;
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < P.N) {
+              dst[r] = (bf16_t)((r < 2 ? hi.x : hi.y) >> ((r & 1) * 16));
+              dst[32 + r] = (bf16_t)((r < 2 ? lo.x : lo.y) >> ((r & 1) * 16));
+            }
+        }
+        // the values a consumer of C would read
+        v[0] = bf2f((bf16_t)(hi.x & 0xFFFFu)) + bf2f((bf16_t)(lo.x & 0xFFFFu)); v[1] = bf2f((bf16_t)(hi.x >> 16)) + bf2f((bf16_t)(lo.x >> 16));
+        v[2] = bf2f((bf16_t)(hi.y & 0xFFFFu)) + bf2f((bf16_t)(lo.y & 0xFFFFu)); v[3] = bf2f((bf16_t)(hi.y >> 16)) + bf2f((bf16_t)(lo.y >> 16));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (nb + r < P.N) sdot += v[r] * dw[r];
+      if (nb == 0 && P.dot_bias) sdot += P.dot_bias[0];
+    }
   }
   if (P.dot_part) {  // uniform
     sdot = wave_sum(sdot);
@@ -514,8 +597,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, al[tm]), __builtin_bit_cast(bf16x8, bh[tn]),
-                                  __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn]);
+            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
+                                  __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);   // (weights first: a lane owns 4 columns of one row)
       }
     } else
 #pragma unroll
@@ -545,7 +628,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
       }
     }
   }
-  epilogue_fwd<TC, TM, TN, X3>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
+  if constexpr (X3) epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
+  else epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
@@ -771,9 +855,12 @@ template <class TC, int NS, int NW> static int launch_dma_nw(GemmLaunch* L, hipS
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel launch");
 }
 
-// split-bf16 forward (x3.h): 8 waves, 32 x 64 logical tile; ring depth by launch size as below
-template <int NS> static int launch_dma_x3(GemmLaunch* L, hipStream_t stream) {
-  constexpr int NW = 8, TM = 1, TN = 1, BM = 32, BN = 64;
+// split-bf16 forward (x3.h), 8 waves.  Every tile streams (BM + BN) x 256 bytes per 64 logical k through one CU's L2 -> LDS path
+// (~41 B / clk): the launch time is (tiles x bytes per tile) / (CUs x rate), so the tile should be as large as still gives
+// every CU a workgroup -- 64 x 128 (wave tile 32 x 32: 8 fragment reads per 12 MFMAs) for the grouped layer-1 / layer-2
+// launches (256 tiles at 2048 rows x 4 networks), 32 x 64 for the small ones.
+template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunch* L, hipStream_t stream) {
+  constexpr int BM = 32 * TM, BN = 16 * TN * (NW / 2);
   constexpr int LDS = NS * (BM + BN) * 256;
   static bool attr_done = false;
   if (!attr_done) {
@@ -795,6 +882,7 @@ template <int NS> static int launch_dma_x3(GemmLaunch* L, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3) launch");
 }
+static int g_x3_big_min_wg = 192;   // launches with at least this many 64 x 128 tiles take them
 int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];
@@ -802,10 +890,17 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
       if (p.seg[s].K % 128) { recnn_set_error("gemm fwd (bf16x3): physical K=%d is not a multiple of 128", p.seg[s].K); return RECNN_E_UNSUPPORTED; }
     if (!p.c_f32 && p.ldc < x3_ld(p.N)) { recnn_set_error("gemm fwd (bf16x3): ldc=%lld below the split row width %lld", (long long)p.ldc, (long long)x3_ld(p.N)); return RECNN_E_INVALID; }
   }
-  long wg = 0;
-  for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
-  if (L->nprob == 0 || wg <= 320) return launch_dma_x3<5>(L, stream);
-  return launch_dma_x3<3>(L, stream);
+  long wg = 0, wg_big = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
+    wg_big += (long)((L->batch.p[i].M + 63) / 64) * ((L->batch.p[i].N + 127) / 128);
+  }
+  // Measured (DDPG, 2048 rows, 4 networks' layer 1 = 256 tiles of 64 x 128): 27.9 us with 16 waves, 29.4 with 8 (wave tile 32 x 32),
+  // 31.5 as 1024 tiles of 32 x 64, 42.5 as 128 tiles of 128 x 128 -- the launch moves 290 MB (590 MB in the small tiling) through
+  // L2 -> LDS at 10-19 TB/s whatever the tile: what is left is the memory system, not the tile shape.
+  if (L->nprob > 0 && wg_big >= g_x3_big_min_wg) return launch_dma_x3<2, 1, 3, 16>(L, stream);
+  if (L->nprob == 0 || wg <= 320) return launch_dma_x3<1, 1, 5>(L, stream);
+  return launch_dma_x3<1, 1, 3>(L, stream);
 }
 
 template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
@@ -849,8 +944,9 @@ int gemm_init() {
   if ((rc = launch_dma_nw<float, 3, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 5, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 3, 8>(&L, nullptr))) return rc;
-  if ((rc = launch_dma_x3<3>(&L, nullptr))) return rc;
-  if ((rc = launch_dma_x3<5>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_x3<1, 1, 3>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_x3<1, 1, 5>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_x3<2, 1, 3, 16>(&L, nullptr))) return rc;
   if ((rc = x3_init())) return rc;
   return launch_dma_nw<bf16_t, 5, 8>(&L, nullptr);
 }

@@ -307,6 +307,26 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
     int row = (int)(o.e / T.cols);
     int col = (int)(o.e - (int64_t)row * T.cols);
     if (a.tc_bf16 == RECNN_BF16X3) {   // split-bf16 shadow (x3.h): hi at the mapped column, lo 32 elements further
+      {
+        int c0 = col + T.col_rot;
+        if (c0 >= T.cols) c0 -= T.cols;
+        // four elements of one row inside one 4-aligned column run (no row end, no rotation wrap): two 8-byte stores per shadow
+        if (o.cnt == 4 && col + 3 < T.cols && c0 + 3 < T.cols && !(c0 & 3) && !(T.sh_ld & 3) && !(T.sh_off & 3)) {
+          const int64_t se = T.sh_off + (int64_t)row * T.sh_ld + x3_col(c0);
+          uint2 hi, lo;
+          if (a.shadow) {
+            x3_split4(p, hi, lo);
+            *(uint2*)((bf16_t*)a.shadow + se) = hi;
+            *(uint2*)((bf16_t*)a.shadow + se + 32) = lo;
+          }
+          if (a.tgt_p && a.tgt_shadow) {
+            x3_split4(tp, hi, lo);
+            *(uint2*)((bf16_t*)a.tgt_shadow + se) = hi;
+            *(uint2*)((bf16_t*)a.tgt_shadow + se + 32) = lo;
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < o.cnt) {

@@ -41,9 +41,12 @@ __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const b
 
 // ------------------------------------------------------------------ dX
 // Workgroup: 64 rows x 32 logical columns (one [hi 32 | lo 32] group of W's physical columns); 4 waves as 2 (row halves) x 2
-// (16-column blocks).  k step = 32 logical n: A stage 64 rows x 64 physical k, B stage 32 rows (n) x 64 physical columns.
-constexpr int DX_BM = 64, DX_BN = 32, DX_PA = 144, DX_PB = 144;
-constexpr int DX_STAGE = DX_BM * DX_PA + 32 * DX_PB;
+// (16-column blocks).  The contraction is short (n <= 256: a hidden layer), so the WHOLE k range of both operands is staged at
+// once -- every global load of the workgroup in flight together, one barrier, then 8 k steps of MFMAs straight from LDS (the
+// first version staged 32 n per step through two buffers and paid a memory latency per step: 12.4 us for 0.27 GFLOP).
+constexpr int DX_BM = 64, DX_BN = 32, DX_KMAX = 256;                 // logical k staged at most
+constexpr int DX_PA = 2 * DX_KMAX * 2 + 16, DX_PB = 144;             // row pitches (bytes): A rows hold 2 K physical k, B rows 64 columns
+constexpr int DX_LDS = DX_BM * DX_PA + DX_KMAX * DX_PB;
 
 __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
   const GemmProb& P = batch.p[blockIdx.y];
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
   if ((int)blockIdx.x >= nwg) return;
   const int tile_n = blockIdx.x % P.tiles_n, tile_m = blockIdx.x / P.tiles_n;
   const int m0 = tile_m * DX_BM, n0 = tile_n * DX_BN;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DX_STAGE];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int wm0 = (wave >> 1) * 32, wc0 = (wave & 1) * 16;   // rows of the tile / logical column block of the group
@@ -60,82 +63,108 @@ __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
   const int nt = (Kc + 31) / 32;
   const bf16_t* A = (const bf16_t*)G.A;
   const bf16_t* B = (const bf16_t*)G.B;
+  unsigned char* sa = smem;
+  unsigned char* sb = smem + DX_BM * DX_PA;
 
-  // staging geometry: A 64 rows x 8 chunks (2 per thread), B 32 rows x 8 chunks (1 per thread)
-  uint4 ra[2], rb;
-  auto load = [&](int t) {
+  // A: 64 rows x (8 nt) chunks of 16 bytes (<= 16 per thread); B: (32 nt) rows x 8 chunks (<= 8 per thread) -- EVERY load of the
+  // thread is requested before its first LDS store (fully unrolled with predicates: a loop with a run-time trip count would wait
+  // for each round of loads before issuing the next)
+  const int ca = 8 * nt;                    // chunks per A row
+  const int na = DX_BM * ca, nb = 32 * nt * 8;
+  uint4 ra[16], rb[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256, row = c >> 3, kc = c & 7;
-      const int gr = min(m0 + row, P.M - 1);
-      ra[i] = *(const uint4*)(A + (int64_t)gr * G.lda + t * 64 + kc * 8);
-    }
-    const int row = tid >> 3, kc = tid & 7;
-    const int n = t * 32 + row;
-    rb = n < Kc ? *(const uint4*)(B + (int64_t)n * G.ldb + 2 * n0 + kc * 8) : make_uint4(0, 0, 0, 0);
-  };
-  auto store = [&](unsigned char* st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256, row = c >> 3, kc = c & 7;
-      *(uint4*)(st + row * DX_PA + kc * 16) = ra[i];
-    }
-    const int row = tid >> 3, kc = tid & 7;
-    *(uint4*)(st + DX_BM * DX_PA + row * DX_PB + kc * 16) = rb;
-  };
-
-  f32x4 acc[2];
-  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (nt > 0) { load(0); store(smem); }
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    unsigned char* cur = smem + (t & 1) * DX_STAGE;
-    if (t + 1 < nt) load(t + 1);
-    const unsigned char* sa = cur;
-    const unsigned char* sb = cur + DX_BM * DX_PA;
-    const bf16x8 bh = tr_frag(sb, DX_PB, wc0, fr, fg), bl = tr_frag(sb, DX_PB, 32 + wc0, fr, fg);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const unsigned char* ar = sa + (wm0 + tm * 16 + fr) * DX_PA;
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + fg * 16));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + 64 + fg * 16));
-      acc[tm] = mfma3(ah, al, bh, bl, acc[tm]);
-    }
-    if (t + 1 < nt) store(smem + ((t + 1) & 1) * DX_STAGE);
-    __syncthreads();
+  for (int u = 0; u < 16; ++u) {
+    const int c = u * 256 + tid;
+    const int row = c / ca, kc = c - row * ca;
+    ra[u] = c < na ? *(const uint4*)(A + (int64_t)min(m0 + row, P.M - 1) * G.lda + kc * 8) : make_uint4(0, 0, 0, 0);
   }
-
-  // ---- epilogue: scale, relu/dropout gate from yref (split rows), column sums per 32-row slab, split store
-  const int j = n0 + wc0 + fr;
-  float cs = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = u * 256 + tid;
+    const int n = c >> 3, kc = c & 7;
+    rb[u] = (c < nb && n < Kc) ? *(const uint4*)(B + (int64_t)n * G.ldb + 2 * n0 + kc * 8) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = u * 256 + tid;
+    const int row = c / ca, kc = c - row * ca;
+    if (c < na) *(uint4*)(sa + row * DX_PA + kc * 16) = ra[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = u * 256 + tid;
+    if (c < nb) *(uint4*)(sb + (c >> 3) * DX_PB + (c & 7) * 16) = rb[u];
+  }
+  // the gate operand of this lane's outputs (rows wm0 + 16 tm + fr, columns jb .. jb + 3), requested with the tile loads
+  const int jb = n0 + wc0 + fg * 4;
+  uint2 yq[2];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
-    const int mb = m0 + wm0 + tm * 16 + fg * 4;
+    const int m = min(m0 + wm0 + tm * 16 + fr, P.M - 1);
+    yq[tm] = (P.yref && jb < P.N) ? *(const uint2*)((const bf16_t*)P.yref + (int64_t)m * P.ldy + x3_col(jb)) : make_uint2(0x3F803F80u, 0x3F803F80u);
+  }
+  __syncthreads();
+
+  // (weights first: acc[tm][r] = C[row wm0 + 16 tm + fr][column jb + r] -- a lane owns four neighbouring columns of one row)
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* sbt = sb + t * 32 * DX_PB;
+    const bf16x8 bh = tr_frag(sbt, DX_PB, wc0, fr, fg), bl = tr_frag(sbt, DX_PB, 32 + wc0, fr, fg);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const unsigned char* ar = sa + (wm0 + tm * 16 + fr) * DX_PA + t * 128;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + fg * 16));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + 64 + fg * 16));
+      acc[tm] = mfma3(bh, bl, ah, al, acc[tm]);
+    }
+  }
+
+  // ---- epilogue: scale, relu/dropout gate from yref, column sums per 32-row slab, split store (8 bytes of hi, 8 of lo per row)
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + fr;
+    float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = mb + r;
-      if (m < P.M && j < P.N) {
-        float v = acc[tm][r] * P.dx_scale;
-        if (P.yref) {
-          const float y = bf2f(((const bf16_t*)P.yref)[(int64_t)m * P.ldy + x3_col(j)]);
-          v = y > 0.f ? v : 0.f;
-        }
-        cs += v;
-        if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + j] = v;
-        else x3_store((bf16_t*)P.C + (int64_t)m * P.ldc, j, v);
+      v[r] = acc[tm][r] * P.dx_scale;
+      const float y = bf2f((bf16_t)((r < 2 ? yq[tm].x : yq[tm].y) >> ((r & 1) * 16)));
+      if (!(y > 0.f) || m >= P.M || jb + r >= P.N) v[r] = 0.f;
+      cs[r] += v[r];
+    }
+    if (m < P.M && jb < P.N) {
+      if (P.c_f32) {
+        for (int r = 0; r < 4; ++r) if (jb + r < P.N) ((float*)P.C)[(int64_t)m * P.ldc + jb + r] = v[r];
+      } else if (jb + 3 < P.N) {
+        uint2 hi, lo;
+        x3_split4(v, hi, lo);
+        bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(jb);
+        *(uint2*)dst = hi;
+        *(uint2*)(dst + 32) = lo;
+      } else {
+        for (int r = 0; r < 4; ++r) if (jb + r < P.N) x3_store((bf16_t*)P.C + (int64_t)m * P.ldc, jb + r, v[r]);
       }
     }
   }
-  if (P.colsum) {   // a wave owns one 32-row slab x 16 columns: fixed tree over (tm, r) in the lane, then the four fg lanes
-    cs += __shfl_xor(cs, 16, 64);
-    cs += __shfl_xor(cs, 32, 64);
-    if (fg == 0 && j < P.N && m0 + wm0 < P.M) P.colsum[(int64_t)((m0 + wm0) >> 5) * P.N + j] = cs;
+  if (P.colsum) {   // a wave owns one 32-row slab: fixed tree over its rows (tm in the lane, then the 16 fr lanes of the column quad)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float c = cs[r];
+      c += __shfl_xor(c, 1, 64);
+      c += __shfl_xor(c, 2, 64);
+      c += __shfl_xor(c, 4, 64);
+      c += __shfl_xor(c, 8, 64);
+      if (fr == 0 && jb + r < P.N && m0 + wm0 < P.M) P.colsum[(int64_t)((m0 + wm0) >> 5) * P.N + jb + r] = c;
+    }
   }
 }
 
 // ------------------------------------------------------------------ dW
 // Workgroup: 64 x 64 logical outputs = 128 physical columns of each operand (two [hi 32 | lo 32] groups); 4 waves as 2 x 2, a
 // wave owns group wm of dZ x group wn of X = 32 x 32 logical = 2 x 2 blocks x 3 MFMAs per 32-row k step.
+// A stage = 32 batch rows (one k step) of both operands, 17 KB: eight workgroups share a CU.  (64-row stages -- a 256-row batch
+// slice four memory latencies deep instead of eight, but 70 KB per workgroup -- measured slower: 15.4 vs 13.2 us.)
 constexpr int DW_ROWS = 32, DW_PITCH = 272, DW_OP = DW_ROWS * DW_PITCH, DW_STAGE = 2 * DW_OP;
 
 __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
@@ -147,24 +176,25 @@ __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
   const int tile_m = (lid / P.tiles_n) % P.tiles_m;
   const int split = lid / (P.tiles_n * P.tiles_m);
   const int m0 = tile_m * 64, n0 = tile_n * 64;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * DW_STAGE];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const GemmSeg& G = P.seg[0];
   const int Kc = G.K;
-  const int chunk = (((Kc + P.dw_splits - 1) / P.dw_splits) + 31) / 32 * 32;
+  const int chunk = (((Kc + P.dw_splits - 1) / P.dw_splits) + 31) / 32 * 32;   // (a multiple of the 32-row k step)
   const int kbeg = split * chunk;
   const int kend = min(Kc, kbeg + chunk);
   const int nt = kend > kbeg ? (kend - kbeg + DW_ROWS - 1) / DW_ROWS : 0;
   const bf16_t* A = (const bf16_t*)G.A + 2 * m0;
   const bf16_t* B = (const bf16_t*)G.B + 2 * n0;
 
-  // staging: per operand 32 rows x 16 chunks of 16 bytes (2 per thread)
-  uint4 ra[2], rb[2];
+  // staging: per operand 64 rows x 16 chunks of 16 bytes (4 per thread)
+  constexpr int NL = DW_ROWS * 16 / 256;
+  uint4 ra[NL], rb[NL];
   auto load = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int c = tid + i * 256, row = c >> 4, cc = c & 15;
       const int k = kbeg + t * DW_ROWS + row;
       const bool in = k < kend;
@@ -174,7 +204,7 @@ __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
   };
   auto store = [&](unsigned char* st) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int c = tid + i * 256, row = c >> 4, cc = c & 15;
       *(uint4*)(st + row * DW_PITCH + cc * 16) = ra[i];
       *(uint4*)(st + DW_OP + row * DW_PITCH + cc * 16) = rb[i];
@@ -192,18 +222,23 @@ __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
     const unsigned char* sa = smem + (t & 1) * DW_STAGE;
     const unsigned char* sb = sa + DW_OP;
     if (t + 1 < nt) load(t + 1);
-    bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      ah[q] = tr_frag(sa, DW_PITCH, wm * 64 + q * 16, fr, fg);
-      al[q] = tr_frag(sa, DW_PITCH, wm * 64 + 32 + q * 16, fr, fg);
-      bh[q] = tr_frag(sb, DW_PITCH, wn * 64 + q * 16, fr, fg);
-      bl[q] = tr_frag(sb, DW_PITCH, wn * 64 + 32 + q * 16, fr, fg);
+    for (int ks = 0; ks < DW_ROWS / 32; ++ks) {
+      const unsigned char* ka = sa + ks * 32 * DW_PITCH;
+      const unsigned char* kb = sb + ks * 32 * DW_PITCH;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ah[q] = tr_frag(ka, DW_PITCH, wm * 64 + q * 16, fr, fg);
+        al[q] = tr_frag(ka, DW_PITCH, wm * 64 + 32 + q * 16, fr, fg);
+        bh[q] = tr_frag(kb, DW_PITCH, wn * 64 + q * 16, fr, fg);
+        bl[q] = tr_frag(kb, DW_PITCH, wn * 64 + 32 + q * 16, fr, fg);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma3(ah[tm], al[tm], bh[tn], bl[tn], acc[tm][tn]);
     }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma3(ah[tm], al[tm], bh[tn], bl[tn], acc[tm][tn]);
     if (t + 1 < nt) store(smem + ((t + 1) & 1) * DW_STAGE);
     __syncthreads();
   }
@@ -278,7 +313,10 @@ int launch_dx(GemmLaunch* L, hipStream_t s) {
     GemmProb& p = L->batch.p[i];
     p.tiles_m = (p.M + DX_BM - 1) / DX_BM;
     p.tiles_n = (p.N + DX_BN - 1) / DX_BN;
-    if (p.seg[0].K % 64) { recnn_set_error("gemm dx (bf16x3): physical contraction length %d is not a multiple of 64", p.seg[0].K); return RECNN_E_UNSUPPORTED; }
+    if (p.seg[0].K % 64 || p.seg[0].K > 2 * DX_KMAX) {
+      recnn_set_error("gemm dx (bf16x3): physical contraction length %d must be a multiple of 64, at most %d", p.seg[0].K, 2 * DX_KMAX);
+      return RECNN_E_UNSUPPORTED;
+    }
     if (p.seg[0].lda < p.seg[0].K || p.seg[0].ldb < (int64_t)p.tiles_n * 64) {
       recnn_set_error("gemm dx (bf16x3): operand pitch below the split width (lda=%lld K=%d, ldb=%lld N=%d)", (long long)p.seg[0].lda, p.seg[0].K,
                       (long long)p.seg[0].ldb, p.N);
@@ -288,7 +326,7 @@ int launch_dx(GemmLaunch* L, hipStream_t s) {
     if (p.tiles_m * p.tiles_n > maxwg) maxwg = p.tiles_m * p.tiles_n;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL(x3_dx_kernel, dim3(maxwg, L->nprob, 1), dim3(256), 0, s, L->batch);
+  hipLaunchKernelGGL(x3_dx_kernel, dim3(maxwg, L->nprob, 1), dim3(256), DX_LDS, s, L->batch);
   return recnn_check_hip(hipGetLastError(), "x3_dx_kernel launch");
 }
 
@@ -307,13 +345,17 @@ int launch_dw(GemmLaunch* L, hipStream_t s) {
     if (p.tiles_m * p.tiles_n * p.dw_splits > maxwg) maxwg = p.tiles_m * p.tiles_n * p.dw_splits;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL(x3_dw_kernel, dim3(maxwg, L->nprob, 1), dim3(256), 0, s, L->batch);
+  hipLaunchKernelGGL(x3_dw_kernel, dim3(maxwg, L->nprob, 1), dim3(256), 2 * DW_STAGE, s, L->batch);
   return recnn_check_hip(hipGetLastError(), "x3_dw_kernel launch");
 }
 
 }  // namespace
 
-int x3_init() { return 0; }
+int x3_init() {
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS), "x3 dx attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE), "x3 dw attr");
+  return rc;
+}
 
 int x3_gemm_launch(GemmLaunch* L, hipStream_t stream) {
   if (L->a_f32 || L->b_f32) { recnn_set_error("gemm (bf16x3): operands must be split-bf16 rows"); return RECNN_E_UNSUPPORTED; }
