@@ -56,69 +56,8 @@ enum {
 int recnn_abi_version(void);
 const char* recnn_last_error(void);
 /* sizeof() of an ABI struct: 0 recnn_gemm_args, 1 recnn_engine_config, 2 recnn_hyper,
- * 3 recnn_engine_sizes, 4 recnn_sampler (lets a binding verify its declarations); -1 if unknown. */
+ * 3 recnn_engine_sizes, 4 recnn_sampler, 5 recnn_engine_tuning (lets a binding verify its declarations); -1 if unknown. */
 int64_t recnn_abi_sizeof(int which);
-/* tuning knob: GEMM tile variant, -1 = per-launch heuristic, 0 = 64x64 tile, 1 = 32x64 tile with a 2x longer
- * k stage. */
-void recnn_tune_gemm_variant(int variant);
-/* tuning knob: the per-launch heuristic takes the 64x64 tile when the launch has at least this many 64x64 tiles. */
-void recnn_tune_gemm_v0_threshold(int workgroups);
-/* tuning knob: 1 (default) = forward GEMMs whose operands are stored in the compute type use the LDS-DMA
- * 3-stage pipeline, 0 = always the register-staged kernel. */
-void recnn_tune_gemm_dma(int on);
-/* tuning knob: 1 (default) = bf16 engines with hidden <= 256 run every network forward as ONE fused row-panel
- * launch (csrc/mlps.hip); 0 = layer-by-layer GEMM launches. */
-void recnn_tune_fused_mlp(int on);
-/* tuning knob: 1 (default) = single-problem forward GEMM launches use a 5-stage LDS-DMA ring, 0 = always 3. */
-void recnn_tune_gemm_dma_depth(int deep);
-/* tuning knob: waves per workgroup of the LDS-DMA forward GEMM, 8 (default) or 4 (same 32x64 tile). */
-void recnn_tune_gemm_dma_waves(int waves);
-/* tuning knob: waves per workgroup of the register-staged dX / dW GEMM (same block tiles), 8 (default) or 4. */
-void recnn_tune_gemm_waves(int waves);
-/* tuning knob: extra elements (rounded up to 8) on every leading dimension the MFMA kernels stream through (weight shadows,
- * packed batch rows); applies to engines created afterwards. */
-void recnn_tune_ld_pad(int elems);
-/* 0 (default): a bf16 engine that samples its own batches (recnn_engine_bind_sampler) writes the batch rows in
- * bf16 only; 1: it also fills the bound fp32 packed rows. */
-void recnn_tune_sampler_f32_rows(int on);
-/* tuning knob: number of batch splits (gradient slabs) of the layer-1 dW GEMM, 1..8. */
-void recnn_tune_dw_splits(int splits);
-/* tuning knob: 1 (default) = bf16 dW GEMMs copy their operands global -> LDS by DMA and read the MFMA fragments with
- * the LDS transpose read; 0 = register-staged transposing loader. */
-void recnn_tune_dw_dma(int on);
-/* tuning knob: 1 (default) = the target critic(s) run inside the fused MLP launch: a producer workgroup computes the
- * next_state part of layer 1 while the target actor's workgroup of the same 32 rows runs, which then adds the
- * next_action part and finishes the critic on chip (flag hand-off); 0 = separate launches after it. */
-void recnn_tune_chain_target_critic(int on);
-/* tuning knob for the chained bf16 path: where the critic head (TD target, loss, dz2, dW3/db2/db3 partials) and the first
- * backward GEMM (dz1, db1 partial) run.  2 (default) = inside the fused MLP launch: the critic's forward workgroup emits
- * UNIT backward tensors (dz / d), the target actor's workgroup evaluates the head (Q(s,a) reaches it through per-row
- * hand-off slots), and the dW launch applies the per-row seed d and adds the bias / last-layer partial sums;
- * 1 = one row-panel launch (bwd.hip); 0 = head kernel + dX GEMM launch. */
-void recnn_tune_bwd_panel(int on);
-/* tuning knob: 1 (default) = on policy steps of the fused bf16 path the gradient chain from the policy loss back into the
- * actor (dz_e2 -> dz_e1 -> dact -> dz_p2 -> dz_p1 with their bias partial sums) runs as ONE row-panel launch; 0 = the
- * row-panel launch for the first two links + one dX GEMM launch per remaining link. */
-void recnn_tune_policy_chain(int on);
-/* tuning knob (before recnn_engine_graph_build): steps per "run" graph. -1 (default) = as many whole policy cycles
- * (policy step + policy_every-1 ordinary steps) as fit 64 steps per graph launch when policy_every <= 32, else runs of
- * 16 ordinary steps; 0 = single-step graphs only. */
-void recnn_tune_graph_run(int steps);
-/* tuning knob (before recnn_engine_graph_build): 1 (default) = inside a run graph the replay sampler + gather of step
- * t+1 runs as extra workgroups of step t's critic optimizer launch, into a second batch buffer set (bf16 engines that
- * sample their own batches); 0 = every step starts with its own gather launch. */
-void recnn_tune_pregather(int on);
-/* tuning knob (before recnn_engine_graph_build): 1 (default) = inside a run graph the policy-loss forward of an ordinary
- * step (critic on [pi(s) | s] with the just-updated weights; nothing later depends on it) rides as an extra problem on
- * the NEXT step's fused forward launch instead of two GEMM launches of its own (DDPG, bf16 sampler engines);
- * policy steps and the last step of a run keep it in order. */
-void recnn_tune_defer_policy_fwd(int on);
-/* tuning knob: lane mapping of the transposing (k-strided) operand loads of the dX / dW kernels:
- * 0 = consecutive lanes along k, 1 = consecutive lanes along the contiguous tile dimension. */
-void recnn_tune_gemm_ks_layout(int tile_fastest);
-/* tuning knob: batch rows built per workgroup by recnn_frame_gather (2, 4 or 8). */
-void recnn_tune_gather_rows(int rows_per_workgroup);
-
 /* =====================================================================================
  * 1. Replay sampler + embedding gather
  *    replaces recnn/data/utils.py:161-187 (prepare_batch_static_size: rolling_window +
@@ -470,10 +409,10 @@ int recnn_engine_finish(recnn_engine* e, int rows, int value_stepped, int policy
 
 /* Capture `recnn_engine_step` for a fixed row count into hipGraphs -- one ordinary step, one policy step, and a family
  * of RUN graphs (k ordinary steps; a policy step + k ordinary steps, k < policy_every; whole policy cycles up to 64
- * steps, see recnn_tune_graph_run) -- and replay `n_steps` consecutive steps starting at `first_step`: ANY
+ * steps, see tuning.graph_run) -- and replay `n_steps` consecutive steps starting at `first_step`: ANY
  * (first_step, n_steps) is covered with at most n_steps / policy_every + 2 graph launches (policy_every <= 17; longer
  * cycles compose power-of-two stretches).  Inside a run graph the device counters are ticked once at its end, the sampler + gather of step t+1 and the policy-loss forward of step t ride on
- * other launches (recnn_tune_pregather, recnn_tune_defer_policy_fwd), and every step's losses land in the history ring
+ * other launches (tuning.pregather, tuning.defer_policy_fwd), and every step's losses land in the history ring
  * (recnn_engine_read_counters). */
 int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream);
 int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream);
@@ -489,7 +428,7 @@ int recnn_engine_graph_prepare(recnn_engine* e, int first_step, int n_steps, voi
  * 8 times back to back inside their event pair and the time divided by 8, which amortises the event overhead.
  * *h_n is in: capacity, out: slots used.  Policy and non-policy steps have different slot
  * lists; only steps with (step % policy_every == 0) == policy_steps are run and averaged.  policy_steps = 2 profiles CYCLE
- * MODE (what run graphs of >= recnn_tune_cycle_min_len steps replay): the gather of one policy cycle's batches, the frozen
+ * MODE (what run graphs of >= tuning.cycle_min_len steps replay): the gather of one policy cycle's batches, the frozen
  * networks on all of them, then one ordinary step of the cycle on the split forward. */
 int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream,
                          float* h_ms, double* h_flops, const char** h_names, int* h_n);
@@ -540,49 +479,52 @@ int recnn_dp_allreduce_flat(recnn_comm* c, float* data, int64_t n, void* stream)
 int recnn_comm_status(recnn_comm* c, int32_t* timed_out_ranks, int32_t* epoch);
 void recnn_comm_destroy(recnn_comm* c);
 int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
-/* tuning knob: memory kind of the peer buffers created afterwards: 0 fine-grained (default), 1 uncached, 2 ordinary */
+/* Process-level settings of the peer communicators created afterwards (a communicator is shared by engines, so these are not part
+ * of an engine's tuning): memory kind of the peer buffers, 0 fine-grained (default), 1 uncached, 2 ordinary; workgroups per
+ * collective launch (default 128; ranks that share ONE GPU in tests need all of them resident at once: 32). */
 void recnn_tune_comm_memory(int kind);
-/* tuning knob: XCD-affine workgroup map of the fused forward (csrc/mlp.h MlpBatch.xcd_map) for launches of up to max_problems
- * networks: a network's weights are fetched into two L2s instead of eight.  0 = off (default: measured slower) */
-void recnn_tune_mlp_xcd(int max_problems);
-/* tuning knob, cycle mode: 1 = the learning critic's step forward is ONE fused row-panel launch that evaluates the TD head in
- * the critic's own workgroups, 0 (default: measured faster) = layer-1 GEMM + tail launches */
-void recnn_tune_cycle_fused_critic(int on);
-/* tuning knob: 1 (default) the critics' gradient exchange runs inside their optimizer launch, 0 as launches of its own */
-void recnn_tune_comm_fused(int on);
-/* tuning knob: workgroups per collective launch (default 128) */
 void recnn_tune_comm_workgroups(int n);
 
-/* In-launch hand-offs (the fused forward chains dependent networks through producer / consumer workgroups) wait with
- * a bound; a wait that runs out sets a device error word and both readers below then return RECNN_E_STATE (and clear
- * the word): the numbers of the steps since the previous read are void.  recnn_tune_mlp_fault(1|2) breaks a hand-off
- * on purpose (tests). */
-void recnn_tune_mlp_fault(int mode);
-/* 1: on the bf16 fused path the critic's weight-gradient GEMMs contract the whole batch per tile and finish the
- * optimizer step (recnn_engine_step / graph replays) or the flat gradient arena (recnn_engine_value_grads, data parallel) in
- * their epilogue (csrc/dwopt.hip: no gradient slabs, no separate Adam launch; 2 / 3 = the same with 8 / 4 waves per workgroup
- * instead of 16); 0 (default: faster at 2048 rows, see csrc/engine.hip) = split-batch slabs + reduce / Adam launches. */
-void recnn_tune_dw_fuse(int on);
-void recnn_tune_cycle_min_seg(int n);   /* cycle mode: segments shorter than n steps use the fused forward (default 3) */
-void recnn_tune_opt_table(int on);   /* 1: run graphs precompute the optimizers' step scalars in one launch at the graph head */
-/* Scheduling of the bf16 step (all variants agree bit for bit): 0 = the fused row-panel forward (csrc/mlps.hip) everywhere;
- * 1 (default) = run graphs of >= recnn_tune_cycle_min_len steps (default 30) run in cycle mode: a policy cycle's batches gathered
- * at once, the frozen networks (target actor / critics, actor) applied to all of them by csrc/mlpf.hip, the per-step launches =
- * split forward of the learning critics (csrc/l1gemm.hip + csrc/mlpt.hip); 2 = split forward and cycle mode everywhere. */
-void recnn_tune_split_fwd(int on);
-void recnn_tune_cycle_min_len(int steps);
-void recnn_tune_frozen_gemm(int on);
-void recnn_tune_frozen_fused(int on);
-void recnn_tune_cycle_fork(int on);   /* cycle mode: gather the next cycle's batches on a side branch of the run graph (measured slower: off) */   /* cycle mode: each frozen network as one launch of 128-row panels (csrc/mlpf.hip; 1, default) */   /* cycle mode: layers 2 / 3 of the frozen networks as tiled GEMMs (1, default) or row-panel tails (0) */
-void recnn_tune_l1_big(int shape);   /* tile of the cycle-batched layer-1 GEMMs: 1 = 128 x 128 (default), 2 = 128 x 64 */
-void recnn_tune_tail_trace(void* device_u64_wg16);   /* shader-clock stamps of mlp_tail_kernel / l1_gemm_kernel, [workgroup][16] uint64 */
-void recnn_tune_l1_trace(void* device_u64_wg16);
-/* timing experiments on csrc/dwopt.hip (results are garbage): 1 = no per-row scale, 2 = no LDS reads / MFMA, 4 = no DMA */
-void recnn_tune_dw_probe(int bits);
-void recnn_tune_dw_trace(void* device_u64_wg8);   /* shader-clock stamps of dw_opt_kernel, [workgroup][8] uint64, NULL = off */
-/* timing experiments on the fused forward (csrc/mlps.hip): bit 0 = no MFMA work / fragment reads, bit 1 = no DMA; results are garbage */
-void recnn_tune_mlp_probe(int bits);
-void recnn_tune_mlp_trace(void* device_u64_wg32);   /* shader-clock stamps of the kernel's phases, [workgroup][32] uint64, NULL = off */
+/* ---- per-engine tuning.  Every field selects among schedules / kernel tilings that produce the SAME numbers (the GPU suite runs
+ * under several of them); nothing here is process-wide: two engines of one process can run different schedules.
+ * recnn_engine_tuning_init fills the defaults, recnn_engine_set_tuning copies a (clamped) tuning into an engine and drops its
+ * graphs.  In-launch hand-offs of the fused forward wait with a bound: a wait that runs out sets a device error word and
+ * recnn_engine_read_losses / read_counters then return RECNN_E_STATE (debug hooks that provoke this: csrc/recnn_hip_debug.h). */
+typedef struct recnn_engine_tuning {
+  int fused_mlp;            /* 1: bf16 engines with hidden <= 256 run the networks of a step as ONE fused row-panel launch (csrc/mlps.hip)
+                               when a launch has >= 3 of them, 2: always, 0: layer-by-layer GEMM launches */
+  int chain_target_critic;  /* 1: the target critics run inside the fused launch (producer workgroups + flag hand-off), 0: after it */
+  int bwd_panel;            /* where the critic head + first backward GEMM run: 2 inside the fused forward launch (unit backward
+                               tensors, per-row seed applied by the dW launch), 1 one row-panel launch (bwd.hip), 0 head + dX launches */
+  int policy_chain;         /* 1: policy steps run the gradient chain from the policy loss into the actor as ONE row-panel launch */
+  int split_fwd;            /* 0: fused forward everywhere; 1: run graphs of >= cycle_min_len steps run in cycle mode (a policy cycle's
+                               batches gathered at once, frozen networks applied to all of them: mlpf.hip; per-step launches = split
+                               forward of the learning critics: l1gemm.hip + mlpt.hip); 2: split forward and cycle mode everywhere */
+  int cycle_min_len;        /* default 30 */
+  int cycle_min_seg;        /* cycle mode: segments shorter than this step through the fused forward (default 3) */
+  int frozen_fused;         /* cycle mode: 1 each frozen network as one launch of 128-row panels, 0 tiled layer 1 + later layers */
+  int frozen_gemm;          /* ... whose later layers run as tiled GEMMs (1) or row-panel tails (0) */
+  int graph_run;            /* steps per run graph: -1 as many whole policy cycles as fit 64 steps, 0 single-step graphs only */
+  int pregather;            /* 1: inside a run graph the sampler + gather of step t+1 ride on step t's critic optimizer launch */
+  int defer_policy_fwd;     /* 1: ... and the policy-loss forward of step t on step t+1's forward launch(es) */
+  int sampler_f32_rows;     /* 1: an engine that samples its own batches also fills the bound fp32 packed rows (inspection) */
+  int dw_splits;            /* batch splits (gradient slabs) of the layer-1 dW GEMM, 1..8 */
+  int comm_fused;           /* data parallel: 1 the critics' gradient exchange runs inside their optimizer launch, 0 as its own launches */
+  int l1_big;               /* tile of the cycle-batched layer-1 GEMMs: 1 = 128 x 128 (default), 2 = 128 x 64 */
+  int gemm_variant;         /* register-staged GEMM tile: -1 per launch, 0 = 64 x 64, 1 = 32 x 64 with a 2x longer k stage */
+  int gemm_v0_threshold;    /* ... the per-launch choice takes 64 x 64 from this many tiles on (512) */
+  int gemm_dma;             /* 1: forward GEMMs on compute-type operands use the LDS-DMA ring kernel */
+  int gemm_dma_depth;       /* 1: 5-stage ring for launches of <= 320 tiles */
+  int gemm_dma_waves;       /* 8 | 4 waves per workgroup of the LDS-DMA forward kernel */
+  int gemm_waves;           /* 8 | 4 waves per workgroup of the register-staged dX kernel */
+  int dw_dma;               /* bf16 dW: 0 register-staged loader, 1..7 LDS-DMA + transpose reads with (rows per stage, ring slots) =
+                               (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3); default 2 */
+  int reserved[9];
+} recnn_engine_tuning;
+void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
+int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);
+int recnn_engine_get_tuning(recnn_engine* e, recnn_engine_tuning* h_t);
+
 /* Device counters {steps finalized, actor optimizer steps, critic 1 steps, critic 2 steps} (synchronises the stream).
  * The debug view "loss_ring" ([1024][4] fp32: value1, value2 / policy, policy per recnn_engine_read_losses' layout)
  * holds the losses of the last 1024 steps at index (step counter value of that step) mod 1024 -- including every

@@ -83,6 +83,16 @@ class Sampler(C.Structure):
     ]
 
 
+TUNING_FIELDS = ("fused_mlp", "chain_target_critic", "bwd_panel", "policy_chain", "split_fwd", "cycle_min_len", "cycle_min_seg",
+                 "frozen_fused", "frozen_gemm", "graph_run", "pregather", "defer_policy_fwd", "sampler_f32_rows", "dw_splits", "comm_fused",
+                 "l1_big", "gemm_variant", "gemm_v0_threshold", "gemm_dma", "gemm_dma_depth", "gemm_dma_waves", "gemm_waves", "dw_dma")
+
+
+class EngineTuning(C.Structure):
+    """include/recnn_hip.h recnn_engine_tuning: schedule / tile choices of ONE engine (all compute the same numbers)."""
+    _fields_ = [(f, C.c_int) for f in TUNING_FIELDS] + [("reserved", C.c_int * 9)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -94,45 +104,13 @@ SIGNATURES = {
     "recnn_abi_version": (_I, []),
     "recnn_last_error": (C.c_char_p, []),
     "recnn_abi_sizeof": (_L, [_I]),
-    "recnn_tune_gather_rows": (None, [_I]),
-    "recnn_tune_gemm_variant": (None, [_I]),
-    "recnn_tune_gemm_v0_threshold": (None, [_I]),
-    "recnn_tune_gemm_dma": (None, [_I]),
-    "recnn_tune_fused_mlp": (None, [_I]),
-    "recnn_tune_gemm_dma_depth": (None, [_I]),
-    "recnn_tune_gemm_dma_waves": (None, [_I]),
-    "recnn_tune_gemm_waves": (None, [_I]),
-    "recnn_tune_dw_splits": (None, [_I]),
-    "recnn_tune_dw_dma": (None, [_I]),
-    "recnn_tune_dw_fuse": (None, [_I]),
-    "recnn_tune_opt_table": (None, [_I]),
-    "recnn_tune_cycle_min_seg": (None, [_I]),
-    "recnn_tune_split_fwd": (None, [_I]),
-    "recnn_tune_cycle_min_len": (None, [_I]),
-    "recnn_tune_l1_big": (None, [_I]),
-    "recnn_tune_frozen_gemm": (None, [_I]),
-    "recnn_tune_frozen_fused": (None, [_I]),
-    "recnn_tune_cycle_fork": (None, [_I]),
-    "recnn_tune_dw_probe": (None, [_I]),
-    "recnn_tune_dw_trace": (None, [_P]),
-    "recnn_tune_tail_trace": (None, [_P]),
-    "recnn_tune_l1_trace": (None, [_P]),
-    "recnn_tune_chain_target_critic": (None, [_I]),
-    "recnn_tune_bwd_panel": (None, [_I]),
-    "recnn_tune_policy_chain": (None, [_I]),
-    "recnn_tune_graph_run": (None, [_I]),
-    "recnn_tune_pregather": (None, [_I]),
-    "recnn_tune_defer_policy_fwd": (None, [_I]),
-    "recnn_tune_mlp_fault": (None, [_I]),
-    "recnn_tune_mlp_probe": (None, [_I]),
-    "recnn_tune_mlp_trace": (None, [_P]),
+    "recnn_engine_tuning_init": (None, [C.POINTER(EngineTuning)]),
+    "recnn_engine_set_tuning": (_I, [_P, C.POINTER(EngineTuning)]),
+    "recnn_engine_get_tuning": (_I, [_P, C.POINTER(EngineTuning)]),
     "recnn_engine_sampler_eager": (_I, [_P, _I]),
     "recnn_engine_unit_backward": (_I, [_P]),
     "recnn_engine_dp_sets": (_I, [_P]),
     "recnn_engine_read_counters": (_I, [_P, _P, _P]),
-    "recnn_tune_sampler_f32_rows": (None, [_I]),
-    "recnn_tune_ld_pad": (None, [_I]),
-    "recnn_tune_gemm_ks_layout": (None, [_I]),
     "recnn_frame_plan_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
@@ -194,15 +172,21 @@ SIGNATURES = {
     "recnn_comm_destroy": (None, [_P]),
     "recnn_engine_set_comm": (_I, [_P, _P, _F]),
     "recnn_tune_comm_memory": (None, [_I]),
-    "recnn_tune_mlp_xcd": (None, [_I]),
-    "recnn_tune_cycle_fused_critic": (None, [_I]),
-    "recnn_tune_comm_fused": (None, [_I]),
     "recnn_tune_comm_workgroups": (None, [_I]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),
     "recnn_topk_item_aux": (_I, [_P, _I, _I, _I, _P, _P]),
     "recnn_topk_workspace_bytes": (_I, [_I, _I, C.POINTER(_L)]),
     "recnn_topk_search": (_I, [_P, _L, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "recnn_engine_buffer": (_P, [_P, C.c_char_p, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), C.POINTER(_I)]),
+}
+
+# private debug / test hooks (recnn_amd/csrc/recnn_hip_debug.h): exported, but not part of the public header
+DEBUG_SIGNATURES = {
+    "recnn_debug_mlp_fault": (None, [_I]),
+    "recnn_debug_mlp_probe": (None, [_I]),
+    "recnn_debug_mlp_trace": (None, [_P]),
+    "recnn_debug_tail_trace": (None, [_P]),
+    "recnn_debug_l1_trace": (None, [_P]),
 }
 
 _lib = None
@@ -219,11 +203,11 @@ def load():
             "(or __graft_entry__.build()).  recnn_amd has no CPU or PyTorch fallback.")
     import torch  # noqa: F401  -- loads libamdhip64.so.7 first; ours must bind to the same runtime
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((GemmArgs, EngineConfig, Hyper, EngineSizes, Sampler)):
+    for which, st in enumerate((GemmArgs, EngineConfig, Hyper, EngineSizes, Sampler, EngineTuning)):
         if lib.recnn_abi_sizeof(which) != C.sizeof(st):
             raise RecnnHipError(f"ABI mismatch for {st.__name__}: C={lib.recnn_abi_sizeof(which)} py={C.sizeof(st)}")
     _lib = lib

@@ -1,59 +1,67 @@
-"""Environment-variable access to librecnn_hip's tuning knobs (A/B experiments from the shell: `RECNN_DW_DMA=3 python bench.py`).
+"""Tuning of the step engines from Python and from the environment (A/B experiments from the shell: `RECNN_DW_DMA=3 python bench.py`).
 
-Nothing here changes what is computed; every knob selects among schedules / tile shapes that produce the same numbers.
-`apply_env_knobs()` is called once by bench.py and the tools before the first engine is created."""
+Nothing here changes what is computed: every field of `recnn_engine_tuning` (include/recnn_hip.h) selects among schedules / tile
+shapes that produce the same numbers.  The C ABI keeps NO process-wide tuning state: each `StepEngine` receives its own copy
+(`recnn_engine_set_tuning`), made here from the library defaults, then the environment, then `set_default_tuning(...)` overrides
+(tests that run a whole facade under another schedule), then the engine's own `set_tuning(...)` keywords."""
 import os
 
 from . import _lib as L
 
-# environment variable -> C ABI knob (include/recnn_hip.h documents each)
-KNOBS = {
-    "RECNN_GEMM_VARIANT": "recnn_tune_gemm_variant",
-    "RECNN_GEMM_DMA": "recnn_tune_gemm_dma",
-    "RECNN_FUSED_MLP": "recnn_tune_fused_mlp",
-    "RECNN_SAMPLER_F32": "recnn_tune_sampler_f32_rows",
-    "RECNN_V0_MIN_WG": "recnn_tune_gemm_v0_threshold",
-    "RECNN_MLP_PROBE": "recnn_tune_mlp_probe",
-    "RECNN_GEMM_WAVES": "recnn_tune_gemm_waves",
-    "RECNN_DMA_WAVES": "recnn_tune_gemm_dma_waves",
-    "RECNN_DMA_DEEP": "recnn_tune_gemm_dma_depth",
-    "RECNN_DEFER_PC": "recnn_tune_defer_policy_fwd",
-    "RECNN_PREGATHER": "recnn_tune_pregather",
-    "RECNN_GRAPH_RUN": "recnn_tune_graph_run",
-    "RECNN_POLICY_CHAIN": "recnn_tune_policy_chain",
-    "RECNN_BWD_PANEL": "recnn_tune_bwd_panel",
-    "RECNN_CHAIN_TC": "recnn_tune_chain_target_critic",
-    "RECNN_DW_DMA": "recnn_tune_dw_dma",
-    "RECNN_DW_SPLITS": "recnn_tune_dw_splits",
-    "RECNN_DW_FUSE": "recnn_tune_dw_fuse",
-    "RECNN_OPT_TABLE": "recnn_tune_opt_table",
-    "RECNN_MLP_XCD": "recnn_tune_mlp_xcd",
-    "RECNN_CYCLE_FUSED_CRITIC": "recnn_tune_cycle_fused_critic",
-    "RECNN_COMM_MEMORY": "recnn_tune_comm_memory",
-    "RECNN_COMM_FUSED": "recnn_tune_comm_fused",
-    "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",
-    "RECNN_CYCLE_MIN_SEG": "recnn_tune_cycle_min_seg",
-    "RECNN_SPLIT_FWD": "recnn_tune_split_fwd",
-    "RECNN_CYCLE_MIN_LEN": "recnn_tune_cycle_min_len",
-    "RECNN_L1_BIG": "recnn_tune_l1_big",
-    "RECNN_FROZEN_GEMM": "recnn_tune_frozen_gemm",
-    "RECNN_FROZEN_FUSED": "recnn_tune_frozen_fused",
-    "RECNN_CYCLE_FORK": "recnn_tune_cycle_fork",
-    "RECNN_DW_PROBE": "recnn_tune_dw_probe",
-    "RECNN_GEMM_TGF": "recnn_tune_gemm_ks_layout",
-    "RECNN_LD_PAD": "recnn_tune_ld_pad",
-    "RECNN_GATHER_ROWS": "recnn_tune_gather_rows",
+# environment variable -> recnn_engine_tuning field
+ENV_FIELDS = {
+    "RECNN_FUSED_MLP": "fused_mlp", "RECNN_CHAIN_TC": "chain_target_critic", "RECNN_BWD_PANEL": "bwd_panel",
+    "RECNN_POLICY_CHAIN": "policy_chain", "RECNN_SPLIT_FWD": "split_fwd", "RECNN_CYCLE_MIN_LEN": "cycle_min_len",
+    "RECNN_CYCLE_MIN_SEG": "cycle_min_seg", "RECNN_FROZEN_FUSED": "frozen_fused", "RECNN_FROZEN_GEMM": "frozen_gemm",
+    "RECNN_GRAPH_RUN": "graph_run", "RECNN_PREGATHER": "pregather", "RECNN_DEFER_PC": "defer_policy_fwd",
+    "RECNN_SAMPLER_F32": "sampler_f32_rows", "RECNN_DW_SPLITS": "dw_splits", "RECNN_COMM_FUSED": "comm_fused", "RECNN_L1_BIG": "l1_big",
+    "RECNN_GEMM_VARIANT": "gemm_variant", "RECNN_V0_MIN_WG": "gemm_v0_threshold", "RECNN_GEMM_DMA": "gemm_dma",
+    "RECNN_DMA_DEEP": "gemm_dma_depth", "RECNN_DMA_WAVES": "gemm_dma_waves", "RECNN_GEMM_WAVES": "gemm_waves", "RECNN_DW_DMA": "dw_dma",
 }
+# process-level settings of the peer communicators (shared by engines: not part of an engine's tuning) and debug hooks
+ENV_CALLS = {"RECNN_COMM_MEMORY": "recnn_tune_comm_memory", "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",
+             "RECNN_MLP_PROBE": "recnn_debug_mlp_probe"}
+
+_overrides = {}
+
+
+def set_default_tuning(**fields):
+    """Overrides for every engine created AFTERWARDS (None removes one): `set_default_tuning(split_fwd=2)`."""
+    for k, v in fields.items():
+        if k not in L.TUNING_FIELDS:
+            raise KeyError(k)
+        if v is None:
+            _overrides.pop(k, None)
+        else:
+            _overrides[k] = int(v)
+
+
+def make_tuning(**fields) -> "L.EngineTuning":
+    t = L.EngineTuning()
+    L.load().recnn_engine_tuning_init(t)
+    for var, f in ENV_FIELDS.items():
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            setattr(t, f, int(v))
+    for k, v in {**_overrides, **fields}.items():
+        if k not in L.TUNING_FIELDS:
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    return t
 
 
 def apply_env_knobs():
-    """Apply every knob whose environment variable is set; returns {variable: value} of what was applied."""
+    """Apply the process-level settings whose environment variable is set (communicator memory / workgroups, debug probes); the
+    per-engine fields are read from the environment whenever an engine is created.  Returns {variable: value} of everything set."""
     lib = L.load()
     done = {}
-    for var, fn in KNOBS.items():
+    for var, fn in ENV_CALLS.items():
         v = os.environ.get(var)
-        if v is None or v == "":
-            continue
-        getattr(lib, fn)(int(v))
-        done[var] = int(v)
+        if v not in (None, ""):
+            getattr(lib, fn)(int(v))
+            done[var] = int(v)
+    for var in ENV_FIELDS:
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            done[var] = int(v)
     return done

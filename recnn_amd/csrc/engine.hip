@@ -34,7 +34,6 @@
 #include "bwd.h"
 #include "optim.h"
 #include "comm.h"
-#include "dwopt.h"
 #include "split.h"
 #include "x3.h"
 
@@ -48,10 +47,8 @@ static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 namespace {
 
 constexpr int W1 = 0, B1 = 1, W2 = 2, B2 = 3, W3 = 4, B3 = 5;
-int SP_W1 = 8;  // batch splits of the layer-1 dW GEMM (tunable)
 constexpr int SP_W1_MAX = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
 
-int ld_pad();   // recnn_tune_ld_pad (defined with the other tuning knobs below)
 struct Net {
   bool critic = false, bound = false;
   float *p = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // canonical flat arenas (caller owned)
@@ -85,6 +82,8 @@ struct recnn_engine {
   int S, A, H, Hp, Ap, K1a, K1c, ldx, Bc, esz;
   int Hl, Al, ldx32;
   bool bf16, td3;
+  recnn_engine_tuning tune;   // schedule / tile choices of THIS engine (recnn_engine_set_tuning)
+  GemmTune gtune;             // ... the part of it the GEMM launchers read (gemm.h)
   bool x3 = false;     // compute type RECNN_BF16X3: split-bf16 rows through the layer-by-layer launches (gemm.hip / x3.hip)
   bool twins = false;  // the compute type differs from the bound fp32 rows: the step reads twins of the packed rows (workspace)
   int n_critic;
@@ -127,10 +126,6 @@ struct recnn_engine {
   float *m_reward = nullptr, *m_done = nullptr;    // [MSET_MAX * Bc]                  steps on one, a side branch of the run graph
   char *m_xs_b[2] = {nullptr, nullptr}, *m_xn_b[2] = {nullptr, nullptr};            //  gathers the next cycle's batches into the other)
   float *m_reward_b[2] = {nullptr, nullptr}, *m_done_b[2] = {nullptr, nullptr};
-  hipStream_t side = nullptr;                      // capture-time side branch (gather look-ahead)
-  static constexpr int EV_POOL = 16;
-  hipEvent_t ev_pool[EV_POOL] = {};
-  int ev_next = 0;
   char* m_ga = nullptr;                            // actor outputs, bf16 [MSET_MAX * Bc, Ap]
   float* m_tq[2] = {nullptr, nullptr};             // Q'(s', pi'(s')) per target critic, fp32 [MSET_MAX * Bc]
   float* m_noise = nullptr;                        // TD3 target-action noise, fp32 [MSET_MAX * Bc, A]
@@ -165,8 +160,6 @@ struct recnn_engine {
   float comm_scale = 1.0f;                 // 1 / world
   bool comm_region = false;                // the arenas have regions of their own inside the communicator's buffers:
   int64_t comm_off[RECNN_NET_COUNT] = {};  //   gradients are produced into in[] and the optimizers read out[] (no copies)
-  OptScalars* opt_tab = nullptr;
-  bool scal_on = false;                    // the table holds the step being issued
   // device-resident sampler (optional)
   recnn_sampler smp;
   bool has_sampler = false;
@@ -205,6 +198,13 @@ struct recnn_engine {
   int graph_rows = 0;
   bool hyper_set = false;
 };
+
+static void sync_gemm_tune(recnn_engine* e) {
+  const recnn_engine_tuning& t = e->tune;
+  GemmTune& g = e->gtune;
+  g.variant = t.gemm_variant; g.v0_min_wg = t.gemm_v0_threshold; g.dma = t.gemm_dma; g.dma_deep = t.gemm_dma_depth;
+  g.dma_waves = t.gemm_dma_waves == 8 ? 8 : 4; g.waves = t.gemm_waves == 4 ? 4 : 8; g.dw_dma = t.dw_dma;
+}
 
 // Every kernel launch of the step goes through slot(): a no-op wrapper normally, a hipEvent pair in profile mode.
 template <class F> int slot(recnn_engine* e, const char* name, double flops, hipStream_t s, F&& launch, bool idempotent = true) {
@@ -251,9 +251,9 @@ void net_dims(recnn_engine* e, int ni) {
   n.off[W3] = n.off[B2] + H;
   n.off[B3] = n.off[W3] + (int64_t)n.out_dim * H;
   n.n_params = n.off[B3] + n.out_dim;
-  n.ld_w1 = (n.critic ? e->K1c : e->K1a) + ld_pad();
-  n.ld_w2 = e->Hp + ld_pad();
-  n.ld_w3 = e->Hp + ld_pad();
+  n.ld_w1 = n.critic ? e->K1c : e->K1a;
+  n.ld_w2 = e->Hp;
+  n.ld_w3 = e->Hp;
   n.sh_off[W1] = 0;
   n.sh_off[W2] = (int64_t)e->Hl * n.ld_w1;
   int64_t tot = n.sh_off[W2] + (int64_t)e->Hl * n.ld_w2;
@@ -365,7 +365,6 @@ int64_t carve(recnn_engine* e, char* base) {
   e->coef_out = (float*)c.take(16);
   e->counters = (int32_t*)c.take(64);
   e->l1_scratch = (float*)c.take(4096);
-  e->opt_tab = (OptScalars*)c.take((int64_t)OPT_TABLE_STEPS * 3 * sizeof(OptScalars));
   e->pa0 = e->pa;
   for (int i = 0; i < 2; ++i) e->tqv0[i] = e->tqv[i];
   return ru(c.off, 256);
@@ -387,7 +386,6 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   e->K1c = (int)ru(e->S + e->A, 128);
   e->ldx = (int)ru(e->A + e->K1a, 128);
   if (e->ldx < e->K1c) e->ldx = e->K1c;
-  e->ldx += ld_pad();
   e->Bc = (int)ru(cfg->max_rows, 64);
   e->bf16 = cfg->dtype == RECNN_BF16;
   e->x3 = cfg->dtype == RECNN_BF16X3;
@@ -426,10 +424,11 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = gemm_init())) { delete e; return rc; }
   if ((rc = mlp_init())) { delete e; return rc; }
   if ((rc = bwd_init())) { delete e; return rc; }
-  if ((rc = dwopt_init())) { delete e; return rc; }
   if ((rc = l1gemm_init())) { delete e; return rc; }
   if ((rc = mlpt_init())) { delete e; return rc; }
   if ((rc = mlpf_init())) { delete e; return rc; }
+  recnn_engine_tuning_init(&e->tune);
+  sync_gemm_tune(e);
   e->ws = (char*)workspace;
   e->ws_bytes = carve(e, e->ws);
   for (int i = 0; i < e->n_critic; ++i) {  // hand-off flags of the chained target critics start (and rest) at 0
@@ -468,9 +467,6 @@ static void drop_graphs(recnn_engine* e) {
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
   if (!e) return;
   drop_graphs(e);
-  for (int i = 0; i < recnn_engine::EV_POOL; ++i)
-    if (e->ev_pool[i]) (void)hipEventDestroy(e->ev_pool[i]);
-  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   delete e;
 }
@@ -611,7 +607,7 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
   L.n_params = n.n_params;
   if (rows > 0 && n.gp[W1]) {
     auto sp = [&](int mx) { int s = rows / 128; if (s < 1) s = 1; return s > mx ? mx : s; };
-    L.t[W1].nslab = sp(SP_W1); L.t[W1].slab_stride = (int64_t)H * n.in_dim;
+    L.t[W1].nslab = sp(e->tune.dw_splits); L.t[W1].slab_stride = (int64_t)H * n.in_dim;
     L.t[W2].nslab = sp(SP_W2); L.t[W2].slab_stride = (int64_t)H * H;
     L.t[B1].nslab = tiles_m; L.t[B1].slab_stride = H;
     if (n.critic) {
@@ -673,8 +669,6 @@ int fill_apply_args(recnn_engine* e, int ni, const NetLayout& L, bool do_adam, i
       a.slow = n.slow; a.la_alpha = e->hy.la_alpha[opt_idx]; a.la_k = e->hy.la_k[opt_idx]; a.nsma_thr = e->hy.nsma_threshold[opt_idx];
     }
   }
-  if (do_adam && e->scal_on && e->run_off < OPT_TABLE_STEPS)
-    a.scal = e->opt_tab + e->run_off * 3 + (ni == RECNN_NET_POLICY ? 0 : (ni == RECNN_NET_VALUE1 ? 1 : 2));
   a.grad_scale = grad_scale;
   a.g_out = n.g;
   a.l1part = clip ? n.l1part : nullptr;
@@ -768,6 +762,7 @@ struct Group {
     L.a_f32 = e->bf16 ? a_f32 : 0;
     L.b_f32 = e->bf16 ? b_f32 : 0;
     L.nprob = 0;
+    L.tune = &e->gtune;
   }
   GemmProb* add() { return &L.batch.p[L.nprob++]; }
   GemmProb* add(double fl) { flops += fl; return &L.batch.p[L.nprob++]; }
@@ -817,83 +812,56 @@ int check_ready(recnn_engine* e, int rows) {
   return 0;
 }
 
-// ---- fused row-panel MLP forward (bf16, hidden <= 256, action_dim <= 128) ------------------------
-static int g_fused_mlp = 1;
-static int g_defer_policy_fwd = 1;
-extern "C" void recnn_tune_defer_policy_fwd(int on) { g_defer_policy_fwd = on; }
-static int g_pregather = 1;
-extern "C" void recnn_tune_pregather(int on) { g_pregather = on; }
-// Extra elements added to every leading dimension the MFMA kernels stream through (weight shadows, packed batch rows): the
-// natural pitches are multiples of 256 B (W2 / W3: 512 B, critic W1 and the batch rows: 3072 B), which may map a k-slab's
-// row segments onto a few L2 channels only.  Set before an engine is created.
-static int g_ld_pad = 0;
-extern "C" void recnn_tune_ld_pad(int elems) { g_ld_pad = elems > 0 ? (elems + 7) & ~7 : 0; }
-int ld_pad() { return g_ld_pad; }
-static int g_sampler_f32_rows = 0;
-extern "C" void recnn_tune_sampler_f32_rows(int on) { g_sampler_f32_rows = on; }
-extern "C" void recnn_tune_dw_splits(int s) { SP_W1 = s < 1 ? 1 : (s > SP_W1_MAX ? SP_W1_MAX : s); }
-extern "C" void recnn_tune_fused_mlp(int on) { g_fused_mlp = on; }
-
-// g_fused_mlp: 0 = never, 1 = groups of >= 3 networks (a single network only occupies 64 CUs and streams its
-// whole W1 per workgroup: the tiled kernels are faster there), 2 = every forward
-int g_chain_target_critic = 1;
-extern "C" void recnn_tune_chain_target_critic(int on) { g_chain_target_critic = on; }
-
-int g_policy_chain = 1;
-extern "C" void recnn_tune_policy_chain(int on) { g_policy_chain = on; }
-// 1: the bf16 forward runs SPLIT (split.h): layer 1 of every network as a full-machine tiled GEMM, the rest (layers 2 / 3,
-// TD head, the critics' layer-2 backward) as a lean row-panel tail launch, the frozen networks first so that the learning
-// critic's own workgroup knows the TD target; 0: the fused row-panel kernel (mlps.hip) with its in-launch hand-offs
-// 0: never.  1 (default): run graphs of at least g_cycle_min_len steps run in CYCLE MODE (capture_run: the batches of a policy
-// cycle gathered at once, the frozen networks applied to all of them by mlpf.hip, per-step launches = split forward of the
-// learning critics); shorter graphs and eager steps keep the fused row-panel kernel -- all paths agree bit for bit, so
-// mixing them is a pure scheduling decision.  2: split forward everywhere, cycle mode in every graph (tests).
-// Measured (round 3, DDPG 2048 rows): sustained 61.2-61.5 us/step in cycle mode vs 62.9-63.2 fused; a 20-step graph
-// (the driver's command) 74.7 vs 69.9 -- three partial cycles and ~30 more graph nodes per launch do not pay there.
-int g_split_fwd = 1;
-int g_cycle_min_len = 30;
-extern "C" void recnn_tune_split_fwd(int on) { g_split_fwd = on; }
-extern "C" void recnn_tune_cycle_min_len(int steps) { g_cycle_min_len = steps < 2 ? 2 : steps; }
-// 1 (default): in cycle mode the frozen networks' layers 2 / 3 run as cycle-wide tiled GEMMs (+ a row-dot launch for the target
-// critics' heads); 0: as row-panel tail launches
-int g_frozen_gemm = 1;
-extern "C" void recnn_tune_frozen_gemm(int on) { g_frozen_gemm = on; }
-// 1 (default): in cycle mode each frozen network runs as ONE launch of 128-row panels that keep all three layers on chip
-// (mlpf.hip); 0: layer 1 as a tiled GEMM + the later layers as GEMMs / tails (the knob above)
-int g_frozen_fused = 1;
-extern "C" void recnn_tune_frozen_fused(int on) { g_frozen_fused = on; }
-// 1: inside a run graph the next cycle's batches are gathered on a side branch while the current cycle steps
-// (measured: 67.5 us/step with the side branch vs 61.5 without -- a graph with parallel branches costs more in
-// cross-queue synchronisation than the 2.8 us/step of gather it hides; off)
-int g_cycle_fork = 0;
-extern "C" void recnn_tune_cycle_fork(int on) { g_cycle_fork = on; }
-// 1: the critic's weight-gradient GEMMs contract the whole batch per tile and finish the optimizer step (single GPU) or the
-// flat gradient arena (phase API / data parallel) in their epilogue (dwopt.hip: no slabs, no Adam launch, results identical
-// to "arena + apply_kernel" bit for bit); 0 (default): split-batch slabs + grad_reduce / slab-summing Adam launches.
-// Measured (round 3, DDPG 2048 rows): the fused launch takes 26.7 us against 12.7 + 5 for the two it replaces -- with 108
-// tiles of K = 2048 only 42 % of the CUs work, and a tile's k loop is bound by the VALU work of applying the per-row loss seed
-// to the unit backward tensors (13k of 44k cycles) and by DMA latency at one workgroup per CU (20 B/cycle).  Off until the
-// forward hands over already-scaled backward tensors.
-int g_dw_fuse = 0;
-int g_cycle_min_seg = 3;   // cycle mode: segments shorter than this step through the fused forward
-extern "C" void recnn_tune_cycle_min_seg(int n) { g_cycle_min_seg = n < 1 ? 1 : n; }
-int g_comm_fused = 1;   // data parallel: 1 = the critics' gradient exchange runs inside their optimizer launch, 0 = launches of its own
-extern "C" void recnn_tune_comm_fused(int on) { g_comm_fused = on; }
-int g_opt_table = 0;   // 1: the run graphs' optimizer launches read their step scalars from the table even without dw_fuse
-extern "C" void recnn_tune_opt_table(int on) { g_opt_table = on; }
-extern "C" void recnn_tune_dw_fuse(int on) { g_dw_fuse = on; if (on) dwopt_set_groups(on == 2 ? 2 : (on == 3 ? 1 : 4)); }
-int g_bwd_panel = 2;  // 0: head + dX launches, 1: row-panel launch (bwd.hip), 2: inside the critic's forward workgroup (mlp.hip)
-extern "C" void recnn_tune_bwd_panel(int on) { g_bwd_panel = on; }
+// ---- per-engine tuning (include/recnn_hip.h recnn_engine_tuning): every field selects among schedules / tile shapes that
+// produce the same numbers.  What the measured-slower variants of earlier rounds taught is recorded in DESIGN.md 5c, not kept in
+// the binary: the optimizer in the dW launch's epilogue (26.7 vs 18.7 us), an XCD-affine workgroup map of the fused forward
+// (-11 MB of HBM traffic, +6 us), the cycle gather on a side branch of the run graph (67.5 vs 61.5 us/step), the learning
+// critic's step forward as one fused launch in cycle mode (67.4 vs 65.1 us/step), padded leading dimensions (no effect).
+//   fused_mlp: 0 = never, 1 = groups of >= 3 networks (a single network only occupies 64 CUs and streams its whole W1 per
+//     workgroup: the tiled kernels are faster there), 2 = every forward
+//   split_fwd: 0 = the fused row-panel kernel (mlps.hip) everywhere; 1 (default) = run graphs of at least cycle_min_len steps
+//     run in CYCLE MODE (capture_run: the batches of a policy cycle gathered at once, the frozen networks applied to all of
+//     them by mlpf.hip, per-step launches = split forward of the learning critics: l1gemm.hip + mlpt.hip); 2 = split forward and
+//     cycle mode everywhere.  Measured (round 3, DDPG 2048 rows): sustained 61.2-61.5 us/step in cycle mode vs 62.9-63.2 fused;
+//     a 20-step graph (the driver's command) 74.7 vs 69.9 -- three partial cycles do not pay there.
+//   bwd_panel: 0 = head + dX launches, 1 = row-panel launch (bwd.hip), 2 = inside the critic's forward workgroup (mlps.hip)
+extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
+  if (!t) return;
+  memset(t, 0, sizeof(*t));
+  t->fused_mlp = 1; t->chain_target_critic = 1; t->bwd_panel = 2; t->policy_chain = 1;
+  t->split_fwd = 1; t->cycle_min_len = 30; t->cycle_min_seg = 3; t->frozen_fused = 1; t->frozen_gemm = 1;
+  t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
+  t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
+  t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
+  t->gemm_waves = 8; t->dw_dma = 2;
+}
+extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
+  RECNN_REQUIRE(e && t, "set_tuning: null pointer");
+  e->tune = *t;
+  recnn_engine_tuning& u = e->tune;
+  u.dw_splits = u.dw_splits < 1 ? 1 : (u.dw_splits > SP_W1_MAX ? SP_W1_MAX : u.dw_splits);
+  u.cycle_min_len = u.cycle_min_len < 2 ? 2 : u.cycle_min_len;
+  u.cycle_min_seg = u.cycle_min_seg < 1 ? 1 : u.cycle_min_seg;
+  u.l1_big = u.l1_big == 2 ? 2 : 1;
+  sync_gemm_tune(e);
+  drop_graphs(e);
+  return 0;
+}
+extern "C" int recnn_engine_get_tuning(recnn_engine* e, recnn_engine_tuning* t) {
+  RECNN_REQUIRE(e && t, "get_tuning: null pointer");
+  *t = e->tune;
+  return 0;
+}
 
 // bf16 value side on the fully fused path: target critics chained inside the forward launch (Q and Q' arrive as
 // per-row scalars), critic head + first backward GEMM in one row-panel launch (bwd.hip)
 bool value_chain_ok(const recnn_engine* e) {
-  return g_fused_mlp && g_chain_target_critic && e->bf16 && e->Hp == 256 && e->Ap == 128 && e->A == e->Ap;
+  return e->tune.fused_mlp && e->tune.chain_target_critic && e->bf16 && e->Hp == 256 && e->Ap == 128 && e->A == e->Ap;
 }
-bool value_panel_ok(const recnn_engine* e) { return value_chain_ok(e) && g_bwd_panel; }
+bool value_panel_ok(const recnn_engine* e) { return value_chain_ok(e) && e->tune.bwd_panel; }
 
 bool fused_mlp_ok(const recnn_engine* e, int nprob) {
-  return g_fused_mlp && e->bf16 && e->Hp == 256 && e->Ap == 128 && (nprob >= 3 || g_fused_mlp >= 2);
+  return e->tune.fused_mlp && e->bf16 && e->Hp == 256 && e->Ap == 128 && (nprob >= 3 || e->tune.fused_mlp >= 2);
 }
 
 struct MlpSpec {
@@ -984,7 +952,7 @@ void fill_tail(const recnn_engine* e, TailProb* p, int kind, int ni, int rows, c
   }
 }
 
-// The forward of one step, split (g_split_fwd): frozen networks first (target actor -> target critics on its action; the
+// The forward of one step, split (e->tune.split_fwd): frozen networks first (target actor -> target critics on its action; the
 // actor), then the learning critics with the TD head and their layer-2 backward in their own workgroups.  Six launches here;
 // inside run graphs the frozen half is hoisted out of the step and applied to a whole policy cycle at once (capture_run).
 int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s, bool frozen_done = false) {
@@ -1082,67 +1050,6 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
     if ((rc = slot(e, "tail_critic", tfl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
   }
   e->panel_bwd_done = true;     // dz2 / dz1 (already times the per-row loss seed) and the small tensors' panel sums exist
-  return 0;
-}
-
-// Cycle mode, per step: the learning critic(s) on the batch -- whole network, TD head (Q' of the rows was computed for the whole
-// cycle by ph_frozen_batched) and UNIT layer-2 backward -- plus the previous step's policy-loss forward, as ONE fused row-panel
-// launch (mlps.hip; 64-128 workgroups: a single round of CUs).  Against the split form (l1gemm + mlpt) a workgroup streams all of
-// W1 again, but starts once and never writes h1 out for somebody else to read.  MEASURED (tools/fused_critic_ab.sh): the launch
-// takes 21.8 us (23.3 in run graphs with the policy-loss forward) against 8.9 + 12.7 for the two split launches, and the dW
-// launch behind it is the unit-tensor form (13.2 vs 9.8 us): 67.4 vs 65.1 us/step -- bit-identical, slower, so a knob (off).
-int g_cycle_fused_critic = 0;
-extern "C" void recnn_tune_cycle_fused_critic(int on) { g_cycle_fused_critic = on; }
-int ph_forward_cycle_fused(recnn_engine* e, int rows, bool value_bwd, hipStream_t s) {
-  const int A = e->A, nc = e->n_critic;
-  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
-  const int64_t aoff = tc_off(e, A);
-  const bool train = e->cfg.mask_mode != RECNN_MASK_NONE;
-  MlpBatch mb;
-  memset(&mb, 0, sizeof(mb));
-  int np = 0, rc;
-  double fl = 0;
-  for (int c = 0; c < nc; ++c) {
-    MlpSpec fc{VAL[c], e->xcs, e->ldx, e->K1c, 0};
-    fc.h1 = e->cv[c].h1; fc.h2 = e->cv[c].h2; fc.mask_idx = 2 * c;
-    fc.q = e->q[c];
-    MlpProb* pc = &mb.p[np];
-    fl += fill_mlp(e, fc, rows, &mb.p[np++]);
-    MlpCriticBwd& B = mb.cbwd[c];
-    pc->cbwd_idx = c;
-    B.enabled = 1;
-    B.q_slot = nullptr;          // Q(s, a) stays inside the workgroup: it evaluates the head itself
-    B.scale = train ? 2.0f : 1.0f;
-    B.dz2 = e->dzc2[c]; B.dz1 = e->dzc1[c];   // UNIT tensors: the dW launch applies the per-row seed e->delta[c]
-    if (value_bwd) RECNN_REQUIRE(e->net[VAL[c]].g, "value backward: network %d has no gradient arena bound", VAL[c]);
-    fl += 2.0 * rows * (double)e->H * e->H;
-  }
-  MlpHead& Hd = mb.head;
-  Hd.n_critic = nc; Hd.n_target = nc;
-  for (int c = 0; c < nc; ++c) {
-    Hd.self_tq[c] = e->tqv[c];
-    Hd.delta_out[c] = e->delta[c]; Hd.loss_part[c] = e->loss_part[c];
-    Hd.db3_part[c] = value_bwd ? e->net[VAL[c]].gp[B3] : nullptr;
-  }
-  Hd.reward = e->reward; Hd.done = e->done; Hd.gamma = e->hy.gamma;
-  Hd.lo = e->td3 ? -INFINITY : e->hy.min_value;
-  Hd.hi = e->td3 ? INFINITY : e->hy.max_value;
-  Hd.expected = e->expected; Hd.target_q = e->target_q;
-  if (e->pending_pc.on && np < MLP_MAX_GROUP) {   // the previous step's policy-loss forward (see ph_forward)
-    const auto& pp = e->pending_pc;
-    MlpSpec f{RECNN_NET_VALUE1, pp.ga, e->Ap, e->Ap, 0};
-    f.A1 = pp.xs + aoff; f.lda1 = e->ldx; f.K1 = e->K1a; f.col1 = A;
-    f.q = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;
-    f.mask_idx = e->td3 ? 6 : 4;
-    MlpProb* pd = &mb.p[np++];
-    fl += fill_mlp(e, f, rows, pd);
-    pd->step_add = pp.run_off;
-    e->pending_pc.on = false;
-  }
-  mb.err = (int32_t*)(e->losses + 4);
-  if ((rc = slot(e, "mlp_fwd_critic", fl, s, [&] { return mlp_launch(mb, np, s); }))) return rc;
-  e->panel_bwd_done = true;     // losses, the per-row seed and the UNIT dz2 / dz1 came out of the forward launch
-  e->unit_bwd = true;
   return 0;
 }
 
@@ -1324,7 +1231,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   const int actor_m1 = e->td3 ? 4 : 2;  // external mask index of the actor's first dropout
   int rc;
   if (e->x3) return ph_forward_x3(e, rows, value_side, actor_side, value_bwd, s);
-  if (g_split_fwd >= 2 && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
+  if (e->tune.split_fwd >= 2 && value_chain_ok(e) && e->tune.bwd_panel >= 2 && e->H % 8 == 0) return ph_forward_split(e, rows, value_side, actor_side, value_bwd, s);
   bool chained = false;  // target critics computed inside the first fused launch
   bool fwd_did_bwd = false;  // ... and the critics' head + layer-2 backward too
   // chained target critics add nc producer problems, so a value-side launch always has >= 3 problems
@@ -1342,7 +1249,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
       int np = 0;
       double fl = 0;
       chained = can_chain;
-      const bool in_fwd_bwd = chained && g_bwd_panel >= 2 && mlp_waves() == 16;
+      const bool in_fwd_bwd = chained && e->tune.bwd_panel >= 2 && mlp_waves() == 16;
       fwd_did_bwd = in_fwd_bwd;
       if (chained) {
         // producers first (launch order = dispatch order): state part of each target critic's layer 1
@@ -1533,7 +1440,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     // launch scales them and adds the bias / last-layer partial sums
     e->panel_bwd_done = true;
     e->unit_bwd = true;
-  } else if (value_side && chained && g_bwd_panel) {
+  } else if (value_side && chained && e->tune.bwd_panel) {
     // critic head + dz2 + dz1 in one row-panel launch (bwd.hip); Q comes from the forward launch, Q' from its tails
     BwdPanelBatch bb;
     memset(&bb, 0, sizeof(bb));
@@ -1597,19 +1504,12 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
   return 0;
 }
 
-// What the caller wants done with the critic gradients beyond producing them (fused single-GPU step): the optimizer step
-// (+ soft target update on policy steps) inside the dW launch's epilogue.
-struct ValueFuse { bool soft; float grad_scale; };
-
-// Backward of the critic(s).  Round-3 default on the bf16 unit-backward path (dwopt.hip): ONE launch contracts the whole batch
-// per 64 x 64 tile and either applies the optimizer in its epilogue (vf != NULL: *applied is set, the caller skips
-// value_apply) or writes the finished gradients to the bound flat arenas (reduce: what the phase API / data parallel
-// all-reduce).  Otherwise (fp32, generic shapes, recnn_tune_dw_fuse(0)): gradient slabs, then slab reduction into the arenas.
-int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, const ValueFuse* vf = nullptr, bool* applied = nullptr) {
+// Backward of the critic(s): dz1 (unless the forward launch produced it), then the weight-gradient GEMMs as split-batch slabs
+// (summed by the slab-reducing Adam launch, or by grad_reduce into the flat arenas when `reduce`: the phase API / data parallel).
+int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
-  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   int rc;
-  if (applied) *applied = false;
   if (!e->panel_bwd_done) {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
@@ -1617,49 +1517,21 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, con
     if ((rc = g.run(s, "dx_critic_l2"))) return rc;
   }
   NetLayout L0 = make_layout(e, VAL[0], rows);
-  const bool fuse = g_dw_fuse && e->bf16 && e->unit_bwd && (vf || reduce);
   {
     Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1 and dW1 = dz1^T [a|s], split over the batch into slabs
     DwVec vec;
     memset(&vec, 0, sizeof(vec));
-    DwOpt o;
-    memset(&o, 0, sizeof(o));
     for (int c = 0; c < nc; ++c) {
       GemmProb* p = g.add();
-      o.prob_net[g.L.nprob - 1] = (signed char)c; o.prob_tensor[g.L.nprob - 1] = W2;
       g.flops += fill_dw(e, p, rows, e->dzc2[c], Hp, H, e->cv[c].h1, Hp, H, 0, e->net[VAL[c]].gp[W2], L0.t[W2].nslab,
                          L0.t[W2].slab_stride);
       if (e->unit_bwd) p->a_row_scale = e->delta[c];
     }
     for (int c = 0; c < nc; ++c) {
       GemmProb* p = g.add();
-      o.prob_net[g.L.nprob - 1] = (signed char)c; o.prob_tensor[g.L.nprob - 1] = W1;
       g.flops += fill_dw(e, p, rows, e->dzc1[c], Hp, H, e->xcs, e->ldx, e->S + e->A, e->S, e->net[VAL[c]].gp[W1],
                          L0.t[W1].nslab, L0.t[W1].slab_stride);
       if (e->unit_bwd) p->a_row_scale = e->delta[c];
-    }
-    if (fuse && dwopt_eligible(&g.L)) {
-      o.mode = vf ? DWOPT_APPLY : DWOPT_GRAD;
-      o.n_net = nc;
-      for (int c = 0; c < nc; ++c) {
-        Net& v = e->net[VAL[c]];
-        const NetLayout L = make_layout(e, VAL[c], 0);
-        for (int t = 0; t < 6; ++t) o.seg[c][t] = L.t[t];
-        if (vf) {
-          if ((rc = fill_apply_args(e, VAL[c], L, true, 1, vf->grad_scale, false, vf->soft ? TVAL[c] : -1, e->hy.soft_tau, &o.a[c]))) return rc;
-        } else {
-          RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
-          if ((rc = fill_apply_args(e, VAL[c], L, false, 1, 1.0f, false, -1, 0.f, &o.a[c]))) return rc;
-        }
-        DwVecProb& q = o.v[c];
-        q.rows = rows; q.H = H; q.delta = e->delta[c]; q.h2 = e->cv[c].h2; q.u2 = e->dzc2[c]; q.U = e->dzc1[c]; q.ldh = Hp;
-      }
-      const GatherArgs* pg = vf ? e->pregather : nullptr;
-      if ((rc = slot(e, vf ? (pg ? "dw_adam_critic+gather" : "dw_adam_critic") : "dw_grad_critic", g.flops, s,
-                     [&] { return dwopt_launch(&g.L, o, pg, s); }, !vf)))
-        return rc;
-      if (applied) *applied = vf != nullptr;
-      return 0;
     }
     if (e->unit_bwd) {  // dW3 / db2 / db1 partial sums per 32-row panel ride on this launch
       vec.n = nc;
@@ -1734,7 +1606,7 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
     if (!backward) return 0;
     Net& pn0 = e->net[POL];
     RECNN_REQUIRE(pn0.g, "policy backward: the actor has no gradient arena bound");
-    if (g_policy_chain) {
+    if (e->tune.policy_chain) {
       // the whole chain dz_e2 -> dz_e1 -> dact -> dz_p2 -> dz_p1 on a row panel that never leaves the CU (bwd.hip)
       BwdChainArgs c;
       memset(&c, 0, sizeof(c));
@@ -1908,7 +1780,7 @@ void use_set(recnn_engine* e, int k) {
   }
 }
 bool lookahead_ok(const recnn_engine* e) {
-  return e->has_sampler && e->twins && !g_sampler_f32_rows && (e->smp.users_per_batch <= 1024 || e->smp.plan) && g_pregather;
+  return e->has_sampler && e->twins && !e->tune.sampler_f32_rows && (e->smp.users_per_batch <= 1024 || e->smp.plan) && e->tune.pregather;
 }
 
 // gather of the batch `cursor_add` steps ahead of the device cursor into buffer set `set`
@@ -1937,7 +1809,7 @@ GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add)
     g.x3 = e->x3;
     // Nothing reads the fp32 rows when the engine samples its own batches in bf16: materialise the batch in
     // the compute type only (recnn_tune_sampler_f32_rows(1) restores the fp32 copies, e.g. for inspection).
-    if (!g_sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
+    if (!e->tune.sampler_f32_rows) { g.state = nullptr; g.next_state = nullptr; g.action = nullptr; }
   }
   return g;
 }
@@ -1983,7 +1855,7 @@ void leave_mset(recnn_engine* e) {
   use_set(e, 0);
 }
 bool cycle_ok(const recnn_engine* e, int rows) {
-  return g_split_fwd && lookahead_ok(e) && value_chain_ok(e) && g_bwd_panel >= 2 && e->H % 8 == 0 && rows % 32 == 0 && e->m_xs != nullptr &&
+  return e->tune.split_fwd && lookahead_ok(e) && value_chain_ok(e) && e->tune.bwd_panel >= 2 && e->H % 8 == 0 && rows % 32 == 0 && e->m_xs != nullptr &&
          !e->ext_noise && e->cfg.mask_mode != RECNN_MASK_EXTERNAL;   // (external masks / noise describe ONE batch)
 }
 
@@ -2014,7 +1886,7 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
       if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->m_noise + (int64_t)j * rows * A, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, run_off0 + j, s); }))) return rc;
   const double l1_fl_a = 2.0 * M * (double)e->H * e->S, l1_fl_c = 2.0 * M * (double)e->H * (e->S + A);
   const double t_fl_a = 2.0 * M * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * M * ((double)e->H * e->H + e->H);
-  if (g_frozen_fused) {
+  if (e->tune.frozen_fused) {
     auto fill = [&](FrozenProb* p, int ni, const void* A0, int K0, int col0, int mask_idx) {
       const Net& n = e->net[ni];
       memset(p, 0, sizeof(*p));
@@ -2080,8 +1952,8 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
     fill_l1(e, &lb.p[0], TPOL, M, e->m_xn + aoff, e->ldx, e->K1a, 0, e->m_tp_h1, -1, run_off0);
     fill_l1(e, &lb.p[1], POL, M, e->m_xs + aoff, e->ldx, e->K1a, 0, e->m_pa_h1, actor_m1, run_off0);
     lb.p[1].rows_per_set = rows;
-    if ((rc = slot(e, "l1_frozen_actors", 2 * l1_fl_a, s, [&] { return l1gemm_launch(lb, 2, 1, s); }))) return rc;
-    if (g_frozen_gemm) {
+    if ((rc = slot(e, "l1_frozen_actors", 2 * l1_fl_a, s, [&] { return l1gemm_launch(lb, 2, e->tune.l1_big, s); }))) return rc;
+    if (e->tune.frozen_gemm) {
       // layers 2 and 3 of both actors as cycle-wide GEMMs through the same tiled kernel (K = 256): per output element the
       // arithmetic of the row-panel tail kernel (k ascending in steps of 32 from a zero accumulator, + bias, relu, dropout /
       // + clipped noise, round to bf16), without 1280 workgroups each starting a 192 KB weight stream for 32 rows
@@ -2093,7 +1965,7 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
       fill_l1(e, &l2.p[1], POL, M, e->m_pa_h1, e->Hp, e->Hp, 0, e->m_pa_h2, actor_m1 + 1, run_off0);
       l2.p[1].W1 = sh_ptr(e, POL, W2); l2.p[1].ldw1 = pn.ld_w2; l2.p[1].b1 = pn.p + pn.off[B2];
       l2.p[1].rows_per_set = rows;
-      if ((rc = slot(e, "l2_frozen_actors", 4.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, 2, 1, s); }))) return rc;
+      if ((rc = slot(e, "l2_frozen_actors", 4.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, 2, e->tune.l1_big, s); }))) return rc;
       L1Batch l3;
       fill_l1(e, &l3.p[0], TPOL, M, e->m_tp_h2, e->Hp, e->Hp, 0, e->m_xn, -1, run_off0);
       l3.p[0].W1 = sh_ptr(e, TPOL, W3); l3.p[0].ldw1 = tn.ld_w3; l3.p[0].b1 = tn.p + tn.off[B3];
@@ -2102,7 +1974,7 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
       fill_l1(e, &l3.p[1], POL, M, e->m_pa_h2, e->Hp, e->Hp, 0, e->m_ga, -1, run_off0);
       l3.p[1].W1 = sh_ptr(e, POL, W3); l3.p[1].ldw1 = pn.ld_w3; l3.p[1].b1 = pn.p + pn.off[B3];
       l3.p[1].H = A; l3.p[1].w_rows = e->Ap; l3.p[1].no_relu = 1; l3.p[1].ldh = e->Ap;
-      if ((rc = slot(e, "l3_frozen_actors", 4.0 * M * (double)A * e->H, s, [&] { return l1gemm_launch(l3, 2, 1, s); }))) return rc;
+      if ((rc = slot(e, "l3_frozen_actors", 4.0 * M * (double)A * e->H, s, [&] { return l1gemm_launch(l3, 2, e->tune.l1_big, s); }))) return rc;
     } else {
       TailBatch tb;
       TailProb* p = &tb.p[0];
@@ -2122,15 +1994,15 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
       fill_l1(e, &lb.p[c], TVAL[c], M, e->m_xn + aoff, e->ldx, e->K1a, A, e->m_tq_h1[c], -1, run_off0);
       l1_seg1(&lb.p[c], e->m_xn, e->ldx, e->Ap, 0);
     }
-    if ((rc = slot(e, "l1_frozen_target_critic", nc * l1_fl_c, s, [&] { return l1gemm_launch(lb, nc, 1, s); }))) return rc;
-    if (g_frozen_gemm) {
+    if ((rc = slot(e, "l1_frozen_target_critic", nc * l1_fl_c, s, [&] { return l1gemm_launch(lb, nc, e->tune.l1_big, s); }))) return rc;
+    if (e->tune.frozen_gemm) {
       L1Batch l2;
       for (int c = 0; c < nc; ++c) {
         const Net& t = e->net[TVAL[c]];
         fill_l1(e, &l2.p[c], TVAL[c], M, e->m_tq_h1[c], e->Hp, e->Hp, 0, c == 0 ? e->m_tp_h2 : e->m_tp_h1, -1, run_off0);   // (the target actor's panels are done with)
         l2.p[c].W1 = sh_ptr(e, TVAL[c], W2); l2.p[c].ldw1 = t.ld_w2; l2.p[c].b1 = t.p + t.off[B2];
       }
-      if ((rc = slot(e, "l2_frozen_target_critic", nc * 2.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, nc, 1, s); }))) return rc;
+      if ((rc = slot(e, "l2_frozen_target_critic", nc * 2.0 * M * (double)e->H * e->H, s, [&] { return l1gemm_launch(l2, nc, e->tune.l1_big, s); }))) return rc;
       for (int c = 0; c < nc; ++c) {
         const Net& t = e->net[TVAL[c]];
         const void* h2 = c == 0 ? e->m_tp_h2 : e->m_tp_h1;
@@ -2148,36 +2020,11 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
   return 0;
 }
 
-// Step scalars of every optimizer instance for the `len` steps about to be issued (step i of them is a policy step when
-// pol[i]): one small launch; afterwards fill_apply_args points every optimizer launch at its table entry.
-int opt_table(recnn_engine* e, int len, const bool* pol, hipStream_t s) {
-  OptTableArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n_steps = len;
-  a.n_nets = e->td3 ? 3 : 2;
-  a.out = e->opt_tab;
-  const int nets[3] = {RECNN_NET_POLICY, RECNN_NET_VALUE1, RECNN_NET_VALUE2};
-  for (int k = 0; k < a.n_nets; ++k) {
-    const int oi = k == 0 ? 0 : 1;
-    OptTableNet& n = a.net[k];
-    n.t_ptr = e->net[nets[k]].t_ptr;
-    n.opt_kind = e->hy.opt_kind[oi]; n.la_k = e->hy.la_k[oi];
-    n.lr = e->hy.lr[oi]; n.nsma_thr = e->hy.nsma_threshold[oi];
-    n.beta1 = e->hy.beta1[oi]; n.beta2 = e->hy.beta2[oi];
-    int n_pol = 0;
-    for (int i = 0; i < len; ++i) {
-      n.t_add[i] = (unsigned char)(k == 0 ? n_pol : i);
-      if (pol[i]) ++n_pol;
-    }
-  }
-  return slot(e, "opt_scalars", 0, s, [&] { return opt_table_launch(a, s); });
-}
-
 // The critics' exchange can run inside their optimizer launch when every workgroup's element range is made of whole float4
 // groups of the arena (all tensor offsets and all but the last tensor's sizes multiples of 4) and there is a flag slot per
 // workgroup.
 bool comm_fused_ok(recnn_engine* e, int rows) {
-  if (!e->comm || !e->comm_region || !g_comm_fused) return false;
+  if (!e->comm || !e->comm_region || !e->tune.comm_fused) return false;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   for (int c = 0; c < e->n_critic; ++c) {
     const NetLayout L = make_layout(e, VAL[c], rows);
@@ -2205,8 +2052,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if (frozen_done) {   // cycle mode: the batch is in place and the frozen networks have been applied to it (ph_frozen_batched)
-    const bool fused = g_cycle_fused_critic && value_chain_ok(e) && g_bwd_panel >= 2 && mlp_waves() == 16;
-    if ((rc = fused ? ph_forward_cycle_fused(e, rows, learn, s) : ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
+    if ((rc = ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
   } else if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
   if (learn) {
     // The critic's soft update reads the just-updated weights and nothing reads the target before the
@@ -2229,10 +2075,8 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
         if (!rc) rc = value_apply(e, policy_step, e->comm_scale, s);
       }
     } else {
-      const ValueFuse vf{policy_step, 1.0f};
-      bool applied = false;
-      rc = ph_value_backward(e, rows, false, s, &vf, &applied);
-      if (!rc && !applied) rc = value_apply(e, policy_step, 1.0f, s, rows);
+      rc = ph_value_backward(e, rows, false, s);
+      if (!rc) rc = value_apply(e, policy_step, 1.0f, s, rows);
     }
     e->pregather = nullptr;
     if (rc) return rc;
@@ -2384,11 +2228,6 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
     e->prof_on = true;
     e->prof_n = 0;
     e->use_sampler = e->has_sampler;
-    if (g_dw_fuse) {   // as the run graphs do: the step scalars of the optimizers come from the table launch
-      const bool pol1[1] = {policy_steps != 0};
-      rc = opt_table(e, 1, pol1, s);
-      e->scal_on = rc == 0;
-    }
     if (!rc && policy_steps == 2) {
       // cycle mode, as the long run graphs issue it: one policy cycle's batches, the frozen networks on all of them, then
       // the first step of the cycle (an ordinary step) on the split forward
@@ -2405,7 +2244,6 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
     } else if (!rc) {
       rc = step_impl(e, rows, true, policy_steps != 0, s);
     }
-    e->scal_on = false;
     e->use_sampler = false;
     e->prof_on = false;
     if (rc) return rc;
@@ -2429,8 +2267,7 @@ extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps,
 }
 
 // ------------------------------------------------------------------------------------ graphs
-static int g_graph_run_len = -1;  // -1: whole policy cycles, up to 64 steps (policy_every > 32: 16 ordinary steps); 0/1: off
-extern "C" void recnn_tune_graph_run(int steps) { g_graph_run_len = steps; }
+// tuning.graph_run: steps per run graph; -1 = whole policy cycles, up to 64 steps (policy_every > 32: 16 ordinary steps); 0 / 1 = off
 
 // Executable graphs: one ordinary step, one policy step, and a family of RUN graphs (several consecutive steps per
 // graph launch) -- between two graph launches the GPU idles for ~8 us (rocprofv3 kernel trace), inside a graph the
@@ -2450,65 +2287,30 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   const bool look = lookahead_ok(e) && len > 1;
   hipGraph_t graph = nullptr;
   int rc = 0;
-  if (!e->side && g_cycle_fork) {   // the side branch of cycle mode (created outside the capture)
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); e->side = nullptr; }
-    for (int i = 0; e->side && i < recnn_engine::EV_POOL; ++i)
-      if (hipEventCreateWithFlags(&e->ev_pool[i], hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipStreamDestroy(e->side); e->side = nullptr;
-      }
-  }
   RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   e->use_sampler = e->has_sampler;
   int n_pol = 0;
-  // the optimizers' step scalars for the whole run: one small launch at the head of the graph.  Only when the optimizer runs in
-  // the dW epilogue (dwopt.hip, where ONE thread per workgroup would otherwise sit on a 6 us fp64 chain): apply_kernel's
-  // threads all evaluate them side by side under their loads' latency -- measured no gain from the table there
-  if ((g_dw_fuse || g_opt_table) && len <= OPT_TABLE_STEPS) {
-    bool polv[OPT_TABLE_STEPS];
-    for (int i = 0; i < len; ++i) polv[i] = phase >= 0 && ((phase + i) % pe) == 0;
-    rc = opt_table(e, len, polv, s);
-    e->scal_on = rc == 0;
-  }
-  const bool cyc = !rc && len > 1 && (g_split_fwd >= 2 || len >= g_cycle_min_len) && cycle_ok(e, rows);
+  const bool cyc = !rc && len > 1 && (e->tune.split_fwd >= 2 || len >= e->tune.cycle_min_len) && cycle_ok(e, rows);
   auto is_pol = [&](int i) { return phase >= 0 && ((phase + i) % pe) == 0; };
   if (cyc) {
     // segments = the steps up to and including the next policy step (the frozen networks change right after it)
-    int seg0[OPT_TABLE_STEPS + 1], seg1[OPT_TABLE_STEPS + 1], nseg = 0;
+    int seg0[recnn_engine::RUN_MAX + 1], seg1[recnn_engine::RUN_MAX + 1], nseg = 0;
     for (int i0 = 0; i0 < len;) {
       int i1 = i0;
       while (i1 + 1 < len && !is_pol(i1) && i1 - i0 + 1 < recnn_engine::MSET_MAX) ++i1;
       seg0[nseg] = i0; seg1[nseg] = i1; ++nseg;
       i0 = i1 + 1;
     }
-    // the next segment's batches depend on nothing but the sampler cursor: they are gathered on a side branch of the graph,
-    // into the other copy of the cycle arrays, while this segment steps (the gather is a latency chain with little
-    // bandwidth or ALU demand; the per-step launches leave half of every CU's wave slots free)
-    const bool fork = g_cycle_fork && nseg > 1;
-    const bool side_ok = fork && e->side != nullptr && 2 * (nseg - 1) <= recnn_engine::EV_POOL;
-    int evi = 0;
     rc = ph_gather_cycle(e, rows, seg1[0] - seg0[0] + 1, seg0[0], 0, s);
     for (int k = 0; k < nseg && !rc; ++k) {
       const int i0 = seg0[k], i1 = seg1[k], n = i1 - i0 + 1, buf = k & 1;
-      hipEvent_t joined = nullptr;
-      if (k + 1 < nseg) {
-        const int n_next = seg1[k + 1] - seg0[k + 1] + 1;
-        if (side_ok) {
-          hipEvent_t forked = e->ev_pool[evi++];
-          joined = e->ev_pool[evi++];
-          rc = recnn_check_hip(hipEventRecord(forked, s), "cycle fork");
-          if (!rc) rc = recnn_check_hip(hipStreamWaitEvent(e->side, forked, 0), "cycle fork wait");
-          if (!rc) rc = ph_gather_cycle(e, rows, n_next, seg0[k + 1], buf ^ 1, e->side);
-          if (!rc) rc = recnn_check_hip(hipEventRecord(joined, e->side), "cycle join");
-          if (rc) break;
-        }
-      }
       select_mbuf(e, buf);
       e->run_off = i0;
       // a one- or two-step segment (a graph that starts ON a policy step has one at its head) does not pay for the batched
       // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays.
       // (The driver's 20-step request in cycle mode, segments 6 + 10 + 4, with this threshold at 3 / 5 / 8: 67.7 / 67.1 / 67.6
       // us/step against 67.8-68.3 all-fused -- inside the noise, so short graphs stay on the fused schedule: cycle_min_len 30.)
-      const bool batched = n >= g_cycle_min_seg;
+      const bool batched = n >= e->tune.cycle_min_seg;
       if (batched) rc = ph_frozen_batched(e, rows, n, i0, s);
       for (int i = i0; i <= i1 && !rc; ++i) {
         const bool pol = is_pol(i);
@@ -2522,13 +2324,11 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
         e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
         // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
         // then: not across a segment boundary)
-        const bool defer = g_defer_policy_fwd && i < i1;
+        const bool defer = e->tune.defer_policy_fwd && i < i1;
         rc = step_impl(e, rows, true, pol, s, true, false, defer, batched);
       }
-      if (!rc && k + 1 < nseg) {
-        if (joined) rc = recnn_check_hip(hipStreamWaitEvent(s, joined, 0), "cycle join wait");
-        else rc = ph_gather_cycle(e, rows, seg1[k + 1] - seg0[k + 1] + 1, seg0[k + 1], buf ^ 1, s);
-      }
+      // (the next segment's batches go into the other copy of the cycle arrays: this segment's deferred forwards still read theirs)
+      if (!rc && k + 1 < nseg) rc = ph_gather_cycle(e, rows, seg1[k + 1] - seg0[k + 1] + 1, seg0[k + 1], buf ^ 1, s);
     }
     select_mbuf(e, 0);
   }
@@ -2546,11 +2346,10 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
     // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
     // buffer set)
-    const bool defer = look && g_defer_policy_fwd && (value_chain_ok(e) || e->x3) && i + 1 < len;
+    const bool defer = look && e->tune.defer_policy_fwd && (value_chain_ok(e) || e->x3) && i + 1 < len;
     rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
   }
   e->run_off = 0;
-  e->scal_on = false;
   use_hist_slot(e, 0);
   e->pending_pc.on = false;
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
@@ -2579,7 +2378,7 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
   RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
   drop_graphs(e);
   const int pe = e->hy.policy_every;
-  int cap = g_graph_run_len < 0 ? recnn_engine::RUN_MAX : g_graph_run_len;   // longest run graph wanted
+  int cap = e->tune.graph_run < 0 ? recnn_engine::RUN_MAX : e->tune.graph_run;   // longest run graph wanted
   if (cap > recnn_engine::RUN_MAX) cap = recnn_engine::RUN_MAX;
   if ((rc = capture_run(e, rows, s, -1, 1, &e->gexec[0]))) return rc;
   if ((rc = capture_run(e, rows, s, 0, 1, &e->gexec[1]))) return rc;
@@ -2739,7 +2538,7 @@ extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad
       // With two buffer sets the policy-loss forward of step t rides on step t+1's forward launch (as in the run
       // graphs); step t's finalize then closes the graph: the head of step t+1 is captured one step ahead of the
       // device counters and writes its loss partial sums into the other per-step slot.
-      const bool defer = look && g_defer_policy_fwd && value_chain_ok(e);
+      const bool defer = look && e->tune.defer_policy_fwd && value_chain_ok(e);
       if (!r) {
         if (defer) {
           e->pending_pc.on = true; e->pending_pc.xs = e->xcs; e->pending_pc.ga = e->gen_action; e->pending_pc.run_off = 0; e->pending_pc.slot = set;

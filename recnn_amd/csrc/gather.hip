@@ -177,8 +177,6 @@ template <int R> static int launch_gather(const GatherArgs& a, int W, hipStream_
   return recnn_check_hip(hipGetLastError(), "frame_gather");
 }
 
-static int g_gather_rows_per_wg = 4;
-extern "C" void recnn_tune_gather_rows(int r) { g_gather_rows_per_wg = r; }
 
 extern "C" int recnn_frame_gather(const int32_t* items, const float* ratings, const int64_t* user_off,
                                   const int32_t* batch_users, const int32_t* row_off, int n_users, int rows, int frame,
@@ -224,11 +222,8 @@ int frame_gather_launch(GatherArgs a, hipStream_t stream) {
   }
   if (emb_dim % W) W = 1;
   if (a.state_h && W != 4) { recnn_set_error("frame_gather: bf16 twin rows need 16-byte aligned fp32 rows"); return RECNN_E_INVALID; }
-  switch (g_gather_rows_per_wg) {
-    case 2: return launch_gather<2>(a, W, stream);
-    case 8: return launch_gather<8>(a, W, stream);
-    default: return launch_gather<4>(a, W, stream);
-  }
+  // (4 rows per workgroup: 2 and 8 were measured in round 2 -- 7.0 / 9.6 us against 7.2 -- and are gone)
+  return launch_gather<4>(a, W, stream);
 }
 
 // ------------------------------------------------------------------ pack a canonical batch

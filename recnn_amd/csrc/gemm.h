@@ -79,11 +79,24 @@ struct DwVec {
   DwVecProb p[2];
 };
 
+// Kernel / tile selection of the launchers (no process-wide state: an engine passes its own, the single-GEMM entry points the
+// defaults).  All choices compute the same numbers.
+struct GemmTune {
+  int variant = -1;      // register-staged kernel tile: -1 = per launch, 0 = 64 x 64, 1 = 32 x 64 with a 2x longer k stage
+  int v0_min_wg = 512;   // the per-launch heuristic takes the 64 x 64 tile from this many tiles on
+  int dma = 1;           // forward GEMMs on compute-type operands use the LDS-DMA ring kernel
+  int dma_deep = 1;      // 5-stage ring for launches of <= 320 tiles, else 3
+  int dma_waves = 8;     // waves per workgroup of the LDS-DMA forward kernel (8 | 4)
+  int waves = 8;         // waves per workgroup of the register-staged dX kernel (8 | 4)
+  int dw_dma = 2;        // bf16 dW: 0 = register-staged; 1..7 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3)
+};
+
 // All problems of one launch share (dtype, mode, a_f32, b_f32).
 struct GemmLaunch {
   int dtype, mode, a_f32, b_f32, nprob;
   GemmBatch batch;
   const DwVec* vec;   // dW launches only (bf16 DMA kernel), may be NULL
+  const GemmTune* tune;   // NULL = defaults
 };
 
 void gemm_prob_init(GemmProb* p);

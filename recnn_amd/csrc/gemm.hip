@@ -724,13 +724,13 @@ template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_ke
     }
 }
 
-static int g_dw_dma = 2;  // 0 = off; 1..7 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3)
-extern "C" void recnn_tune_dw_dma(int on) { g_dw_dma = on; }
+static const GemmTune kDefaultTune;
+static inline const GemmTune& tune_of(const GemmLaunch* L) { return L->tune ? *L->tune : kDefaultTune; }
 
 // both operands bf16 in memory, 64-column tiles readable inside the row pitch (padding columns may hold anything:
 // they only reach outputs that are never written)
 static bool dw_dma_eligible(const GemmLaunch* L) {
-  if (!g_dw_dma || L->mode != GEMM_DW || L->dtype != RECNN_BF16 || L->a_f32 || L->b_f32) return false;
+  if (!tune_of(L).dw_dma || L->mode != GEMM_DW || L->dtype != RECNN_BF16 || L->a_f32 || L->b_f32) return false;
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];
     if (p.nseg != 1 || p.seg[0].K <= 0) return false;
@@ -770,7 +770,7 @@ template <int SUB, int NS> static int launch_dw_dma_v(GemmLaunch* L, hipStream_t
   return recnn_check_hip(hipGetLastError(), "gemm_dw_dma_kernel launch");
 }
 static int launch_dw_dma(GemmLaunch* L, hipStream_t stream, int variant = 0) {
-  switch (variant ? variant : g_dw_dma) {
+  switch (variant ? variant : tune_of(L).dw_dma) {
     case 2: return launch_dw_dma_v<64, 2>(L, stream);
     case 3: return launch_dw_dma_v<64, 3>(L, stream);
     case 4: return launch_dw_dma_v<64, 4>(L, stream);
@@ -792,16 +792,8 @@ void gemm_prob_init(GemmProb* p) {
 
 // Tile variants: 0 = 64x64 block tile, short k stage; 1 = 32x64 block tile, 2x longer k stage (more, smaller
 // workgroups with more bytes in flight each: these GEMMs have M = batch rows only, so they are latency bound).
-static int g_gemm_variant = -1;  // -1 = choose per launch
-static int g_gemm_v0_min_wg = 512;
-extern "C" void recnn_tune_gemm_v0_threshold(int wg) { g_gemm_v0_min_wg = wg; }
-extern "C" void recnn_tune_gemm_variant(int v) { g_gemm_variant = v; }
 
-static int g_gemm_tgf = 0;
-extern "C" void recnn_tune_gemm_ks_layout(int tile_fastest) { g_gemm_tgf = tile_fastest; }  // measured: no effect; only the k-fastest mapping is built
 
-static int g_gemm_waves = 8;
-extern "C" void recnn_tune_gemm_waves(int w) { g_gemm_waves = (w == 4) ? 4 : 8; }
 
 template <class TC, int MODE, bool A32, bool B32, int TM, int TN, int KB, int NW>
 static int launch_v(GemmLaunch* L, hipStream_t stream) {
@@ -822,14 +814,8 @@ static int launch_v(GemmLaunch* L, hipStream_t stream) {
   return recnn_check_hip(hipGetLastError(), "gemm_kernel launch");
 }
 
-static int g_gemm_dma = 1;
-extern "C" void recnn_tune_gemm_dma(int on) { g_gemm_dma = on; }
 
-static int g_dma_deep = 1;
-extern "C" void recnn_tune_gemm_dma_depth(int deep) { g_dma_deep = deep; }
 
-static int g_dma_waves = 8;
-extern "C" void recnn_tune_gemm_dma_waves(int w) { g_dma_waves = (w == 8) ? 8 : 4; }
 
 template <class TC, int NS, int NW> static int launch_dma_nw(GemmLaunch* L, hipStream_t stream) {
   constexpr int TM = 1, TN = (NW == 8 ? 1 : 2), BM = 32 * TM, BN = 16 * TN * (NW / 2);
@@ -882,7 +868,7 @@ template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunc
   hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3) launch");
 }
-static int g_x3_big_min_wg = 192;   // launches with at least this many 64 x 128 tiles take them
+static constexpr int g_x3_big_min_wg = 192;   // launches with at least this many 64 x 128 tiles take them
 int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   for (int i = 0; i < L->nprob; ++i) {
     const GemmProb& p = L->batch.p[i];
@@ -904,7 +890,7 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
 }
 
 template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
-  if (g_dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
+  if (tune_of(L).dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
   return launch_dma_nw<TC, NS, 4>(L, stream);
 }
 
@@ -913,13 +899,13 @@ template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t 
 template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
   long wg = 0;
   for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
-  if (L->nprob == 0 || (g_dma_deep && wg <= 320)) return launch_dma_ns<TC, 5>(L, stream);
+  if (L->nprob == 0 || (tune_of(L).dma_deep && wg <= 320)) return launch_dma_ns<TC, 5>(L, stream);
   return launch_dma_ns<TC, 3>(L, stream);
 }
 
 // the DMA pipeline needs both operands stored in the compute type and whole 256-byte k stages
 template <class TC> static bool dma_eligible(const GemmLaunch* L) {
-  if (!g_gemm_dma || L->mode != GEMM_FWD) return false;
+  if (!tune_of(L).dma || L->mode != GEMM_FWD) return false;
   if (sizeof(TC) == 2 && (L->a_f32 || L->b_f32)) return false;
   const int KB = 256 / (int)sizeof(TC);
   for (int i = 0; i < L->nprob; ++i)
@@ -965,18 +951,18 @@ static int launch_t(GemmLaunch* L, hipStream_t stream) {
     for (int i = 0; i < L->nprob; ++i) scaled = scaled || L->batch.p[i].a_row_scale != nullptr;
     if (scaled) { recnn_set_error("gemm dw: row scaling / vector partials need the bf16 DMA kernel"); return RECNN_E_UNSUPPORTED; }
   }
-  int v = g_gemm_variant;
+  int v = tune_of(L).variant;
   if (v < 0) {  // enough 64x64 tiles to give every CU a few workgroups?  else take the small-tile variant
     long wg = 0;
     for (int i = 0; i < L->nprob; ++i) {
       const GemmProb& p = L->batch.p[i];
       wg += (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * (MODE == GEMM_DW ? p.dw_splits : 1);
     }
-    v = wg >= g_gemm_v0_min_wg ? 0 : 1;
+    v = wg >= tune_of(L).v0_min_wg ? 0 : 1;
   }
   // same block tiles with 4 waves (2x2) or 8 waves (2x4): more waves = more loads in flight per CU
   // (measured: dX 7.5 -> 6.5 us with 8 waves, the dW launch 14 -> 19.5 us: its k-strided loads are spread too thin)
-  if (g_gemm_waves == 8 && MODE != GEMM_DW) {
+  if (tune_of(L).waves == 8 && MODE != GEMM_DW) {
     if (v == 0) return launch_v<TC, MODE, A32, B32, 2, 1, KB0, 8>(L, stream);
     return launch_v<TC, MODE, A32, B32, 1, 1, 2 * KB0, 8>(L, stream);
   }

@@ -199,15 +199,13 @@ template <int TM, int TN, int WM, int WN, int NS> constexpr int lds_bytes() { re
 // 16 waves as 4 x 4 everywhere (the more waves issue the DMAs, the closer a CU gets to its ~45 B/clk: DESIGN.md 5):
 //   SMALL  64 x  64, wave tile 16 x 16, 4-slot ring (128 KB)      per-step launches
 //   BIG   128 x 128, wave tile 32 x 32, 2-slot ring (128 KB)      cycle-batched launches
-//   MID   128 x  64, wave tile 32 x 16, 3-slot ring (144 KB)      cycle-batched launches (recnn_tune_l1_big(2)): no 2.5-round tail
+//   MID   128 x  64, wave tile 32 x 16, 3-slot ring (144 KB)      cycle-batched launches (tuning.l1_big = 2): no 2.5-round tail
 #define L1_SMALL 1, 1, 4, 4, 4
 #define L1_BIG 2, 2, 4, 4, 2
 #define L1_MID 2, 1, 4, 4, 3
-static int g_l1_big = 1;
-extern "C" void recnn_tune_l1_big(int shape) { g_l1_big = shape == 2 ? 2 : 1; }
 
 static unsigned long long* g_l1_trace = nullptr;
-extern "C" void recnn_tune_l1_trace(void* p) { g_l1_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
+extern "C" void recnn_debug_l1_trace(void* p) { g_l1_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
 
 int l1gemm_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_SMALL>()), "l1gemm attr");
@@ -218,7 +216,7 @@ int l1gemm_init() {
 
 int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s) {
   RECNN_REQUIRE(nprob >= 1 && nprob <= L1_MAX_GROUP, "l1gemm: 1..%d problems per launch", L1_MAX_GROUP);
-  const int shape = big ? g_l1_big : 0;
+  const int shape = big == 2 ? 2 : (big ? 1 : 0);   // 0: 64 x 64 per-step tiles, 1: 128 x 128, 2: 128 x 64 (cycle-batched launches)
   const int BM = shape ? 128 : 64, BN = shape == 1 ? 128 : 64;
   int maxwg = 0;
   for (int i = 0; i < nprob; ++i) {

@@ -110,13 +110,7 @@ struct MlpBatch {
   // step's losses / counters are read (recnn_engine_read_losses), so a broken hand-off never passes as a number.
   int32_t* err;
   int spin_limit;    // polls before giving up (0: the default, ~0.2 s)
-  int fault;         // test hook (recnn_tune_mlp_fault): 1 = producers do not raise their flag, 2 = critics do not fill the Q slot
-  // Workgroup -> (problem, panel) map.  0: 2-D grid (panel, problem): workgroup ids go round the 8 XCDs, so every XCD meets every
-  // network and fetches all weights into its own L2 (8 copies: the 2x over-fetch of round 2's PMC numbers).  > 0: XCD-affine 1-D
-  // grid of 8 x (panels / 2) x rounds workgroups: XCD pair q runs problem 4 r + q in round r (panels split over the pair), so a
-  // network's weights enter two L2s; launch order still puts a producer problem's panel in front of its consumers' (same slot,
-  // lower XCD).  xcd_map = panels per problem.
-  int xcd_map;
+  int fault;         // test hook (recnn_debug_mlp_fault): 1 = producers do not raise their flag, 2 = critics do not fill the Q slot
   int nprob;
 };
 constexpr int MLP_ERR_PART_TIMEOUT = 1;   // layer-1 part of a chained target critic never arrived

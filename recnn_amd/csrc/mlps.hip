@@ -95,21 +95,15 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 // that drain to whatever phase a stamp followed)
 #define MLPS_STAMP(i) do { if (trow) trow[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-// PROBE (timing experiments, recnn_tune_mlp_fault bits 0x100 / 0x200 = bench.py RECNN_MLP_PROBE 1 / 2): 1 = no MFMA work, 2 = no DMA
+// PROBE (timing experiments, recnn_debug_mlp_probe): 1 = no MFMA work, 2 = no DMA
 template <int PROBE>
 __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch, unsigned long long* trace) {
-  int by, bx, panels;
-  if (batch.xcd_map > 0) {   // XCD-affine map (mlp.h): id = slot * 8 + xcd
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, half = batch.xcd_map >> 1;
-    by = (slot / half) * 4 + (xcd >> 1);
-    bx = (slot % half) * 2 + (xcd & 1);
-    panels = batch.xcd_map;
-    if (by >= batch.nprob) return;
-  } else {
-    by = blockIdx.y; bx = blockIdx.x; panels = gridDim.x;
-  }
-  by = __builtin_amdgcn_readfirstlane(by);
-  bx = __builtin_amdgcn_readfirstlane(bx);
+  // (2-D grid (panel, problem): workgroup ids go round the 8 XCDs, so every XCD meets every network and fetches all weights into
+  // its own L2 -- 8 copies, the 2x over-fetch of the PMC numbers.  An XCD-affine map (a network's panels on one XCD pair) was
+  // measured in round 3: 54.4 -> 43.5 MB of HBM traffic per launch, 26.1 -> 32.2 us: two L2s feeding a network's 64 workgroups
+  // are slower than eight; removed.)
+  const int by = __builtin_amdgcn_readfirstlane((int)blockIdx.y), bx = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  const int panels = gridDim.x;
   const MlpProb& P = batch.p[by];
   const int m0 = bx * BM;
   if (m0 >= P.rows) return;
@@ -634,13 +628,14 @@ __global__ __launch_bounds__(NW * 64) void mlps_fwd_kernel(const MlpBatch batch,
   MLPS_STAMP(9);
 }
 
+// ---- debug hooks (recnn_hip_debug.h: not part of the public ABI; process-wide by nature -- a trace buffer, a fault to inject)
 static unsigned long long* g_mlps_trace = nullptr;
-extern "C" void recnn_tune_mlp_trace(void* device_u64_wg32) { g_mlps_trace = (unsigned long long*)device_u64_wg32; }
+extern "C" void recnn_debug_mlp_trace(void* device_u64_wg32) { g_mlps_trace = (unsigned long long*)device_u64_wg32; }
 static int g_mlp_fault = 0;
 // test hook: break a hand-off on purpose (1: layer-1 part flags, 2: Q slots) with a short spin bound, to exercise the
 // error path (tests/test_gpu_engine.py::test_broken_handoff_is_reported); bits 0x100 / 0x200 select the timing probes
-extern "C" void recnn_tune_mlp_fault(int mode) { g_mlp_fault = mode; }
-extern "C" void recnn_tune_mlp_probe(int bits) { g_mlp_fault = (g_mlp_fault & 0xFF) | ((bits & 3) << 8); }
+extern "C" void recnn_debug_mlp_fault(int mode) { g_mlp_fault = mode; }
+extern "C" void recnn_debug_mlp_probe(int bits) { g_mlp_fault = (g_mlp_fault & 0xFF) | ((bits & 3) << 8); }
 
 int mlp_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlps_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlps attr");
@@ -656,9 +651,6 @@ int mlp_waves() { return NW; }
 // mlpr.hip (weights straight into MFMA registers) were measured slower at every shape the engine produces (47 and 70 us vs
 // 26 at DDPG / 2048 rows) and are gone; their bit-for-bit agreement with this kernel was tested up to their removal
 // (tests/test_gpu_kernels.py history, profiles/r02_gpu_tests_v7.log).
-static int g_mlp_xcd_max_prob = 0;   // 0: off; n: launches of up to n problems take the XCD-affine map
-extern "C" void recnn_tune_mlp_xcd(int max_problems) { g_mlp_xcd_max_prob = max_problems < 0 ? 0 : max_problems; }
-
 int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   MlpBatch b = b_in;
   b.fault = g_mlp_fault;
@@ -689,16 +681,6 @@ int mlp_launch(const MlpBatch& b_in, int nprob, hipStream_t s) {
   dim3 grid(panels, nprob);
   const dim3 block(NW * 64);
   b.nprob = nprob;
-  b.xcd_map = 0;
-  // the XCD-affine map needs equal-sized problems with an even panel count, and is a gain only while the problems of the second
-  // round land behind SHORT first-round problems (DDPG: the deferred policy-loss forward behind the target critic's layer-1
-  // producer; TD3's seven problems would queue the target actor behind a producer)
-  bool same = true;
-  for (int i = 0; i < nprob; ++i) same = same && b.p[i].rows == rows;
-  if (same && panels >= 2 && !(panels & 1) && nprob <= g_mlp_xcd_max_prob) {
-    b.xcd_map = panels;
-    grid = dim3(8 * (panels / 2) * ((nprob + 3) / 4), 1);
-  }
   switch ((b.fault >> 8) & 3) {
     case 1: hipLaunchKernelGGL(mlps_fwd_kernel<1>, grid, block, LDS_TOTAL, s, b, g_mlps_trace); break;
     case 2: hipLaunchKernelGGL(mlps_fwd_kernel<2>, grid, block, LDS_TOTAL, s, b, g_mlps_trace); break;

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
 }
 
 static unsigned long long* g_mlpt_trace = nullptr;
-extern "C" void recnn_tune_tail_trace(void* p) { g_mlpt_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
+extern "C" void recnn_debug_tail_trace(void* p) { g_mlpt_trace = (unsigned long long*)p; }   // [workgroup][16] uint64 shader-clock stamps
 
 // ---- the critic head alone: q[m] = h2[m, :] . w3 + b3, one wave per row -- the q-dot loop of mlp_tail_kernel, same lane ->
 // column map (lane owns columns 4 lane .. 4 lane + 3), same products, same wave_sum tree

@@ -1,0 +1,21 @@
+/* recnn_hip_debug.h -- PRIVATE debug / test hooks of librecnn_hip.so: in-kernel shader-clock traces, timing probes and fault
+ * injection.  Not part of the public C ABI (include/recnn_hip.h): process-wide, not thread-safe, results of probe runs are
+ * garbage by design.  Used by tests/test_gpu_engine.py::test_broken_handoff_is_reported and tools/{mlp,split}_trace.py. */
+#ifndef RECNN_HIP_DEBUG_H
+#define RECNN_HIP_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* break an in-launch hand-off of the fused forward on purpose: 1 = producers do not raise their flag, 2 = critics do not fill the
+ * Q slot; the bounded waits then report through recnn_engine_read_losses / read_counters (RECNN_E_STATE).  0 = off. */
+void recnn_debug_mlp_fault(int mode);
+/* timing experiments on the fused forward (csrc/mlps.hip): bit 0 = no MFMA work / fragment reads, bit 1 = no DMA */
+void recnn_debug_mlp_probe(int bits);
+/* shader-clock stamps of a kernel's phases: device uint64 [workgroup][32] (mlps_fwd_kernel) / [workgroup][16]; NULL = off */
+void recnn_debug_mlp_trace(void* device_u64_wg32);
+void recnn_debug_tail_trace(void* device_u64_wg16);
+void recnn_debug_l1_trace(void* device_u64_wg16);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -62,6 +62,7 @@ class StepEngine:
             h = C.c_void_p()
             L.call("recnn_engine_create", C.byref(cfg), L.ptr(self.workspace), C.byref(h))
             self.handle = h
+            self.set_tuning()                # library defaults, the environment, _tune.set_default_tuning(...)
             self.nets = sorted((NET_NAMES_TD3 if self.td3 else NET_NAMES_DDPG).values())
             self.params: Dict[int, torch.Tensor] = {}
             self.grads: Dict[int, torch.Tensor] = {}
@@ -102,6 +103,13 @@ class StepEngine:
 
     def _stream(self):
         return L.current_stream()
+
+    def set_tuning(self, **fields):
+        """Schedule / tile choices of THIS engine (`recnn_engine_tuning`, all compute the same numbers); drops built graphs."""
+        from .._tune import make_tuning
+        cur = {f: getattr(self.tuning, f) for f in L.TUNING_FIELDS} if fields and getattr(self, "tuning", None) is not None else {}
+        self.tuning = make_tuning(**{**cur, **fields}) if cur else make_tuning(**fields)
+        L.call("recnn_engine_set_tuning", self.handle, C.byref(self.tuning))
 
     def in_dim(self, ni: int) -> int:
         return self.S + self.A if ni >= L.NET_VALUE1 else self.S

@@ -96,9 +96,9 @@ def test_world_one_collective_steps_equal_single_gpu_steps(cuda, fused):
         for t in range(4):
             ref.step(rows, True, t)
         ref.graph_run(4, 10)
-        L.load().recnn_tune_comm_fused(fused)
         try:
             eng = _ddpg_engine(rows)
+            eng.set_tuning(comm_fused=fused)
             comm = PeerComm(PeerComm.floats_for(eng))
             eng.set_comm(comm)
             eng.graph_build(rows)
@@ -108,7 +108,7 @@ def test_world_one_collective_steps_equal_single_gpu_steps(cuda, fused):
             side.synchronize()
             comm.check()
         finally:
-            L.load().recnn_tune_comm_fused(1)
+            pass
     side.synchronize()
     assert ref.counters() == eng.counters()
     for ni in (L.NET_POLICY, L.NET_VALUE1, L.NET_TARGET_POLICY, L.NET_TARGET_VALUE1):

@@ -418,8 +418,8 @@ def test_chained_target_critic_equals_separate_launches(cuda, algo, B):
     out = {}
     try:
         for chain in (1, 0, 1):
-            L.load().recnn_tune_chain_target_critic(chain)
             eng = _engine(algo, S, A, H, B, "bf16", mask_mode="none")
+            eng.set_tuning(chain_target_critic=chain)
             nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
             if td3:
                 nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
@@ -435,7 +435,7 @@ def test_chained_target_critic_equals_separate_launches(cuda, algo, B):
             torch.cuda.synchronize()
             out.setdefault(chain, []).append((eng.buffer("expected")[:B].float().cpu().clone(), eng.losses()))
     finally:
-        L.load().recnn_tune_chain_target_critic(1)
+        pass
     y1, l1 = out[1][0]
     y0, l0 = out[0][0]
     y1b, _ = out[1][1]

@@ -190,7 +190,7 @@ def test_value_update_multi_step_advances_device_counters(cuda):
 @pytest.mark.parametrize("fault", [1, 2])
 def test_broken_handoff_is_reported(cuda, fault):
     """The cross-workgroup waits of the fused forward are bounded; a wait that runs out must surface as RECNN_E_STATE at
-    the next loss / counter read instead of a silently wrong TD target.  recnn_tune_mlp_fault breaks one hand-off on
+    the next loss / counter read instead of a silently wrong TD target.  recnn_debug_mlp_fault (csrc/recnn_hip_debug.h) breaks one hand-off on
     purpose: 1 = the layer-1 part flags of the chained target critic are never raised, 2 = Q(s, a) never reaches the
     head.  Afterwards the engine is usable again (flags / slots are back at rest, the error word is cleared)."""
     from recnn_amd import _lib as L
@@ -213,15 +213,14 @@ def test_broken_handoff_is_reported(cuda, fault):
     try:
         # (the hand-offs belong to the fused row-panel forward: a suite run with RECNN_SPLIT_FWD=2 evaluates eager steps with
         # the split forward, which has none -- this test is about csrc/mlps.hip)
-        L.load().recnn_tune_split_fwd(1)
-        L.load().recnn_tune_mlp_fault(fault)
+        eng.set_tuning(split_fwd=1)
+        L.load().recnn_debug_mlp_fault(fault)
         eng.step(B, False, 1)
         with pytest.raises(L.RecnnHipError, match="hand-off timed out"):
             eng.losses()
     finally:
-        L.load().recnn_tune_mlp_fault(0)
-        from recnn_amd._tune import apply_env_knobs
-        apply_env_knobs()
+        L.load().recnn_debug_mlp_fault(0)
+        eng.set_tuning()
     eng.step(B, False, 1)
     again = eng.losses()                                   # the error word was cleared, flags and slots are at rest
     assert again["value"] == good["value"] and again["policy"] == good["policy"]

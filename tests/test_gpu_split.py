@@ -21,8 +21,8 @@ def _run(algo, B, split, mask_mode, steps, L, learn_last=True):
     td3 = algo == "td3"
     actor, critics = _init_nets(8, S, A, H, 2 if td3 else 1)
     batch = _rand_batch(B, S, A, torch.Generator().manual_seed(31))
-    L.load().recnn_tune_split_fwd(split)
     eng = _engine(algo, S, A, H, B, "bf16", mask_mode=mask_mode, seed=17)
+    eng.set_tuning(split_fwd=split)          # per-engine: nothing process-wide is touched
     nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
     if td3:
         nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
@@ -50,11 +50,8 @@ def _run(algo, B, split, mask_mode, steps, L, learn_last=True):
                                               ("ddpg", 4100, "hash")])
 def test_split_forward_equals_fused_row_panel_forward(cuda, algo, B, mask_mode):
     from recnn_amd import _lib as L
-    try:
-        ref = _run(algo, B, 0, mask_mode, 3, L)
-        new = _run(algo, B, 2, mask_mode, 3, L)      # 2 = split forward for eager steps too
-    finally:
-        L.load().recnn_tune_split_fwd(1)
+    ref = _run(algo, B, 0, mask_mode, 3, L)
+    new = _run(algo, B, 2, mask_mode, 3, L)      # 2 = split forward for eager steps too
     for t, (a, b) in enumerate(zip(ref, new)):
         for n in a["bufs"]:
             assert torch.equal(a["bufs"][n], b["bufs"][n]), (t, n, (a["bufs"][n] - b["bufs"][n]).abs().max().item())
@@ -63,3 +60,33 @@ def test_split_forward_equals_fused_row_panel_forward(cuda, algo, B, mask_mode):
             assert torch.equal(a["g"][ni], b["g"][ni]), (t, "grad", ni, (a["g"][ni] - b["g"][ni]).abs().max().item())
         for ni in a["p"]:
             assert torch.equal(a["p"][ni], b["p"][ni]), (t, "param", ni, (a["p"][ni] - b["p"][ni]).abs().max().item())
+
+
+def test_two_engines_with_different_schedules_coexist(cuda):
+    """The tuning is per engine (recnn_engine_set_tuning): an engine on the fused row-panel forward and one on the split forward,
+    created side by side and stepped ALTERNATELY in one process, stay bit-identical -- no process-wide schedule state."""
+    from recnn_amd import _lib as L
+    B = 512
+    actor, critics = _init_nets(8, S, A, H, 1)
+    batch = _rand_batch(B, S, A, torch.Generator().manual_seed(31))
+    engs = []
+    for split in (0, 2):
+        eng = _engine("ddpg", S, A, H, B, "bf16", mask_mode="hash", seed=17)
+        eng.set_tuning(split_fwd=split, dw_dma=2 if split == 0 else 3)
+        for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])):
+            eng.load_params(ni, p)
+        eng.set_hyper(policy_opt=dict(lr=1e-3), value_opt=dict(lr=1e-3), policy_every=2)
+        eng.set_counters()
+        eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+        engs.append(eng)
+    assert engs[0].tuning.split_fwd == 0 and engs[1].tuning.split_fwd == 2
+    for t in range(4):
+        for eng in engs:                          # interleaved: each launch sequence is planned from its own engine's tuning
+            eng.step(B, True, t)
+        torch.cuda.synchronize()
+        assert engs[0].losses() == engs[1].losses(), t
+    for ni in (L.NET_POLICY, L.NET_VALUE1, L.NET_TARGET_POLICY, L.NET_TARGET_VALUE1):
+        assert torch.equal(engs[0].params[ni], engs[1].params[ni]), ni
+    got = L.EngineTuning()
+    L.call("recnn_engine_get_tuning", engs[1].handle, got)
+    assert got.split_fwd == 2 and got.dw_dma == 3

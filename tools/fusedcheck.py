@@ -17,7 +17,7 @@ for algo, B in (("ddpg", 2048), ("td3", 777)):
     noise = torch.randn(B, A, generator=gen) * 0.5
     outs = []
     for fused in (0, 1):
-        lib.recnn_tune_fused_mlp(fused)
+        from recnn_amd._tune import set_default_tuning; set_default_tuning(fused_mlp=fused)
         eng = StepEngine(algo, S, A, H, B, dtype="bf16", mask_mode="external")
         nets = [(0, actor), (1, actor), (2, critics[0]), (3, critics[0])] + ([(4, critics[1]), (5, critics[1])] if nc == 2 else [])
         for ni, p in nets: eng.load_params(ni, p)

@@ -24,14 +24,14 @@ eng.set_hyper(policy_opt=dict(lr=1e-5), value_opt=dict(lr=1e-5))
 eng.set_counters()
 eng.pack_batch(torch.randn(B, S), torch.randn(B, A), torch.randn(B), torch.randn(B, S), (torch.rand(B) < 0.1).float())
 trace = torch.zeros(1024, 32, dtype=torch.int64, device=dev)
-L.load().recnn_tune_mlp_probe(probe)
+L.load().recnn_debug_mlp_probe(probe)
 for t in range(5):
     eng.step(B, True, 1)
 torch.cuda.synchronize()
-L.load().recnn_tune_mlp_trace(L.ptr(trace))
+L.load().recnn_debug_mlp_trace(L.ptr(trace))
 eng.step(B, True, 1)
 torch.cuda.synchronize()
-L.load().recnn_tune_mlp_trace(None)
+L.load().recnn_debug_mlp_trace(None)
 tr = trace.cpu().numpy()
 npanel = B // 32
 names = ["tc_producer", "critic", "target_actor+tail+head", "actor"]

@@ -16,7 +16,8 @@ def mk(inp, out):
     return {"w1": torch.randn(H, inp) * 0.03, "b1": torch.randn(H) * 0.1, "w2": torch.randn(H, H) * 0.06, "b2": torch.randn(H) * 0.1,
             "w3": torch.randn(out, H) * 0.3, "b3": torch.randn(out) * 0.3}
 actor, critic = mk(S, A), mk(S + A, 1)
-L.load().recnn_tune_split_fwd(2)
+from recnn_amd._tune import set_default_tuning
+set_default_tuning(split_fwd=2)
 eng = StepEngine("ddpg", S, A, H, B, dtype="bf16", mask_mode="hash", seed=1, device=dev)
 for ni, p in ((L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critic), (L.NET_TARGET_VALUE1, critic)):
     eng.load_params(ni, p)
@@ -28,12 +29,12 @@ for t in range(5):
 torch.cuda.synchronize()
 t_tail = torch.zeros(4 * 64, 16, dtype=torch.int64, device=dev)
 t_l1 = torch.zeros(4 * 256, 16, dtype=torch.int64, device=dev)
-L.load().recnn_tune_tail_trace(L.ptr(t_tail))
-L.load().recnn_tune_l1_trace(L.ptr(t_l1))
+L.load().recnn_debug_tail_trace(L.ptr(t_tail))
+L.load().recnn_debug_l1_trace(L.ptr(t_l1))
 eng.step(B, True, 1)
 torch.cuda.synchronize()
-L.load().recnn_tune_tail_trace(None)
-L.load().recnn_tune_l1_trace(None)
+L.load().recnn_debug_tail_trace(None)
+L.load().recnn_debug_l1_trace(None)
 
 def show(name, tr, labels):
     tr = tr.cpu().numpy()
