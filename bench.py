@@ -204,9 +204,8 @@ def timed_subrun(recnn_amd, env, dev, stream, algo_name, dtype, rows, steps, war
     """A second engine on the same replay store, timed like the headline (made-to-order run graphs, `reps` regions of `steps`
     steps bracketed by synchronize, median): the sub-records of the JSON line (parity mode, configs[2])."""
     algo = _make_algo(recnn_amd, algo_name, dtype, dev, 1234)
-    upb = max(USERS_PER_BATCH, -(-rows // 10))
     torch.manual_seed(100)
-    algo.attach_env(env, rows_per_batch=rows, users_per_batch=upb)
+    algo.attach_env(env, rows_per_batch=rows)
     samples = []
     with torch.cuda.stream(stream):
         if 2 <= steps <= 64:
@@ -353,9 +352,12 @@ def main():
         algo = recnn_amd.nn.TD3(policy_net, value_net, value_net2).to(dev)
     else:
         algo = recnn_amd.nn.DDPG(policy_net, value_net).to(dev)   # optimizers: fused Adam(lr=1e-5, wd=1e-2)
-    users_per_batch = max(USERS_PER_BATCH, -(-rows // 10))        # every user has >= 10 windows: always >= `rows` rows
     torch.manual_seed(100 + rank)                                 # epoch permutations differ per rank
-    algo.attach_env(env, rows_per_batch=rows, users_per_batch=users_per_batch, shard=(rank, world))
+    # dense epochs (round 4): the windows of the shuffled users concatenated and cut into `rows`-row batches -- every window of every
+    # user once per epoch, as the reference's whole-user batches (recnn/data/utils.py:161-187); RECNN_SAMPLER_DENSE=0: round 1-3's
+    # "256 users per batch, keep the first 2048 rows"
+    dense = os.environ.get("RECNN_SAMPLER_DENSE", "1") != "0"
+    algo.attach_env(env, rows_per_batch=rows, users_per_batch=None if dense else max(USERS_PER_BATCH, -(-rows // 10)), shard=(rank, world))
     ctx = algo._fused_ctx
     eng = ctx.engine
 
@@ -466,7 +468,7 @@ def main():
             "config": {"workload": ("configs[1]: DDPG" if args.algo == "ddpg" else "configs[2]: TD3 (twin critics, delayed actor)")
                                    + f", {rows} transition rows/step/GPU ({args.scaling} scaling), frame_size 10, emb_dim 128, "
                                    "Actor/Critic hidden 256, Adam, policy+soft update every 10th step, synthetic ML20M-shaped "
-                                   "replay store (138,493 users, 26,744 items, ~20M ratings)",
+                                   "replay store (138,493 users, 26,744 items, ~20M ratings), " + ("dense epochs: every window of every user once" if dense else "256 users per batch, first rows kept"),
                        "rows_per_step_per_gpu": rows, "parallelism": (f"dp{world}" if world > 1 else "single") + (f" ({collective} collective)" if use_dp else ""),
                        "final_losses": losses},
         }

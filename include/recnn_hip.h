@@ -346,6 +346,14 @@ int recnn_engine_bind_batch(recnn_engine* e, float* xs, float* xn, float* reward
  *   replaces, ahead of time, the per-step users -> offsets -> prefix scan -> row search of recnn_frame_gather. */
 int recnn_frame_plan_rows(const int64_t* user_off, const int32_t* perm, int users_per_batch, int n_batches, int frame,
                           int rows, int64_t* plan, void* stream);
+/* Plan table of a DENSE epoch: the windows of the users seq[0 .. n_seq) (store slots) concatenated in that order -- every L - F
+ * windows of every user, as the reference's collate builds them (recnn/data/utils.py:161-187) -- and cut into batches of `rows`
+ * rows: plan[g] for global row g, same encoding as recnn_frame_plan_rows, done = 1 at each user's last window wherever it falls.
+ * skip0: windows of seq[0] already consumed (the previous epoch's leftover is carried into this one).  Slots past the epoch's last
+ * whole batch repeat its first batches.  row_off: scratch int32[n_seq + 1] (prefix sums of the window counts; the total must fit
+ * 31 bits).  Bind the table with recnn_sampler.plan / plan_rows = rows; the sampler's perm / users_per_batch are then unused. */
+int recnn_frame_plan_dense(const int64_t* user_off, const int32_t* seq, int n_seq, int skip0, int frame, int rows, int32_t* row_off,
+                           int64_t n_rows, int64_t* plan, void* stream);
 typedef struct recnn_sampler {
   const int32_t* items; const float* ratings; const int64_t* user_off;  /* CSR replay store */
   const int32_t* perm;        /* epoch permutation of store user slots, int32[n_batches*users_per_batch] */

@@ -112,6 +112,7 @@ SIGNATURES = {
     "recnn_engine_dp_sets": (_I, [_P]),
     "recnn_engine_read_counters": (_I, [_P, _P, _P]),
     "recnn_frame_plan_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "recnn_frame_plan_dense": (_I, [_P, _P, _I, _I, _I, _I, _P, _L, _P, _P]),
     "recnn_frame_plan": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "recnn_frame_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _P]),
     "recnn_pack_batch": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _P]),

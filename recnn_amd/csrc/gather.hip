@@ -120,6 +120,79 @@ extern "C" int recnn_frame_plan_rows(const int64_t* user_off, const int32_t* per
   return recnn_check_hip(hipGetLastError(), "frame_plan_rows");
 }
 
+// ------------------------------------------------------------------ dense epoch plan: every window of every user, once
+// The reference trains on ALL L - F windows of every user of a batch (recnn/data/utils.py:161-187: rolling_window over each
+// user's whole history, concatenated); a fixed-row batch that keeps only the first `rows` rows of its users drops the rest.
+// Here the windows of the epoch's user SEQUENCE are concatenated in sequence order and cut into batches of `rows` rows: batch
+// b = global rows [b rows, (b + 1) rows), a user's windows continue in the next batch, `done` marks each user's last window
+// (utils.py:70-71) wherever it falls.  skip0 = windows of the first sequence entry already consumed by the previous epoch's last
+// batch (the leftover of an epoch is carried, so that over consecutive epochs every (user, window) is visited exactly once per
+// epoch).  Two launches: prefix sums of the window counts over the sequence, then one thread per plan row.
+__global__ __launch_bounds__(1024) void frame_plan_seq_kernel(const int64_t* __restrict__ user_off, const int32_t* __restrict__ seq, int n,
+                                                              int frame, int skip0, int32_t* __restrict__ row_off) {
+  __shared__ int sc[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry = 0; row_off[0] = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    int v = 0;
+    if (i < n) {
+      const int u = seq[i];
+      v = max((int)(user_off[u + 1] - user_off[u]) - frame - (i == 0 ? skip0 : 0), 0);
+    }
+    sc[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+      const int t = tid >= o ? sc[tid - o] : 0;
+      __syncthreads();
+      sc[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) row_off[i + 1] = carry + sc[tid];
+    __syncthreads();
+    if (tid == 0) carry += sc[1023];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void frame_plan_dense_kernel(const int64_t* __restrict__ user_off, const int32_t* __restrict__ seq,
+                                                               const int32_t* __restrict__ row_off, int n, int frame, int skip0, int rows,
+                                                               int64_t n_rows, int64_t* __restrict__ plan) {
+  const int total = row_off[n];
+  const int64_t usable = (int64_t)(total / rows) * rows;      // whole batches of this epoch
+  for (int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x; g0 < n_rows; g0 += (int64_t)gridDim.x * 256) {
+    long long p = -1;
+    // plan slots past the epoch's last whole batch repeat its first batches: a caller that lets the device cursor run past the
+    // epoch (raw recnn_engine_graph_run without the host's epoch logic) reads valid rows, not garbage
+    const int64_t g = (g0 < usable || usable == 0) ? g0 : (g0 - usable) % usable;
+    if (g < total) {
+      int lo = 0, hi = n;               // largest i with row_off[i] <= g   (row_off non-decreasing, row_off[n] > g)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_off[mid] <= g) lo = mid; else hi = mid;
+      }
+      const int u = seq[lo];
+      const long long o0 = user_off[u];
+      const int t = (int)(g - row_off[lo]) + (lo == 0 ? skip0 : 0);
+      const int last = (int)(user_off[u + 1] - o0) - frame - 1;
+      p = ((o0 + t) << 1) | (t == last ? 1 : 0);
+    }
+    plan[g0] = p;
+  }
+}
+
+extern "C" int recnn_frame_plan_dense(const int64_t* user_off, const int32_t* seq, int n_seq, int skip0, int frame, int rows,
+                                      int32_t* row_off, int64_t n_rows, int64_t* plan, void* stream) {
+  RECNN_REQUIRE(user_off && seq && row_off && plan && n_seq > 0 && skip0 >= 0 && frame > 0 && rows > 0 && n_rows > 0, "frame_plan_dense: bad arguments");
+  hipLaunchKernelGGL(frame_plan_seq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, user_off, seq, n_seq, frame, skip0, row_off);
+  int grid = (int)((n_rows + 255) / 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(frame_plan_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, user_off, seq, row_off, n_seq, frame, skip0, rows,
+                     n_rows, plan);
+  return recnn_check_hip(hipGetLastError(), "frame_plan_dense");
+}
+
 // ------------------------------------------------------------------ gather
 template <int R, int W>
 __global__ __launch_bounds__(256) void frame_gather_kernel(const GatherArgs a) {

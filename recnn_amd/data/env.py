@@ -246,6 +246,26 @@ class FrameEnv(Env):
                "users": meta["users"]}
         return self.embed_batch(batch=win, item_embeddings_tensor=self._table, frame_size=self.frame_size)
 
+    def collate_rows(self, seq_slots, skip0: int, row_start: int, rows: int):
+        """`rows` consecutive rows, starting at global row `row_start`, of the concatenated windows of the users `seq_slots` (store
+        slots; the first one with its first `skip0` windows left out): what a DENSE epoch's batch holds (fused.attach_sampler).  The
+        users that overlap the range are collated whole -- `prepare_batch_static_size` semantics, `done` at each user's last
+        window -- and the range is cut out of that."""
+        st = self.store
+        seq = np.asarray(seq_slots, dtype=np.int64)
+        wins = np.maximum(st.lengths[seq].astype(np.int64) - self.frame_size, 0)
+        wins[0] = max(int(wins[0]) - int(skip0), 0)
+        cum = np.cumsum(wins)
+        if row_start + rows > int(cum[-1]):
+            raise IndexError("collate_rows: the sequence holds fewer rows")
+        i0 = int(np.searchsorted(cum, row_start, side="right"))
+        i1 = int(np.searchsorted(cum, row_start + rows - 1, side="right"))
+        before = int(cum[i0 - 1]) if i0 > 0 else 0
+        a = row_start - before + (int(skip0) if i0 == 0 else 0)       # offset inside the whole-user collate of seq[i0 .. i1]
+        whole = self.collate_slots(seq[i0:i1 + 1].astype(np.int32), rows_per_batch=None)
+        out = {k: (v[a:a + rows] if isinstance(v, torch.Tensor) else v) for k, v in whole.items()}
+        return out
+
     def prepare_batch_wrapper(self, x):
         """collate_fn-compatible entry (env.py:241-248): x = list of UserDataset items."""
         return self.collate_users([b["users"] for b in x])

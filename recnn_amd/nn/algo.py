@@ -178,11 +178,13 @@ class Algo:
         `dtype`: 'fp32' | 'bf16' compute type of the engine (default: fused.DEFAULTS['dtype']); only honoured before the
         networks' first update.
 
-        Batches are FIXED-SIZE: `users_per_batch` users are drawn per step and their windows are cut to the first
-        `rows_per_batch` rows, so with the default `users_per_batch` (sized so that even the shortest histories fill the
-        batch) most windows of long-history users are not visited in an epoch.  The equivalence with
-        `for batch in env.train_dataloader` therefore holds for such truncated batches (`env.collate_users(users)` with
-        `rows_per_batch` set), not for the reference's variable-size whole-user batches."""
+        Batches are FIXED-SIZE (`rows_per_batch` rows; the run graphs are captured for one size).  `users_per_batch=None` (default):
+        DENSE epochs -- the windows of the epoch's shuffled users are concatenated in that order and cut into `rows_per_batch`-row
+        batches; a user's windows continue in the next batch, `done` marks each user's last window, and what an epoch leaves over
+        (< one batch) opens the next one: one epoch visits every (user, window) exactly once, like the reference's whole-user
+        batches (`recnn/data/utils.py:161-187`), and `env.collate_rows(...)` materialises any of these batches.
+        `users_per_batch=k`: every batch draws k users and keeps the first `rows_per_batch` rows of their windows (rounds 1-3;
+        long histories are then mostly not visited)."""
         from . import fused
         algo = "td3" if "value_net1" in self.nets else "ddpg"
         keys = ("policy_optimizer", "value_optimizer1", "value_optimizer2") if algo == "td3" else ("policy_optimizer", "value_optimizer")
@@ -252,6 +254,15 @@ class Algo:
         so that the epoch permutation the position falls into has been drawn."""
         self.flush()
         sm = self._fused_ctx.sampler
+        if sm.get("dense"):
+            ep = max((e for e, p0 in sm["epoch_pos"].items() if p0 <= pos), default=None)
+            if ep is None:
+                raise KeyError("the user sequence of that epoch is no longer kept (planned batches can be read up to two epochs back)")
+            seq, skip0, n_e = sm["seqs"][ep]
+            idx = pos - sm["epoch_pos"][ep]
+            if idx >= n_e:
+                raise RuntimeError("this batch belongs to an epoch whose permutation is drawn when the previous epoch's last step runs")
+            return sm["env"].collate_rows(seq, skip0, idx * sm["rows"], sm["rows"])
         epoch, idx = divmod(pos, sm["n_batches"])
         if pos > sm["pos"] and epoch > sm["epoch"]:
             raise RuntimeError("this batch belongs to an epoch whose permutation is drawn when the previous epoch's last step runs")
@@ -336,6 +347,12 @@ class Algo:
         if ctx is None:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
         self.flush()
+        # the device keeps the losses of the last 1024 steps: steps queued-and-flushed earlier whose lazy losses nobody read yet
+        # are banked BEFORE this call's steps overwrite them (~900 unread steps + run(500) lost the oldest), and a
+        # long run is cut so that no more than 900 unread steps ever sit in the ring
+        pending = getattr(self, "_since_ring_read", 0)
+        if pending and pending + n_steps > 900:
+            self._bank_losses()
         self._execute(self._step, n_steps)
         self._step += n_steps
         self._since_ring_read = getattr(self, "_since_ring_read", 0) + n_steps

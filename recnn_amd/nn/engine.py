@@ -246,6 +246,36 @@ class StepEngine:
         self.n_batches = n_batches
         self.has_sampler = True
 
+    def bind_sampler_dense(self, items, ratings, user_off, rows: int, frame: int, emb_dim: int, table, n_seq_max: int, n_batches_max: int):
+        """Attach a device-resident replay store in DENSE mode: the batches of an epoch are consecutive `rows`-row cuts of the
+        concatenated windows of the epoch's user sequence (every window of every user, once: `recnn_frame_plan_dense`).  The plan
+        table (one int64 per batch row of up to `n_batches_max` batches) is (re)made per epoch by `plan_dense`."""
+        dev = self.device
+        assert items.dtype == torch.int32 and ratings.dtype == torch.float32 and user_off.dtype == torch.int64 and table.dtype == torch.float32
+        self._seq = torch.zeros(n_seq_max, dtype=torch.int32, device=dev)
+        self._row_off = torch.zeros(n_seq_max + 1, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._plan = torch.full((n_batches_max * rows,), -1, dtype=torch.int64, device=dev)
+        self._plan_args = None
+        self._dense = (user_off, frame, rows, n_batches_max)
+        self._smp_keep = (items, ratings, user_off, table)
+        # (perm / users_per_batch are not read by a planned gather; the device cursor wraps at n_batches_max, which the host's epoch
+        # logic never reaches: it resets the cursor at every epoch end)
+        m = L.Sampler(items.data_ptr(), ratings.data_ptr(), user_off.data_ptr(), self._seq.data_ptr(), 1, n_batches_max, frame, emb_dim,
+                      table.data_ptr(), self._row_off.data_ptr(), self.cursor.data_ptr(), self._plan.data_ptr(), rows)
+        L.call("recnn_engine_bind_sampler", self.handle, C.byref(m))
+        self.n_batches = n_batches_max
+        self.has_sampler = True
+
+    def plan_dense(self, seq_host, skip0: int):
+        """Make the plan table of the epoch whose user sequence (store slots, numpy int32) is `seq_host` (stream-ordered)."""
+        user_off, frame, rows, n_batches_max = self._dense
+        n = int(len(seq_host))
+        assert 0 < n <= self._seq.numel()
+        self._seq[:n].copy_(torch.from_numpy(seq_host), non_blocking=False)
+        L.call("recnn_frame_plan_dense", L.ptr(user_off), L.ptr(self._seq), n, int(skip0), frame, rows, L.ptr(self._row_off),
+               n_batches_max * rows, L.ptr(self._plan), L.current_stream())
+
     def plan_sampler(self):
         """(Re)make the plan table for the current contents of the bound permutation (stream-ordered on the current stream)."""
         if getattr(self, "_plan", None) is None:

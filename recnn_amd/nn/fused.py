@@ -264,12 +264,32 @@ class FusedContext:
     # ------------------------------------------------------------------ fused training loop on a device-resident env
     def attach_sampler(self, env, rows: int, users_per_batch: int = None, shard=(0, 1)):
         """Bind `env`'s replay store to the engine: every step then builds its own `rows`-row batch on the GPU from an
-        epoch permutation of the env's TRAIN users, `users_per_batch` users per batch."""
+        epoch permutation of the env's TRAIN users.
+        users_per_batch = None (default): DENSE epochs -- the windows of the shuffled users are concatenated and cut into
+        `rows`-row batches (a user's windows continue in the next batch; the epoch's leftover is carried into the next epoch), so
+        one epoch visits every (user, window) exactly once, like the reference's whole-user batches (recnn/data/utils.py:161-187).
+        users_per_batch = k: every batch draws k users and keeps the first `rows` rows of their windows (rounds 1-3)."""
         eng = self.engine
         st = env.store
         train = np.asarray(st.slots(env.base.train_user_dataset.users), dtype=np.int64)
         train = train[shard[0]::shard[1]]          # data parallel: rank r of W owns every W-th train user
         lens = st.lengths[train] - env.frame_size
+        if users_per_batch is None and os.environ.get("RECNN_SAMPLER_DENSE", "1") != "0":
+            wins = np.maximum(lens, 0).astype(np.int64)
+            total = int(wins.sum())
+            if total < rows:
+                raise ValueError(f"attach_env: the train users hold {total} windows, fewer than one batch of {rows} rows")
+            if total + rows >= 2 ** 31:
+                raise ValueError("attach_env: more than 2^31 windows per epoch (shard the users over more ranks)")
+            nb_max = (total + rows) // rows + 1
+            self.sampler = dict(env=env, rows=rows, upb=0, dense=True, train_host=train.astype(np.int32), win_of=None,
+                                n_batches=0, cursor=0, pos=0, epoch=-1, perms={}, seqs={}, epoch_pos={}, carry=(np.zeros(0, np.int32), 0),
+                                lengths=st.lengths, frame=env.frame_size)
+            self.perm = None
+            eng.bind_sampler_dense(st.items, st.ratings, st.user_off, rows, env.frame_size, self.A, env.table, 2 * len(train) + 1, nb_max)
+            self._reshuffle()
+            self.graph_rows = None
+            return
         if users_per_batch is None:       # enough users that even the shortest histories fill `rows` rows
             k = np.sort(lens)
             users_per_batch = int(np.searchsorted(np.cumsum(k), rows) + 1)
@@ -282,8 +302,25 @@ class FusedContext:
                          plan_rows=rows if os.environ.get("RECNN_SAMPLER_PLAN", "1") != "0" else 0)
         self.graph_rows = None
 
+    def _reshuffle_dense(self):
+        """Next dense epoch: [the previous epoch's leftover] + a fresh permutation of the train users; plan table on the device."""
+        sm = self.sampler
+        order = torch.randperm(len(sm["train_host"])).numpy()                                      # CPU generator, as RandomSampler
+        seq, skip0, n_e, sm["carry"] = dense_epoch(sm["carry"], sm["train_host"][order], sm["lengths"], sm["frame"], sm["rows"])
+        sm["epoch"] += 1
+        sm["n_batches"] = n_e
+        sm["seqs"][sm["epoch"]] = (seq, skip0, n_e)
+        sm["epoch_pos"][sm["epoch"]] = sm["pos"]
+        for old in (sm["epoch"] - 3,):
+            sm["seqs"].pop(old, None)
+            sm["epoch_pos"].pop(old, None)
+        self.engine.cursor.zero_()                     # the device cursor counts batches of the CURRENT epoch (stream-ordered)
+        self.engine.plan_dense(seq, skip0)
+
     def _reshuffle(self):
         sm = self.sampler
+        if sm.get("dense"):
+            return self._reshuffle_dense()
         order = torch.randperm(sm["train"].numel())[: self.perm.numel()]                            # CPU generator, as RandomSampler
         # the host keeps the last epochs' permutations (store slots): a planned batch can be materialised for inspection
         sm["epoch"] += 1
@@ -381,6 +418,28 @@ class FusedContext:
                     st["step"].fill_(float(t))
                 else:
                     st["step"] = torch.tensor(float(t)) if is_torch else t
+
+
+def dense_epoch(carry, perm_slots, lengths, frame: int, rows: int):
+    """Host bookkeeping of one DENSE epoch (no device work): the epoch's user sequence is the previous epoch's leftover -- `carry` =
+    (slots, windows of slots[0] already consumed) -- followed by the new permutation; its windows, concatenated, give
+    n_e = total // rows whole batches; what is left (the tail of the sequence from the user that holds global row n_e * rows) is
+    the next carry.  Returns (seq int32, skip0, n_e, new_carry)."""
+    carry_slots, skip0 = carry
+    seq = np.concatenate([np.asarray(carry_slots, dtype=np.int32), np.asarray(perm_slots, dtype=np.int32)])
+    wins = np.maximum(np.asarray(lengths)[seq].astype(np.int64) - frame, 0)
+    wins[0] = max(int(wins[0]) - int(skip0), 0)
+    cum = np.cumsum(wins)
+    total = int(cum[-1])
+    n_e = total // rows
+    end = n_e * rows
+    if end == total:
+        new_carry = (np.zeros(0, np.int32), 0)
+    else:
+        idx = int(np.searchsorted(cum, end, side="right"))            # the entry that holds global row `end`
+        before = int(cum[idx - 1]) if idx > 0 else 0
+        new_carry = (seq[idx:].copy(), (end - before) + (int(skip0) if idx == 0 else 0))
+    return seq, int(skip0), n_e, new_carry
 
 
 def context_for(algo: str, nets) -> FusedContext:

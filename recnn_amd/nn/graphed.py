@@ -59,8 +59,27 @@ class GraphedUpdate:
         self.use_graphs = graphs
         self.step = first_step
         self._outs = {}
+        self._kinds_seen = {}
+        self._params = [p for n in nets.values() if isinstance(n, torch.nn.Module) for p in n.parameters()]
         for _ in range(warmup):
             self._eager(batch)
+
+    def _mark_written(self):
+        """The captured kernels update the parameters without moving their `_version`: the module-level forward's cached derived
+        layouts (bf16 shadows, padded / transposed copies: functional._derived) must hear about it, or an eager call after a
+        replay -- `bcq_update(..., learn=False)`, `policy_net(state)` -- multiplies with the weights of the previous eager call
+        (ADVICE r3).  One counter bump per parameter, no device work."""
+        F_hip.mark_written(self._params)
+
+    def _state_ready(self) -> bool:
+        """Every optimizer has created its lazy per-parameter state (moments, device step count): a capture that had to allocate
+        it would zero it again on EVERY replay."""
+        for o in self.optimizer.values():
+            for g in o.param_groups:
+                for p in g["params"]:
+                    if p.requires_grad and p.grad is not None and len(o.state.get(p, {})) == 0:
+                        return False
+        return True
 
     def _kind(self, step):
         return bool(self.period) and step % self.period == 0
@@ -81,11 +100,13 @@ class GraphedUpdate:
                 v.copy_(batch[k], non_blocking=True)
 
     def _eager(self, batch):
+        self._kinds_seen[self._kind(self.step)] = True
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self._load(batch)
             out = self._run(self.step)
         torch.cuda.current_stream().wait_stream(self.stream)
+        self._mark_written()
         self.step += 1
         return out
 
@@ -94,6 +115,13 @@ class GraphedUpdate:
         if not self.use_graphs:
             return self._eager(batch)
         kind = self._kind(self.step)
+        if kind not in self.graphs and not (self._kinds_seen.get(kind) and self._state_ready()):
+            # a step of this kind has not run eagerly yet (warmup = 0, or a resumed run whose warm-up steps were all of the other
+            # kind): its first occurrence runs eagerly, so that the optimizers touched only by it create their state OUTSIDE the
+            # capture (zeros allocated inside a graph are re-zeroed by every replay)
+            self._kinds_seen[kind] = True
+            out = self._eager(batch)
+            return {k: (_Lazy(v) if isinstance(v, torch.Tensor) else v) for k, v in out.items()} if isinstance(out, dict) else out
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self._load(batch)
@@ -109,8 +137,12 @@ class GraphedUpdate:
                 self._outs[kind] = out
                 # (capture does not execute: the replay below runs this very step)
             self.graphs[kind].replay()
+            # the graph's outputs are static tensors the next replay of this kind overwrites: hand out copies (a few scalars, one
+            # tiny device copy each), so that losses collected over an epoch and formatted at its end are each step's own
+            outs = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in self._outs[kind].items()}
         torch.cuda.current_stream().wait_stream(self.stream)
-        out = {k: (_Lazy(v) if isinstance(v, torch.Tensor) else v) for k, v in self._outs[kind].items()}
+        self._mark_written()
+        out = {k: (_Lazy(v) if isinstance(v, torch.Tensor) else v) for k, v in outs.items()}
         out["step"] = self.step
         self.step += 1
         return out

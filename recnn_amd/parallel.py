@@ -44,11 +44,15 @@ class PeerComm:
         self.handle = h
         self.max_floats = int(max_floats)
         if self.world > 1:
+            # every rank contributes its handle, or None when it could not create / export its buffer: the gather below is the
+            # agreement (a rank that failed EARLIER still takes part in it: see `create`), and nobody connects to a partial set
             nb = int(self.lib.recnn_comm_handle_bytes())
             mine = C.create_string_buffer(nb)
             L.call("recnn_comm_export", self.handle, mine, nb)
             every = [None] * self.world
             dist.all_gather_object(every, bytes(mine.raw), group=group)
+            if any(not isinstance(h, (bytes, bytearray)) or len(h) != nb for h in every):
+                raise L.RecnnHipError("PeerComm: a rank could not export its peer buffer")
             blob = C.create_string_buffer(b"".join(every), nb * self.world)
             L.call("recnn_comm_connect", self.handle, blob, nb)
 
@@ -62,12 +66,23 @@ class PeerComm:
     def create(cls, max_floats: int, group=None):
         """A connected communicator, or None on EVERY rank if any rank failed (agreement over the group)."""
         comm, ok = None, 1
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
         try:
             comm = cls(max_floats, group)
             ok = int(comm.self_test())
-        except L.RecnnHipError:
-            ok = 0
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        except Exception as ex:          # RecnnHipError, an allocation failure, ...: this rank votes no instead of leaving its peers
+            ok = 0                       # inside a collective it never joins
+            if multi and comm is None and not isinstance(ex, L.RecnnHipError):
+                raise                    # (not a library failure: nothing sensible to agree on)
+            if multi and comm is None:
+                # the constructor failed before (or in) the handle exchange: take part in it with a non-handle so that the other
+                # ranks' constructors see the failure instead of waiting / joining garbage
+                try:
+                    every = [None] * dist.get_world_size(group)
+                    dist.all_gather_object(every, 0, group=group)
+                except Exception:
+                    pass
+        if multi:
             votes = [None] * dist.get_world_size(group)
             dist.all_gather_object(votes, ok, group=group)
             ok = min(votes)
@@ -211,6 +226,36 @@ class DataParallelStepper:
             if self._eager_sampler:
                 e.sampler_eager(False)
 
+    check_every = 16     # run() calls between two polls of the communicator's error word (a poll synchronises the device)
+
+    def grad_sync_error(self, raise_on_all_ranks: bool = True) -> bool:
+        """True when a bounded wait of the device collective ran out on ANY rank since the last poll (the sums of those steps
+        are invalid and rank-divergent): every rank then raises together (a training run must not continue silently
+        on corrupt gradients).  Synchronises the device and the group."""
+        if self.comm is None:
+            return False
+        bad = 0
+        try:
+            self.comm.check()
+        except L.RecnnHipError:
+            bad = 1
+        if self.world > 1:
+            votes = [None] * self.world
+            dist.all_gather_object(votes, bad, group=self.group)
+            bad = max(votes)
+        if bad and raise_on_all_ranks:
+            raise L.RecnnHipError("data parallel: a gradient exchange timed out on at least one rank -- the parameters of the "
+                                  "steps since the previous check are invalid (recnn_comm_status names the peers)")
+        return bool(bad)
+
+    def _poll(self):
+        if self.comm is None:
+            return
+        self._runs_since_check = getattr(self, "_runs_since_check", 0) + 1
+        if self._runs_since_check >= self.check_every:
+            self._runs_since_check = 0
+            self.grad_sync_error()
+
     def run(self, first: int, n: int, learn: bool = True):
         """`n` consecutive steps.  With phase graphs (and no overlap mode) the tail of step t and the head of step t+1
         replay as ONE graph -- one graph launch per step instead of two -- and, when the engine samples its own
@@ -220,10 +265,12 @@ class DataParallelStepper:
             return
         if self.comm is not None and self.graphs and learn:
             e.graph_run(first, n)
+            self._poll()
             return
         if not (self.graphs and learn) or self.overlap:
             for t in range(first, first + n):
                 self.step(t, learn)
+            self._poll()
             return
         two = e.dp_sets() == 2
         s = 0

@@ -110,3 +110,19 @@ def test_handles_carry_their_sampler_position():
     a.run(10)
     assert next(a.batches()).pos == 11 and a.batches_left_in_epoch() == 989
     assert set(h1.keys()) >= {"state", "action", "reward", "next_state", "done"} and "state" in h1
+
+
+def test_run_banks_unread_losses_before_it_overwrites_the_ring():
+    """~900 queued-and-flushed steps whose lazy losses nobody read, then run(500): the device ring holds 1024 steps, so the
+    oldest unread ones must be banked BEFORE the run executes -- they are still readable afterwards."""
+    a = _algo()
+    lazies = []
+    for batch in a.batches(840):
+        lazies.append(a.update(batch, learn=True))
+        a.step()
+    a.flush()
+    assert a._since_ring_read == 840
+    a.run(500)
+    assert a._fused_ctx.engine.steps == 1340
+    assert float(lazies[0]["value"]) == 100.0 and float(lazies[839]["value"]) == 939.0      # steps 0 and 839, not ring garbage
+    assert float(lazies[3]["policy"]) == -3.0

@@ -417,3 +417,62 @@ def test_graphed_bcq_update_equals_the_eager_update(cuda):
         for k in eager[net]:
             assert torch.equal(eager[net][k], graphed[net][k]), (net, k)
     print(f"bcq step, host time until the call returns: eager {t_eager * 1e3:.2f} ms, graphed {t_graph * 1e3:.2f} ms (incl. 2 captures)")
+
+
+def test_eager_forward_between_graph_replays_sees_the_replayed_weights(cuda):
+    """graph replays update the parameters from captured kernels without moving `p._version`; the module-level
+    forward keeps derived layouts (bf16 shadows, padded / transposed copies) per weight version, so an eager `value_net1(state,
+    action)` / `bcq_update(learn=False)`-style call AFTER replays used the weights of the previous eager call.  GraphedUpdate now
+    reports its writes (functional.mark_written): the eager forwards of a graphed run and of its eager twin agree bit for bit, in
+    bf16 mode (every leaf weight goes through a cached shadow there) -- and they do move between the probes."""
+    import copy
+    from recnn_amd import optim
+    from recnn_amd.nn import GraphedUpdate, bcq_update, functional
+    from recnn_amd.nn import models as M
+    S, A, L, H, B, n, steps = 1290, 128, 256, 256, 128, 10, 9
+    params = {"gamma": 0.99, "soft_tau": 0.01, "n_generator_samples": n, "perturbator_step": 3}
+    gcpu = torch.Generator().manual_seed(21)
+    batches = [{"state": torch.randn(B, S, generator=gcpu).cuda(), "action": (torch.randn(B, A, generator=gcpu) * 0.5).cuda(),
+                "reward": (torch.randn(B, generator=gcpu) * 2.0).cuda(), "next_state": torch.randn(B, S, generator=gcpu).cuda(),
+                "done": (torch.rand(B, generator=gcpu) < 0.1).float().cuda()} for _ in range(steps)]
+    noise = [[torch.randn(B, L, generator=gcpu).cuda(), torch.randn(B * n, L, generator=gcpu).cuda(), torch.randn(B, L, generator=gcpu).cuda()]
+             for _ in range(steps)]
+    probe_s, probe_a = batches[0]["state"], batches[0]["action"]
+
+    def build(graphs):
+        torch.manual_seed(5)
+        gen, pert, v1, v2 = M.bcqGenerator(S, A, L), M.bcqPerturbator(S, A, H), M.Critic(S, A, H, 2e-1), M.Critic(S, A, H, 2e-1)
+        tpert, tv1, tv2 = copy.deepcopy(pert).eval(), copy.deepcopy(v1).eval(), copy.deepcopy(v2).eval()
+        for m in (gen, pert, tpert, v1, v2, tv1, tv2):
+            m.cuda()
+        nets = {"generator_net": gen, "perturbator_net": pert, "target_perturbator_net": tpert, "value_net1": v1,
+                "target_value_net1": tv1, "value_net2": v2, "target_value_net2": tv2}
+        opt = {k: optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+               for k, m in (("generator_optimizer", gen), ("value_optimizer1", v1), ("value_optimizer2", v2), ("perturbator_optimizer", pert))}
+        static_noise = [torch.empty_like(z) for z in noise[0]]
+        gen.forced_noise = [z.clone() for z in noise[0]] + [z.clone() for z in noise[1]]
+        gu = GraphedUpdate(bcq_update, batches[0], params, nets, opt, period_key="perturbator_step", warmup=2, graphs=graphs)
+        probes = []
+        for t in range(2, steps):
+            for s_, z in zip(static_noise, noise[t]):
+                s_.copy_(z)
+            gen.forced_noise[:] = static_noise
+            gu(batches[t])
+            if t in (2, 5, 8):              # an eager evaluation between replays (the reference loop's periodic test pass)
+                with torch.no_grad():
+                    tv1_was = tv1.training
+                    probes.append((tv1(probe_s, probe_a).float().clone(), tpert(probe_s, probe_a).float().clone()))
+                    assert tv1.training == tv1_was
+        torch.cuda.synchronize()
+        return probes
+
+    functional.set_mlp_dtype("bf16")
+    try:
+        eager = build(False)
+        graphed = build(True)
+    finally:
+        functional.set_mlp_dtype("fp32")
+    for i, ((q_e, a_e), (q_g, a_g)) in enumerate(zip(eager, graphed)):
+        assert torch.equal(q_e, q_g), (i, float((q_e - q_g).abs().max()))
+        assert torch.equal(a_e, a_g), (i, float((a_e - a_g).abs().max()))
+    assert not torch.equal(graphed[0][0], graphed[2][0])          # the target critic did move between the probes (soft updates)
