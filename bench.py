@@ -294,8 +294,16 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of `--steps` steps each; value = their median")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (parity_mode, other_configs, loss-curve deviation)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="N > 1 diagnostics instead of the benchmark: one JSON object per stage (tools/multigpu_preflight.py)")
     args = ap.parse_args()
 
+    if args.preflight:
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            spawn_ranks(args)                             # (does not return)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import multigpu_preflight
+        raise SystemExit(multigpu_preflight.main())
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

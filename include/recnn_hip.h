@@ -485,6 +485,9 @@ int recnn_comm_export(recnn_comm* c, void* handle_out, int64_t bytes);
 int recnn_comm_connect(recnn_comm* c, const void* handles, int64_t bytes_each);
 int recnn_dp_allreduce_flat(recnn_comm* c, float* data, int64_t n, void* stream);
 int recnn_comm_status(recnn_comm* c, int32_t* timed_out_ranks, int32_t* epoch);
+/* bound (ms, default 4000) of every peer wait of the collectives launched or captured afterwards; clear a reported time-out */
+int recnn_comm_set_timeout_ms(recnn_comm* c, int ms);
+int recnn_comm_clear_status(recnn_comm* c);
 void recnn_comm_destroy(recnn_comm* c);
 int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
 /* Process-level settings of the peer communicators created afterwards (a communicator is shared by engines, so these are not part

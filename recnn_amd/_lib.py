@@ -170,6 +170,8 @@ SIGNATURES = {
     "recnn_comm_connect": (_I, [_P, _P, _L]),
     "recnn_dp_allreduce_flat": (_I, [_P, _P, _L, _P]),
     "recnn_comm_status": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "recnn_comm_set_timeout_ms": (_I, [_P, _I]),
+    "recnn_comm_clear_status": (_I, [_P]),
     "recnn_comm_destroy": (None, [_P]),
     "recnn_engine_set_comm": (_I, [_P, _P, _F]),
     "recnn_tune_comm_memory": (None, [_I]),

@@ -146,6 +146,8 @@ struct recnn_comm {
   hipIpcMemHandle_t handle;
   bool exported = false, connected = false;
   unsigned long long timeout = 0;
+  int khz = 100000;              // wall_clock64 rate
+  unsigned timeout_ms = COMM_TIMEOUT_MS;
 };
 
 // 0 (default) fine-grained device memory, 1 uncached, 2 ordinary hipMalloc (relies on the system-scope fences alone)
@@ -220,6 +222,7 @@ extern "C" int recnn_comm_create(int world, int rank, int64_t max_floats, recnn_
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
   if (khz <= 0) khz = 100000;
+  c->khz = khz;
   c->timeout = (unsigned long long)khz * COMM_TIMEOUT_MS;
   c->connected = world == 1;
   *out = c;
@@ -264,9 +267,25 @@ extern "C" int recnn_comm_status(recnn_comm* c, int32_t* timed_out_ranks, int32_
   if (epoch) *epoch = (int32_t)h[0];
   if (h[4]) {
     recnn_set_error("dp_allreduce_flat: a wait for peer rank(s) 0x%x ran out after %u ms (rank %d of %d, epoch %u): the reduced "
-                    "gradients since then are invalid", h[4], COMM_TIMEOUT_MS, c->rank, c->world, h[0]);
+                    "gradients since then are invalid", h[4], c->timeout_ms, c->rank, c->world, h[0]);
     return RECNN_E_STATE;
   }
+  return 0;
+}
+
+// Bound of every peer wait of the collectives launched -- or captured into graphs -- AFTERWARDS (the value travels in the kernel
+// arguments).  A first contact across a fabric is better made with a short bound (a pre-flight: 200 ms), training with the default.
+extern "C" int recnn_comm_set_timeout_ms(recnn_comm* c, int ms) {
+  RECNN_REQUIRE(c && ms > 0 && ms <= 600000, "comm_set_timeout_ms: 1 .. 600000 ms");
+  c->timeout_ms = (unsigned)ms;
+  c->timeout = (unsigned long long)c->khz * (unsigned)ms;
+  return 0;
+}
+/* clears the timed-out word (after a reported time-out, e.g. between the stages of a pre-flight) */
+extern "C" int recnn_comm_clear_status(recnn_comm* c) {
+  RECNN_REQUIRE(c, "comm_clear_status: null communicator");
+  RECNN_HIP(hipDeviceSynchronize());
+  RECNN_HIP(hipMemset(c->ctl + 4, 0, sizeof(uint32_t)));
   return 0;
 }
 

@@ -122,6 +122,13 @@ class PeerComm:
         """Raises if a wait for a peer ran out since the last check (synchronises the device)."""
         L.call("recnn_comm_status", self.handle, None, None)
 
+    def set_timeout_ms(self, ms: int):
+        """Bound of every peer wait of the collectives launched / captured afterwards (default 4000 ms)."""
+        L.call("recnn_comm_set_timeout_ms", self.handle, int(ms))
+
+    def clear_status(self):
+        L.call("recnn_comm_clear_status", self.handle)
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             self.lib.recnn_comm_destroy(self.handle)

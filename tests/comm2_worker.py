@@ -67,7 +67,7 @@ def run_allreduce(out):
     out["allreduce"] = {"world": world, "collectives": reps, "worst_rel": worst}
 
 
-def run_stepper(out, dtype, mode):
+def run_stepper(out, dtype, mode, small=False):
     from recnn_amd import _lib as L
     from recnn_amd.nn.engine import StepEngine
     from recnn_amd.parallel import DataParallelStepper, PeerComm
@@ -75,6 +75,10 @@ def run_stepper(out, dtype, mode):
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", 0)
     S, A, H, B, steps, pe = 1290, 128, 256, 2048, 8, 3
+    if small:
+        # networks small enough that the critics' optimizer launch is a few dozen workgroups: both ranks' launches are resident
+        # at once on the shared GPU, so the exchange can run INSIDE them (optim.hip exchange_grads, RECNN_COMM_FUSED=1)
+        S, A, H, B = 34, 16, 32, 128
     Bl = B // world
     actor, critic = init_nets(0, S, A, H)
     gen = torch.Generator().manual_seed(1)
@@ -112,7 +116,8 @@ def run_stepper(out, dtype, mode):
         host_losses = drive(host, DataParallelStepper(host, Bl, use_graphs=(mode == "graphs")))
         # bf16: a region per network (gradients produced into / consumed from the peer buffer); fp32: one shared region, every
         # collective copies its arena in and out (both paths of recnn_engine_set_comm)
-        comm = PeerComm(PeerComm.floats_for(host) if dtype == "bf16" else max(int(g.numel()) for g in host.grads.values()))
+        # (the exchange inside the optimizer launch needs the per-network regions: `small` takes them in fp32 too)
+        comm = PeerComm(PeerComm.floats_for(host) if (dtype == "bf16" or small) else max(int(g.numel()) for g in host.grads.values()))
         devc = make()
         dp = DataParallelStepper(devc, Bl, use_graphs=(mode == "graphs"), comm=comm)
         dev_losses = drive(devc, dp)
@@ -125,7 +130,8 @@ def run_stepper(out, dtype, mode):
         diff[name] = float((host.params[ni] - devc.params[ni]).abs().max())
     for name, ni in (("policy_m", L.NET_POLICY), ("value_m", L.NET_VALUE1)):
         diff[name] = float((host.adam_m[ni] - devc.adam_m[ni]).abs().max())
-    out["stepper"] = {"world": world, "param_diff": diff, "host_losses": host_losses, "dev_losses": dev_losses, "replica_gap": gap}
+    out["stepper"] = {"world": world, "param_diff": diff, "host_losses": host_losses, "dev_losses": dev_losses, "replica_gap": gap,
+                      "comm_fused": int(devc.tuning.comm_fused), "optimizer_workgroups_hint": int(sum((g.numel() + 1023) // 1024 for g in devc.grads.values()))}
     dist.barrier()
     devc.set_comm(None)
     comm.close()
@@ -140,6 +146,8 @@ def main():
     out = {}
     if what == "allreduce":
         run_allreduce(out)
+    elif what == "stepper_small":
+        run_stepper(out, sys.argv[3], sys.argv[4], small=True)
     else:
         run_stepper(out, sys.argv[3], sys.argv[4])
     if dist.get_rank() == 0:

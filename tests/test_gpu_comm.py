@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, tmp_path, *args):
+def _launch(world, tmp_path, *args, fused="0"):
     port = 29850 + (os.getpid() % 100)
     # ranks sharing ONE GPU spin on each other inside their collective launches: all of them must be resident at once, so each
     # takes 32 workgroups here (128 by default: with 3 ranks the third found no free CU until a time slice ended, measured)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
-               RECNN_COMM_WORKGROUPS="32", RECNN_COMM_FUSED="0")
+               RECNN_COMM_WORKGROUPS="32", RECNN_COMM_FUSED=fused)
     # (RECNN_COMM_FUSED=0: with the exchange inside the critics' optimizer launch every one of its 420 workgroups waits for its
     # counterpart on the other rank -- on separate GPUs they all run at once, on a shared one the second rank's launch finds no
     # free CU until a time slice ends.  The fused form is covered at world 1 below, against both the single-GPU step and the
@@ -43,6 +43,18 @@ def test_device_collective_steps_equal_host_collective_steps(cuda, dtype, mode, 
     """DataParallelStepper(comm=PeerComm): 8 DDPG steps (3 policy steps) of 2 x 1024 rows with the collectives as launches
     inside the step / run graph == the same stepper on dist.all_reduce between phase graphs: bit for bit."""
     js = _launch(2, tmp_path, "stepper", dtype, mode)["stepper"]
+    assert js["replica_gap"] == 0.0
+    assert js["host_losses"] == js["dev_losses"], (js["host_losses"], js["dev_losses"])
+    assert all(v == 0.0 for v in js["param_diff"].values()), js["param_diff"]
+
+
+def test_fused_in_optimizer_exchange_with_two_ranks(cuda, tmp_path):
+    """The critics' gradient exchange INSIDE their optimizer launch (optim.hip exchange_grads: workgroup b publishes its elements'
+    slab sums, meets workgroup b of the other rank, reduces its share, reads the sums back) with TWO ranks -- so far it had only
+    ever run at world 1.  Networks of 34 / 16 / 32 units make that launch a few dozen workgroups, so both ranks' launches are
+    resident on the one GPU at once.  Against the same steps on dist.all_reduce between phases: bit for bit."""
+    js = _launch(2, tmp_path, "stepper_small", "fp32", "graphs", fused="1")["stepper"]
+    assert js["comm_fused"] == 1
     assert js["replica_gap"] == 0.0
     assert js["host_losses"] == js["dev_losses"], (js["host_losses"], js["dev_losses"])
     assert all(v == 0.0 for v in js["param_diff"].values()), js["param_diff"]
