@@ -211,3 +211,35 @@ def reinforce_step(st: ReinforceState, batch, pi_action: torch.Tensor, masks: Se
         soft_update(st.policy, st.target_policy, st.soft_tau, POLICY_ORDER)
         out["policy"] = float(loss)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# The learned behaviour policy `Beta` of the Top-K correction notebook
+# (examples/2. REINFORCE TopK Off Policy Correction/3. TopK Reinforce Off Policy Correction.ipynb, cell 3; consumed by
+# recnn/nn/models.py:113-141,143-184 as `beta(state, action=...) -> probabilities`).  Pinned by oracle/make_golden_beta.py, which
+# exec()s the notebook's own class.
+# --------------------------------------------------------------------------------------
+
+
+def beta_step(p: Dict[str, torch.Tensor], opt: "AdamDict", state: torch.Tensor, target: torch.Tensor):
+    """One `Beta.forward(state, action)` of the notebook with torch.optim.Adam in place of the absent torch_optimizer.RAdam:
+
+        probs = Softmax()(Linear(state))                       (returned: the probabilities BEFORE this call's optimizer step)
+        loss  = CrossEntropyLoss()(probs, action.argmax(1))    -- the cross entropy of the PROBABILITIES taken as logits (sic)
+        zero_grad(); loss.backward(); optim.step()
+
+    Backward by hand: d loss / d probs = (softmax(probs) - onehot(target)) / B;  through the softmax:
+    d logits = probs * (g - sum_j g_j probs_j);  dW = d logits^T state, db = column sums.  p = {"w": [N, K], "b": [N]}, updated
+    in place.  Returns (probs, loss)."""
+    B = state.shape[0]
+    logits = torch.addmm(p["b"], state, p["w"].t())
+    probs = torch.softmax(logits, dim=1)
+    q = torch.softmax(probs, dim=1)                       # log_softmax of the "logits" CrossEntropyLoss is given
+    loss = -torch.log(q.gather(1, target.view(-1, 1)).squeeze(1)).mean()
+    g = q.clone()
+    g[torch.arange(B), target] -= 1.0
+    g /= B
+    dlogits = probs * (g - (g * probs).sum(1, keepdim=True))
+    grads = {"w": dlogits.t() @ state, "b": dlogits.sum(0)}
+    opt.step(p, grads)
+    return probs, float(loss)

@@ -666,6 +666,59 @@ def discrete_policy(x, module, actions=None, sample=False):
                                         module.linear2.bias, actions, bool(sample), torch.initial_seed())
 
 
+def beta_train_forward(state, target, weight, bias):
+    """The learned behaviour policy of the Top-K off-policy correction (`Beta` of the reference's notebook
+    `examples/2. REINFORCE TopK Off Policy Correction/3. TopK Reinforce Off Policy Correction.ipynb`, cell 3):
+
+        p    = Softmax()(Linear(state))                      # the probabilities it returns (detached)
+        loss = CrossEntropyLoss()(p, action.argmax(1))       # NB: the cross entropy of the PROBABILITIES taken as logits
+
+    Returns (p float32 [B, n_items] -- a view into a 16-byte aligned buffer --, loss (device scalar), dW [n_items, K], db [n_items]): every
+    catalogue-wide pass runs in HIP kernels -- the logits GEMM, the two softmaxes (of the logits, and of p inside the loss:
+    recnn_categorical_rows), d loss / d p = (softmax(p) - onehot) / B (recnn_logprob_bwd with g = -1 / B), the softmax backward
+    (recnn_softmax_bwd) and the weight-gradient GEMM; the bias gradient is the column sum of d logits, taken by the same dW
+    kernel against a row of ones.  No autograd graph is recorded (the notebook's forward steps its optimizer itself)."""
+    if not state.is_cuda:
+        raise L.RecnnHipError("recnn_amd Beta: needs GPU tensors (no CPU fallback)")
+    x = state.detach().float()
+    B, K = x.shape
+    N = weight.shape[0]
+    dev = x.device
+    Kp, ldn = _r64(K), _r64(N)
+    s = L.current_stream()
+    xp = _pad(x, B, Kp)
+    wp = _derived_of(weight, "padded", lambda w: _pad(w.detach(), _r4(N), Kp)) if (K != Kp or N != _r4(N)) else weight.detach()
+    p = torch.empty(B, ldn, device=dev)
+    if ldn != N:
+        p[:, N:].zero_()
+    _fwd(xp, Kp, wp, bias.detach().float().contiguous(), p, ldn, N, False, None)
+    tgt = target.to(device=dev, dtype=torch.int64).contiguous()
+    L.call("recnn_categorical_rows", L.ptr(p), ldn, B, N, L.CAT_SOFTMAX, 0, 0, None, None, None, s)          # p = softmax(logits)
+    q = p.clone()
+    stat = torch.empty(B, 4, device=dev)
+    lp = torch.empty(B, device=dev)
+    L.call("recnn_categorical_rows", L.ptr(q), ldn, B, N, L.CAT_SOFTMAX, 0, 0, L.ptr(tgt), L.ptr(lp), L.ptr(stat), s)   # q = softmax(p), lp = log q[target]
+    loss = -lp.mean()
+    g = torch.full((B,), -1.0 / B, device=dev)
+    dprobs = torch.empty(B, ldn, device=dev)
+    if ldn != _r4(N):
+        dprobs[:, _r4(N):].zero_()
+    L.call("recnn_logprob_bwd", L.ptr(q), ldn, B, N, L.ptr(tgt), L.ptr(g), L.ptr(stat), L.ptr(dprobs), ldn, 0, None, None, s)
+    del q
+    dlog = torch.empty(B, ldn, device=dev)
+    if ldn != _r4(N):
+        dlog[:, _r4(N):].zero_()
+    L.call("recnn_softmax_bwd", L.ptr(p), ldn, B, N, L.ptr(dprobs), ldn, L.ptr(dlog), ldn, s)
+    del dprobs
+    gw = torch.empty(N, K, device=dev)
+    _dw(dlog, N, xp, K, gw)
+    ones = torch.zeros(B, 64, device=dev)
+    ones[:, 0] = 1.0
+    gb16 = torch.empty(16, N, device=dev)
+    _dw(ones, 16, dlog, N, gb16)            # row 0: sum over the batch rows of d logits
+    return p[:, :N], loss, gw, gb16[0].contiguous()
+
+
 def onehot_rows(idx, n):
     """float[B, n] one-hot rows of int64 indices (recnn/data/utils.py:108-109: zeros + scatter_).  The result remembers
     its indices (`onehot_index`): a Critic reading it gathers the B weight columns instead of multiplying a [B, n] matrix

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import functional as F_hip
 
-__all__ = ["Actor", "Critic", "DiscreteActor", "bcqPerturbator", "bcqGenerator", "StateCritic", "SoftQ", "StochasticActor"]
+__all__ = ["Actor", "Critic", "DiscreteActor", "Beta", "bcqPerturbator", "bcqGenerator", "StateCritic", "SoftQ", "StochasticActor"]
 
 
 class Actor(nn.Module):
@@ -60,6 +60,60 @@ class Critic(nn.Module):
         dropout or gradient (`functional.mlp_candidates`: the state part of layer 1 once per state)."""
         return F_hip.mlp_candidates(state, actions, n, self.linear1.weight, self.linear1.bias, self.linear2.weight,
                                     self.linear2.bias, self.linear3.weight, self.linear3.bias)
+
+
+class Beta(nn.Module):
+    """The learned behaviour policy of the Top-K off-policy correction -- the `Beta` class the reference DEFINES IN ITS NOTEBOOK
+    (`examples/2. REINFORCE TopK Off Policy Correction/3. TopK Reinforce Off Policy Correction.ipynb`, cell 3) and hands to
+    `DiscreteActor._select_action_with_TopK_correction` as `beta_net.forward` (recnn/nn/models.py:113-141,143-184):
+
+        self.net = Sequential(Linear(1290, num_items), Softmax());  optim = RAdam(lr=1e-5, weight_decay=1e-5);  CrossEntropyLoss
+        forward(state, action):  p = net(state);  loss = criterion(p, action.argmax(1));  zero_grad / backward / optim.step();
+                                 return p.detach()
+
+    i.e. it TRAINS on every call (one optimizer step on the cross entropy of its own probabilities taken as logits -- the
+    notebook's quirk, kept) and returns the probabilities it had BEFORE that step.  Same sub-module names (`net.0.weight`,
+    `net.0.bias` in the state dict), same attributes `optim` / `criterion`.  Forward, loss, backward and optimizer run on the
+    HIP kernels (`functional.beta_train_forward`, `recnn_amd.optim`).  Optimizer: the notebook's `torch_optimizer.RAdam` is an
+    absent, un-pinned package; the default here follows `recnn_amd.nn.algo.set_default_optimizer` (this package's fused Ranger
+    or Adam, lr = 1e-5, weight_decay = 1e-5), `optimizer=lambda params: ...` injects any other (the parity fixture injects
+    torch.optim.Adam).  `last_loss` keeps the loss of the latest call as a device scalar."""
+
+    def __init__(self, input_dim=1290, num_items=5000, lr=1e-5, weight_decay=1e-5, optimizer=None):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(input_dim, num_items), nn.Softmax(dim=1))
+        self.criterion = nn.CrossEntropyLoss()
+        self._opt_args = (lr, weight_decay, optimizer)
+        self.optim = None
+        self.last_loss = None
+
+    def _optimizer(self):
+        if self.optim is None:
+            from .. import optim as O
+            from . import algo
+            lr, wd, make = self._opt_args
+            if make is not None:
+                self.optim = make(self.net.parameters())
+            else:
+                cls = O.Ranger if algo._DEFAULT_OPTIMIZER == "ranger" else O.Adam
+                self.optim = cls(self.net.parameters(), lr=lr, weight_decay=wd)
+        return self.optim
+
+    def forward(self, state, action=None):
+        lin = self.net[0]
+        if action is None:                      # plain evaluation (no label, nothing to learn from)
+            with torch.no_grad():
+                tgt = torch.zeros(state.shape[0], dtype=torch.int64, device=state.device)
+                p, _, _, _ = F_hip.beta_train_forward(state, tgt, lin.weight, lin.bias)
+            return p
+        idx = F_hip.onehot_index_of(action)
+        tgt = idx if idx is not None else action.argmax(1)
+        p, loss, gw, gb = F_hip.beta_train_forward(state, tgt, lin.weight, lin.bias)
+        opt = self._optimizer()
+        lin.weight.grad, lin.bias.grad = gw, gb          # (zero_grad + backward of the notebook)
+        opt.step()
+        self.last_loss = loss
+        return p
 
 
 class DiscreteActor(nn.Module):

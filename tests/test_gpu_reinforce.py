@@ -503,3 +503,38 @@ def test_vocab_parallel_head_on_hip_gemms(cuda, tmp_path):
         assert x["sample_mismatch"] <= 1, x          # (a draw within rounding of a shard boundary may land on the neighbour)
         assert x["n1"] - x["n0"] == 50_000           # half of linear2 (weights, gradient, optimizer state) and of [B, n_items] per rank
     print("vocab-parallel head:", json.dumps(res))
+
+
+@pytest.mark.parametrize("opt_kind", ["torch_adam", "hip_adam"])
+def test_beta_net_replays_the_notebooks_class(cuda, golden_dir, opt_kind):
+    """recnn_amd.nn.Beta -- the learned behaviour policy of the Top-K correction notebook (cell 3: Linear + Softmax, cross entropy of
+    the probabilities, an optimizer step inside every forward) -- on the HIP kernels against the fixture made by exec()ing the
+    notebook's OWN class (oracle/make_golden_beta.py): returned probabilities of every call and the parameters after 8 calls."""
+    import os
+    import recnn_amd
+    from recnn_amd import optim
+    g = np.load(os.path.join(golden_dir, "beta_net.npz"))
+    S, N, B, steps, _ = (int(x) for x in g["dims"])
+    lr, wd = (float(x) for x in g["hyper"])
+    make = (lambda ps: torch.optim.Adam(ps, lr=lr, weight_decay=wd)) if opt_kind == "torch_adam" else (lambda ps: optim.Adam(ps, lr=lr, weight_decay=wd))
+    beta = recnn_amd.nn.Beta(S, N, optimizer=make).to(cuda)
+    with torch.no_grad():
+        beta.net[0].weight.copy_(torch.from_numpy(g["w0"]))
+        beta.net[0].bias.copy_(torch.from_numpy(g["b0"]))
+    assert set(beta.state_dict()) == {"net.0.weight", "net.0.bias"}                 # the notebook class's keys
+    for t in range(steps):
+        state = torch.from_numpy(g["states"][t]).to(cuda)
+        tgt = torch.from_numpy(g["targets"][t]).to(cuda)
+        action = torch.zeros(B, N, device=cuda).scatter_(1, tgt.view(-1, 1), 1.0)
+        probs = beta(state, action)
+        assert not probs.requires_grad and probs.shape == (B, N)
+        ref = torch.from_numpy(g["probs"][t])
+        assert float((probs.cpu() - ref).abs().max() / ref.max()) < 1e-4, t
+        assert abs(float(beta.last_loss) - float(g["losses"][t])) < 1e-4 * abs(float(g["losses"][t]))
+    for k, p in (("w", beta.net[0].weight), ("b", beta.net[0].bias)):
+        ref = torch.from_numpy(g["final_" + k])
+        assert float((p.detach().cpu() - ref).abs().max() / ref.abs().max()) < 1e-4, k
+    # evaluation without a label leaves the parameters alone
+    w = beta.net[0].weight.detach().clone()
+    p_eval = beta(torch.from_numpy(g["states"][0]).to(cuda))
+    assert torch.equal(w, beta.net[0].weight) and float(p_eval.sum(1).sub(1).abs().max()) < 1e-5

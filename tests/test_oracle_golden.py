@@ -195,3 +195,24 @@ def test_bcq_oracle_reproduces_the_reference_run(golden_dir):
         assert np.abs(losses[:, j] - ref[:, j]).max() <= 5e-5 * np.abs(ref[:, j]).max(), j
     worst = BR.compare_final(fx, final, rtol=1e-4)
     assert worst < 1e-4
+
+
+def test_beta_oracle_matches_the_notebooks_class(golden_dir):
+    """oracle.reinforce_oracle.beta_step against the fixture made by exec()ing the reference notebook's own `Beta` class
+    (oracle/make_golden_beta.py): the probabilities each call returns and the parameters after 8 training calls."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import reinforce_oracle as R
+    g = np.load(os.path.join(golden_dir, "beta_net.npz"))
+    S, N, B, steps, _ = (int(x) for x in g["dims"])
+    lr, wd = (float(x) for x in g["hyper"])
+    p = {"w": torch.from_numpy(g["w0"].copy()), "b": torch.from_numpy(g["b0"].copy())}
+    opt = R.AdamDict(("w", "b"), lr=lr, weight_decay=wd)
+    for t in range(steps):
+        probs, loss = R.beta_step(p, opt, torch.from_numpy(g["states"][t]), torch.from_numpy(g["targets"][t]))
+        assert float((probs - torch.from_numpy(g["probs"][t])).abs().max() / g["probs"][t].max()) < 2e-6, t
+        assert abs(loss - float(g["losses"][t])) < 1e-6
+    for k in ("w", "b"):
+        ref = torch.from_numpy(g["final_" + k])
+        assert float((p[k] - ref).abs().max() / ref.abs().max()) < 5e-5, k

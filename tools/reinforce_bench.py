@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--method", default="topk")
     ap.add_argument("--optimizer", default="ranger")
     ap.add_argument("--dtype", default="fp32", help="compute type of the catalogue GEMMs: fp32 | bf16")
+    ap.add_argument("--beta", default="learned", choices=["learned", "frozen"],
+                    help="behaviour policy of the Top-K correction: the notebook's Beta net trained inside every step (default) or a frozen projection")
     a = ap.parse_args()
     recnn_amd.nn.algo.set_default_optimizer(a.optimizer)
     F_hip.set_catalogue_dtype(a.dtype)
@@ -31,11 +33,25 @@ def main():
     value = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda()
     policy = recnn_amd.nn.DiscreteActor(S, N, H).cuda()
     algo = recnn_amd.nn.Reinforce(policy, value).to(torch.device("cuda"))
+    beta_ms = []
     if a.method == "topk":
-        Wb = torch.randn(S, N, device="cuda") * 0.02
+        if a.beta == "learned":
+            # the notebook's configuration (3. TopK Reinforce Off Policy Correction.ipynb, cells 3-5): the behaviour policy is a
+            # `Beta` net -- Linear(1290, n_items) + softmax -- that takes one optimizer step on its cross entropy inside EVERY call
+            beta_net = recnn_amd.nn.Beta(S, N).cuda()
 
-        def beta(state, action=None):
-            return torch.softmax(state @ Wb, dim=1)
+            def beta(state, action=None):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = beta_net(state, action)
+                e1.record()
+                beta_ms.append((e0, e1))
+                return out
+        else:
+            Wb = torch.randn(S, N, device="cuda") * 0.02      # rounds 2-3: a FROZEN random projection (not the notebook's setup)
+
+            def beta(state, action=None):
+                return torch.softmax(state @ Wb, dim=1)
         policy.select_action = lambda state, action, K, writer, step, **kw: \
             policy._select_action_with_TopK_correction(state, beta, action, K=K, writer=writer, step=step)
         ch = recnn_amd.nn.ChooseREINFORCE
@@ -56,7 +72,10 @@ def main():
     ordinary = sorted(x for x, k in zip(times[1:], kinds[1:]) if not k)
     pol = [x for x, k in zip(times, kinds) if k]
     cyc = times[11:31] if len(times) >= 31 else times[1:]
+    beta_step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in beta_ms[1:])
     print(json.dumps({"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer, "dtype": a.dtype,
+                      "beta": a.beta if a.method == "topk" else None,
+                      "beta_train_call_ms": round(beta_step_ms[len(beta_step_ms) // 2], 3) if beta_step_ms else None,
                       "ordinary_step_ms": round(ordinary[len(ordinary) // 2], 3), "policy_step_ms": [round(x, 2) for x in pol],
                       "it_per_s": round(1e3 * len(cyc) / sum(cyc), 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
