@@ -504,7 +504,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 
 // X3 (x3.h): the operands are split-bf16 rows; a 256-byte stage row is two logical 32-k groups [hi 32 | lo 32 | hi 32 | lo 32], each
 // contracted with three MFMAs (hi hi + hi lo + lo hi); K / lda / ldb are physical, the epilogue writes split columns.
-template <class TC, int TM, int TN, int NS, int NW, bool X3 = false>
+// MFAST: consecutive workgroup ids walk the ROW tiles of one column tile (catalogue-wide products: few rows, 100k columns) -- the
+// two / four row tiles that share a weight panel run side by side on one XCD, so the panel leaves HBM once.
+template <class TC, int TM, int TN, int NS, int NW, bool X3 = false, bool MFAST = false>
 __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch batch) {
   // NW waves arranged (NW/2) x 2 ... 4 waves: 2x2 wave tiles of (16 TM) x (16 TN); 8 waves: 2x4 wave tiles
   constexpr int WCOLS = NW / 2;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
   const int nwg = P.tiles_m * P.tiles_n;
   if ((int)blockIdx.x >= nwg) return;
   const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  const int tile_n = MFAST ? lid / P.tiles_m : lid % P.tiles_n, tile_m = MFAST ? lid % P.tiles_m : lid / P.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
@@ -889,6 +891,33 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   return launch_dma_x3<1, 1, 3>(L, stream);
 }
 
+// Catalogue-wide forward products ([256, 2048] x [2048, 100k], recnn/nn/models.py:93-95 at a 100k-item catalogue): 128 x 128
+// tiles (wave tile 64 x 32: 6 fragment reads per 8 MFMAs), two 64 KB ring stages, row tiles fastest.  The 32 x 64 tile tuned
+// for the 256-wide MLPs streams 4.5 GB through L2 -> LDS for this shape (0.093 of the bf16 peak, round 3); this one 1.6 GB.
+template <class TC> static int launch_dma_wide(GemmLaunch* L, hipStream_t stream) {
+  constexpr int TM = 4, TN = 2, NS = 2, NW = 8, BM = 128, BN = 128;
+  constexpr int LDS = NS * (BM + BN) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<TC, TM, TN, NS, NW, false, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm dma wide attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.dot_parts = nwg * NW;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<TC, TM, TN, NS, NW, false, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (wide) launch");
+}
+
 template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
   if (tune_of(L).dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
   return launch_dma_nw<TC, NS, 4>(L, stream);
@@ -897,6 +926,7 @@ template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t 
 // Ring depth by launch size: a launch with at most ~1 workgroup per CU keeps 4 k stages in flight per workgroup
 // (5-stage ring, 120 KB of LDS); bigger grouped launches use the 3-stage ring so that 2 workgroups share a CU.
 template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
+  if (L->nprob == 1 && L->batch.p[0].N >= 8192 && L->batch.p[0].M >= 128 && !L->batch.p[0].dot_part) return launch_dma_wide<TC>(L, stream);
   long wg = 0;
   for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
   if (L->nprob == 0 || (tune_of(L).dma_deep && wg <= 320)) return launch_dma_ns<TC, 5>(L, stream);
@@ -927,6 +957,8 @@ int gemm_init() {
   if ((rc = launch_dma_nw<float, 5, 4>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 3, 4>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 5, 4>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_wide<float>(&L, nullptr))) return rc;
+  if ((rc = launch_dma_wide<bf16_t>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 3, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<float, 5, 8>(&L, nullptr))) return rc;
   if ((rc = launch_dma_nw<bf16_t, 3, 8>(&L, nullptr))) return rc;
