@@ -530,7 +530,9 @@ typedef struct recnn_engine_tuning {
   int gemm_waves;           /* 8 | 4 waves per workgroup of the register-staged dX kernel */
   int dw_dma;               /* bf16 dW: 0 register-staged loader, 1..7 LDS-DMA + transpose reads with (rows per stage, ring slots) =
                                (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3); default 2 */
-  int reserved[9];
+  int x3_tail;              /* split-bf16 engines (hidden 256, action 128): 1 layers 2 + 3 of a step's networks as row-panel launches
+                               that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
+  int reserved[8];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -36,6 +36,7 @@
 #include "comm.h"
 #include "split.h"
 #include "x3.h"
+#include "x3tail.h"
 
 constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
 
@@ -427,6 +428,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = l1gemm_init())) { delete e; return rc; }
   if ((rc = mlpt_init())) { delete e; return rc; }
   if ((rc = mlpf_init())) { delete e; return rc; }
+  if ((rc = x3tail_init())) { delete e; return rc; }
   recnn_engine_tuning_init(&e->tune);
   sync_gemm_tune(e);
   e->ws = (char*)workspace;
@@ -833,7 +835,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -1053,6 +1055,28 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
   return 0;
 }
 
+// layers 2 (+ 3) of network ni as a problem of the split-bf16 row-panel launch (x3tail.hip); mask_idx: dropout stream of layer 2
+void fill_x3tail(const recnn_engine* e, X3TailProb* p, int ni, int rows, const void* h1, int mask_idx, int step_add) {
+  const Net& n = e->net[ni];
+  memset(p, 0, sizeof(*p));
+  p->h1 = h1; p->ldh = e->Hp;
+  p->W2 = sh_ptr(e, ni, W2); p->ldw2 = n.ld_w2;
+  p->b2 = n.p + n.off[B2]; p->b3 = n.p + n.off[B3];
+  if (n.out_dim > 1) { p->W3 = sh_ptr(e, ni, W3); p->ldw3 = n.ld_w3; }
+  else p->w3row = n.p + n.off[W3];
+  p->rows = rows; p->H = e->H; p->out_dim = n.out_dim;
+  p->mask_mode = RECNN_MASK_NONE;
+  if (mask_idx >= 0 && e->cfg.mask_mode != RECNN_MASK_NONE) {
+    p->mask_mode = e->cfg.mask_mode;
+    if (e->cfg.mask_mode == RECNN_MASK_EXTERNAL) { p->mask2 = e->ext_masks + (int64_t)mask_idx * e->cfg.max_rows * e->H; p->ld_mask = e->H; }
+    else { p->seed = e->cfg.seed; p->stream2 = (uint32_t)mask_idx; p->step_ptr = e->counters; p->step_add = step_add; }
+  }
+}
+bool x3_tail_ok(const recnn_engine* e) {
+  return e->x3 && e->tune.x3_tail && e->H == 256 && e->Hp == 512 && e->A == 128 && e->net[RECNN_NET_POLICY].ld_w2 == e->net[RECNN_NET_POLICY].ld_w3;
+}
+
+
 // The forward of one step in the split-bf16 type (x3.h): layer-by-layer GEMM launches like the fp32 path, arranged so that every
 // launch is as full as the data dependencies allow (each launch streams its tiles at one CU's L2 -> LDS rate: time = bytes / CUs):
 //   L1  {target actor(s'), critic(s, a), actor(s), target critic STATE part (raw fp32, 1290 of its 1418 k: it does not depend on
@@ -1075,6 +1099,27 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
   const recnn_engine::PendingPc pp = e->pending_pc;
   e->pending_pc.on = false;
   const int m0 = e->td3 ? 6 : 4;
+  // DDPG's first launch is exactly one round of 64 x 128 tiles on 256 CUs without the deferred policy-loss critic (4 problems x 64
+  // tiles); a fifth problem would cost a whole second round (measured 44.6 us against ~28).  It rides with the target critic's
+  // k = 128 launch and panel tail instead, which fill a quarter of the machine.  (TD3's first launch is two rounds either way.)
+  const bool pend_late = pend && value_side && !e->td3 && x3_tail_ok(e);
+  auto pc_l1 = [&](Group& g) {     // layer 1 of the deferred policy-loss critic on [pi(s) | s] of the previous batch
+    FwdSpec f{RECNN_NET_VALUE1, 1, pp.ga, e->Ap, 0, e->Ap};
+    f.b_col = 0;
+    f.A2 = pp.xs + aoff; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
+    f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
+    GemmProb* p = g.add();
+    g.flops += fill_fwd(e, f, rows, p);
+    p->step_add = pp.run_off;
+  };
+  auto pc_tail = [&](X3TailProb* p) -> int {
+    fill_x3tail(e, p, RECNN_NET_VALUE1, rows, e->pc.h1, m0 + 1, pp.run_off);
+    p->q_part = e->pl_part_base + (int64_t)pp.slot * e->pl_cap;
+    const int parts = ((rows + 31) / 32) * x3tail_parts_per_panel();
+    RECNN_REQUIRE(parts <= e->pl_cap, "policy loss: %d partial sums do not fit %d", parts, e->pl_cap);
+    if (pp.slot < LOSS_HIST_MAX) { e->hist_pol_count[pp.slot] = parts; e->hist_pol_add[pp.slot] = 0; }
+    return 0;
+  };
   {  // ---- L1
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
@@ -1103,17 +1148,45 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
         g.flops += 2.0 * rows * (double)e->H * e->S;
       }
     }
-    if (pend && g.L.nprob < GEMM_MAX_GROUP) {
-      FwdSpec f{RECNN_NET_VALUE1, 1, pp.ga, e->Ap, 0, e->Ap};
-      f.b_col = 0;
-      f.A2 = pp.xs + aoff; f.lda2 = e->ldx; f.K2 = e->K1a; f.b2_col = A;
-      f.C = e->pc.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = m0;
-      GemmProb* p = g.add();
-      g.flops += fill_fwd(e, f, rows, p);
-      p->step_add = pp.run_off;
-    }
+    if (pend && !pend_late && g.L.nprob < GEMM_MAX_GROUP) pc_l1(g);
     if ((rc = g.run(s, "fwd_l1"))) return rc;
   }
+  const bool tails = x3_tail_ok(e);
+  if (value_side && e->td3 && !e->ext_noise) {
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
+  }
+  if (tails) {
+    // ---- layers 2 + 3 of everything whose layer 1 exists, ONE launch of 32-row panels (x3tail.hip): target actor -> next_action
+    // (+ TD3 noise), critics -> h2 (the head and the backward read it), actor -> h2, gen_action, deferred policy-loss critic -> sums of Q
+    X3TailBatch tb;
+    int np = 0;
+    double fl = 0;
+    const double fl2 = 2.0 * rows * (double)e->H * e->H;
+    if (value_side) {
+      X3TailProb* p = &tb.p[np++];
+      fill_x3tail(e, p, TPOL, rows, e->tp.h1, -1, e->run_off);
+      p->out = e->xcn; p->ldo = e->ldx;
+      if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->noise_buf; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
+      fl += fl2 + 2.0 * rows * (double)e->H * A;
+      for (int c = 0; c < nc; ++c) {
+        p = &tb.p[np++];
+        fill_x3tail(e, p, VAL[c], rows, e->cv[c].h1, 2 * c + 1, e->run_off);
+        p->h2 = e->cv[c].h2;
+        fl += fl2;
+      }
+    }
+    if (actor_side) {
+      X3TailProb* p = &tb.p[np++];
+      fill_x3tail(e, p, POL, rows, e->pa.h1, actor_m1 + 1, e->run_off);
+      p->h2 = e->pa.h2; p->out = e->gen_action; p->ldo = e->Ap;
+      fl += fl2 + 2.0 * rows * (double)e->H * A;
+    }
+    if (pend && !pend_late) {
+      if ((rc = pc_tail(&tb.p[np++]))) return rc;
+      fl += fl2;
+    }
+    if (np && (rc = slot(e, "x3_tail", fl, s, [&] { return x3tail_launch(tb, np, s); }))) return rc;
+  } else {
   {  // ---- L2
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
@@ -1149,9 +1222,6 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
       if (pp.slot < LOSS_HIST_MAX) { e->hist_pol_count[pp.slot] = parts; e->hist_pol_add[pp.slot] = 0; }
     }
   }
-  if (value_side && e->td3 && !e->ext_noise) {
-    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, s); }))) return rc;
-  }
   {  // ---- L3 of the actors: next_action into the action slot of the packed next rows, gen_action
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
@@ -1167,6 +1237,7 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     }
     if ((rc = g.run(s, "fwd_l3_actors"))) return rc;
   }
+  }
   e->panel_bwd_done = false;
   e->unit_bwd = false;
   if (!value_side) return 0;
@@ -1179,9 +1250,19 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
       g.flops += 2.0 * rows * (double)e->H * A;
       fill_fwd(e, f, rows, g.add());
     }
+    if (pend_late) pc_l1(g);
     if ((rc = g.run(s, "fwd_l1_target_critic"))) return rc;
   }
-  {
+  if (tails) {   // Q'(s', a') per row: layer 2 and the last layer's dot in one panel launch
+    X3TailBatch tb;
+    for (int c = 0; c < nc; ++c) {
+      fill_x3tail(e, &tb.p[c], TVAL[c], rows, e->tq[c].h1, -1, e->run_off);
+      tb.p[c].q = e->tqv[c];
+    }
+    int np = nc;
+    if (pend_late && (rc = pc_tail(&tb.p[np++]))) return rc;
+    if ((rc = slot(e, "x3_tail_target_critic", np * 2.0 * rows * (double)e->H * e->H, s, [&] { return x3tail_launch(tb, np, s); }))) return rc;
+  } else {
     Group g(e, GEMM_FWD, 0, 0);
     for (int c = 0; c < nc; ++c) {
       FwdSpec f{TVAL[c], 2, e->tq[c].h1, Hp, 0, Hp};
@@ -1198,6 +1279,7 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     for (int c = 0; c < nc; ++c) {
       const Net& t = e->net[TVAL[c]];
       h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
+      if (tails) h.tq_in[c] = e->tqv[c];
       const Net& v = e->net[VAL[c]];
       h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
       h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];

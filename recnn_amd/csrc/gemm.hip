@@ -886,6 +886,11 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   // Measured (DDPG, 2048 rows, 4 networks' layer 1 = 256 tiles of 64 x 128): 27.9 us with 16 waves, 29.4 with 8 (wave tile 32 x 32),
   // 31.5 as 1024 tiles of 32 x 64, 42.5 as 128 tiles of 128 x 128 -- the launch moves 290 MB (590 MB in the small tiling) through
   // L2 -> LDS at 10-19 TB/s whatever the tile: what is left is the memory system, not the tile shape.
+  // Counters (profiles/r04_x3_pmc.txt): matrix cores 25 % busy, LDS array 25 % busy, no bank conflicts -- the time goes into ISSUING
+  // the LDS-DMA (one 1 KB global_load_lds_dwordx4 ~ 60 clk of CU-serial issue: 48 per 64-k stage of this tile = 1440 clk per 32
+  // logical k, 1680 observed).  Tried instead: every wave loading its own MFMA fragments straight from L2 into registers (16-byte
+  // loads, 16 rows x 64 B per instruction, 3 steps ahead, no LDS): bit-identical and 3.5x SLOWER (202 us / step against 117) -- a
+  // wave instruction that touches 16 lines costs far more than one that touches 8 contiguous ones.  Removed again.
   if (L->nprob > 0 && wg_big >= g_x3_big_min_wg) return launch_dma_x3<2, 1, 3, 16>(L, stream);
   if (L->nprob == 0 || wg <= 320) return launch_dma_x3<1, 1, 5>(L, stream);
   return launch_dma_x3<1, 1, 3>(L, stream);

@@ -13,7 +13,7 @@ import ctypes as C
 import pytest
 import torch
 
-from tests.helpers import rel_err, x3_cols, x3_pack_ref, x3_unpack_ref, x3_value
+from tests.helpers import fro_err, rel_err, x3_cols, x3_pack_ref, x3_unpack_ref, x3_value
 
 pytestmark = pytest.mark.gpu
 
@@ -154,3 +154,54 @@ def test_gemm_dw(cuda, rows, M, N, splits):
     assert rel_err(got, ref) < 3e-5
     ref_split = torch.roll(x3_value(dz).double().t() @ x3_value(x).double(), rot, dims=1)
     assert rel_err(got, ref_split) < 6e-6
+
+
+# ---------------------------------------------------------------- the row-panel launch of layers 2 + 3 (csrc/x3tail.hip)
+def _tail_run(L, algo, B, tail, mask_mode, steps=3):
+    from tests.test_gpu_engine import _engine, _init_nets, _rand_batch
+    S, A, H = 1290, 128, 256
+    td3 = algo == "td3"
+    actor, critics = _init_nets(8, S, A, H, 2 if td3 else 1)
+    batch = _rand_batch(B, S, A, torch.Generator().manual_seed(31))
+    eng = _engine(algo, S, A, H, B, "bf16x3", mask_mode=mask_mode, seed=17)
+    eng.set_tuning(x3_tail=tail)
+    nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
+    if td3:
+        nets += [(L.NET_VALUE2, critics[1]), (L.NET_TARGET_VALUE2, critics[1])]
+    for ni, p in nets:
+        eng.load_params(ni, p)
+    eng.set_hyper(policy_opt=dict(lr=1e-4, weight_decay=1e-2), value_opt=dict(lr=1e-4, weight_decay=1e-2), policy_every=2)
+    eng.set_counters()
+    eng.pack_batch(batch["state"], batch["action"], batch["reward"], batch["next_state"], batch["done"])
+    if mask_mode == "external":
+        gm = torch.Generator().manual_seed(5)
+        masks = [(torch.rand(B, H, generator=gm) < 0.5).to(torch.uint8) for _ in range(8 if td3 else 6)]
+        eng.set_external(masks=masks, noise=(torch.randn(B, A, generator=gm) * 0.3) if td3 else None)
+    out = []
+    names = ("next_action", "gen_action", "expected", "target_q", "q1", "delta1", "critic1_h2", "actor_h2") + (("q2",) if td3 else ())
+    for t in range(steps):
+        eng.step(B, True, t)
+        torch.cuda.synchronize()
+        out.append(dict(loss=eng.losses(), bufs={n: eng.buffer(n, B).float().clone() for n in names},
+                        p={ni: eng.params[ni].clone() for ni, _ in nets}))
+    return out
+
+
+@pytest.mark.parametrize("algo,B,mask_mode", [("ddpg", 2048, "hash"), ("ddpg", 333, "hash"), ("td3", 1024, "external"), ("ddpg", 31, "none")])
+def test_row_panel_tail_equals_per_layer_gemms(cuda, algo, B, mask_mode):
+    """x3_tail = 1 (layers 2 + 3 as row-panel launches, h2 kept on chip) against x3_tail = 0 (one grouped GEMM launch per layer):
+    the same three-product contraction of the same split operands in a different k order, so every buffer of a step agrees to
+    fp32 summation-order distance -- and the dropout pattern, which is a function of (row, column, stream, step) only, exactly."""
+    L = _lib()
+    ref = _tail_run(L, algo, B, 0, mask_mode)
+    new = _tail_run(L, algo, B, 1, mask_mode)
+    for t, (a, b) in enumerate(zip(ref, new)):
+        for n in a["bufs"]:
+            x, y = a["bufs"][n], b["bufs"][n]
+            assert rel_err(y, x) < 2e-5, (t, n, rel_err(y, x))
+            if n.endswith("_h2") and mask_mode != "none":
+                assert torch.equal(x == 0, y == 0) or float(((x == 0) != (y == 0)).float().mean()) < 1e-4, (t, n)
+        for k in a["loss"]:
+            assert abs(a["loss"][k] - b["loss"][k]) <= 2e-5 * max(1.0, abs(a["loss"][k])), (t, k, a["loss"], b["loss"])
+        for ni in a["p"]:
+            assert fro_err(b["p"][ni], a["p"][ni]) < 2e-4, (t, ni)     # Adam at the sign-sensitive elements
