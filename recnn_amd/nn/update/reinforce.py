@@ -7,6 +7,11 @@ action distribution with the critic, critic TD update, and every `policy_step` s
 The catalogue-sized work (the [B, hidden] x [hidden, n_items] GEMMs, softmax / sampling / log-prob over n_items, their
 backward, the optimizer passes over the n_items x hidden weights, the soft updates) runs in the HIP kernels; what is left
 to torch here is algebra on per-row vectors of length B and on the `policy_step` episode scalars.
+
+`nets["policy_net"]` / `nets["target_policy_net"]` may be `recnn_amd.parallel.VocabParallelDiscreteActor` and the critics
+`VocabParallelCritic` (one process per GPU, the catalogue dimension of the actor's head and of the critic's first layer sharded over
+the ranks): the same function body runs on every rank, "probabilities" are then each rank's columns (tests/test_vocab_parallel_gloo.py,
+tests/test_gpu_reinforce.py).
 """
 import torch
 
@@ -67,8 +72,9 @@ class ChooseREINFORCE:
 def reinforce_update(batch, params, nets, optimizer, device=torch.device("cpu"), debug=None, writer=utils.DummyWriter(),
                      learn=True, step=-1):
     learn = True   # REINFORCE has no evaluation mode: every call acts and records (reinforce.py:80-81)
-    state, action, reward, next_state, done = data.get_base_batch(batch)
     policy = nets["policy_net"]
+    # (the policy's device, not get_base_batch's default "cuda" = cuda:0: reinforce.py:83 passes device=device)
+    state, action, reward, next_state, done = data.get_base_batch(batch, device=next(policy.parameters()).device)
     predicted_probs = policy.select_action(state=state, action=action, K=params["K"], learn=learn, writer=writer, step=step)
     if not isinstance(writer, utils.DummyWriter):
         mx = predicted_probs.max(dim=1).values

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 
-__all__ = ["DataParallelStepper", "PeerComm", "VocabParallelDiscreteActor", "shard_users"]
+__all__ = ["DataParallelStepper", "PeerComm", "VocabParallelCritic", "VocabParallelDiscreteActor", "shard_users"]
 
 
 def shard_users(perm: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -430,6 +430,11 @@ class VocabParallelDiscreteActor(torch.nn.Module):
         self.linear1 = torch.nn.Linear(input_dim, hidden_size)
         self.linear2 = torch.nn.Linear(hidden_size, self.n1 - self.n0)
         self.ops = ops
+        self.saved_log_probs, self.rewards, self.correction, self.lambda_k = [], [], [], []
+        self.action_source = {"pi": "pi", "beta": "beta"}
+        self.select_action = self._select_action
+        self.forced_actions = []
+        self._draws = 0
 
     @classmethod
     def from_full(cls, actor, group=None, ops=None):
@@ -447,6 +452,75 @@ class VocabParallelDiscreteActor(torch.nn.Module):
         if not x.is_cuda:
             raise L.RecnnHipError("VocabParallelDiscreteActor runs on the GPU only (no CPU fallback); tests pass ops= explicitly")
         return _HipOps
+
+    # ---- the episode interface of DiscreteActor (recnn/nn/models.py:86-184), so that `reinforce_update` takes this module as
+    # nets["policy_net"] / nets["target_policy_net"]: every "probabilities" it returns is THIS RANK'S COLUMNS [n0, n1) of the
+    # softmax over the whole catalogue -- what VocabParallelCritic contracts with its own columns of layer 1.
+    def forward(self, inputs):
+        with torch.no_grad():
+            _, probs = self.log_prob(inputs, torch.zeros(inputs.shape[0], dtype=torch.int64, device=inputs.device))
+        return probs
+
+    def gc(self):
+        del self.rewards[:]
+        del self.saved_log_probs[:]
+        del self.correction[:]
+        del self.lambda_k[:]
+
+    def _draw(self, state):
+        """the policy's own action: queued in `forced_actions` (replays, parity tests) or sampled, the same on every rank"""
+        if self.forced_actions:
+            return self.forced_actions.pop(0).to(state.device)
+        self._draws += 1
+        return self.sample(state, seed=(torch.initial_seed() + 7919 * self._draws) % (1 << 62))
+
+    def _select_action(self, state, **kwargs):
+        log_prob, probs = self.log_prob(state, self._draw(state))
+        self.saved_log_probs.append(log_prob)
+        return probs
+
+    def pi_beta_sample(self, state, beta, action, **kwargs):
+        """models.py:113-141 with a REPLICATED behaviour policy: `beta(state, action=...)` returns probabilities over the whole
+        catalogue on every rank (the notebook's Beta is one Linear: it is not sharded here); its action is drawn by inverse CDF
+        from a generator seeded alike on every rank."""
+        beta_probs = beta(state.detach(), action=action).detach()
+        self._draws += 1
+        u = torch.rand(state.shape[0], generator=torch.Generator().manual_seed((torch.initial_seed() + 7919 * self._draws) % (1 << 62)))
+        cdf = beta_probs.cumsum(1)
+        beta_action = torch.searchsorted((cdf / cdf[:, -1:]).contiguous(), u.to(state.device)[:, None].contiguous(), right=True)[:, 0]
+        beta_action = beta_action.clamp(max=beta_probs.shape[1] - 1)
+        eps = torch.finfo(torch.float32).eps
+
+        def beta_lp(act):
+            pr = beta_probs / beta_probs.sum(-1, keepdim=True)
+            return torch.log(pr.clamp(eps, 1 - eps)).gather(-1, act.reshape(-1, 1).to(torch.int64)).reshape(act.shape)
+        pi_action = beta_action if self.action_source["pi"] == "beta" else self._draw(state)
+        pi_log_prob, pi_probs = self.log_prob(state, pi_action)
+        beta_log_prob = beta_lp(beta_action if self.action_source["beta"] == "beta" else pi_action)
+        return pi_log_prob, beta_log_prob, pi_probs
+
+    def _select_action_with_correction(self, state, beta, action, writer, step, **kwargs):
+        pi_log_prob, beta_log_prob, pi_probs = self.pi_beta_sample(state, beta, action)
+        corr = torch.exp(pi_log_prob) / torch.exp(beta_log_prob)
+        writer.add_histogram("correction", corr, step)
+        writer.add_histogram("pi_log_prob", pi_log_prob, step)
+        writer.add_histogram("beta_log_prob", beta_log_prob, step)
+        self.correction.append(corr)
+        self.saved_log_probs.append(pi_log_prob)
+        return pi_probs
+
+    def _select_action_with_TopK_correction(self, state, beta, action, K, writer, step, **kwargs):
+        pi_log_prob, beta_log_prob, pi_probs = self.pi_beta_sample(state, beta, action)
+        corr = torch.exp(pi_log_prob) / torch.exp(beta_log_prob)
+        l_k = K * (1 - torch.exp(pi_log_prob)) ** (K - 1)
+        writer.add_histogram("correction", corr, step)
+        writer.add_histogram("l_k", l_k, step)
+        writer.add_histogram("pi_log_prob", pi_log_prob, step)
+        writer.add_histogram("beta_log_prob", beta_log_prob, step)
+        self.correction.append(corr)
+        self.lambda_k.append(l_k)
+        self.saved_log_probs.append(pi_log_prob)
+        return pi_probs
 
     def log_prob(self, state, actions):
         """(log_prob [B], this rank's columns [n0, n1) of the probabilities)."""
@@ -473,3 +547,112 @@ class VocabParallelDiscreteActor(torch.nn.Module):
         out = torch.where(mine, idx + 1, torch.zeros_like(idx))
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out - 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The REINFORCE critic over [state | action distribution] (recnn/nn/models.py:187-213 with action_dim = n_items): its first layer
+# is [hidden, 1290 + n_items] -- as wide as the actor's head.  Sharded the same way: rank r keeps the action columns [n0, n1) of
+# linear1 (with their gradient and optimizer state) and contracts them with ITS columns of the action distribution (what
+# VocabParallelDiscreteActor returns) or of a one-hot batch action; the [B, hidden] partial products are summed over the ranks
+# (one all-reduce of B x hidden floats per forward) and enter the replicated rest of the MLP before the first relu.
+class _ShardMatmul(torch.autograd.Function):
+    """a_shard [B, ns] x w_shard^T [ns, H] -> this rank's partial of the layer-1 pre-activation (local backward)"""
+
+    @staticmethod
+    def forward(ctx, a, w, ops):
+        ctx.save_for_backward(a, w)
+        ctx.ops = ops
+        return ops.linear(a, w, torch.zeros(w.shape[0], device=w.device), False).contiguous()
+
+    @staticmethod
+    def backward(ctx, dz):
+        a, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        ga = ctx.ops.grad_x(dz, w) if ctx.needs_input_grad[0] else None
+        gw = ctx.ops.grad_w(dz, a) if ctx.needs_input_grad[1] else None
+        return ga, gw, None
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of the partials; dL/d partial_r = dL/dy, which every rank computes alike from replicated layers"""
+
+    @staticmethod
+    def forward(ctx, partial, group):
+        out = partial.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class VocabParallelCritic(torch.nn.Module):
+    """Critic(input_dim, n_items, hidden) with linear1's ACTION columns sharded over the ranks of `group`.
+
+    Parameters: `linear1_state` (weight [H, S] and the layer's bias; replicated), `w1_action` [H, n1 - n0] (this rank's columns),
+    `linear2`, `linear3` (replicated).  Replicated layers see the same inputs on every rank, so their gradients come out
+    identical without a reduction.  `forward(state, action)`: `action` is [B, n_items] (sliced here; one-hot rows made by
+    `functional.onehot_rows` are gathered instead of contracted) or already this rank's [B, n1 - n0] columns."""
+
+    def __init__(self, input_dim, action_dim, hidden_size, group=None, ops=None):
+        super().__init__()
+        ready = dist.is_initialized()
+        self.group = group
+        self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
+        per = -(-action_dim // self.world)
+        self.n_items = action_dim
+        self.n0, self.n1 = min(per * self.rank, action_dim), min(per * (self.rank + 1), action_dim)
+        self.drop_layer = torch.nn.Dropout(p=0.5)
+        self.linear1_state = torch.nn.Linear(input_dim, hidden_size)
+        self.w1_action = torch.nn.Parameter(torch.zeros(hidden_size, self.n1 - self.n0))
+        self.linear2 = torch.nn.Linear(hidden_size, hidden_size)
+        self.linear3 = torch.nn.Linear(hidden_size, 1)
+        self.ops = ops
+
+    @classmethod
+    def from_full(cls, critic, state_dim, group=None, ops=None):
+        """this rank's share of a replicated Critic(state_dim, n_items, hidden) (same init on every rank)"""
+        n_items = critic.linear1.weight.shape[1] - state_dim
+        m = cls(state_dim, n_items, critic.linear1.weight.shape[0], group, ops)
+        with torch.no_grad():
+            m.linear1_state.weight.copy_(critic.linear1.weight[:, :state_dim])
+            m.linear1_state.bias.copy_(critic.linear1.bias)
+            m.w1_action.copy_(critic.linear1.weight[:, state_dim + m.n0:state_dim + m.n1])
+            for a, b in ((m.linear2, critic.linear2), (m.linear3, critic.linear3)):
+                a.weight.copy_(b.weight)
+                a.bias.copy_(b.bias)
+        return m.to(critic.linear1.weight.device)
+
+    def _action_part(self, action, ops):
+        from .nn import functional as Fh
+        ns = self.n1 - self.n0
+        idx = Fh.onehot_index_of(action)
+        if idx is not None:          # a one-hot batch action: the owned rows' weight columns, zeros elsewhere
+            local = idx.to(torch.int64) - self.n0
+            own = (local >= 0) & (local < ns)
+            cols = self.w1_action.index_select(1, local.clamp(0, max(ns - 1, 0))).t()
+            part = torch.where(own[:, None], cols, torch.zeros_like(cols))
+        else:
+            a = action[:, self.n0:self.n1] if action.shape[1] == self.n_items and self.world > 1 else action
+            if a.shape[1] != ns:
+                raise ValueError(f"VocabParallelCritic: action has {action.shape[1]} columns, expected {self.n_items} or this rank's {ns}")
+            part = _ShardMatmul.apply(a.float().contiguous(), self.w1_action, ops)
+        return _AllReduceSum.apply(part, self.group)
+
+    def forward(self, state, action):
+        ops = self.ops
+        if ops is None:
+            if not state.is_cuda:
+                raise L.RecnnHipError("VocabParallelCritic runs on the GPU only (no CPU fallback); tests pass ops= explicitly")
+            ops = _HipOps
+        part = self._action_part(action, ops)
+        if ops is _HipOps:
+            from .nn import functional as Fh
+            return Fh.MLPFunction.apply(state.float(), self.linear1_state.weight, self.linear1_state.bias, self.linear2.weight,
+                                        self.linear2.bias, self.linear3.weight, self.linear3.bias, self.training, torch.initial_seed(),
+                                        Fh._take_forced_masks(self, self.training), part)
+        h = self.drop_layer(torch.relu(self.linear1_state(state.float()) + part))
+        h = self.drop_layer(torch.relu(self.linear2(h)))
+        return self.linear3(h)

@@ -505,6 +505,32 @@ def test_vocab_parallel_head_on_hip_gemms(cuda, tmp_path):
     print("vocab-parallel head:", json.dumps(res))
 
 
+def test_reinforce_update_sharded_over_two_ranks_on_hip_kernels(cuda, tmp_path):
+    """`reinforce_update` (recnn/nn/update/reinforce.py:69-129), unchanged, with the catalogue dimension of the
+    actor's head and of the critic's first layer sharded over 2 ranks (both on this GPU; HIP GEMM / MLP kernels, [B, hidden]
+    partials summed over gloo) == the same 12 steps on the unsharded recnn_amd.nn.DiscreteActor / Critic: the two policy updates'
+    losses and every network's parameters (targets included) at 1e-4."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29910 + (os.getpid() % 30)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "vp2_worker.py"), str(tmp_path), "update"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    res = json.load(open(os.path.join(tmp_path, "vp2_update.json")))
+    assert [x["n0"] for x in res] == [0, 10_000] and res[1]["n1"] == 20_000
+    for x in res:
+        a, b = np.asarray(x["losses_shard"]), np.asarray(x["losses_full"])
+        assert a.shape == (2, 2) and rel_err(a, b) < 1e-4, (a, b)
+        for k, v in x.items():
+            if k.startswith(("policy_", "value_", "target_")):
+                assert v < 1e-4, (x["rank"], k, v)
+    print("sharded reinforce_update:", json.dumps(res))
+
+
 @pytest.mark.parametrize("opt_kind", ["torch_adam", "hip_adam"])
 def test_beta_net_replays_the_notebooks_class(cuda, golden_dir, opt_kind):
     """recnn_amd.nn.Beta -- the learned behaviour policy of the Top-K correction notebook (cell 3: Linear + Softmax, cross entropy of
