@@ -5,7 +5,7 @@ T=${1:-stats}
 mkdir -p gpurun_out
 cd /tmp
 rm -rf /tmp/prof_$T
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 4000 --warmup 200 --repeats 1 --no-cpu-baseline --no-traffic $BENCH_ARGS > /tmp/prof_$T.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$T -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 4000 --warmup 200 --repeats 1 --no-cpu-baseline --no-traffic --no-extras $BENCH_ARGS > /tmp/prof_$T.json 2>/dev/null
 f=$(find /tmp/prof_$T -name "*kernel_stats.csv" | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/${T}_kernel_stats.csv 2>/dev/null
 python - <<PY
