@@ -137,6 +137,11 @@ typedef struct recnn_gemm_args {
   int64_t dw_slab_stride;
   int dw_valid_cols;      /* dw: columns >= this are not stored */
   int dw_col_rot;         /* dw: stored column = (col + rot) mod valid_cols */
+  void* ws; int64_t ws_bytes;   /* fwd, optional: caller-owned scratch.  A one-segment product with a LONG contraction and few output
+                             tiles (K >= 32768, at most 64 tiles of 128 x 128: [256, 2048] x K = 100k, the catalogue-wide
+                             contractions of REINFORCE) is then split into up to 8 K slices, one workgroup column each; their fp32
+                             partial products (slices * M * N floats must fit) are summed in slice order by a second launch that
+                             applies the epilogue.  NULL: one workgroup per tile walks the whole K. */
 } recnn_gemm_args;
 
 /* C[M,N] = epi( sum_seg A_seg[M,K] * B_seg[N,K]^T ) */

@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ("colsum", C.c_void_p),
         ("dw_splits", C.c_int), ("dw_slab_stride", C.c_int64),
         ("dw_valid_cols", C.c_int), ("dw_col_rot", C.c_int),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 

@@ -97,6 +97,8 @@ struct GemmLaunch {
   GemmBatch batch;
   const DwVec* vec;   // dW launches only (bf16 DMA kernel), may be NULL
   const GemmTune* tune;   // NULL = defaults
+  float* ws;              // forward, optional: scratch for split-K partial products (recnn_gemm_args::ws)
+  int64_t ws_bytes;
 };
 
 void gemm_prob_init(GemmProb* p);

@@ -923,6 +923,92 @@ template <class TC> static int launch_dma_wide(GemmLaunch* L, hipStream_t stream
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (wide) launch");
 }
 
+// ------------------------------------------------------------------ split-K forward (long contraction, few output tiles)
+// [256, 2048] x K = 100k (REINFORCE: d loss / d hidden = dlogits x W2 over the catalogue, and the critic's first layer over action
+// distributions, recnn/nn/models.py:93-95, 207-209) is 32 tiles of 128 x 128: one workgroup per tile leaves 7/8 of the machine
+// idle and walks 100k k each (448 us with the 32 x 64 tiling).  Here K is cut into S <= 8 slices, slice s a grouped problem of the
+// wide kernel that writes its raw fp32 partial product; splitk_finish_kernel sums the slices in slice order (deterministic) and
+// applies the forward epilogue -- the arithmetic of epilogue_fwd, element by element.
+template <class TC>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmProb P, const float* __restrict__ ws, int S, int64_t stride) {
+  const int n4 = (P.N + 3) / 4;
+  const int64_t total = (int64_t)P.M * n4;
+  uint32_t key = 0;
+  if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), nb = (int)(i - (int64_t)m * n4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = nb + 3 < P.N && !(P.N & 3);
+    for (int s = 0; s < S; ++s) {
+      const float* src = ws + s * stride + (int64_t)m * P.N + nb;
+      if (vec) { const float4 t = *(const float4*)src; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+      else for (int r = 0; r < 4; ++r) if (nb + r < P.N) v[r] += src[r];
+    }
+    uint32_t word = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(nb >> 2));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb + r;
+      if (n >= P.N) break;
+      float x = v[r] + (P.bias ? P.bias[n] : 0.f);
+      if (P.addend) {
+        const int ma = P.add_row_div > 1 ? m / P.add_row_div : m;
+        const float z = P.addend[(int64_t)ma * P.ld_add + n];
+        x += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+      }
+      if (P.relu) x = fmaxf(x, 0.f);
+      if (P.yref) {
+        const float y = tc_load((const TC*)P.yref + (int64_t)m * P.ldy + n);
+        x = y > 0.f ? x * P.dx_scale : 0.f;
+      }
+      if (P.mask_mode == RECNN_MASK_EXTERNAL) x = P.mask[(int64_t)m * P.ld_mask + n] ? x * 2.f : 0.f;
+      else if (P.mask_mode == RECNN_MASK_HASH) x = mask_keep(word, m & 3, r) ? x * 2.f : 0.f;
+      if (P.c_f32) ((float*)P.C)[(int64_t)m * P.ldc + n] = x;
+      else tc_store((TC*)P.C + (int64_t)m * P.ldc + n, x);
+    }
+  }
+}
+
+constexpr int SPLITK_MIN_K = 32768, SPLITK_MAX_TILES = 64;
+template <class TC> static bool splitk_wanted(const GemmLaunch* L) {
+  if (L->nprob != 1 || !L->ws) return false;
+  const GemmProb& p = L->batch.p[0];
+  if (p.nseg != 1 || p.seg[0].K < SPLITK_MIN_K || p.M < 128 || p.dot_part || p.dot_w) return false;
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  return tiles <= SPLITK_MAX_TILES;
+}
+template <class TC> static int launch_dma_splitk(GemmLaunch* L, hipStream_t stream) {
+  const GemmProb P = L->batch.p[0];
+  constexpr int ES = sizeof(TC), KB = 256 / ES;
+  const int tiles = ((P.M + 127) / 128) * ((P.N + 127) / 128);
+  const int nstage = P.seg[0].K / KB;
+  int S = 256 / tiles;
+  S = S > GEMM_MAX_GROUP ? GEMM_MAX_GROUP : S;
+  const int per = (nstage + S - 1) / S;
+  S = (nstage + per - 1) / per;
+  const int64_t stride = (int64_t)P.M * P.N;
+  if (S < 2 || S * stride * 4 > L->ws_bytes) return launch_dma_wide<TC>(L, stream);
+  GemmLaunch L2 = *L;
+  L2.nprob = S;
+  L2.ws = nullptr;
+  for (int s = 0; s < S; ++s) {
+    GemmProb& q = L2.batch.p[s];
+    q = P;
+    const int st0 = s * per, cnt = (st0 + per <= nstage ? per : nstage - st0);
+    q.seg[0].A = (const char*)P.seg[0].A + (int64_t)st0 * 256;
+    q.seg[0].B = (const char*)P.seg[0].B + (int64_t)st0 * 256;
+    q.seg[0].K = cnt * KB;
+    q.C = L->ws + s * stride; q.ldc = P.N; q.c_f32 = 1;
+    q.bias = nullptr; q.relu = 0; q.mask_mode = RECNN_MASK_NONE; q.addend = nullptr; q.yref = nullptr;
+  }
+  int rc = launch_dma_wide<TC>(&L2, stream);
+  if (rc) return rc;
+  const int64_t total = (int64_t)P.M * ((P.N + 3) / 4);
+  const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(splitk_finish_kernel<TC>, dim3(grid), dim3(256), 0, stream, P, (const float*)L->ws, S, stride);
+  return recnn_check_hip(hipGetLastError(), "splitk_finish_kernel launch");
+}
+
 template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t stream) {
   if (tune_of(L).dma_waves == 8 && L->nprob > 0) return launch_dma_nw<TC, NS, 8>(L, stream);
   return launch_dma_nw<TC, NS, 4>(L, stream);
@@ -931,6 +1017,7 @@ template <class TC, int NS> static int launch_dma_ns(GemmLaunch* L, hipStream_t 
 // Ring depth by launch size: a launch with at most ~1 workgroup per CU keeps 4 k stages in flight per workgroup
 // (5-stage ring, 120 KB of LDS); bigger grouped launches use the 3-stage ring so that 2 workgroups share a CU.
 template <class TC> static int launch_dma(GemmLaunch* L, hipStream_t stream) {
+  if (splitk_wanted<TC>(L)) return launch_dma_splitk<TC>(L, stream);
   if (L->nprob == 1 && L->batch.p[0].N >= 8192 && L->batch.p[0].M >= 128 && !L->batch.p[0].dot_part) return launch_dma_wide<TC>(L, stream);
   long wg = 0;
   for (int i = 0; i < L->nprob; ++i) wg += (long)((L->batch.p[i].M + 31) / 32) * ((L->batch.p[i].N + 63) / 64);
@@ -1090,6 +1177,7 @@ int gemm_from_args(const recnn_gemm_args* a, int mode, GemmLaunch* L) {
   p.dw_valid_cols = a->dw_valid_cols > 0 ? a->dw_valid_cols : a->N;
   p.dw_col_rot = a->dw_col_rot;
   if (mode == GEMM_DW) p.c_f32 = 1;
+  if (mode == GEMM_FWD) { L->ws = (float*)a->ws; L->ws_bytes = a->ws ? a->ws_bytes : 0; }
   return 0;
 }
 

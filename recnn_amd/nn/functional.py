@@ -168,7 +168,25 @@ def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1
         a.yref, a.ldy, a.dx_scale = yref.data_ptr(), yref.stride(0), scale
     if mask is not None:
         a.mask_mode, a.mask, a.ld_mask = L.MASK_EXTERNAL, mask.data_ptr(), mask.stride(0)
+    if K >= 32768 and x.shape[0] * N <= (1 << 20):
+        # a catalogue-long contraction with a small output: scratch for the library's split-K (recnn_gemm_args::ws)
+        ws = _splitk_scratch(x.device, 8 * x.shape[0] * N)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+
+
+_splitk_ws = {}
+
+
+def _splitk_scratch(device, floats):
+    """fp32 scratch of at least `floats` elements on `device`, kept for the process (one per device; stream-ordered reuse: every
+    product that uses it is launched on the current stream)."""
+    key = (device.type, device.index)
+    t = _splitk_ws.get(key)
+    if t is None or t.numel() < floats:
+        t = torch.empty(floats, dtype=torch.float32, device=device)
+        _splitk_ws[key] = t
+    return t
 
 
 def _dx(dz, Kc, w, N, out, yref, scale, colsum, dtype=None, c_f32=1):

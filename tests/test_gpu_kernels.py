@@ -167,6 +167,47 @@ def test_gemm_fwd(cuda, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K,tc_out", [(256, 512, 40960, False), (200, 300, 33024, True), (128, 130, 65536, False)])
+def test_gemm_fwd_split_k(cuda, dtype, M, N, K, tc_out):
+    """recnn_gemm_args::ws: a catalogue-long contraction with few output tiles is cut into K slices (gemm.hip launch_dma_splitk);
+    the second launch sums them in slice order and applies the whole forward epilogue (bias, clamped addend, relu, the backward
+    gate, external dropout mask, fp32 or compute-type output).  Against the float64 product, and against the same call without
+    scratch (one workgroup per tile): equal up to fp32 summation order.  Deterministic: two calls, the same bits."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 0.1
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    add = torch.randn(M, N, generator=g) * 3.0
+    y = torch.randn(M, N, generator=g)
+    mask = (torch.rand(M, N, generator=g) < 0.5).to(torch.uint8)
+    X, W = _tc(x, dtype).to(cuda), _tc(w, dtype).to(cuda)
+    Y = _tc(y, dtype).to(cuda)
+    bd, md, ad = b.to(cuda), mask.to(cuda), add.to(cuda)
+    ws = torch.empty(8 * M * N, device=cuda)
+    outs = []
+    for use_ws in (True, True, False):
+        out = torch.zeros(M, N, device=cuda, dtype=(torch.float32 if dtype == "fp32" else torch.bfloat16) if tc_out else torch.float32)
+        a = _args(L, dtype, M, N)
+        a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), K, K, K
+        a.C, a.ldc, a.c_f32 = out.data_ptr(), N, 0 if tc_out else 1
+        a.bias, a.relu, a.mask_mode, a.mask, a.ld_mask = bd.data_ptr(), 1, L.MASK_EXTERNAL, md.data_ptr(), N
+        a.addend, a.ld_add, a.add_clip = ad.data_ptr(), N, 1.5
+        a.yref, a.ldy, a.dx_scale = Y.data_ptr(), N, 0.5
+        if use_ws:
+            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+    ref = torch.relu(X.double().cpu() @ W.double().cpu().t() + b.double() + add.double().clamp(-1.5, 1.5))
+    ref = torch.where(Y.double().cpu() > 0, ref * 0.5, torch.zeros_like(ref)) * mask.double() * 2.0
+    tol = _tol(dtype) if not (tc_out and dtype == "bf16") else 1e-2
+    assert rel_err(outs[0], ref) < tol
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], outs[2]) < (1e-5 if not (tc_out and dtype == "bf16") else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gemm_fwd_two_segments_f32_inputs_tc_output(cuda, dtype):
     """critic layer 1 on [gen_action | state]: 2 contraction segments, fp32 packed inputs, tc output."""
     L = _lib()
