@@ -180,6 +180,19 @@ int recnn_soft_update_flat(float* target, const float* net, int64_t n, float tau
 int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step_t, float grad_scale, void* stream);
 
+/* ... and, in the same pass, a row-padded copy of the updated [n / cols, cols] parameter in another leading dimension and
+ * optionally in bfloat16 (the layout the GEMM kernels read in place of a weight whose rows are not 16-byte aligned, or the bf16
+ * operand of the catalogue-wide products): the optimizer has the new value in a register, a separate conversion pass would
+ * read 4 bytes per element again.  Padding columns [cols, ld) are not touched.  h_shadow NULL or dst NULL: plain step. */
+typedef struct recnn_shadow_out {
+  void* dst;       /* float or bfloat16 [n / cols, ld] */
+  int cols;        /* n % cols == 0 */
+  int64_t ld;      /* >= cols */
+  int bf16;        /* 1: dst is bfloat16 (round to nearest even), 0: float */
+} recnn_shadow_out;
+int recnn_adam_flat_shadow(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int step_t, float grad_scale, const recnn_shadow_out* h_shadow, void* stream);
+
 /* The same step with the 1-based step count taken from device memory: t = *step_dev + step_add.  For captured graphs
  * (recnn_amd.optim.Adam(capturable=True)): the graph advances *step_dev itself, every replay steps with the right count. */
 int recnn_adam_flat_at(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
@@ -262,6 +275,9 @@ int recnn_engine_bind_slow(recnn_engine* e, int net, float* slow);
 int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold, int step_t,
                       float grad_scale, void* stream);
+int recnn_ranger_flat_shadow(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold, int step_t,
+                             float grad_scale, const recnn_shadow_out* h_shadow, void* stream);
 
 /* =====================================================================================
  * 3b. Categorical policy head (REINFORCE)
@@ -289,6 +305,10 @@ int recnn_softmax_bwd(const float* p, int64_t ldp, int rows, int n, const float*
                       int64_t ldd, void* stream);
 /* out[r, :] = onehot(idx[r]) over n columns (columns [n, ld) zeroed). */
 int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t ld, void* stream);
+/* dst[c, r] = src[r, c]: float [rows, cols] (row stride ld) -> float or bfloat16 [cols, ldt] (ldt >= rows; columns [rows, ldt) are
+ * not touched).  The transposed copy of the policy head's W2 [n_items, hidden] that puts the catalogue on the contiguous axis
+ * for the backward product d logits x W2 (made once per weight version). */
+int recnn_transpose_rows(const float* src, int64_t ld, int rows, int cols, void* dst, int64_t ldt, int dst_bf16, void* stream);
 
 /* =====================================================================================
  * 3c. Conditional-VAE latent layer and loss (BCQ)

@@ -49,6 +49,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ShadowOut(C.Structure):
+    """include/recnn_hip.h recnn_shadow_out"""
+    _fields_ = [("dst", C.c_void_p), ("cols", C.c_int), ("ld", C.c_int64), ("bf16", C.c_int)]
+
+
 class EngineConfig(C.Structure):
     _fields_ = [
         ("algo", C.c_int), ("dtype", C.c_int), ("state_dim", C.c_int), ("action_dim", C.c_int),
@@ -126,6 +131,7 @@ SIGNATURES = {
     "recnn_hash_mask_dump_at": (_I, [_U, _P, _I, _U, _I, _I, _P, _P]),
     "recnn_soft_update_flat": (_I, [_P, _P, _L, _F, _P]),
     "recnn_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "recnn_adam_flat_shadow": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _P]),
     "recnn_adam_flat_at": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _I, _F, _P]),
     "recnn_l1_norm_flat": (_I, [_P, _L, _P, _P, _P]),
     "recnn_engine_query": (_I, [C.POINTER(EngineConfig), C.POINTER(EngineSizes)]),
@@ -138,6 +144,7 @@ SIGNATURES = {
     "recnn_logprob_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "recnn_softmax_bwd": (_I, [_P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_onehot_rows": (_I, [_P, _I, _I, _P, _L, _P]),
+    "recnn_transpose_rows": (_I, [_P, _L, _I, _I, _P, _L, _I, _P]),
     "recnn_vae_latent_fwd": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_vae_latent_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "recnn_vae_loss_fwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _P, _P]),
@@ -145,6 +152,7 @@ SIGNATURES = {
     "recnn_csr_workspace_bytes": (_I, [_L, C.POINTER(_L)]),
     "recnn_csr_build": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P, _P, C.POINTER(_L), _P, _L, _P]),
     "recnn_ranger_flat": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P]),
+    "recnn_ranger_flat_shadow": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _I, _F, _I, _F, _P, _P]),
     "recnn_engine_bind_external": (_I, [_P, _P, _P]),
     "recnn_engine_bind_sampler": (_I, [_P, C.POINTER(Sampler)]),
     "recnn_engine_profile": (_I, [_P, _I, _I, _I, _P, C.POINTER(_F), C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(_I)]),

@@ -479,10 +479,31 @@ extern "C" int recnn_soft_update_flat(float* target, const float* net, int64_t n
   return recnn_check_hip(hipGetLastError(), "soft_update_flat");
 }
 
+// A row-padded copy of a 2-D parameter in another leading dimension / type (recnn_shadow_out: what the GEMM kernels read in place of
+// a [rows, cols] weight whose rows are not 16-byte aligned or not in the compute type), rewritten by the optimizer pass that has the
+// new value in a register anyway: element i of the flat array is (i / cols, i % cols) of the copy.
+struct ShadowDst { void* dst; int cols; int64_t ld; int bf16; };
+__device__ __forceinline__ void shadow_put(const ShadowDst& sh, int64_t i, float v) {
+  const int64_t r = i / sh.cols;
+  const int c = (int)(i - r * sh.cols);
+  if (sh.bf16) ((bf16_t*)sh.dst)[r * sh.ld + c] = f2bf(v);
+  else ((float*)sh.dst)[r * sh.ld + c] = v;
+}
+static int shadow_arg(const recnn_shadow_out* h, int64_t n, ShadowDst* out) {
+  out->dst = nullptr; out->cols = 1; out->ld = 0; out->bf16 = 0;
+  if (!h || !h->dst) return 0;
+  RECNN_REQUIRE(h->cols > 0 && h->ld >= h->cols && n % h->cols == 0, "optimizer shadow: the flat length %lld is not rows x cols = . x %d (ld %lld)",
+                (long long)n, h->cols, (long long)h->ld);
+  out->dst = h->dst; out->cols = h->cols; out->ld = h->ld; out->bf16 = h->bf16 ? 1 : 0;
+  return 0;
+}
+
+template <bool SH>
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float lr, float beta1, float beta2,
                                                         float eps, float wd, float step_size, float bc2_sqrt, float gs, float omb1,
-                                                        float omb2) {
+                                                        float omb2, const ShadowDst sh) {
+#pragma clang fp contract(off)      // (both instantiations must round alike: which products fuse into FMAs is the compiler's choice per body)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pi = p[i];
     float gi = g[i] * gs;
@@ -493,19 +514,32 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if (SH) shadow_put(sh, i, pi);
   }
 }
-extern "C" int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, int step_t, float grad_scale, void* stream) {
+extern "C" int recnn_adam_flat_shadow(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                      float eps, float weight_decay, int step_t, float grad_scale, const recnn_shadow_out* h_shadow,
+                                      void* stream) {
   RECNN_REQUIRE(p && g && m && v && n >= 0 && step_t >= 1, "adam_flat: bad arguments");
   if (n == 0) return 0;
+  ShadowDst sh;
+  int rc = shadow_arg(h_shadow, n, &sh);
+  if (rc) return rc;
   const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
   const double bc1 = 1.0 - pow(b1, (double)step_t), bc2 = 1.0 - pow(b2, (double)step_t);
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2));
+  if (sh.dst)
+    hipLaunchKernelGGL(adam_flat_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
+  else
+    hipLaunchKernelGGL(adam_flat_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
   return recnn_check_hip(hipGetLastError(), "adam_flat");
+}
+extern "C" int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step_t, float grad_scale, void* stream) {
+  return recnn_adam_flat_shadow(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_t, grad_scale, nullptr, stream);
 }
 
 // The same step with the step count on the DEVICE (t = *t_ptr + t_add): a captured graph replays it with the count the graph
@@ -514,6 +548,7 @@ __global__ __launch_bounds__(256) void adam_flat_at_kernel(float* __restrict__ p
                                                            float* __restrict__ v, int64_t n, float lr, float beta2, float eps, float wd,
                                                            double b1, double b2, const int32_t* __restrict__ t_ptr, int t_add, float gs,
                                                            float omb1, float omb2) {
+#pragma clang fp contract(off)      // the same roundings as adam_flat_kernel: a captured step and an eager one stay bit-identical
   const double t = (double)(*t_ptr + t_add);
   const float step_size = (float)((double)lr / (1.0 - pow(b1, t)));
   const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, t));
@@ -565,10 +600,12 @@ extern "C" int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, flo
   return recnn_check_hip(hipGetLastError(), "l1_norm_flat");
 }
 
+template <bool SH>
 __global__ __launch_bounds__(256) void ranger_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, float* __restrict__ slow, int64_t n, float lr,
                                                           float beta1, float beta2, float eps, float wd, float la_alpha, int la_sync,
-                                                          int rect, float step, float gs, float omb1, float omb2) {
+                                                          int rect, float step, float gs, float omb1, float omb2, const ShadowDst sh) {
+#pragma clang fp contract(off)
   const float sl_lr = step * lr;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pi = p[i], mi = m[i], vi = v[i];
@@ -585,19 +622,33 @@ __global__ __launch_bounds__(256) void ranger_flat_kernel(float* __restrict__ p,
       slow[i] = si;
     }
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if (SH) shadow_put(sh, i, pi);
   }
 }
-extern "C" int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold,
-                                 int step_t, float grad_scale, void* stream) {
+extern "C" int recnn_ranger_flat_shadow(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1,
+                                        float beta2, float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold,
+                                        int step_t, float grad_scale, const recnn_shadow_out* h_shadow, void* stream) {
   RECNN_REQUIRE(p && g && m && v && slow && n >= 0 && step_t >= 1, "ranger_flat: bad arguments");
   if (n == 0) return 0;
+  ShadowDst sh;
+  int rc = shadow_arg(h_shadow, n, &sh);
+  if (rc) return rc;
   const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
   const RadamScalars rs = radam_scalars(step_t, log(b1), log(b2), b2, (double)nsma_threshold);
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(ranger_flat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
-                     weight_decay, la_alpha, (la_k > 0 && step_t % la_k == 0) ? 1 : 0, rs.rect, rs.step, grad_scale,
-                     (float)(1.0 - b1), (float)(1.0 - b2));
+  const int sync = (la_k > 0 && step_t % la_k == 0) ? 1 : 0;
+  if (sh.dst)
+    hipLaunchKernelGGL(ranger_flat_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
+                       weight_decay, la_alpha, sync, rs.rect, rs.step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
+  else
+    hipLaunchKernelGGL(ranger_flat_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
+                       weight_decay, la_alpha, sync, rs.rect, rs.step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
   return recnn_check_hip(hipGetLastError(), "ranger_flat");
+}
+extern "C" int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, float la_alpha, int la_k, float nsma_threshold,
+                                 int step_t, float grad_scale, void* stream) {
+  return recnn_ranger_flat_shadow(p, g, m, v, slow, n, lr, beta1, beta2, eps, weight_decay, la_alpha, la_k, nsma_threshold, step_t,
+                                  grad_scale, nullptr, stream);
 }

@@ -290,6 +290,29 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// dst[c][r] = src[r][c]: fp32 [R, C] -> fp32 or bf16 [C, ldt].  The backward of the policy head contracts d logits [rows, n_items]
+// with W2 [n_items, hidden] over the CATALOGUE -- W2 is k-strided for that product; its transpose (made once per weight version)
+// puts the contraction on the contiguous axis for the LDS-DMA kernels.  64 x 64 tiles through LDS (pitch 65: no bank conflicts),
+// both sides coalesced: 256-byte reads, 128 / 256-byte writes.  (torch's strided copy_ takes 3.4 ms for [100k, 2048]; this 0.3.)
+template <class TD>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const float* __restrict__ src, int64_t ld, int R, int C, TD* __restrict__ dst,
+                                                             int64_t ldt) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = r0 + ty + 4 * j, c = c0 + tx;
+    tile[ty + 4 * j][tx] = (r < R && c < C) ? src[(int64_t)r * ld + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = c0 + ty + 4 * j, r = r0 + tx;
+    if (c < C && r < R) tc_store(dst + (int64_t)c * ldt + r, tile[tx][ty + 4 * j]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -345,6 +368,16 @@ int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t l
   const int l4 = (int)(ld / 4);
   hipLaunchKernelGGL(onehot_kernel, dim3((l4 + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, (hipStream_t)stream, idx, rows, n, out, ld);
   return recnn_check_hip(hipGetLastError(), "onehot_kernel launch");
+}
+
+int recnn_transpose_rows(const float* src, int64_t ld, int rows, int cols, void* dst, int64_t ldt, int dst_bf16, void* stream) {
+  RECNN_REQUIRE(src && dst && rows >= 0 && cols >= 0 && ld >= cols && ldt >= rows, "transpose_rows: bad arguments");
+  if (rows == 0 || cols == 0) return 0;
+  RECNN_REQUIRE((rows + 63) / 64 <= 65535, "transpose_rows: more than 4M rows");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dst_bf16) hipLaunchKernelGGL(transpose_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, cols, (bf16_t*)dst, ldt);
+  else hipLaunchKernelGGL(transpose_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, cols, (float*)dst, ldt);
+  return recnn_check_hip(hipGetLastError(), "transpose_rows_kernel launch");
 }
 
 }  // extern "C"

@@ -115,6 +115,35 @@ def _derived_of(w, kind, build):
     return out
 
 
+def shadow_target(p):
+    """(kind, tensor) of a cached row-padded copy of the 2-D parameter `p` (same rows and columns, wider leading dimension, fp32 or
+    bf16: the "padded" / "bf16..." layouts above; transposed copies do not qualify) that is CURRENT -- an optimizer kernel that
+    writes `p` can rewrite it in the same pass (`recnn_*_flat_shadow`) instead of leaving a full conversion pass to the next
+    forward -- or None.  The caller reports the write with `shadow_written`."""
+    if p.dim() != 2 or not p.is_cuda or torch.cuda.is_current_stream_capturing():
+        return None
+    tag = (p._version, p.data_ptr(), tuple(p.shape), _written.get(id(p), 0))
+    best = None
+    for (pid, kind), (ref, have, out) in _derived.items():
+        if pid != id(p) or ref() is not p or have != tag or kind.startswith("transposed"):
+            continue
+        if out.dim() != 2 or out.stride(1) != 1 or out.shape[0] < p.shape[0] or out.shape[1] < p.shape[1]:
+            continue
+        if out.dtype not in (torch.float32, torch.bfloat16) or out.data_ptr() == p.data_ptr():
+            continue
+        if best is None or (out.dtype == torch.bfloat16 and best[1].dtype != torch.bfloat16):
+            best = (kind, out)
+    return best
+
+
+def shadow_written(p, kind):
+    """`p` was stepped (its version already bumped) and the kernel rewrote the cached layout `kind`: it is current again."""
+    key = (id(p), kind)
+    hit = _derived.get(key)
+    if hit is not None and hit[0]() is p:
+        _derived[key] = (hit[0], (p._version, p.data_ptr(), tuple(p.shape), _written.get(id(p), 0)), hit[2])
+
+
 _catalogue_dtype = "fp32"
 
 
@@ -223,7 +252,9 @@ class MLPFunction(torch.autograd.Function):
         # catalogue-wide layer 1 (the critic over action distributions) in bf16 mode: the fp32 operands are only
         # materialised when a backward pass will need them
         big16 = _catalogue_dtype == "bf16" and K >= 4096
-        lean = big16 and not any(ctx.needs_input_grad)
+        # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(): the reward / target forwards of
+        #  reinforce_update run there and must not pay an 830 MB fp32 copy of W1 they never read)
+        lean = big16 and not (torch.is_grad_enabled() and any(ctx.needs_input_grad))
         xp = None if lean else _pad(x, B, Kp)
         if lean:
             w1p = None
@@ -653,20 +684,23 @@ class DiscretePolicyFunction(torch.autograd.Function):
         L.call("recnn_logprob_bwd", L.ptr(probs), probs.stride(0), B, N, L.ptr(act), L.ptr(g), L.ptr(stat), L.ptr(dlog), ldn, acc,
                L.ptr(gb2), L.ptr(scratch), s)
         del scratch
-        gw2 = torch.empty(N, H, device=dev)
         gdt = L.BF16 if bf16 else None
         h_op = h.to(torch.bfloat16) if bf16 else h       # [rows, hidden]: small next to the catalogue operands
-        _dw(dlog, N, h_op, H, gw2, dtype=gdt)
+        if _episode["on"] and dprobs is None and ctx.w2_param.is_leaf:
+            gw2 = None                                   # ONE dW over the whole episode's rows at the end of the pass (episode_backward)
+        else:
+            gw2 = torch.empty(N, H, device=dev)
+            _dw(dlog, N, h_op, H, gw2, dtype=gdt)
         dz1 = torch.zeros(B, Hp, device=dev)
         # dZ1 = (dlogits W2) * [h > 0]: contraction over the catalogue.  W2 is [n_items, hidden], k-strided for this product;
         # its transpose (made once per weight version, shared by the backward passes of a whole episode) puts the
         # contraction on the contiguous axis, so the LDS-DMA forward kernel runs it (measured 4.2 -> 1.3 ms at 256 x 100k x 2048)
         def transposed(w):
-            t = torch.zeros(H, ldn, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
-            t[:, :N] = w.t()
-            return t
+            return transposed_rows(w, ldn, bf16)
         w2t = _derived_of(ctx.w2_param, "transposed_bf16" if bf16 else "transposed", transposed)
         _fwd(dlog, ldn, w2t, None, dz1, Hp, H, False, None, yref=h_op, scale=1.0, dtype=gdt)
+        if gw2 is None:
+            _episode["pending"].setdefault(id(ctx.w2_param), (ctx.w2_param, []))[1].append((dlog, h_op, gdt))
         del dlog
         gb1 = dz1[:, :H].sum(0)
         gw1 = torch.empty(H, K, device=dev)
@@ -676,6 +710,53 @@ class DiscretePolicyFunction(torch.autograd.Function):
             gx = torch.empty(B, K, device=dev)
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
         return gx, gw1, gb1, gw2, gb2, None, None, None
+
+
+def transposed_rows(w, ldt, bf16=False):
+    """[cols, ldt] (fp32 or bf16, padding columns zero) with out[c, r] = w[r, c], by the tiled HIP transpose (recnn_transpose_rows)."""
+    w = w.detach().float().contiguous()
+    R, Cc = w.shape
+    t = torch.zeros(Cc, ldt, device=w.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+    L.call("recnn_transpose_rows", L.ptr(w), w.stride(0), R, Cc, L.ptr(t), ldt, int(bool(bf16)), L.current_stream())
+    return t
+
+
+# ---- the policy head's weight gradient over an EPISODE.  ChooseREINFORCE's loss is a sum over the `policy_step` steps of the
+# episode, each term a separate autograd node of DiscretePolicyFunction: left to autograd, every node computes its own
+# [n_items, hidden] gradient (a dW launch that writes 819 MB at 100k x 2048) and AccumulateGrad adds them one by one (nine 819 MB
+# add_ passes).  Inside `episode_backward()` the nodes keep their d logits instead and ONE dW GEMM over all the episode's rows
+# (k = steps x batch) writes the gradient once; it is added to `.grad` like autograd would.
+_episode = {"on": False, "pending": {}}
+
+
+class episode_backward:
+    """`with episode_backward(): loss.backward()` -- see above.  Only nodes whose log-prob (not the probabilities) carries the
+    gradient take part; everything else in the graph is untouched."""
+
+    def __enter__(self):
+        if _episode["on"]:
+            raise RuntimeError("episode_backward is not re-entrant")
+        _episode["on"], _episode["pending"] = True, {}
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        pending, _episode["pending"], _episode["on"] = _episode["pending"], {}, False
+        if exc_type is not None:
+            return False
+        for w2, terms in pending.values():
+            N, H = w2.shape
+            gdt = terms[0][2]
+            dlog = terms[0][0] if len(terms) == 1 else torch.cat([t[0] for t in terms], 0)
+            h_op = terms[0][1] if len(terms) == 1 else torch.cat([t[1] for t in terms], 0)
+            gw2 = torch.empty(N, H, device=w2.device)
+            _dw(dlog, N, h_op, H, gw2, dtype=gdt)
+            del dlog, h_op
+            with torch.no_grad():
+                if w2.grad is None:
+                    w2.grad = gw2
+                else:
+                    w2.grad.add_(gw2)
+        return False
 
 
 def discrete_policy(x, module, actions=None, sample=False):
@@ -763,12 +844,36 @@ def onehot_index_of(t):
     return tag[0]
 
 
+class OneHotLayer1Function(torch.autograd.Function):
+    """(W1[:, :S], W1[:, S + idx]^T) of a critic's first layer over [state | one-hot action].  Written as plain slicing +
+    index_select, autograd answers with TWO catalogue-wide gradients for W1 -- zeros(W1) with the state block copied in, zeros(W1)
+    with the columns scattered -- a clone and an add_ over them (at [2048, 101290]: two 830 MB fills, a copy and an add per step,
+    1.2 ms); this node builds the ONE dense gradient the optimizer reads: a fill and two small writes."""
+
+    @staticmethod
+    def forward(ctx, w1, idx, n_state):
+        ctx.save_for_backward(idx)
+        ctx.meta = (tuple(w1.shape), int(n_state))
+        return w1[:, :n_state].contiguous(), w1.index_select(1, idx + n_state).t().contiguous()
+
+    @staticmethod
+    def backward(ctx, g_state, g_cols):
+        (idx,) = ctx.saved_tensors
+        shape, n_state = ctx.meta
+        ref = g_state if g_state is not None else g_cols
+        g = torch.zeros(shape, dtype=torch.float32, device=ref.device)
+        if g_state is not None:
+            g[:, :n_state] = g_state
+        if g_cols is not None:
+            g.index_add_(1, idx + n_state, g_cols.t().float())
+        return g, None, None
+
+
 def mlp_onehot(state, idx, n_state, module, train: bool):
     """`mlp(cat([state, onehot(idx)], 1))` without the one-hot operand: layer 1 is state W1[:, :S]^T + W1[:, S + idx]^T + b1
     (the column gather enters the GEMM epilogue before the relu); autograd scatters the gathered columns' gradient back."""
     w1 = module.linear1.weight
-    w_state = w1[:, :n_state]
-    cols = w1.index_select(1, idx + n_state).t()          # [B, H]
+    w_state, cols = OneHotLayer1Function.apply(w1, idx, n_state)           # [H, S], [B, H]
     return MLPFunction.apply(state.float(), w_state, module.linear1.bias, module.linear2.weight, module.linear2.bias,
                              module.linear3.weight, module.linear3.bias, train, torch.initial_seed(),
                              _take_forced_masks(module, train), cols)

@@ -63,7 +63,12 @@ class ChooseREINFORCE:
         policy_loss = self.method(policy, returns)
         if learn:
             optimizer.zero_grad()
-            policy_loss.backward()
+            if policy_loss.is_cuda:
+                from .. import functional as F_hip
+                with F_hip.episode_backward():     # one weight-gradient GEMM for the whole episode instead of one (+ an add_) per step
+                    policy_loss.backward()
+            else:
+                policy_loss.backward()
             optimizer.step()
         policy.gc()
         return policy_loss

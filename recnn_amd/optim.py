@@ -15,11 +15,34 @@
 """
 import math
 
+import ctypes as C
+
 import torch
 
 from . import _lib as L
 
 __all__ = ["Adam", "Ranger", "adam_config", "fused_config"]
+
+
+def _shadow_of(p):
+    """(kind, ctypes reference to a recnn_shadow_out) for the cached compute-layout copy of a catalogue-sized 2-D parameter the
+    kernel should rewrite in the same pass (recnn_amd.nn.functional.shadow_target), or (None, None).  Only worth it for big
+    weights: below 4M elements the next forward's rebuild is noise."""
+    if p.dim() != 2 or p.numel() < (1 << 22):
+        return None, None
+    from .nn import functional as Fh
+    hit = Fh.shadow_target(p)
+    if hit is None:
+        return None, None
+    kind, out = hit
+    sh = L.ShadowOut()
+    sh.dst, sh.cols, sh.ld, sh.bf16 = out.data_ptr(), int(p.shape[1]), int(out.stride(0)), int(out.dtype == torch.bfloat16)
+    return kind, C.byref(sh)
+
+
+def _shadow_done(p, kind):
+    from .nn import functional as Fh
+    Fh.shadow_written(p, kind)
 
 
 class Adam(torch.optim.Optimizer):
@@ -71,10 +94,13 @@ class Adam(torch.optim.Optimizer):
                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                            L.ptr(self._step_dev), 1, 1.0, stream)
                 else:
-                    L.call("recnn_adam_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
+                    kind, sh = _shadow_of(p)
+                    L.call("recnn_adam_flat_shadow", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(),
                            float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                           int(st["step"]), 1.0, stream)
+                           int(st["step"]), 1.0, sh, stream)
                 torch.autograd.graph.increment_version(p)    # the kernel wrote p behind autograd's back
+                if not self.capturable and kind is not None:
+                    _shadow_done(p, kind)
         if stepped:
             self._step_dev.add_(1)
         return loss
@@ -152,11 +178,14 @@ class Ranger(torch.optim.Optimizer):
                 st["step"] = int(st["step"]) + 1
                 g = p.grad.data if p.grad.data.is_contiguous() else p.grad.data.contiguous()
                 stream = stream or L.current_stream()
-                L.call("recnn_ranger_flat", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                kind, sh = _shadow_of(p)
+                L.call("recnn_ranger_flat_shadow", L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
                        L.ptr(st["slow_buffer"]), p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                        float(group["weight_decay"]), float(group["alpha"]), int(group["k"]), float(group["N_sma_threshhold"]),
-                       int(st["step"]), 1.0, stream)
+                       int(st["step"]), 1.0, sh, stream)
                 torch.autograd.graph.increment_version(p)
+                if kind is not None:
+                    _shadow_done(p, kind)
         return loss
 
     @torch.no_grad()

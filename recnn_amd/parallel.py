@@ -350,9 +350,7 @@ class _HipOps:
         ldn, Kp = Fh._r64(N), Fh._r64(K)
 
         def transposed(t):
-            o = torch.zeros(K, ldn, device=t.device)
-            o[:, :N] = t.t()
-            return o
+            return Fh.transposed_rows(t, ldn)
         wt = Fh._derived_of(w, "transposed", transposed) if isinstance(w, torch.nn.Parameter) else transposed(w)
         out = torch.zeros(B, Kp, device=dz.device)
         Fh._fwd(Fh._pad(dz, B, ldn), ldn, wt, None, out, Kp, K, False, None)

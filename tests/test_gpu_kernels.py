@@ -340,3 +340,16 @@ def test_flat_optimizer_kernels(cuda):
     scratch, out = torch.zeros(1024, device=cuda), torch.zeros(1, device=cuda)
     L.call("recnn_l1_norm_flat", L.ptr(gd), n, L.ptr(scratch), L.ptr(out), L.current_stream())
     assert abs(out.item() / gr.double().abs().sum().item() - 1) < 1e-5
+
+
+@pytest.mark.parametrize("R,Cc,bf16", [(1000, 130, False), (4099, 64, True), (63, 257, True), (1, 1, False)])
+def test_transpose_rows(cuda, R, Cc, bf16):
+    """recnn_transpose_rows: dst[c, r] = src[r, c] (exact in fp32, round-to-nearest-even in bf16), padding columns untouched."""
+    L = _lib()
+    src = torch.randn(R, Cc + 3, device=cuda)[:, :Cc]           # a strided source (row stride cols + 3)
+    ldt = (R + 7) // 8 * 8 + 8
+    dst = torch.full((Cc, ldt), 5.0, device=cuda, dtype=torch.bfloat16 if bf16 else torch.float32)
+    L.call("recnn_transpose_rows", L.ptr(src), src.stride(0), R, Cc, L.ptr(dst), ldt, int(bf16), L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :R], src.t().to(dst.dtype))
+    assert bool((dst[:, R:] == 5).all())

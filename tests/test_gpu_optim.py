@@ -156,3 +156,44 @@ def test_run_graphs_with_default_ranger(cuda):
         for k in outs[0][0][nn]:
             assert torch.equal(outs[0][0][nn][k], outs[1][0][nn][k]), (nn, k)
     assert not torch.equal(outs[0][1], outs[0][0]["value_net"]["linear1.weight"])     # fast and slow weights differ between syncs
+
+
+@pytest.mark.parametrize("opt_name", ["ranger", "adam"])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_optimizer_rewrites_the_cached_compute_layout_in_the_same_pass(cuda, opt_name, bf16):
+    """recnn_*_flat_shadow: the optimizer kernel also writes the row-padded (optionally bf16) copy of a catalogue-sized weight that
+    the GEMM kernels read (recnn_amd.nn.functional `_derived_of` layouts), so the next forward does not spend a conversion pass over
+    it.  The parameter and optimizer state equal the plain step bit for bit; the copy equals a rebuild from the new parameter, bit
+    for bit (fp32: the value; bf16: round to nearest even), padding columns untouched; the cache reports it current."""
+    import recnn_amd
+    from recnn_amd.nn import functional as Fh
+    torch.manual_seed(1)
+    rows, cols, ld = 2050, 2049, 2112                       # > 4M elements; odd column count: flat quads straddle rows
+    w0 = torch.randn(rows, cols, device=cuda)
+    make = (lambda ps: recnn_amd.optim.Ranger(ps, lr=1e-3, weight_decay=1e-2)) if opt_name == "ranger" else \
+        (lambda ps: recnn_amd.optim.Adam(ps, lr=1e-3, weight_decay=1e-2))
+    pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+    oa, ob = make([pa]), make([pb])
+    dt = torch.bfloat16 if bf16 else torch.float32
+    kind = "bf16_padded" if bf16 else "padded"
+
+    def build(w):
+        t = torch.full((rows + 2, ld), 7.0, dtype=dt, device=cuda)      # (7 in the padding: the kernel must not touch it)
+        t[:rows, :cols] = w
+        return t
+    for it in range(7):                                      # crosses a Lookahead sync for Ranger
+        shadow = Fh._derived_of(pa, kind, build)             # current before the step (a forward would have made it)
+        assert Fh.shadow_target(pa) is not None and Fh.shadow_target(pa)[1] is shadow
+        assert Fh.shadow_target(pb) is None                  # nothing cached for the twin: plain step
+        g = torch.randn(rows, cols, device=cuda) * 1e-2
+        pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb), it
+        hit = Fh._derived_of(pa, kind, lambda w: (_ for _ in ()).throw(AssertionError("the cached copy was not reported current")))
+        assert hit is shadow
+        assert torch.equal(hit[:rows, :cols], pa.detach().to(dt)), it
+        assert bool((hit[:rows, cols:] == 7).all()) and bool((hit[rows:] == 7).all())
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(oa.state[pa][k], ob.state[pb][k]), k
