@@ -305,6 +305,9 @@ int recnn_softmax_bwd(const float* p, int64_t ldp, int rows, int n, const float*
                       int64_t ldd, void* stream);
 /* out[r, :] = onehot(idx[r]) over n columns (columns [n, ld) zeroed). */
 int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t ld, void* stream);
+/* out[c] = sum over rows of x[r, c], c < n (rows added in order; x rows 16-byte aligned, ld % 4 == 0, padded to 4 floats): the bias
+ * gradient of a catalogue-wide Linear from d logits. */
+int recnn_colsum_rows(const float* x, int64_t ld, int rows, int n, float* out, void* stream);
 /* dst[c, r] = src[r, c]: float [rows, cols] (row stride ld) -> float or bfloat16 [cols, ldt] (ldt >= rows; columns [rows, ldt) are
  * not touched).  The transposed copy of the policy head's W2 [n_items, hidden] that puts the catalogue on the contiguous axis
  * for the backward product d logits x W2 (made once per weight version). */

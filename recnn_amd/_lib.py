@@ -144,6 +144,7 @@ SIGNATURES = {
     "recnn_logprob_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "recnn_softmax_bwd": (_I, [_P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_onehot_rows": (_I, [_P, _I, _I, _P, _L, _P]),
+    "recnn_colsum_rows": (_I, [_P, _L, _I, _I, _P, _P]),
     "recnn_transpose_rows": (_I, [_P, _L, _I, _I, _P, _L, _I, _P]),
     "recnn_vae_latent_fwd": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_vae_latent_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),

@@ -255,6 +255,22 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     if (4 * i4 + c < n) out[4 * i4 + c] = e[c];
 }
 
+// out[c] = sum_r x[r, c], rows added in order (the bias gradient of a catalogue-wide Linear: column sums of d logits [rows, n_items];
+// as a dW GEMM against a column of ones it cost a 277 us launch, this reads the 102 MB once)
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ x, int64_t ld, int rows, int n4, int n,
+                                                          float* __restrict__ out) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= n4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < rows; ++r) {
+    const float4 v = *(const float4*)(x + (int64_t)r * ld + 4 * i4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float e[4] = {s.x, s.y, s.z, s.w};
+  for (int c = 0; c < 4; ++c)
+    if (4 * i4 + c < n) out[4 * i4 + c] = e[c];
+}
+
 // d logits (+)= p (dp - sum_j dp_j p_j): backward of p = softmax(logits).  One workgroup per row.
 __global__ __launch_bounds__(PT) void softmax_bwd_kernel(const float* __restrict__ p, int64_t ldp, int n,
                                                          const float* __restrict__ dp, int64_t lddp, float* __restrict__ d,
@@ -368,6 +384,14 @@ int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t l
   const int l4 = (int)(ld / 4);
   hipLaunchKernelGGL(onehot_kernel, dim3((l4 + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, (hipStream_t)stream, idx, rows, n, out, ld);
   return recnn_check_hip(hipGetLastError(), "onehot_kernel launch");
+}
+
+int recnn_colsum_rows(const float* x, int64_t ld, int rows, int n, float* out, void* stream) {
+  RECNN_REQUIRE(x && out && rows >= 0 && n > 0, "colsum_rows: bad arguments");
+  RECNN_REQUIRE(aligned16(x) && ld % 4 == 0 && ld >= ((n + 3) & ~3), "colsum_rows: rows must be 16-byte aligned and padded to 4 floats");
+  const int n4 = (n + 3) >> 2;
+  hipLaunchKernelGGL(colsum_rows_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ld, rows, n4, n, out);
+  return recnn_check_hip(hipGetLastError(), "colsum_rows_kernel launch");
 }
 
 int recnn_transpose_rows(const float* src, int64_t ld, int rows, int cols, void* dst, int64_t ldt, int dst_bf16, void* stream) {

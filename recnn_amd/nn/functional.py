@@ -775,8 +775,7 @@ def beta_train_forward(state, target, weight, bias):
     Returns (p float32 [B, n_items] -- a view into a 16-byte aligned buffer --, loss (device scalar), dW [n_items, K], db [n_items]): every
     catalogue-wide pass runs in HIP kernels -- the logits GEMM, the two softmaxes (of the logits, and of p inside the loss:
     recnn_categorical_rows), d loss / d p = (softmax(p) - onehot) / B (recnn_logprob_bwd with g = -1 / B), the softmax backward
-    (recnn_softmax_bwd) and the weight-gradient GEMM; the bias gradient is the column sum of d logits, taken by the same dW
-    kernel against a row of ones.  No autograd graph is recorded (the notebook's forward steps its optimizer itself)."""
+    (recnn_softmax_bwd) and the weight-gradient GEMM; the bias gradient is the column sum of d logits (recnn_colsum_rows).  No autograd graph is recorded (the notebook's forward steps its optimizer itself)."""
     if not state.is_cuda:
         raise L.RecnnHipError("recnn_amd Beta: needs GPU tensors (no CPU fallback)")
     x = state.detach().float()
@@ -811,11 +810,9 @@ def beta_train_forward(state, target, weight, bias):
     del dprobs
     gw = torch.empty(N, K, device=dev)
     _dw(dlog, N, xp, K, gw)
-    ones = torch.zeros(B, 64, device=dev)
-    ones[:, 0] = 1.0
-    gb16 = torch.empty(16, N, device=dev)
-    _dw(ones, 16, dlog, N, gb16)            # row 0: sum over the batch rows of d logits
-    return p[:, :N], loss, gw, gb16[0].contiguous()
+    gb = torch.empty(N, device=dev)
+    L.call("recnn_colsum_rows", L.ptr(dlog), ldn, B, N, L.ptr(gb), s)      # sum over the batch rows of d logits
+    return p[:, :N], loss, gw, gb
 
 
 def onehot_rows(idx, n):
