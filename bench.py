@@ -274,6 +274,27 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def reinforce_subrun():
+    """BASELINE configs[4] on ONE GPU (the 8-GPU form is unmeasured): REINFORCE with Top-K off-policy correction at a 100k-item
+    catalogue, the notebook's Beta behaviour policy learning inside every step, bf16 catalogue GEMMs (tools/reinforce_bench.py;
+    SURVEY 8 row f1).  update iterations / s over two whole policy cycles (31 steps, 3 policy updates)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "reinforce_bench.py")
+    spec = importlib.util.spec_from_file_location("reinforce_bench", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import recnn_amd
+    from recnn_amd.nn import functional as F_hip
+    try:
+        rec = mod.run(dtype="bf16")
+    finally:
+        F_hip.set_catalogue_dtype("fp32")
+        recnn_amd.nn.algo.set_default_optimizer("adam")      # (main()'s setting: north_star's optimizer for the headline)
+        torch.cuda.empty_cache()
+    rec.update(algo="reinforce_topk", unit="update iterations/s", value=rec["it_per_s"])
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -597,6 +618,7 @@ def main():
                     out["parity_mode"] = pm
                 out["other_configs"] = {"configs[2]": timed_subrun(recnn_amd, env, dev, stream, "td3", args.dtype, 4096, min(args.steps, 60),
                                                                     min(args.warmup, 20), reps)}
+                out["other_configs"]["configs[4] (1 GPU)"] = reinforce_subrun()
             except L.RecnnHipError as ex:
                 out["extras_error"] = str(ex)
         if world == 1 and not args.no_cpu_baseline and (args.algo, rows) == ("ddpg", B_ROWS):

@@ -14,6 +14,12 @@ import recnn_amd  # noqa: E402
 from recnn_amd.nn import functional as F_hip  # noqa: E402
 
 
+def run(items=100000, rows=256, hidden=2048, steps=31, method="topk", optimizer="ranger", dtype="fp32", beta="learned"):
+    """One measurement (the body of `main`): returns the record as a dict."""
+    a = argparse.Namespace(items=items, rows=rows, hidden=hidden, steps=steps, method=method, optimizer=optimizer, dtype=dtype, beta=beta)
+    return _measure(a)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--items", type=int, default=100000)
@@ -26,6 +32,10 @@ def main():
     ap.add_argument("--beta", default="learned", choices=["learned", "frozen"],
                     help="behaviour policy of the Top-K correction: the notebook's Beta net trained inside every step (default) or a frozen projection")
     a = ap.parse_args()
+    print(json.dumps(_measure(a)))
+
+
+def _measure(a):
     recnn_amd.nn.algo.set_default_optimizer(a.optimizer)
     F_hip.set_catalogue_dtype(a.dtype)
     N, S, H, B = a.items, 1290, a.hidden, a.rows
@@ -73,11 +83,11 @@ def main():
     pol = [x for x, k in zip(times, kinds) if k]
     cyc = times[11:31] if len(times) >= 31 else times[1:]
     beta_step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in beta_ms[1:])
-    print(json.dumps({"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer, "dtype": a.dtype,
-                      "beta": a.beta if a.method == "topk" else None,
-                      "beta_train_call_ms": round(beta_step_ms[len(beta_step_ms) // 2], 3) if beta_step_ms else None,
-                      "ordinary_step_ms": round(ordinary[len(ordinary) // 2], 3), "policy_step_ms": [round(x, 2) for x in pol],
-                      "it_per_s": round(1e3 * len(cyc) / sum(cyc), 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+    return {"n_items": N, "rows": B, "hidden": H, "method": a.method, "optimizer": a.optimizer, "dtype": a.dtype,
+            "beta": a.beta if a.method == "topk" else None,
+            "beta_train_call_ms": round(beta_step_ms[len(beta_step_ms) // 2], 3) if beta_step_ms else None,
+            "ordinary_step_ms": round(ordinary[len(ordinary) // 2], 3), "policy_step_ms": [round(x, 2) for x in pol],
+            "it_per_s": round(1e3 * len(cyc) / sum(cyc), 2), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
 
 
 if __name__ == "__main__":
