@@ -149,7 +149,8 @@ _catalogue_dtype = "fp32"
 
 def set_catalogue_dtype(dtype: str):
     """Compute type of the catalogue-sized GEMMs of the REINFORCE path ([rows, hidden] x [hidden, n_items] of the policy
-    head and its backward, [rows, state + n_items] x [., hidden] of the critic over action distributions):
+    head and its backward, [rows, state + n_items] x [., hidden] of the critic over action distributions, the logits GEMM of the
+    learned behaviour policy `Beta`):
     'fp32' (default; exact-fp32 MFMA, the parity mode) or 'bf16' (bf16 MFMA with fp32 accumulation over bf16 copies of the
     weights kept per weight version; softmax, log-prob, optimizer and all small layers stay fp32)."""
     global _catalogue_dtype
@@ -785,11 +786,25 @@ def beta_train_forward(state, target, weight, bias):
     Kp, ldn = _r64(K), _r64(N)
     s = L.current_stream()
     xp = _pad(x, B, Kp)
-    wp = _derived_of(weight, "padded", lambda w: _pad(w.detach(), _r4(N), Kp)) if (K != Kp or N != _r4(N)) else weight.detach()
     p = torch.empty(B, ldn, device=dev)
     if ldn != N:
         p[:, N:].zero_()
-    _fwd(xp, Kp, wp, bias.detach().float().contiguous(), p, ldn, N, False, None)
+    if _catalogue_dtype == "bf16" and N >= 4096:
+        # the logits GEMM is catalogue-sized ([B, 1290] x [n_items, 1290]^T): bf16 operands in the bf16 catalogue mode, like the policy
+        # head's; the bf16 copy of the weight is kept current by the optimizer pass (shadow_target)
+        K16 = _r128(K)
+        x16 = torch.zeros(B, K16, dtype=torch.bfloat16, device=dev)
+        x16[:, :K] = x
+
+        def shadow(w):
+            t = torch.zeros(_r4(N), K16, dtype=torch.bfloat16, device=dev)
+            t[:N, :K] = w
+            return t
+        w16 = _derived_of(weight, "bf16_padded", shadow)
+        _fwd(x16, K16, w16, bias.detach().float().contiguous(), p, ldn, N, False, None, dtype=L.BF16)
+    else:
+        wp = _derived_of(weight, "padded", lambda w: _pad(w.detach(), _r4(N), Kp)) if (K != Kp or N != _r4(N)) else weight.detach()
+        _fwd(xp, Kp, wp, bias.detach().float().contiguous(), p, ldn, N, False, None)
     tgt = target.to(device=dev, dtype=torch.int64).contiguous()
     L.call("recnn_categorical_rows", L.ptr(p), ldn, B, N, L.CAT_SOFTMAX, 0, 0, None, None, None, s)          # p = softmax(logits)
     q = p.clone()
