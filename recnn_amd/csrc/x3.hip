@@ -34,6 +34,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* s, int pitch, int
   return __builtin_bit_cast(bf16x8, f);
 }
 
+// The same fragment from a SWIZZLED image (pitch 256 bytes, no padding): the 32-byte chunk c of row r lives at chunk c ^ g(r),
+// g(r) = (r & 3) | ((r >> 3) & 1) << 2.  A transpose read's lane group touches rows {0..3, 8..11} (+4, +16) and 32 bytes of
+// each: with a plain pitch of 256 + 16 (the dW kernel's first layout) neighbouring rows overlap in 4 of their 8 banks -- a third
+// of that kernel's LDS cycles were conflicts (SQ_LDS_BANK_CONFLICT, profiles/r04_x3_pmc.txt); g maps the 8 rows to the 8 disjoint
+// bank windows.
+__device__ __forceinline__ int swz32(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8 tr_frag_swz(const unsigned char* s, int col0, int fr, int fg) {
+  Frag f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = fg * 8 + half * 4 + (fr >> 2);
+    const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) v4s16*)(s + row * 256 + (((col0 >> 4) ^ swz32(row)) << 5) + (fr & 3) * 8));
+    if (half == 0) f.lo = v; else f.hi = v;
+  }
+  return __builtin_bit_cast(bf16x8, f);
+}
+
 __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 acc) {
   if (X3_LO_LO) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bl, acc, 0, 0, 0);
   return x3_mfma(ah, al, bh, bl, acc);
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
 // wave owns group wm of dZ x group wn of X = 32 x 32 logical = 2 x 2 blocks x 3 MFMAs per 32-row k step.
 // A stage = 32 batch rows (one k step) of both operands, 17 KB: eight workgroups share a CU.  (64-row stages -- a 256-row batch
 // slice four memory latencies deep instead of eight, but 70 KB per workgroup -- measured slower: 15.4 vs 13.2 us.)
-constexpr int DW_ROWS = 32, DW_PITCH = 272, DW_OP = DW_ROWS * DW_PITCH, DW_STAGE = 2 * DW_OP;
+constexpr int DW_ROWS = 32, DW_PITCH = 256, DW_OP = DW_ROWS * DW_PITCH, DW_STAGE = 2 * DW_OP;   // swizzled rows (tr_frag_swz)
 
 __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
   const GemmProb& P = batch.p[blockIdx.y];
@@ -206,8 +224,9 @@ __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int c = tid + i * 256, row = c >> 4, cc = c & 15;
-      *(uint4*)(st + row * DW_PITCH + cc * 16) = ra[i];
-      *(uint4*)(st + DW_OP + row * DW_PITCH + cc * 16) = rb[i];
+      const int pc = ((((cc >> 1) ^ swz32(row)) << 1) | (cc & 1)) * 16;
+      *(uint4*)(st + row * DW_PITCH + pc) = ra[i];
+      *(uint4*)(st + DW_OP + row * DW_PITCH + pc) = rb[i];
     }
   };
 
@@ -229,10 +248,10 @@ __global__ __launch_bounds__(256) void x3_dw_kernel(const GemmBatch batch) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        ah[q] = tr_frag(ka, DW_PITCH, wm * 64 + q * 16, fr, fg);
-        al[q] = tr_frag(ka, DW_PITCH, wm * 64 + 32 + q * 16, fr, fg);
-        bh[q] = tr_frag(kb, DW_PITCH, wn * 64 + q * 16, fr, fg);
-        bl[q] = tr_frag(kb, DW_PITCH, wn * 64 + 32 + q * 16, fr, fg);
+        ah[q] = tr_frag_swz(ka, wm * 64 + q * 16, fr, fg);
+        al[q] = tr_frag_swz(ka, wm * 64 + 32 + q * 16, fr, fg);
+        bh[q] = tr_frag_swz(kb, wn * 64 + q * 16, fr, fg);
+        bl[q] = tr_frag_swz(kb, wn * 64 + 32 + q * 16, fr, fg);
       }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
