@@ -560,7 +560,9 @@ typedef struct recnn_engine_tuning {
                                (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3); default 2 */
   int x3_tail;              /* split-bf16 engines (hidden 256, action 128): 1 layers 2 + 3 of a step's networks as row-panel launches
                                that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
-  int reserved[8];
+  int x3_fwd;               /* split-bf16 forward GEMM kernel: 0 every wave loads and multiplies (round 4), 1 the same with the DMA issue between
+                               the MFMAs, 2.. wave-specialised (loader waves + consumer waves, csrc/gemm.hip x3_fwd_ws_kernel) */
+  int reserved[7];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

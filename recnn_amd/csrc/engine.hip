@@ -204,7 +204,7 @@ static void sync_gemm_tune(recnn_engine* e) {
   const recnn_engine_tuning& t = e->tune;
   GemmTune& g = e->gtune;
   g.variant = t.gemm_variant; g.v0_min_wg = t.gemm_v0_threshold; g.dma = t.gemm_dma; g.dma_deep = t.gemm_dma_depth;
-  g.dma_waves = t.gemm_dma_waves == 8 ? 8 : 4; g.waves = t.gemm_waves == 4 ? 4 : 8; g.dw_dma = t.dw_dma;
+  g.dma_waves = t.gemm_dma_waves == 8 ? 8 : 4; g.waves = t.gemm_waves == 4 ? 4 : 8; g.dw_dma = t.dw_dma; g.x3_fwd = t.x3_fwd;
 }
 
 // Every kernel launch of the step goes through slot(): a no-op wrapper normally, a hipEvent pair in profile mode.

@@ -506,7 +506,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 // contracted with three MFMAs (hi hi + hi lo + lo hi); K / lda / ldb are physical, the epilogue writes split columns.
 // MFAST: consecutive workgroup ids walk the ROW tiles of one column tile (catalogue-wide products: few rows, 100k columns) -- the
 // two / four row tiles that share a weight panel run side by side on one XCD, so the panel leaves HBM once.
-template <class TC, int TM, int TN, int NS, int NW, bool X3 = false, bool MFAST = false>
+template <class TC, int TM, int TN, int NS, int NW, bool X3 = false, bool MFAST = false, bool LATE = false>
 __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch batch) {
   // NW waves arranged (NW/2) x 2 ... 4 waves: 2x2 wave tiles of (16 TM) x (16 TN); 8 waves: 2x4 wave tiles
   constexpr int WCOLS = NW / 2;
@@ -543,27 +543,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
   // per-lane source geometry (constant over the k loop): chunk q = (j*4 + wave)*64 + lane of a tile
   const int q_row = lane >> 4, q_pos = lane & 15;  // within the 4 rows one wave instruction covers
 
-  auto issue = [&](int t, int stage) {
+  // the i-th of the wave's NA + NB DMA instructions of tile t (A rows first)
+  auto issue_one = [&](int t, int stage, int i) {
     const int sidx = (t < nt0) ? 0 : 1;
     const GemmSeg& G = P.seg[sidx];
     const int k0 = (sidx == 0 ? t : t - nt0) * KB;
     const unsigned sbase = lds0 + stage * STAGE_BYTES;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int row = (j * NW + wave) * 4 + q_row;
-      const int c = q_pos ^ (row & 15);
+    const bool isa = i < NA;
+    const int j = isa ? i : i - NA;
+    const int row = (j * NW + wave) * 4 + q_row;
+    const int c = q_pos ^ (row & 15);
+    if (isa) {
       const int gr = min(m0 + row, P.M - 1);
-      const char* src = (const char*)G.A + ((int64_t)gr * G.lda + k0) * ES + c * 16;
-      dma16(src, sbase + (j * NW + wave) * 1024);
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int row = (j * NW + wave) * 4 + q_row;
-      const int c = q_pos ^ (row & 15);
+      dma16((const char*)G.A + ((int64_t)gr * G.lda + k0) * ES + c * 16, sbase + (j * NW + wave) * 1024);
+    } else {
       const int gr = min(n0 + row, P.N - 1);
-      const char* src = (const char*)G.B + ((int64_t)gr * G.ldb + k0) * ES + c * 16;
-      dma16(src, sbase + BM * 256 + (j * NW + wave) * 1024);
+      dma16((const char*)G.B + ((int64_t)gr * G.ldb + k0) * ES + c * 16, sbase + BM * 256 + (j * NW + wave) * 1024);
     }
+  };
+  auto issue = [&](int t, int stage) {
+#pragma unroll
+    for (int i = 0; i < NA + NB; ++i) issue_one(t, stage, i);
   };
 
 #pragma unroll
@@ -577,10 +577,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; every wave is done reading tile t-1
-    if (t + D < nt) issue(t + D, (t + D) % NS);
+    const bool more = t + D < nt;
+    if (!LATE && more) issue(t + D, (t + D) % NS);
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
     const unsigned char* sb = sa + BM * 256;
-    if constexpr (X3) {
+    if constexpr (X3 && LATE) {
+      // LATE: the wave's DMA instructions of tile t + D go out BETWEEN its MFMA triples (the matrix pipe keeps running while the
+      // vector-memory issue of the next instruction stalls), instead of all up front where every wave's MFMAs queue behind them
+      constexpr int NSLOT = 2 * TM * TN, NDMA = NA + NB;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
+        uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + ph);
+          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pl);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + ph);
+          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pl);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
+                                  __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);
+            const int slot = (g * TM + tm) * TN + tn;
+            const int from = (slot * NDMA + NSLOT - 1) / NSLOT, upto = ((slot + 1) * NDMA + NSLOT - 1) / NSLOT;
+            if (more) {
+#pragma unroll
+              for (int i = from; i < upto; ++i) issue_one(t + D, (t + D) % NS, i);   // DMA instructions issued after this triple
+            }
+          }
+      }
+    } else if constexpr (X3) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
@@ -632,6 +665,151 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
   }
   if constexpr (X3) epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
   else epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
+}
+
+// ------------------------------------------------------------------ split-bf16 forward GEMM, wave-specialised (round 5)
+// Same tile image, arithmetic and epilogue as gemm_fwd_dma_kernel<.., X3>, different division of labour: NL LOADER waves do nothing
+// but issue the LDS-DMA of the ring (tile t + D while tile t is multiplied), WR x WC CONSUMER waves do nothing but read fragments and
+// issue MFMAs.  In the all-waves-do-everything kernel a wave's MFMAs of tile t sit behind its own DMA instructions of tile t + D in
+// program order, and those stall at the CU's vector-memory issue (one 1 KB global_load_lds_dwordx4 ~ 25-60 clk, CU-serial), so the
+// matrix pipe idles for the whole issue burst of every stage (profiles/r04_x3_pmc.txt: matrix cores 25 % busy, waves parked 40 %).
+// One s_barrier per k stage, taken by all waves; loaders leave after the last one.
+template <bool NT> __device__ __forceinline__ void dma16_ws(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false>
+__global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
+  // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
+  // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads)
+  constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
+  constexpr int KB = 128;                         // physical k elements per stage (256-byte rows = 64 logical k)
+  constexpr int D = NS - 1;
+  constexpr int STAGE_BYTES = (BM + BN) * 256;
+  constexpr int NINST = (BM + BN) / 4;            // 1 KB DMA instructions per stage (4 tile rows each)
+  static_assert(NINST % NL == 0, "loader waves must divide the stage");
+  constexpr int PER = NINST / NL;
+  static_assert(PER * (D - 1) <= 60, "vmcnt range");
+  const GemmProb& P = batch.p[blockIdx.y];
+  const int nwg = P.tiles_m * P.tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  if (probe & 32) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+  const unsigned lds0 = (unsigned)(size_t)dsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt0 = P.seg[0].K / KB;
+  const int nt1 = P.nseg > 1 ? P.seg[1].K / KB : 0;
+  const int nt = nt0 + nt1;
+
+  if (wave >= NC) {
+    // ------------------------------------------------------------ loader wave lw: instructions lw, lw + NL, ... of every stage
+    const int lw = wave - NC;
+    const int q_row = lane >> 4, q_pos = lane & 15;
+    const char* rp[PER];      // this lane's source address of instruction j at k = 0 of the current segment
+    auto setup = [&](int sidx) {
+      const GemmSeg& G = P.seg[sidx];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int trow = (j * NL + lw) * 4 + q_row;          // row of the [A tile | B tile] stage image
+        const bool isa = trow < BM;
+        const int row = isa ? trow : trow - BM;
+        const int c = q_pos ^ (row & 15);
+        const int gr = isa ? min(m0 + row, P.M - 1) : min(n0 + row, P.N - 1);
+        rp[j] = (isa ? (const char*)G.A + (int64_t)gr * G.lda * 2 : (const char*)G.B + (int64_t)gr * G.ldb * 2) + c * 16;
+      }
+    };
+    int cur = 0;
+    setup(0);
+    auto issue = [&](int t, int stage) {
+      const int sidx = (t < nt0) ? 0 : 1;
+      if (sidx != cur) { setup(sidx); cur = sidx; }
+      const int koff = (sidx == 0 ? t : t - nt0) * (KB * 2);
+      const unsigned sbase = lds0 + stage * STAGE_BYTES + lw * 1024;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) dma16_ws<NT>(rp[j] + koff, sbase + j * (NL * 1024));
+    };
+    const bool dma_on = !(probe & 2);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < nt && dma_on) issue(i, i);
+    for (int t = 0; t < nt; ++t) {
+      const int younger = min(D - 1, nt - 1 - t);
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // this wave's part of tile t has landed; the consumers are done with tile t - 1
+      if (t + D < nt && dma_on) issue(t + D, (t + D) % NS);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------- consumer wave
+  const int wm0 = (wave / WC) * 16 * TM, wn0 = (wave % WC) * 16 * TN;
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 sink = make_uint4(0, 0, 0, 0);
+  uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ah[i] = al[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) bh[i] = bl[i] = make_uint4(0, 0, 0, 0);
+  for (int t = 0; t < nt; ++t) {
+    __builtin_amdgcn_s_barrier();     // every loader's part of tile t is in LDS
+    if (probe & 1) continue;
+    const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
+    const unsigned char* sb = sa + BM * 256;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
+      if (!(probe & 8)) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + ph);
+          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pl);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + ph);
+          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pl);
+        }
+      }
+      if (probe & 4) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) { sink.x ^= ah[tm].x ^ al[tm].y; sink.y ^= ah[tm].z ^ al[tm].w; }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) { sink.z ^= bh[tn].x ^ bl[tn].y; sink.w ^= bh[tn].z ^ bl[tn].w; }
+        continue;
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
+                                __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);   // (weights first: a lane owns 4 columns of one row)
+    }
+  }
+  if (probe && (sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x9E3779B9u) acc[0][0][0] += 1.f;
+  if (probe & 16) {   // no epilogue (one store keeps the accumulators alive)
+    if (acc[0][0][0] == 12345.678f) ((float*)P.C)[0] = acc[TM - 1][TN - 1][3];
+    return;
+  }
+  epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave);
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
@@ -870,6 +1048,56 @@ template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunc
   hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3) launch");
 }
+static int g_x3_ws_probe = 0;    // recnn_debug_x3_ws_probe (csrc/recnn_hip_debug.h)
+extern "C" void recnn_debug_x3_ws_probe(int bits) { g_x3_ws_probe = bits; }
+template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
+  constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
+  constexpr int LDS = NS * (BM + BN) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 ws attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.dot_parts = nwg * NC;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
+  return recnn_check_hip(hipGetLastError(), "x3_fwd_ws_kernel launch");
+}
+template <int TM, int TN, int NS, int NW> static int launch_dma_x3_late(GemmLaunch* L, hipStream_t stream) {
+  constexpr int BM = 32 * TM, BN = 16 * TN * (NW / 2);
+  constexpr int LDS = NS * (BM + BN) * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true, false, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 dma (late) attr");
+    if (rc) return rc;
+    attr_done = true;
+  }
+  int maxwg = 0;
+  for (int i = 0; i < L->nprob; ++i) {
+    GemmProb& p = L->batch.p[i];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    p.dot_parts = nwg * NW;
+    if (nwg > maxwg) maxwg = nwg;
+  }
+  if (maxwg == 0) return 0;
+  hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true, false, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
+  return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3, late) launch");
+}
+static int g_x3_fwd_debug = -1;   // recnn_debug_x3_fwd (csrc/recnn_hip_debug.h): overrides GemmTune::x3_fwd, probes only
+extern "C" void recnn_debug_x3_fwd(int v) { g_x3_fwd_debug = v; }
 static constexpr int g_x3_big_min_wg = 192;   // launches with at least this many 64 x 128 tiles take them
 int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   for (int i = 0; i < L->nprob; ++i) {
@@ -891,7 +1119,18 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   // logical k, 1680 observed).  Tried instead: every wave loading its own MFMA fragments straight from L2 into registers (16-byte
   // loads, 16 rows x 64 B per instruction, 3 steps ahead, no LDS): bit-identical and 3.5x SLOWER (202 us / step against 117) -- a
   // wave instruction that touches 16 lines costs far more than one that touches 8 contiguous ones.  Removed again.
-  if (L->nprob > 0 && wg_big >= g_x3_big_min_wg) return launch_dma_x3<2, 1, 3, 16>(L, stream);
+  const int var = g_x3_fwd_debug >= 0 ? g_x3_fwd_debug : tune_of(L).x3_fwd;
+  const bool big = L->nprob > 0 && wg_big >= (var >= 20 ? 48 : g_x3_big_min_wg);
+  switch (var % 20) {
+    case 1: if (big) return launch_dma_x3_late<2, 1, 3, 16>(L, stream); return launch_dma_x3_late<1, 1, 5, 8>(L, stream);
+    case 2: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);
+    case 3: if (big) return launch_x3_ws<2, 2, 2, 4, 2, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 2, 5>(L, stream);
+    case 4: if (big) return launch_x3_ws<2, 2, 2, 4, 8, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);
+    case 5: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3, true>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5, true>(L, stream);
+    case 6: if (big) return launch_x3_ws<2, 4, 2, 2, 4, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);   // one consumer wave per SIMD, wave tile 32 x 64
+    default: break;
+  }
+  if (big) return launch_dma_x3<2, 1, 3, 16>(L, stream);
   if (L->nprob == 0 || wg <= 320) return launch_dma_x3<1, 1, 5>(L, stream);
   return launch_dma_x3<1, 1, 3>(L, stream);
 }

@@ -15,6 +15,12 @@ void recnn_debug_mlp_probe(int bits);
 void recnn_debug_mlp_trace(void* device_u64_wg32);
 void recnn_debug_tail_trace(void* device_u64_wg16);
 void recnn_debug_l1_trace(void* device_u64_wg16);
+/* kernel variant of the split-bf16 forward GEMM for the single-problem entry point recnn_gemm_fwd (engines carry their own:
+ * recnn_engine_tuning::x3_fwd); -1 = off */
+void recnn_debug_x3_fwd(int variant);
+/* timing experiments on the wave-specialised split-bf16 forward GEMM (results garbage): bit 0 consumers idle, bit 1 no DMA, bit 2 fragment
+ * reads without MFMAs, bit 3 MFMAs without fragment reads */
+void recnn_debug_x3_ws_probe(int bits);
 #ifdef __cplusplus
 }
 #endif

@@ -239,8 +239,15 @@ def _dw(dz, M, x, N, out, dtype=None):
 
 
 class MLPFunction(torch.autograd.Function):
+    @classmethod
+    def apply(cls, *args):
+        # autograd runs Function.forward with grad mode OFF whatever the caller's mode is, so the caller's mode (does a backward
+        # pass through this call exist at all?) is captured here and handed in as the last argument
+        args = tuple(args) + (None,) * (11 - len(args))
+        return super().apply(*args, torch.is_grad_enabled())
+
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks=None, addend1=None):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, train, seed, masks=None, addend1=None, grad_mode=True):
         if not x.is_cuda:
             raise L.RecnnHipError("recnn_amd networks run on the GPU only (no CPU fallback): move the module and its "
                                   "inputs to 'cuda'")
@@ -255,7 +262,7 @@ class MLPFunction(torch.autograd.Function):
         big16 = _catalogue_dtype == "bf16" and K >= 4096
         # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(): the reward / target forwards of
         #  reinforce_update run there and must not pay an 830 MB fp32 copy of W1 they never read)
-        lean = big16 and not (torch.is_grad_enabled() and any(ctx.needs_input_grad))
+        lean = big16 and not (grad_mode and any(ctx.needs_input_grad))
         xp = None if lean else _pad(x, B, Kp)
         if lean:
             w1p = None
@@ -379,7 +386,7 @@ class MLPFunction(torch.autograd.Function):
             _dx(dz1, Hp, w1s, K, gx, None, 1.0, None, dtype=L.BF16)
         gadd = dz1[:, :H].float() if need[10] else None
         return (gx, gw1, cs1.sum(0) if need[2] else None, gw2, cs2.sum(0) if need[4] else None, gw3, gb3, None, None, None,
-                gadd)
+                gadd, None)
 
     @staticmethod
     def backward(ctx, dout):
@@ -416,7 +423,7 @@ class MLPFunction(torch.autograd.Function):
             _dx(dz1, Hp, w1p, K, gx, None, 1.0, None)
         gadd = dz1[:, :H] if need[10] else None     # d/d addend1 = dZ1
         return (gx, gw1, cs1.sum(0) if need[2] else None, gw2, cs2.sum(0) if need[4] else None, gw3, gb3, None, None, None,
-                gadd)
+                gadd, None)
 
 
 def mlp(x, module, train: bool):

@@ -32,29 +32,60 @@ class PeerComm:
     group is not used again.  `PeerComm.create` returns None on every rank when any rank cannot map its peers (another node,
     IPC unavailable): the caller then stays on RCCL (`dist.all_reduce`)."""
 
-    def __init__(self, max_floats: int, group=None):
-        import ctypes as C
-        self.lib = L.load()
+    def __init__(self, max_floats: int, group=None, _state=None):
         self.group = group
         ready = dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
         self.rank = dist.get_rank(group) if ready else 0
-        h = C.c_void_p()
-        L.call("recnn_comm_create", self.world, self.rank, int(max_floats), C.byref(h))
-        self.handle = h
         self.max_floats = int(max_floats)
-        if self.world > 1:
-            # every rank contributes its handle, or None when it could not create / export its buffer: the gather below is the
-            # agreement (a rank that failed EARLIER still takes part in it: see `create`), and nobody connects to a partial set
-            nb = int(self.lib.recnn_comm_handle_bytes())
-            mine = C.create_string_buffer(nb)
-            L.call("recnn_comm_export", self.handle, mine, nb)
-            every = [None] * self.world
-            dist.all_gather_object(every, bytes(mine.raw), group=group)
-            if any(not isinstance(h, (bytes, bytearray)) or len(h) != nb for h in every):
-                raise L.RecnnHipError("PeerComm: a rank could not export its peer buffer")
-            blob = C.create_string_buffer(b"".join(every), nb * self.world)
-            L.call("recnn_comm_connect", self.handle, blob, nb)
+        self.handle = None
+        try:
+            mine, err = 0, None
+            try:
+                self._open()
+                if self.world > 1:
+                    mine = self._export()
+            except L.RecnnHipError as ex:
+                if self.world == 1:
+                    raise
+                err = ex
+            if self.world > 1:
+                # every rank contributes its handle, or a non-handle when it could not create / export its buffer: this gather is
+                # the agreement -- EVERY rank takes part in it exactly once (`_state` tells `create` that this rank has), and nobody
+                # connects to a partial set
+                every = [None] * self.world
+                dist.all_gather_object(every, mine, group=group)
+                if _state is not None:
+                    _state["exchanged"] = True
+                if err is not None:
+                    raise err
+                if any(not isinstance(h, (bytes, bytearray)) or len(h) != len(mine) for h in every):
+                    raise L.RecnnHipError("PeerComm: a rank could not export its peer buffer")
+                self._connect(every)
+        except Exception:
+            self.close()
+            raise
+
+    # ---- the three library steps of the constructor (tests/test_peercomm_vote_gloo.py replaces them to provoke failures)
+    def _open(self):
+        import ctypes as C
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.call("recnn_comm_create", self.world, self.rank, self.max_floats, C.byref(h))
+        self.handle = h
+
+    def _export(self) -> bytes:
+        import ctypes as C
+        nb = int(self.lib.recnn_comm_handle_bytes())
+        mine = C.create_string_buffer(nb)
+        L.call("recnn_comm_export", self.handle, mine, nb)
+        return bytes(mine.raw)
+
+    def _connect(self, every):
+        import ctypes as C
+        nb = len(every[0])
+        blob = C.create_string_buffer(b"".join(every), nb * self.world)
+        L.call("recnn_comm_connect", self.handle, blob, nb)
 
     @staticmethod
     def floats_for(engine) -> int:
@@ -65,18 +96,19 @@ class PeerComm:
     @classmethod
     def create(cls, max_floats: int, group=None):
         """A connected communicator, or None on EVERY rank if any rank failed (agreement over the group)."""
-        comm, ok = None, 1
+        comm, ok, err = None, 1, None
         multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        state = {"exchanged": False}
         try:
-            comm = cls(max_floats, group)
+            comm = cls(max_floats, group, _state=state)
             ok = int(comm.self_test())
         except Exception as ex:          # RecnnHipError, an allocation failure, ...: this rank votes no instead of leaving its peers
-            ok = 0                       # inside a collective it never joins
-            if multi and comm is None and not isinstance(ex, L.RecnnHipError):
-                raise                    # (not a library failure: nothing sensible to agree on)
-            if multi and comm is None:
-                # the constructor failed before (or in) the handle exchange: take part in it with a non-handle so that the other
-                # ranks' constructors see the failure instead of waiting / joining garbage
+            ok, err = 0, ex              # inside a collective it never joins
+            if multi and not state["exchanged"]:
+                # the constructor failed BEFORE the handle exchange: take part in it with a non-handle so that the other ranks'
+                # constructors see the failure instead of waiting / joining garbage.  (A constructor that failed AFTER its gather --
+                # connect, "a rank could not export" -- must NOT gather again: every rank runs exactly one exchange gather and one
+                # vote gather, ADVICE r4.)
                 try:
                     every = [None] * dist.get_world_size(group)
                     dist.all_gather_object(every, 0, group=group)
@@ -89,6 +121,8 @@ class PeerComm:
         if not ok:
             if comm is not None:
                 comm.close()
+            if err is not None and not isinstance(err, L.RecnnHipError):
+                raise err                # not a library failure: reported, but only after the agreement
             return None
         return comm
 

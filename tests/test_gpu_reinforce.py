@@ -470,6 +470,38 @@ def test_bf16_catalogue_mode_tracks_fp32(cuda):
     assert not torch.equal(a[0], b[0])          # the bf16 kernels did run
 
 
+def test_bf16_catalogue_mode_backward_through_a_dense_catalogue_wide_input(cuda):
+    """in bf16 catalogue mode the fp32 layer-1 operands are only kept when a backward pass will need them, and that
+    was decided from torch.is_grad_enabled() INSIDE Function.forward -- where it is always False -- so a Critic over a DENSE
+    [B, >= 4096] action (no one-hot tag: value_update with an untagged action) crashed in backward.  Gradients of all three layers
+    and of the input, bf16 catalogue mode against fp32, and the no-grad forward still takes the lean path."""
+    import recnn_amd
+    from recnn_amd.nn import functional as F_hip
+    from tests.helpers import fro_err
+    S, N, H, B = 130, 4100, 64, 37
+    torch.manual_seed(11)
+    crit = recnn_amd.nn.Critic(S, N, H, 54e-2).cuda().eval()
+    state = torch.randn(B, S, device="cuda")
+    action = torch.softmax(torch.randn(B, N, device="cuda"), 1).requires_grad_(True)       # dense, untagged
+    out = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            F_hip.set_catalogue_dtype(mode)
+            crit.zero_grad()
+            action.grad = None
+            q = crit(state, action)
+            (q * q).mean().backward()
+            out[mode] = [q.detach().clone(), action.grad.clone()] + [p.grad.clone() for p in crit.parameters()]
+            with torch.no_grad():
+                q0 = crit(state, action)
+            assert torch.equal(q0, q.detach())
+    finally:
+        F_hip.set_catalogue_dtype("fp32")
+    for i, (x, y) in enumerate(zip(out["bf16"], out["fp32"])):
+        assert torch.isfinite(x).all() and fro_err(x, y) < 3e-2, i
+    assert not torch.equal(out["bf16"][0], out["fp32"][0])
+
+
 def test_bf16_catalogue_mode_replays_reference_run_loosely(cuda, golden_dir):
     from recnn_amd.nn import functional as F_hip
     try:

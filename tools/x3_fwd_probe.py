@@ -36,7 +36,26 @@ def run(lda, ldb, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for name, lda, ldb in (("as is", 2 * K, 2 * K), ("A rows aliased", 0, 2 * K), ("W rows aliased", 2 * K, 0), ("both aliased", 0, 0)):
-    us = run(lda, ldb)
-    gb = (M // 64) * (N // 128) * (2 * K // 128) * 48 * 1024 / 1e9
-    print(f"{name:16s} {us:7.2f} us   ({gb / (us * 1e-6) / 1e3:.1f} TB/s of LDS-DMA bytes, {2.0 * M * N * K * 3 / (us * 1e-6) / 1e12:.0f} TFLOP/s executed)")
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+res = {}
+PROBES = [int(v) for v in os.environ.get("PROBES", "0").split(",")]
+for var, probe in [(v, p) for v in VARIANTS for p in PROBES]:
+    L.load().recnn_debug_x3_fwd(var)
+    L.load().recnn_debug_x3_ws_probe(probe)
+    for name, lda, ldb in ((f"as is p{probe}", 2 * K, 2 * K), (f"both aliased p{probe}", 0, 0)):
+        us = run(lda, ldb)
+        big = (M // 64) * (N // 128) >= (48 if var >= 20 else 192)
+        tiles, rows_per_tile = ((M // 64) * (N // 128), 192) if big else ((M // 32) * (N // 64), 96)
+        gb = tiles * (2 * K // 128) * rows_per_tile * 256 / 1e9
+        cus = min(tiles, 256)
+        bclk = gb * 1e9 / cus / (us * 1e-6 * 2.4e9)
+        print(f"variant {var:2d} M={M:5d} {name:18s} {us:7.2f} us   {tiles} tiles, {gb / (us * 1e-6) / 1e3:.1f} TB/s of LDS-DMA bytes, "
+              f"{bclk:.1f} B/clk/CU at 2.4 GHz, {2.0 * M * N * K * 3 / (us * 1e-6) / 1e12:.0f} TFLOP/s executed")
+        res[f"v{var}_{name.replace(' ', '_')}"] = {"us": us, "tiles": tiles, "dma_bytes": gb * 1e9, "B_per_clk_per_CU": bclk}
+L.load().recnn_debug_x3_fwd(-1)
+L.load().recnn_debug_x3_ws_probe(0)
+out_path = os.environ.get("OUT")
+if out_path:
+    import json
+    with open(out_path, "w") as f:
+        json.dump({"M": M, "N": N, "K_logical": K, "results": res}, f, indent=1)
