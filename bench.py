@@ -112,13 +112,12 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
                       f"intra-op threads (fastest of 8/16/32/64 on this {ncpu}-core host)"}
 
 
-# launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports (the default fused forward
-# is mlps.hip's mlps_fwd_kernel; the opt-in variants mlp_fwd_kernel / mlp64 / mlpr are reached through recnn_tune_*)
+# launch-slot name (recnn_engine_profile) -> substring of the kernel symbol rocprofv3 reports
 KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_fwd_critic": "mlps_fwd_kernel", "l1_critic": "l1_gemm_kernel", "tail_critic": "mlp_tail_kernel",
                   "frozen_actors": "mlp_frozen_kernel", "frozen_target_critics": "mlp_frozen_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",
-                  "dw_adam_critic": "dw_opt_kernel", "dw_adam_critic+gather": "dw_opt_kernel"}
+                  "fwd_l1": "_fwd_", "x3_tail": "x3_tail_kernel"}
 
 
 def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):

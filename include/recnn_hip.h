@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define RECNN_ABI_VERSION 1
+/* 2 (round 5): recnn_engine_tuning replaced the recnn_tune_* setters, recnn_gemm_args grew ws / ws_bytes, recnn_shadow_out and the
+ * split-bf16 type were added (round 4), recnn_engine_tuning::x3_fwd took a reserved slot. */
+#define RECNN_ABI_VERSION 2
 
 enum {
   RECNN_OK = 0,
@@ -56,7 +58,8 @@ enum {
 int recnn_abi_version(void);
 const char* recnn_last_error(void);
 /* sizeof() of an ABI struct: 0 recnn_gemm_args, 1 recnn_engine_config, 2 recnn_hyper,
- * 3 recnn_engine_sizes, 4 recnn_sampler, 5 recnn_engine_tuning (lets a binding verify its declarations); -1 if unknown. */
+ * 3 recnn_engine_sizes, 4 recnn_sampler, 5 recnn_engine_tuning, 6 recnn_shadow_out (lets a binding verify its declarations);
+ * -1 if unknown. */
 int64_t recnn_abi_sizeof(int which);
 /* =====================================================================================
  * 1. Replay sampler + embedding gather
@@ -561,8 +564,13 @@ typedef struct recnn_engine_tuning {
   int x3_tail;              /* split-bf16 engines (hidden 256, action 128): 1 layers 2 + 3 of a step's networks as row-panel launches
                                that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
   int x3_fwd;               /* split-bf16 forward GEMM kernel: 0 every wave loads and multiplies (round 4), 1 the same with the DMA issue between
-                               the MFMAs, 2.. wave-specialised (loader waves + consumer waves, csrc/gemm.hip x3_fwd_ws_kernel) */
-  int reserved[7];
+                               the MFMAs, 2 (default) wave-specialised: loader waves + consumer waves (csrc/gemm.hip x3_fwd_ws_kernel), 11 only the
+                               64 x 128-tile launches; other values: tile experiments, see x3_fwd_launch */
+  int x3_head_fused;        /* split-bf16 DDPG engines with x3_tail: 1 the target critic's panel launch also runs the critic head of its rows
+                               (TD target, losses, dz2: csrc/x3tail.hip), 0 a head launch of its own */
+  int x3_fork;              /* split-bf16 run graphs: 1 the step's forward is captured as two graph branches (frozen networks' chain || learning
+                               critic), joined in front of the head; 0 one stream */
+  int reserved[5];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

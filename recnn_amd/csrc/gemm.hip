@@ -684,18 +684,25 @@ template <bool NT> __device__ __forceinline__ void dma16_ws(const void* gsrc, un
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
-template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false>
+// SR = bytes per stage row: 256 (two logical 32-k groups per stage, chunk c of row r at position c ^ (r & 15)) or 128 (one group per
+// stage -- tiles of 128 x 128 / 128 x 256 then fit a 3-4 deep ring; chunk c of row r at position c ^ ((r >> 1) & 7): rows r, r + 1 sit in
+// the two halves of one 256-byte bank row, so the 16 rows x 16 bytes of a fragment read still cover all 64 banks exactly once).
+template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false, int SR = 256>
 __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
-  // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads)
+  // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
+  // bit 4 no epilogue, bit 5 exit at entry
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
-  constexpr int KB = 128;                         // physical k elements per stage (256-byte rows = 64 logical k)
+  constexpr int KB = SR / 2;                      // physical k elements per stage
+  constexpr int NG = SR / 128;                    // logical 32-k groups per stage
+  constexpr int RPI = 1024 / SR, CPR = SR / 16;   // tile rows per 1 KB DMA instruction, 16-byte chunks per stage row
   constexpr int D = NS - 1;
-  constexpr int STAGE_BYTES = (BM + BN) * 256;
-  constexpr int NINST = (BM + BN) / 4;            // 1 KB DMA instructions per stage (4 tile rows each)
+  constexpr int STAGE_BYTES = (BM + BN) * SR;
+  constexpr int NINST = (BM + BN) / RPI;          // DMA instructions per stage
+  static_assert(SR == 256 || SR == 128, "stage rows of 256 or 128 bytes");
   static_assert(NINST % NL == 0, "loader waves must divide the stage");
   constexpr int PER = NINST / NL;
-  static_assert(PER * (D - 1) <= 60, "vmcnt range");
+  static_assert(PER * (D - 1 > 3 ? 3 : D - 1) <= 60, "vmcnt range");
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n;
   if ((int)blockIdx.x >= nwg) return;
@@ -715,16 +722,16 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   if (wave >= NC) {
     // ------------------------------------------------------------ loader wave lw: instructions lw, lw + NL, ... of every stage
     const int lw = wave - NC;
-    const int q_row = lane >> 4, q_pos = lane & 15;
+    const int q_row = lane / CPR, q_pos = lane % CPR;
     const char* rp[PER];      // this lane's source address of instruction j at k = 0 of the current segment
     auto setup = [&](int sidx) {
       const GemmSeg& G = P.seg[sidx];
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
-        const int trow = (j * NL + lw) * 4 + q_row;          // row of the [A tile | B tile] stage image
+        const int trow = (j * NL + lw) * RPI + q_row;        // row of the [A tile | B tile] stage image
         const bool isa = trow < BM;
         const int row = isa ? trow : trow - BM;
-        const int c = q_pos ^ (row & 15);
+        const int c = SR == 256 ? (q_pos ^ (row & 15)) : (q_pos ^ ((row >> 1) & 7));
         const int gr = isa ? min(m0 + row, P.M - 1) : min(n0 + row, P.N - 1);
         rp[j] = (isa ? (const char*)G.A + (int64_t)gr * G.lda * 2 : (const char*)G.B + (int64_t)gr * G.ldb * 2) + c * 16;
       }
@@ -745,7 +752,8 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
       if (i < nt && dma_on) issue(i, i);
     for (int t = 0; t < nt; ++t) {
       const int younger = min(D - 1, nt - 1 - t);
-      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+      if (younger >= 4 && 4 * PER <= 60) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER <= 60 ? 4 * PER : 0) : "memory");
+      else if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
       else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -773,20 +781,22 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
     __builtin_amdgcn_s_barrier();     // every loader's part of tile t is in LDS
     if (probe & 1) continue;
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
-    const unsigned char* sb = sa + BM * 256;
+    const unsigned char* sb = sa + BM * SR;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
+    for (int g = 0; g < NG; ++g) {
+      int ph, pl;
+      if constexpr (SR == 256) { ph = ((g * 8 + fg) ^ fr) * 16; pl = ((g * 8 + 4 + fg) ^ fr) * 16; }
+      else { const int sw = (fr >> 1) & 7; ph = (fg ^ sw) * 16; pl = ((4 + fg) ^ sw) * 16; }
       if (!(probe & 8)) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + ph);
-          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pl);
+          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + ph);
+          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + pl);
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + ph);
-          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pl);
+          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + ph);
+          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + pl);
         }
       }
       if (probe & 4) {
@@ -1050,12 +1060,12 @@ template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunc
 }
 static int g_x3_ws_probe = 0;    // recnn_debug_x3_ws_probe (csrc/recnn_hip_debug.h)
 extern "C" void recnn_debug_x3_ws_probe(int bits) { g_x3_ws_probe = bits; }
-template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
+template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false, int SR = 256> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
-  constexpr int LDS = NS * (BM + BN) * 256;
+  constexpr int LDS = NS * (BM + BN) * SR;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT>,
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT, SR>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 ws attr");
     if (rc) return rc;
     attr_done = true;
@@ -1070,7 +1080,7 @@ template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false> stati
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
+  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT, SR>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
   return recnn_check_hip(hipGetLastError(), "x3_fwd_ws_kernel launch");
 }
 template <int TM, int TN, int NS, int NW> static int launch_dma_x3_late(GemmLaunch* L, hipStream_t stream) {
@@ -1123,11 +1133,18 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   const bool big = L->nprob > 0 && wg_big >= (var >= 20 ? 48 : g_x3_big_min_wg);
   switch (var % 20) {
     case 1: if (big) return launch_dma_x3_late<2, 1, 3, 16>(L, stream); return launch_dma_x3_late<1, 1, 5, 8>(L, stream);
-    case 2: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);
+    case 2: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream);
+            if (wg > 320) return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);     // (72 KB of LDS: two workgroups share a CU)
+            return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);
+    case 11: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream); break;   // small launches stay on the round-4 kernel
     case 3: if (big) return launch_x3_ws<2, 2, 2, 4, 2, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 2, 5>(L, stream);
     case 4: if (big) return launch_x3_ws<2, 2, 2, 4, 8, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);
     case 5: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3, true>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5, true>(L, stream);
     case 6: if (big) return launch_x3_ws<2, 4, 2, 2, 4, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);   // one consumer wave per SIMD, wave tile 32 x 64
+    case 7: return launch_x3_ws<4, 2, 2, 4, 4, 4, false, 128>(L, stream);    // 128 x 128, wave tile 64 x 32
+    case 8: return launch_x3_ws<4, 4, 2, 4, 4, 3, false, 128>(L, stream);    // 128 x 256, wave tile 64 x 64
+    case 9: return launch_x3_ws<2, 2, 2, 4, 4, 6, false, 128>(L, stream);    // 64 x 128 on 128-byte stage rows, 6-deep ring
+    case 10: return launch_x3_ws<4, 2, 2, 4, 8, 4, false, 128>(L, stream);   // 128 x 128, 8 loader waves
     default: break;
   }
   if (big) return launch_dma_x3<2, 1, 3, 16>(L, stream);

@@ -63,7 +63,6 @@ struct ApplyArgs {
   float la_alpha;
   int la_k;
   float nsma_thr;
-  const struct OptScalars* scal;   // optional: this launch's step scalars, precomputed on the device (opt_table_launch)
   // Data parallel, from_slabs only (comm.world > 0): the exchange of the slab-summed gradient runs INSIDE this launch, workgroup by
   // workgroup -- workgroup b publishes ITS elements into the peer buffer, meets workgroup b of every other rank (flags, no
   // grid-wide counter), reduces its 1 / world share of those elements over the ranks, and reads its elements' sums back
@@ -101,10 +100,9 @@ struct OptScalars {
   int pad;
 };
 // The step scalars are double-precision arithmetic (bias corrections 1 - beta^t = -expm1(t ln beta), sqrt, a division: torch
-// computes them in Python floats) on a DEPENDENT chain of ~500 fp64 instructions: ~13k shader cycles = 6 us per evaluation
-// (in-kernel trace, round 3) -- half of round 2's whole Adam launch, where every thread evaluated them.  They depend on the
-// device-side step counter only, so a one-workgroup kernel evaluates them for every step of a run graph at the graph's start
-// (opt_table_launch) and the optimizer kernels just load their entry; without a table (`scal` NULL) they compute in place.
+// computes them in Python floats) on a dependent chain of ~500 fp64 instructions (~13k shader cycles, in-kernel trace, round 3).
+// Every thread of apply_kernel evaluates them under the latency of its own loads; a per-graph table of precomputed scalars was
+// measured (round 3: no change) and removed (round 5).
 __host__ __device__ inline OptScalars opt_scalars_at(int do_adam, int opt_kind, int t, float lr, double log_beta1, double log_beta2,
                                                      float nsma_thr, int la_k) {
   OptScalars S;
@@ -132,7 +130,6 @@ __host__ __device__ inline OptScalars opt_scalars_at(int do_adam, int opt_kind, 
 }
 #if defined(__HIPCC__)
 __device__ inline OptScalars opt_scalars(const ApplyArgs& a) {
-  if (a.scal) return *a.scal;
   const int t = a.do_adam ? *a.t_ptr + 1 + a.t_add : 0;
   return opt_scalars_at(a.do_adam, a.opt_kind, t, a.lr, a.log_beta1, a.log_beta2, a.nsma_thr, a.la_k);
 }
@@ -167,22 +164,6 @@ int grad_reduce_launch(const NetLayout& L, float* gflat, float* l1part, hipStrea
 // fills the launch-time scalars of an ApplyArgs (log betas in double, 1 - beta as torch rounds them)
 void apply_args_finish(ApplyArgs* a);
 
-// Step scalars of up to 3 optimizer instances for every step of a run: out[step * 3 + net] (see OptScalars).
-constexpr int OPT_TABLE_STEPS = 64;
-struct OptTableNet {
-  const int32_t* t_ptr;            // device: optimizer steps already taken
-  int opt_kind, la_k;
-  float lr, nsma_thr;
-  float beta1, beta2;              // (log betas in double are derived by opt_table_launch, as apply_args_finish does)
-  double log_beta1, log_beta2;
-  unsigned char t_add[OPT_TABLE_STEPS];   // steps taken earlier in the run, per step of the run
-};
-struct OptTableArgs {
-  int n_steps, n_nets;
-  OptTableNet net[3];
-  OptScalars* out;
-};
-int opt_table_launch(const OptTableArgs& a, hipStream_t s);
 struct GatherArgs;
 // pregather != NULL: the sampler + gather of the NEXT step runs as extra workgroups of this launch
 int apply_launch(const NetLayout& L, const ApplyArgs& a, hipStream_t s, const GatherArgs* pregather = nullptr);

@@ -401,29 +401,6 @@ void apply_args_finish(ApplyArgs* a) {
   a->omb2 = (float)(1.0 - recnn_snap7(a->beta2));
 }
 
-// one thread per (step of the run, optimizer instance): 192 independent fp64 chains side by side instead of one per consumer
-__global__ __launch_bounds__(256) void opt_table_kernel(const OptTableArgs a) {
-  const int i = threadIdx.x;
-  if (i >= a.n_steps * 3) return;
-  const int step = i / 3, ni = i % 3;
-  if (ni >= a.n_nets) return;
-  const OptTableNet& n = a.net[ni];
-  const int t = *n.t_ptr + 1 + (int)n.t_add[step];
-  a.out[i] = opt_scalars_at(1, n.opt_kind, t, n.lr, n.log_beta1, n.log_beta2, n.nsma_thr, n.la_k);
-}
-
-int opt_table_launch(const OptTableArgs& a0, hipStream_t s) {
-  OptTableArgs a = a0;
-  RECNN_REQUIRE(a.out && a.n_steps >= 1 && a.n_steps <= OPT_TABLE_STEPS && a.n_nets >= 1 && a.n_nets <= 3, "opt_table: bad arguments");
-  for (int i = 0; i < a.n_nets; ++i) {
-    RECNN_REQUIRE(a.net[i].t_ptr, "opt_table: null step counter");
-    a.net[i].log_beta1 = log(recnn_snap7(a.net[i].beta1));
-    a.net[i].log_beta2 = log(recnn_snap7(a.net[i].beta2));
-  }
-  hipLaunchKernelGGL(opt_table_kernel, dim3(1), dim3(256), 0, s, a);
-  return recnn_check_hip(hipGetLastError(), "opt_table_kernel");
-}
-
 int apply_launch(const NetLayout& L, const ApplyArgs& a0, hipStream_t s, const GatherArgs* pregather) {
   ApplyArgs a = a0;
   apply_args_finish(&a);

@@ -29,6 +29,7 @@ extern "C" int64_t recnn_abi_sizeof(int which) {
     case 3: return (int64_t)sizeof(recnn_engine_sizes);
     case 4: return (int64_t)sizeof(recnn_sampler);
     case 5: return (int64_t)sizeof(recnn_engine_tuning);
+    case 6: return (int64_t)sizeof(recnn_shadow_out);
     default: return -1;
   }
 }

@@ -348,8 +348,8 @@ class Algo:
             raise RuntimeError("call attach_env(env, rows_per_batch) first")
         self.flush()
         # the device keeps the losses of the last 1024 steps: steps queued-and-flushed earlier whose lazy losses nobody read yet
-        # are banked BEFORE this call's steps overwrite them (~900 unread steps + run(500) lost the oldest), and a
-        # long run is cut so that no more than 900 unread steps ever sit in the ring
+        # are banked BEFORE this call's steps overwrite them (~900 unread steps + run(500) lost the oldest).  (Of a single
+        # run(n) with n > 1024 the device keeps the last 1024 steps' losses; `history=True` returns those.)
         pending = getattr(self, "_since_ring_read", 0)
         if pending and pending + n_steps > 900:
             self._bank_losses()

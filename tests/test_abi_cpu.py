@@ -19,7 +19,7 @@ def _declared():
 def test_library_loads_and_exports_every_declared_symbol():
     from recnn_amd import _lib as L
     lib = L.load()
-    assert lib.recnn_abi_version() == 1
+    assert lib.recnn_abi_version() == 2
     names = _declared()
     assert len(names) >= 35
     for n in names:

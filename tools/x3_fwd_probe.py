@@ -45,7 +45,11 @@ for var, probe in [(v, p) for v in VARIANTS for p in PROBES]:
     for name, lda, ldb in ((f"as is p{probe}", 2 * K, 2 * K), (f"both aliased p{probe}", 0, 0)):
         us = run(lda, ldb)
         big = (M // 64) * (N // 128) >= (48 if var >= 20 else 192)
-        tiles, rows_per_tile = ((M // 64) * (N // 128), 192) if big else ((M // 32) * (N // 64), 96)
+        v = var % 20
+        if v in (7, 10): tiles, rows_per_tile = -(-M // 128) * (N // 128), 256
+        elif v == 8: tiles, rows_per_tile = -(-M // 128) * (N // 256), 384
+        elif v == 9: tiles, rows_per_tile = (M // 64) * (N // 128), 192
+        else: tiles, rows_per_tile = ((M // 64) * (N // 128), 192) if big else ((M // 32) * (N // 64), 96)
         gb = tiles * (2 * K // 128) * rows_per_tile * 256 / 1e9
         cus = min(tiles, 256)
         bclk = gb * 1e9 / cus / (us * 1e-6 * 2.4e9)
