@@ -563,14 +563,9 @@ typedef struct recnn_engine_tuning {
                                (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3); default 2 */
   int x3_tail;              /* split-bf16 engines (hidden 256, action 128): 1 layers 2 + 3 of a step's networks as row-panel launches
                                that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
-  int x3_fwd;               /* split-bf16 forward GEMM kernel: 0 every wave loads and multiplies (round 4), 1 the same with the DMA issue between
-                               the MFMAs, 2 (default) wave-specialised: loader waves + consumer waves (csrc/gemm.hip x3_fwd_ws_kernel), 11 only the
-                               64 x 128-tile launches; other values: tile experiments, see x3_fwd_launch */
-  int x3_head_fused;        /* split-bf16 DDPG engines with x3_tail: 1 the target critic's panel launch also runs the critic head of its rows
-                               (TD target, losses, dz2: csrc/x3tail.hip), 0 a head launch of its own */
-  int x3_fork;              /* split-bf16 run graphs: 1 the step's forward is captured as two graph branches (frozen networks' chain || learning
-                               critic), joined in front of the head; 0 one stream */
-  int reserved[5];
+  int x3_fwd;               /* split-bf16 forward GEMM kernel: 2 (default) wave-specialised -- loader waves + consumer waves (csrc/gemm.hip
+                               x3_fwd_ws_kernel), 11 only its 64 x 128-tile launches, 0 every wave loads and multiplies (round 4) */
+  int reserved[7];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -197,13 +197,6 @@ struct recnn_engine {
   hipGraphExec_t gdp[7][2] = {};           // data-parallel phase graphs [kind][batch buffer set]
   int dp_sets = 1;                         // 2: merged tail+head graphs alternate the batch buffer sets (look-ahead gather)
   int graph_rows = 0;
-  // split-bf16 run graphs (round 5): the forward of a step is captured as TWO branches -- the frozen networks' chain (target actor ->
-  // target critic -> Q') on a side stream, the learning critic's launches on the main stream -- joined in front of the head
-  hipStream_t side = nullptr;
-  static constexpr int EV_POOL = 2 * RUN_MAX;
-  hipEvent_t ev_pool[EV_POOL] = {};
-  bool ev_ready = false;
-  bool capturing_run = false;    // inside capture_run (the only place the fork is taken)
   bool hyper_set = false;
 };
 
@@ -476,9 +469,6 @@ static void drop_graphs(recnn_engine* e) {
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
   if (!e) return;
   drop_graphs(e);
-  if (e->ev_ready)
-    for (int i = 0; i < recnn_engine::EV_POOL; ++i) (void)hipEventDestroy(e->ev_pool[i]);
-  if (e->side) (void)hipStreamDestroy(e->side);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   delete e;
 }
@@ -845,7 +835,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->x3_head_fused = 0; t->x3_fork = 1;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -1130,142 +1120,6 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     if (pp.slot < LOSS_HIST_MAX) { e->hist_pol_count[pp.slot] = parts; e->hist_pol_add[pp.slot] = 0; }
     return 0;
   };
-  // ---- problem builders shared by the two launch plans below
-  auto l1_target_actor = [&](Group& g) {
-    FwdSpec f{TPOL, 1, e->xcn + aoff, e->ldx, 0, e->K1a};
-    f.C = e->tp.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-    g.flops += fill_fwd(e, f, rows, g.add());
-  };
-  auto l1_critics = [&](Group& g) {
-    for (int c = 0; c < nc; ++c) {
-      FwdSpec fc{VAL[c], 1, e->xcs, e->ldx, 0, e->K1c};
-      fc.C = e->cv[c].h1; fc.ldc = Hp; fc.c_f32 = 0; fc.relu = 1; fc.mask_idx = 2 * c;
-      g.flops += fill_fwd(e, fc, rows, g.add());
-    }
-  };
-  auto l1_actor = [&](Group& g) {
-    FwdSpec f{POL, 1, e->xcs + aoff, e->ldx, 0, e->K1a};
-    f.C = e->pa.h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = actor_m1;
-    g.flops += fill_fwd(e, f, rows, g.add());
-  };
-  auto l1_target_critic_state = [&](Group& g) {
-    for (int c = 0; c < nc; ++c) {   // state columns of the target critic's W1 shadow ([action | state] order): raw fp32, no bias
-      FwdSpec f{TVAL[c], 1, e->xcn + aoff, e->ldx, 0, e->K1a};
-      f.b_col = A;
-      f.C = e->tc_part[c]; f.ldc = ldp; f.c_f32 = 1; f.relu = 0; f.mask_idx = -1;
-      GemmProb* p = g.add();
-      fill_fwd(e, f, rows, p);
-      p->bias = nullptr;
-      g.flops += 2.0 * rows * (double)e->H * e->S;
-    }
-  };
-  auto l1_target_critic_action = [&](Group& g) {   // the action part on top of the state part
-    for (int c = 0; c < nc; ++c) {
-      FwdSpec f{TVAL[c], 1, e->xcn, e->ldx, 0, e->Ap};
-      f.C = e->tq[c].h1; f.ldc = Hp; f.c_f32 = 0; f.relu = 1; f.mask_idx = -1;
-      f.addend = e->tc_part[c]; f.ld_add = ldp; f.add_clip = INFINITY;
-      g.flops += 2.0 * rows * (double)e->H * A;
-      fill_fwd(e, f, rows, g.add());
-    }
-  };
-  const double fl2 = 2.0 * rows * (double)e->H * e->H, fl3 = 2.0 * rows * (double)e->H * A;
-  auto tail_target_actor = [&](X3TailProb* p) {
-    fill_x3tail(e, p, TPOL, rows, e->tp.h1, -1, e->run_off);
-    p->out = e->xcn; p->ldo = e->ldx;
-    if (e->td3) { p->addend = e->ext_noise ? e->ext_noise : e->noise_buf; p->ld_add = A; p->add_clip = e->hy.noise_clip; }
-  };
-  auto tail_critic = [&](X3TailProb* p, int c) {
-    fill_x3tail(e, p, VAL[c], rows, e->cv[c].h1, 2 * c + 1, e->run_off);
-    p->h2 = e->cv[c].h2;
-  };
-  auto tail_actor = [&](X3TailProb* p) {
-    fill_x3tail(e, p, POL, rows, e->pa.h1, actor_m1 + 1, e->run_off);
-    p->h2 = e->pa.h2; p->out = e->gen_action; p->ldo = e->Ap;
-  };
-  auto head_args = [&](HeadArgs& h) -> int {
-    memset(&h, 0, sizeof(h));
-    h.rows = rows; h.H = e->H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
-    h.n_target = nc;
-    for (int c = 0; c < nc; ++c) {
-      const Net& t = e->net[TVAL[c]];
-      h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
-      if (x3_tail_ok(e)) h.tq_in[c] = e->tqv[c];
-      const Net& v = e->net[VAL[c]];
-      h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
-      h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];
-    }
-    h.reward = e->reward; h.done = e->done;
-    h.gamma = e->hy.gamma;
-    h.lo = e->td3 ? -INFINITY : e->hy.min_value;
-    h.hi = e->td3 ? INFINITY : e->hy.max_value;
-    h.expected = e->expected; h.target_q = e->target_q;
-    h.n_critic = nc;
-    h.policy_mode = 0;
-    h.do_bwd = value_bwd;
-    h.train = e->cfg.mask_mode != RECNN_MASK_NONE;
-    if (value_bwd) {
-      for (int c = 0; c < nc; ++c) {
-        Net& v = e->net[VAL[c]];
-        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
-        h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
-      }
-    }
-    return 0;
-  };
-  // ---- forked plan (run graphs): the step's forward as two branches of the graph.  The chain that decides when the head can run is
-  // target actor -> next_action -> target critic -> Q' (four dependent launches, none of which fills the machine after the first);
-  // the learning critic's forward (and the previous step's deferred policy-loss critic) does not depend on it.  Captured on two
-  // streams they overlap: side stream = {target actor, actor, target critic's state part} -> panel tails -> target critic;
-  // main stream = {critics, deferred policy-loss critic} -> their panel tail; joined in front of the head.  Same kernels on the same
-  // operands as the single-stream plan, problem by problem: the results are bit-identical.
-  if (e->capturing_run && e->tune.x3_fork && e->side && e->ev_ready && value_side && actor_side && x3_tail_ok(e) &&
-      2 * e->run_off + 1 < recnn_engine::EV_POOL) {
-    hipStream_t sf = e->side;
-    hipEvent_t ev_fork = e->ev_pool[2 * e->run_off], ev_join = e->ev_pool[2 * e->run_off + 1];
-    RECNN_HIP(hipEventRecord(ev_fork, s));
-    RECNN_HIP(hipStreamWaitEvent(sf, ev_fork, 0));
-    {  // ---- side branch
-      Group g(e, GEMM_FWD, 0, 0);
-      l1_target_actor(g);
-      l1_actor(g);
-      l1_target_critic_state(g);
-      if ((rc = g.run(sf, "fwd_l1_frozen"))) return rc;
-      if (e->td3 && !e->ext_noise) {
-        if ((rc = slot(e, "td3_noise", 0, sf, [&] { return noise_fill_launch(e->noise_buf, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, e->run_off, sf); }))) return rc;
-      }
-      X3TailBatch tb;
-      tail_target_actor(&tb.p[0]);
-      tail_actor(&tb.p[1]);
-      if ((rc = slot(e, "x3_tail_frozen", 2 * (fl2 + fl3), sf, [&] { return x3tail_launch(tb, 2, sf); }))) return rc;
-      Group g2(e, GEMM_FWD, 0, 0);
-      l1_target_critic_action(g2);
-      if ((rc = g2.run(sf, "fwd_l1_target_critic"))) return rc;
-      X3TailBatch tq;
-      for (int c = 0; c < nc; ++c) {
-        fill_x3tail(e, &tq.p[c], TVAL[c], rows, e->tq[c].h1, -1, e->run_off);
-        tq.p[c].q = e->tqv[c];
-      }
-      if ((rc = slot(e, "x3_tail_target_critic", nc * fl2, sf, [&] { return x3tail_launch(tq, nc, sf); }))) return rc;
-      RECNN_HIP(hipEventRecord(ev_join, sf));
-    }
-    {  // ---- main branch
-      Group g(e, GEMM_FWD, 0, 0);
-      l1_critics(g);
-      if (pend) pc_l1(g);
-      if ((rc = g.run(s, "fwd_l1_critic"))) return rc;
-      X3TailBatch tb;
-      int np = 0;
-      for (int c = 0; c < nc; ++c) tail_critic(&tb.p[np++], c);
-      if (pend && (rc = pc_tail(&tb.p[np++]))) return rc;
-      if ((rc = slot(e, "x3_tail_critic", np * fl2, s, [&] { return x3tail_launch(tb, np, s); }))) return rc;
-    }
-    RECNN_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    e->panel_bwd_done = false;
-    e->unit_bwd = false;
-    HeadArgs h;
-    if ((rc = head_args(h))) return rc;
-    return slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); });
-  }
   {  // ---- L1
     Group g(e, GEMM_FWD, 0, 0);
     if (value_side) {
@@ -1399,37 +1253,6 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     if (pend_late) pc_l1(g);
     if ((rc = g.run(s, "fwd_l1_target_critic"))) return rc;
   }
-  // heads: TD target, Q, dQ, loss partials (+ dz2 and the last layer's gradient partials)
-  HeadArgs h;
-  memset(&h, 0, sizeof(h));
-  h.rows = rows; h.H = e->H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
-  h.n_target = nc;
-  for (int c = 0; c < nc; ++c) {
-    const Net& t = e->net[TVAL[c]];
-    h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
-    if (tails) h.tq_in[c] = e->tqv[c];
-    const Net& v = e->net[VAL[c]];
-    h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
-    h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];
-  }
-  h.reward = e->reward; h.done = e->done;
-  h.gamma = e->hy.gamma;
-  h.lo = e->td3 ? -INFINITY : e->hy.min_value;
-  h.hi = e->td3 ? INFINITY : e->hy.max_value;
-  h.expected = e->expected; h.target_q = e->target_q;
-  h.n_critic = nc;
-  h.policy_mode = 0;
-  h.do_bwd = value_bwd;
-  h.train = e->cfg.mask_mode != RECNN_MASK_NONE;
-  if (value_bwd) {
-    for (int c = 0; c < nc; ++c) {
-      Net& v = e->net[VAL[c]];
-      RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
-      h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
-    }
-  }
-  // DDPG: the target critic's panel workgroups run the head of their rows themselves (x3tail.hip): no head launch on the chain
-  const bool head_fused = tails && nc == 1 && e->tune.x3_head_fused;
   if (tails) {   // Q'(s', a') per row: layer 2 and the last layer's dot in one panel launch
     X3TailBatch tb;
     for (int c = 0; c < nc; ++c) {
@@ -1438,8 +1261,7 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     }
     int np = nc;
     if (pend_late && (rc = pc_tail(&tb.p[np++]))) return rc;
-    if ((rc = slot(e, head_fused ? "x3_tail_target_critic+head" : "x3_tail_target_critic", np * 2.0 * rows * (double)e->H * e->H, s,
-                   [&] { return x3tail_launch(tb, np, s, head_fused ? &h : nullptr, 0); }))) return rc;
+    if ((rc = slot(e, "x3_tail_target_critic", np * 2.0 * rows * (double)e->H * e->H, s, [&] { return x3tail_launch(tb, np, s); }))) return rc;
   } else {
     Group g(e, GEMM_FWD, 0, 0);
     for (int c = 0; c < nc; ++c) {
@@ -1449,7 +1271,37 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
     }
     if ((rc = g.run(s, "fwd_l2_target_critic"))) return rc;
   }
-  if (!head_fused && (rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
+  {  // heads: TD target, Q, dQ, loss partials (+ dz2 and the last layer's gradient partials)
+    HeadArgs h;
+    memset(&h, 0, sizeof(h));
+    h.rows = rows; h.H = e->H; h.tc_bf16 = e->cfg.dtype; h.ld_h = Hp;
+    h.n_target = nc;
+    for (int c = 0; c < nc; ++c) {
+      const Net& t = e->net[TVAL[c]];
+      h.th2[c] = e->tq[c].h2; h.tw3[c] = t.p + t.off[W3]; h.tb3[c] = t.p + t.off[B3];
+      if (tails) h.tq_in[c] = e->tqv[c];
+      const Net& v = e->net[VAL[c]];
+      h.ch2[c] = e->cv[c].h2; h.cw3[c] = v.p + v.off[W3]; h.cb3[c] = v.p + v.off[B3];
+      h.q[c] = e->q[c]; h.delta[c] = e->delta[c]; h.loss_part[c] = e->loss_part[c];
+    }
+    h.reward = e->reward; h.done = e->done;
+    h.gamma = e->hy.gamma;
+    h.lo = e->td3 ? -INFINITY : e->hy.min_value;
+    h.hi = e->td3 ? INFINITY : e->hy.max_value;
+    h.expected = e->expected; h.target_q = e->target_q;
+    h.n_critic = nc;
+    h.policy_mode = 0;
+    h.do_bwd = value_bwd;
+    h.train = e->cfg.mask_mode != RECNN_MASK_NONE;
+    if (value_bwd) {
+      for (int c = 0; c < nc; ++c) {
+        Net& v = e->net[VAL[c]];
+        RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
+        h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
+      }
+    }
+    if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
+  }
   return 0;
 }
 
@@ -2519,7 +2371,6 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
   int rc = 0;
   RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   e->use_sampler = e->has_sampler;
-  e->capturing_run = len > 1;
   int n_pol = 0;
   const bool cyc = !rc && len > 1 && (e->tune.split_fwd >= 2 || len >= e->tune.cycle_min_len) && cycle_ok(e, rows);
   auto is_pol = [&](int i) { return phase >= 0 && ((phase + i) % pe) == 0; };
@@ -2581,7 +2432,6 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
     rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
   }
   e->run_off = 0;
-  e->capturing_run = false;
   use_hist_slot(e, 0);
   e->pending_pc.on = false;
   for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
@@ -2609,19 +2459,6 @@ extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream)
   hipStream_t s = (hipStream_t)stream;
   RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
   drop_graphs(e);
-  if (e->x3 && e->tune.x3_fork && !e->side) {   // the side branch of the forked forward (created outside any capture)
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); e->side = nullptr; }
-    if (e->side && !e->ev_ready) {
-      bool ok = true;
-      int made = 0;
-      for (; made < recnn_engine::EV_POOL && ok; ++made) ok = hipEventCreateWithFlags(&e->ev_pool[made], hipEventDisableTiming) == hipSuccess;
-      if (!ok) {
-        (void)hipGetLastError();
-        for (int i = 0; i + 1 < made; ++i) (void)hipEventDestroy(e->ev_pool[i]);
-        (void)hipStreamDestroy(e->side); e->side = nullptr;
-      } else e->ev_ready = true;
-    }
-  }
   const int pe = e->hy.policy_every;
   int cap = e->tune.graph_run < 0 ? recnn_engine::RUN_MAX : e->tune.graph_run;   // longest run graph wanted
   if (cap > recnn_engine::RUN_MAX) cap = recnn_engine::RUN_MAX;

@@ -88,8 +88,8 @@ struct GemmTune {
   int dma_deep = 1;      // 5-stage ring for launches of <= 320 tiles, else 3
   int dma_waves = 8;     // waves per workgroup of the LDS-DMA forward kernel (8 | 4)
   int waves = 8;         // waves per workgroup of the register-staged dX kernel (8 | 4)
-  int x3_fwd = 2;        // split-bf16 forward GEMM: 0 = every wave loads and multiplies, 1 = ... with the DMA issue between the MFMAs,
-                         // 2.. = wave-specialised (loader waves + consumer waves; gemm.hip x3_fwd_launch); +20: big tiles from 48 tiles on
+  int x3_fwd = 2;        // split-bf16 forward GEMM: 2 = wave-specialised (loader waves + consumer waves), 11 = ... only for 64 x 128-tile
+                         // launches, 0 = every wave loads and multiplies (round 4); gemm.hip x3_fwd_launch
   int dw_dma = 2;        // bf16 dW: 0 = register-staged; 1..7 = (rows per stage, ring slots) = (128,2) (64,2) (64,3) (64,4) (32,2) (32,4) (32,3)
 };
 

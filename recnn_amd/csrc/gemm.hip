@@ -506,7 +506,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 // contracted with three MFMAs (hi hi + hi lo + lo hi); K / lda / ldb are physical, the epilogue writes split columns.
 // MFAST: consecutive workgroup ids walk the ROW tiles of one column tile (catalogue-wide products: few rows, 100k columns) -- the
 // two / four row tiles that share a weight panel run side by side on one XCD, so the panel leaves HBM once.
-template <class TC, int TM, int TN, int NS, int NW, bool X3 = false, bool MFAST = false, bool LATE = false>
+template <class TC, int TM, int TN, int NS, int NW, bool X3 = false, bool MFAST = false>
 __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch batch) {
   // NW waves arranged (NW/2) x 2 ... 4 waves: 2x2 wave tiles of (16 TM) x (16 TN); 8 waves: 2x4 wave tiles
   constexpr int WCOLS = NW / 2;
@@ -577,43 +577,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; every wave is done reading tile t-1
-    const bool more = t + D < nt;
-    if (!LATE && more) issue(t + D, (t + D) % NS);
+    if (t + D < nt) issue(t + D, (t + D) % NS);
     const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
     const unsigned char* sb = sa + BM * 256;
-    if constexpr (X3 && LATE) {
-      // LATE: the wave's DMA instructions of tile t + D go out BETWEEN its MFMA triples (the matrix pipe keeps running while the
-      // vector-memory issue of the next instruction stalls), instead of all up front where every wave's MFMAs queue behind them
-      constexpr int NSLOT = 2 * TM * TN, NDMA = NA + NB;
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
-        uint4 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + ph);
-          al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * 256 + pl);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + ph);
-          bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * 256 + pl);
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
-                                  __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);
-            const int slot = (g * TM + tm) * TN + tn;
-            const int from = (slot * NDMA + NSLOT - 1) / NSLOT, upto = ((slot + 1) * NDMA + NSLOT - 1) / NSLOT;
-            if (more) {
-#pragma unroll
-              for (int i = from; i < upto; ++i) issue_one(t + D, (t + D) % NS, i);   // DMA instructions issued after this triple
-            }
-          }
-      }
-    } else if constexpr (X3) {
+    if constexpr (X3) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
@@ -674,20 +641,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 // program order, and those stall at the CU's vector-memory issue (one 1 KB global_load_lds_dwordx4 ~ 25-60 clk, CU-serial), so the
 // matrix pipe idles for the whole issue burst of every stage (profiles/r04_x3_pmc.txt: matrix cores 25 % busy, waves parked 40 %).
 // One s_barrier per k stage, taken by all waves; loaders leave after the last one.
-template <bool NT> __device__ __forceinline__ void dma16_ws(const void* gsrc, unsigned lds_dst_uniform) {
-  unsigned keep;
-  if constexpr (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-}
-
 // SR = bytes per stage row: 256 (two logical 32-k groups per stage, chunk c of row r at position c ^ (r & 15)) or 128 (one group per
 // stage -- tiles of 128 x 128 / 128 x 256 then fit a 3-4 deep ring; chunk c of row r at position c ^ ((r >> 1) & 7): rows r, r + 1 sit in
 // the two halves of one 256-byte bank row, so the 16 rows x 16 bytes of a fragment read still cover all 64 banks exactly once).
-template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false, int SR = 256>
+template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256>
 __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
   // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
@@ -744,7 +701,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
       const int koff = (sidx == 0 ? t : t - nt0) * (KB * 2);
       const unsigned sbase = lds0 + stage * STAGE_BYTES + lw * 1024;
 #pragma unroll
-      for (int j = 0; j < PER; ++j) dma16_ws<NT>(rp[j] + koff, sbase + j * (NL * 1024));
+      for (int j = 0; j < PER; ++j) dma16(rp[j] + koff, sbase + j * (NL * 1024));
     };
     const bool dma_on = !(probe & 2);
 #pragma unroll
@@ -1060,12 +1017,12 @@ template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunc
 }
 static int g_x3_ws_probe = 0;    // recnn_debug_x3_ws_probe (csrc/recnn_hip_debug.h)
 extern "C" void recnn_debug_x3_ws_probe(int bits) { g_x3_ws_probe = bits; }
-template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false, int SR = 256> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
+template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
   constexpr int LDS = NS * (BM + BN) * SR;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT, SR>,
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 ws attr");
     if (rc) return rc;
     attr_done = true;
@@ -1080,31 +1037,8 @@ template <int TM, int TN, int WR, int WC, int NL, int NS, bool NT = false, int S
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, NT, SR>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
+  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
   return recnn_check_hip(hipGetLastError(), "x3_fwd_ws_kernel launch");
-}
-template <int TM, int TN, int NS, int NW> static int launch_dma_x3_late(GemmLaunch* L, hipStream_t stream) {
-  constexpr int BM = 32 * TM, BN = 16 * TN * (NW / 2);
-  constexpr int LDS = NS * (BM + BN) * 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true, false, true>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 dma (late) attr");
-    if (rc) return rc;
-    attr_done = true;
-  }
-  int maxwg = 0;
-  for (int i = 0; i < L->nprob; ++i) {
-    GemmProb& p = L->batch.p[i];
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = p.tiles_m * p.tiles_n;
-    p.dot_parts = nwg * NW;
-    if (nwg > maxwg) maxwg = nwg;
-  }
-  if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true, false, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
-  return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3, late) launch");
 }
 static int g_x3_fwd_debug = -1;   // recnn_debug_x3_fwd (csrc/recnn_hip_debug.h): overrides GemmTune::x3_fwd, probes only
 extern "C" void recnn_debug_x3_fwd(int v) { g_x3_fwd_debug = v; }
@@ -1129,22 +1063,21 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   // logical k, 1680 observed).  Tried instead: every wave loading its own MFMA fragments straight from L2 into registers (16-byte
   // loads, 16 rows x 64 B per instruction, 3 steps ahead, no LDS): bit-identical and 3.5x SLOWER (202 us / step against 117) -- a
   // wave instruction that touches 16 lines costs far more than one that touches 8 contiguous ones.  Removed again.
+  // Kernel choice (GemmTune::x3_fwd; all compute the same bits).  2 (default): the wave-specialised kernel -- 64 x 128 tiles for launches
+  // that fill the machine with them, else 32 x 64 tiles with a 3-stage ring (72 KB: two workgroups share a CU) above 320 tiles and a
+  // 5-stage ring below.  Measured in the step's run graphs (profiles/r05_x3_fwd_ab.txt): 113.6 us/step with 0, 111.1 with 11 (only the
+  // big launches), 108.6 with 2.  7 / 8: 128 x 128 and 128 x 256 tiles on 128-byte stage rows for cycle-sized M -- no faster per row
+  // than 64 x 128 at M = 20480 (profiles/r05_x3_ws_big_tiles_m20480.txt: the consumer waves, not the bytes, bound those), kept for
+  // tools/x3_fwd_probe.py.
   const int var = g_x3_fwd_debug >= 0 ? g_x3_fwd_debug : tune_of(L).x3_fwd;
-  const bool big = L->nprob > 0 && wg_big >= (var >= 20 ? 48 : g_x3_big_min_wg);
-  switch (var % 20) {
-    case 1: if (big) return launch_dma_x3_late<2, 1, 3, 16>(L, stream); return launch_dma_x3_late<1, 1, 5, 8>(L, stream);
+  const bool big = L->nprob > 0 && wg_big >= g_x3_big_min_wg;
+  switch (var) {
     case 2: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream);
-            if (wg > 320) return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);     // (72 KB of LDS: two workgroups share a CU)
+            if (wg > 320) return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);
             return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);
     case 11: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3>(L, stream); break;   // small launches stay on the round-4 kernel
-    case 3: if (big) return launch_x3_ws<2, 2, 2, 4, 2, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 2, 5>(L, stream);
-    case 4: if (big) return launch_x3_ws<2, 2, 2, 4, 8, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 3>(L, stream);
-    case 5: if (big) return launch_x3_ws<2, 2, 2, 4, 4, 3, true>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5, true>(L, stream);
-    case 6: if (big) return launch_x3_ws<2, 4, 2, 2, 4, 3>(L, stream); return launch_x3_ws<1, 2, 2, 2, 4, 5>(L, stream);   // one consumer wave per SIMD, wave tile 32 x 64
-    case 7: return launch_x3_ws<4, 2, 2, 4, 4, 4, false, 128>(L, stream);    // 128 x 128, wave tile 64 x 32
-    case 8: return launch_x3_ws<4, 4, 2, 4, 4, 3, false, 128>(L, stream);    // 128 x 256, wave tile 64 x 64
-    case 9: return launch_x3_ws<2, 2, 2, 4, 4, 6, false, 128>(L, stream);    // 64 x 128 on 128-byte stage rows, 6-deep ring
-    case 10: return launch_x3_ws<4, 2, 2, 4, 8, 4, false, 128>(L, stream);   // 128 x 128, 8 loader waves
+    case 7: return launch_x3_ws<4, 2, 2, 4, 4, 4, 128>(L, stream);    // 128 x 128, wave tile 64 x 32
+    case 8: return launch_x3_ws<4, 4, 2, 4, 4, 3, 128>(L, stream);    // 128 x 256, wave tile 64 x 64
     default: break;
   }
   if (big) return launch_dma_x3<2, 1, 3, 16>(L, stream);

@@ -1,7 +1,6 @@
 // x3tail.h -- layers 2 + 3 of the step's networks for the split-bf16 compute type, one launch (x3tail.hip)
 #pragma once
 #include "common.h"
-#include "head.h"
 
 constexpr int X3TAIL_MAX_GROUP = 8;
 
@@ -28,5 +27,4 @@ struct X3TailBatch { X3TailProb p[X3TAIL_MAX_GROUP]; };
 
 int x3tail_init();
 int x3tail_parts_per_panel();
-// head != NULL: the workgroups of problem head_prob (a target critic with q set) also run the critic head of their rows (x3tail.hip)
-int x3tail_launch(const X3TailBatch& b, int nprob, hipStream_t s, const HeadArgs* head = nullptr, int head_prob = -1);
+int x3tail_launch(const X3TailBatch& b, int nprob, hipStream_t s);

@@ -13,7 +13,6 @@
 // 128-column blocks of 32 rows x 256 bytes (chunk c of row r at c ^ (r & 15)): the layouts of mlps.hip / mlp_panel.h.
 #include "x3tail.h"
 #include "x3.h"
-#include "head_dev.h"
 
 namespace {
 constexpr int NW = 16, BM = 32;
@@ -66,10 +65,7 @@ __device__ __forceinline__ void panel_get4(const unsigned char* panel, int row, 
 }
 }  // namespace
 
-// head / head_prob: the workgroups of problem `head_prob` (the target critic, DDPG) run the critic head of their panel's rows --
-// TD target, Q(s, a), dQ, loss partials, dz2 and the last layer's gradient partials (head_dev.h, the arithmetic and the 16-row blocks
-// of head_kernel) -- as soon as Q' of those rows exists: no head launch between the target critic and the backward GEMMs.
-__global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batch, const HeadArgs head, const int head_prob) {
+__global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batch) {
   const int by = __builtin_amdgcn_readfirstlane((int)blockIdx.y), bx = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
   const X3TailProb& P = batch.p[by];
   const int m0 = bx * BM;
@@ -81,7 +77,6 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
   const int fr = lane & 15, fg = lane >> 4;
   unsigned char* panel = lds + PANEL_OFF;
   const bool actor = P.W3 != nullptr;
-  const bool hd = by == head_prob;     // this workgroup also runs the critic head of its rows (uniform)
 
   // ---- the h1 panel: 32 rows x 1 KB.  One DMA instruction = one 128-column block of 4 rows (1 KB, contiguous in the image);
   // wave w: block w & 3, rows 8 (w >> 2) .. + 7 as two instructions.  Source chunk of image position p of row r: p ^ (r & 15).
@@ -103,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
   const unsigned voff_sq = (unsigned)(l_row * (int)P.ldw2 * 2 + l_c);       // W2 / W3 share the pitch (x3tail_launch)
   const unsigned wave_kb = wave * 1024;
   const int nslab = 8 + (actor ? 4 : 0);
-  int issued = 0, consumed = 0, xtra = 0;
+  int issued = 0, consumed = 0;
   auto issue = [&]() {
     const int k = issued;
     if (k >= nslab) return;
@@ -121,25 +116,12 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
   };
   auto next = [&]() -> const unsigned char* {
     const int c = consumed++;
-    const int out = 2 * (issued - c - 1) + xtra;                 // instructions that may stay in flight: the younger slabs (2 each; + the head's panel)
-    if (out >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else if (out == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if (out == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    const int y = issued - c - 1;                                // younger slabs in flight (2 instructions each)
+    if (y >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if (y == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();    // slab c (and everything older: the panel) landed for every wave; slab c - 1's stage is free
     issue();
-    if (hd && c == 5) {
-      // the head will read the LEARNING critic's h2 rows of this panel twice (row dots, then dz2): fetch them now into ring stage 0
-      // (slab 4 is consumed, slabs 5..7 sit in stages 1..3) as plain 1 KB rows, wave w: rows w and w + 16 -- the head then runs from
-      // LDS instead of behind two L2 round trips at the end of the workgroup's chain
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wave + 16 * j;
-        const int gr = min(m0 + row, head.rows - 1);
-        dma_s((unsigned)(gr * (int)head.ld_h * 2 + lane * 16), head.ch2[0], lds0 + row * 1024);
-      }
-      xtra = 2;
-    }
     return lds + (c & (NST - 1)) * SLAB;
   };
   issue(); issue(); issue();
@@ -155,12 +137,6 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
   for (int r = 0; r < 4; ++r)
     v3[r] = actor ? (no + r < P.out_dim ? P.b3[no + r] : 0.f) : ((lane * 4 + r < P.H) ? P.w3row[lane * 4 + r] : 0.f);
   const float b3s = actor ? 0.f : P.b3[0];
-  float rew_r = 0.f, done_r = 0.f;                               // head: reward / done of row m0 + tid (threads 0..31)
-  if (hd && tid < BM) {
-    const int r = min(m0 + tid, head.rows - 1);
-    rew_r = head.reward[r];
-    done_r = head.done[r];
-  }
   uint32_t key2 = 0;
   if (P.mask_mode == RECNN_MASK_HASH) key2 = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream2);
   asm volatile("" : "+v"(b2v));
@@ -256,10 +232,6 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
       }
     }
     float qsum = 0.f;
-    // head scratch in ring stage 1 (the ring is idle from here on; stage 0 holds the learning critic's h2 rows): Q', reward, done
-    float* sq = (float*)(lds + SLAB);
-    float* srew = sq + BM;
-    float* sdone = srew + BM;
     for (int i = 0; i < RW; ++i) {
       const int row = wave * RW + i;
       float hv[4];
@@ -269,24 +241,12 @@ __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batc
       for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hv[j] * v3[j] : 0.f;
       s = wave_sum(s);
       const float qv = s + b3s;
-      if (lane == 0 && hd) sq[row] = qv;
       if (m0 + row < P.rows) {
         qsum += qv;
         if (lane == 0 && P.q) P.q[m0 + row] = qv;
       }
     }
     if (P.q_part && lane == 0) P.q_part[(int64_t)bx * NW + wave] = qsum;   // sum of Q over this wave's rows (policy loss partials)
-    if (hd) {                        // (uniform per workgroup)
-      if (tid < BM) { srew[tid] = rew_r; sdone[tid] = done_r; }
-      __syncthreads();
-      // the head's per-row inputs now live in LDS
-      HeadRows hr;
-      hr.ch2 = lds; hr.tq = sq; hr.reward = srew; hr.done = sdone; hr.row0 = m0;
-      HeadSmem* sm = (HeadSmem*)(lds + SLAB + 512);
-      const int grp = wave >> 2, blk = 2 * bx + (grp & 1);
-      const bool active = grp < 2 && blk * HEAD_ROWS_PER_BLOCK < head.rows;
-      head_block<x3_t, 1, 1, true>(head, blk, tid & 255, active, sm[grp & 1], &hr);
-    }
   }
 }
 
@@ -296,7 +256,7 @@ int x3tail_init() {
 
 int x3tail_parts_per_panel() { return NW; }
 
-int x3tail_launch(const X3TailBatch& b, int nprob, hipStream_t s, const HeadArgs* head, int head_prob) {
+int x3tail_launch(const X3TailBatch& b, int nprob, hipStream_t s) {
   int rows = 0;
   for (int i = 0; i < nprob; ++i) {
     const X3TailProb& p = b.p[i];
@@ -311,16 +271,6 @@ int x3tail_launch(const X3TailBatch& b, int nprob, hipStream_t s, const HeadArgs
   }
   if (rows <= 0 || nprob <= 0) return 0;
   if (nprob > X3TAIL_MAX_GROUP) { recnn_set_error("x3 tail: group too large"); return RECNN_E_INVALID; }
-  HeadArgs h;
-  memset(&h, 0, sizeof(h));
-  if (head) {
-    if (head_prob < 0 || head_prob >= nprob || b.p[head_prob].W3 || head->rows != b.p[head_prob].rows || head->n_target != 1 || head->n_critic != 1 ||
-        head->tc_bf16 != RECNN_BF16X3 || head->policy_mode || !head->tq_in[0] || head->H != 256) {
-      recnn_set_error("x3 tail: the fused head needs a DDPG target-critic problem (one target, one critic, split rows, Q' precomputed)");
-      return RECNN_E_INVALID;
-    }
-    h = *head;
-  } else head_prob = -1;
-  hipLaunchKernelGGL(x3_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b, h, head_prob);
+  hipLaunchKernelGGL(x3_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b);
   return recnn_check_hip(hipGetLastError(), "x3_tail_kernel");
 }
