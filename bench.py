@@ -207,9 +207,12 @@ def timed_subrun(recnn_amd, env, dev, stream, algo_name, dtype, rows, steps, war
     algo.attach_env(env, rows_per_batch=rows)
     samples = []
     with torch.cuda.stream(stream):
+        t_build = time.perf_counter()
         if 2 <= steps <= 64:
             for r in range(reps):
                 algo.prepare_run(steps, first_step=warmup + r * steps)
+        torch.cuda.synchronize(dev)
+        build_s = time.perf_counter() - t_build
         algo.run(warmup)
         for r in range(reps):
             torch.cuda.synchronize(dev)
@@ -223,6 +226,7 @@ def timed_subrun(recnn_amd, env, dev, stream, algo_name, dtype, rows, steps, war
     tfl = FLOP_PER_ROW[algo_name] * rows / (el / steps) / 1e12
     return {"algo": algo_name, "dtype": dtype, "rows": rows, "value": steps / el, "unit": "steps/s", "ms_per_step": el / steps * 1e3,
             "steps": steps, "warmup": warmup, "repeats": reps, "spread": (max(samples) - min(samples)) / el,
+            "ms_per_step_samples": [round(x / steps * 1e3, 6) for x in samples], "graph_setup_s": round(build_s, 4),
             "end_to_end": {"tflops": tfl, "peak": peak, "frac": tfl / peak}, "final_losses": losses}
 
 
@@ -294,13 +298,44 @@ def reinforce_subrun():
     return rec
 
 
+def reinforce_main(args, world, rank):
+    """`python bench.py --algo reinforce --gpus N`: BASELINE configs[4] -- REINFORCE with Top-K off-policy correction at a 100k-item
+    catalogue, learned Beta, bf16 catalogue GEMMs, batches from a discrete-action FrameEnv; for N > 1 the catalogue dimension of the
+    actor's head and of the critic's first layer is sharded over the ranks (recnn_amd/parallel.py).  One JSON line from rank 0."""
+    import importlib.util
+    path = os.path.join(ROOT, "tools", "reinforce_bench.py")
+    spec = importlib.util.spec_from_file_location("reinforce_bench", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dtype = "bf16" if args.dtype == "bf16" else "fp32"
+    steps = args.steps if 11 <= args.steps <= 2000 else 31
+    # (RECNN_REINFORCE_ITEMS / _HIDDEN: smaller shapes for the functional tests of this entry point; the benchmark is the default)
+    rec = mod.run(dtype=dtype, world=world, steps=steps, items=int(os.environ.get("RECNN_REINFORCE_ITEMS", "100000")),
+                  hidden=int(os.environ.get("RECNN_REINFORCE_HIDDEN", "2048")))
+    if rank == 0:
+        cyc = steps - 11 if steps >= 31 else steps - 1
+        out = {"metric": "REINFORCE Top-K update iterations/sec (100k-item catalogue, 256 rows, hidden 2048, learned Beta)",
+               "value": rec["it_per_s"], "unit": "update iterations/s", "n_gpus": world, "steps": min(cyc, 20) if steps >= 31 else cyc,
+               "warmup": 11 if steps >= 31 else 1, "ms_per_step": round(1e3 / rec["it_per_s"], 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": "configs[4]: REINFORCE with Top-K off-policy correction, 100,000-item catalogue, 256 transition rows per step "
+                                      "(the SAME batch on every rank), DiscreteActor / Critic hidden 2048, the notebook's Beta trained inside every "
+                                      "step, fused Ranger, policy update every 10th step; catalogue dimension sharded over the ranks",
+                          "parallelism": "single" if world == 1 else f"vocab-parallel x{world}"},
+               "detail": rec}
+        print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
-    ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3"], help="td3 --rows 4096 = BASELINE.json configs[2]")
+    ap.add_argument("--algo", default="ddpg", choices=["ddpg", "td3", "reinforce"],
+                    help="td3 --rows 4096 = BASELINE.json configs[2]; reinforce = configs[4]: Top-K REINFORCE at a 100k-item catalogue, the catalogue "
+                         "dimension sharded over --gpus ranks (tools/reinforce_bench.py)")
     ap.add_argument("--rows", type=int, default=B_ROWS, help="transition rows per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs behind roofline.traffic")
@@ -331,6 +366,8 @@ def main():
         spawn_ranks(args)                                 # no launcher around us: be the launcher (does not return)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if args.algo == "reinforce":
+        raise SystemExit(reinforce_main(args, world, rank))
     if os.environ.get("RECNN_BENCH_SINGLE_DEVICE"):      # functional test of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
         os.environ.setdefault("RECNN_BENCH_BACKEND", "gloo")
@@ -344,6 +381,7 @@ def main():
             raise SystemExit(f"--scaling strong: {rows} rows do not split over {world} ranks")
         rows //= world
     use_dp = world > 1 or args.force_dp
+    preflight = None
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -353,10 +391,23 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("RECNN_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        if world > 1 and not os.environ.get("RECNN_BENCH_NO_PREFLIGHT"):
+            # the N > 1 path has never run on more than one GPU (README): walk it stage by stage FIRST (tools/multigpu_preflight.py:
+            # one JSON line per stage, so a hang is attributed), keep its process group, embed its summary in the JSON line
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import multigpu_preflight
+            try:
+                multigpu_preflight.main(keep_group=True)
+                preflight = multigpu_preflight.LAST_SUMMARY
+            except Exception as ex:       # diagnostic only: the benchmark still runs
+                preflight = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
+            if preflight and not preflight.get("ok") and not all(preflight.get("stages", {}).get(k, True) for k in ("peer_connect", "peer_self_test", "bench_peer")):
+                args.collective = "rccl"          # the device collective did not pass on this machine: host-issued RCCL all-reduces
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
 
     from recnn_amd import _lib as L
     from recnn_amd._tune import apply_env_knobs
@@ -427,15 +478,24 @@ def main():
     # (one 20-step region is ~1.3 ms: a single sample of that moves +-8 % from box to box and call to call).
     reps = max(1, args.repeats)
     samples = []
+    graph_setup = {"made_to_order_graphs": 0, "build_s": 0.0}
     with torch.cuda.stream(stream):
+        t_build = time.perf_counter()
         if use_dp and comm is not None and 2 <= args.steps <= 64:
             for r in range(reps):
                 eng.graph_prepare(args.warmup + r * args.steps, args.steps)
+            graph_setup["made_to_order_graphs"] = len({(args.warmup + r * args.steps) % int(eng.policy_every) for r in range(reps)})
         if not use_dp and 2 <= args.steps <= 64:
             # setup, like the rest of the graph family: every timed `run(steps)` call gets a run graph made to order for
-            # (first step mod policy_step, steps), i.e. ONE graph launch instead of [ordinary stretch][cycles][policy + tail]
+            # (first step mod policy_step, steps), i.e. ONE graph launch instead of [ordinary stretch][cycles][policy + tail].
+            # OUTSIDE the timed regions -- a capture, like building the graph family -- and its cost is reported (graph_setup)
             for r in range(reps):
                 algo.prepare_run(args.steps, first_step=args.warmup + r * args.steps)
+            graph_setup["made_to_order_graphs"] = len({(args.warmup + r * args.steps) % int(eng.policy_every) for r in range(reps)})
+        torch.cuda.synchronize(dev)
+        graph_setup["build_s"] = round(time.perf_counter() - t_build, 4)
+        graph_setup["note"] = ("run graphs captured for exactly (first step mod policy_every, --steps) of each timed region, outside the timer; "
+                               "0 graphs = the request is served by the standing graph family")
         run(0, args.warmup)
         if use_dp and comm is not None:
             # the warm-up steps were the first to run the exchange INSIDE the optimizer launches (PeerComm's own self-test covers the
@@ -487,11 +547,15 @@ def main():
             # strong scaling: the ranks share ONE `args.rows`-row batch per step -> `steps` updates in total
             "value": (world if args.scaling == "weak" else 1) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "repeats": reps, "ms_per_step_samples": [round(x / args.steps * 1e3, 6) for x in samples],
+            "repeats": reps, "ms_per_step_samples": [round(x / args.steps * 1e3, 6) for x in samples], "graph_setup": graph_setup,
             "spread": (max(samples) - min(samples)) / elapsed,     # (slowest - fastest region) / median region
             "scaling": args.scaling,
             # synchronised optimizer updates per second (one per step whatever N is) and transition rows consumed per second
             "global_updates_per_s": args.steps / elapsed, "rows_per_s": world * rows * args.steps / elapsed,
+            # N > 1: `value` counts RANK-steps (weak scaling: N ranks x steps / time -- what BASELINE's "steps/sec at 1/2/4/8 GPU" and
+            # north_star's 50,000 target are read against, every rank-step being one 2048-row DDPG update's worth of work); the number
+            # of SYNCHRONISED optimizer updates per second is global_updates_per_s
+            "value_is": "rank-steps/s (n_gpus x steps / time)" if (world > 1 and args.scaling == "weak") else "optimizer updates/s",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("configs[1]: DDPG" if args.algo == "ddpg" else "configs[2]: TD3 (twin critics, delayed actor)")
                                    + f", {rows} transition rows/step/GPU ({args.scaling} scaling), frame_size 10, emb_dim 128, "
@@ -500,6 +564,18 @@ def main():
                        "rows_per_step_per_gpu": rows, "parallelism": (f"dp{world}" if world > 1 else "single") + (f" ({collective} collective)" if use_dp else ""),
                        "final_losses": losses},
         }
+        if use_dp:
+            out["multi_gpu"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "collective": collective,
+                                "collective_requested": args.collective,
+                                "decision": ("in-graph two-shot all-reduce over hipIpc peer buffers (csrc/comm.hip): every rank mapped its peers and "
+                                             "passed the self-test" if comm is not None else
+                                             "host-issued all-reduces between phase graphs (torch.distributed backend above)"),
+                                "ranks_share_one_gpu": bool(os.environ.get("RECNN_BENCH_SINGLE_DEVICE")),
+                                "global_updates_per_s": args.steps / elapsed, "rank_steps_per_s": world * args.steps / elapsed,
+                                "preflight": preflight}
+            if world > 1:
+                out["config"]["workload"] += (f"; N = {world}: value = rank-steps/s (every rank steps on its own {rows}-row batch, one gradient "
+                                              "all-reduce per optimizer step), global_updates_per_s = synchronised updates/s")
         # ---- per-launch times, measured live with HIP events around every launch (eager replays of the same steps on the stream
         # the kernels run on), and the rooflines they imply.  Two schedules exist and agree bit for bit:
         #   "fused": one row-panel launch for all networks of a step (csrc/mlps.hip) -- eager steps and run graphs shorter than

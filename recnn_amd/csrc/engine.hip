@@ -24,208 +24,11 @@
 #include <math.h>
 #include <functional>
 #include <new>
-#include <string>
-#include <vector>
+#include "engine_internal.h"
 
-#include "gather.h"
-#include "gemm.h"
-#include "head.h"
-#include "mlp.h"
-#include "bwd.h"
-#include "optim.h"
-#include "comm.h"
-#include "split.h"
-#include "x3.h"
-#include "x3tail.h"
-
-constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
-
-int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s);
-int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s);
-
-static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-namespace {
-
-constexpr int W1 = 0, B1 = 1, W2 = 2, B2 = 3, W3 = 4, B3 = 5;
-constexpr int SP_W1_MAX = 8, SP_W2 = 16, SP_W3 = 16;  // max batch splits of the dW GEMMs
-
-struct Net {
-  bool critic = false, bound = false;
-  float *p = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;  // canonical flat arenas (caller owned)
-  float* slow = nullptr;                                          // Lookahead slow weights (Ranger), caller owned
-  int in_dim = 0, out_dim = 0;
-  int64_t off[6] = {0, 0, 0, 0, 0, 0};
-  int64_t n_params = 0;
-  // compute-type shadows (workspace)
-  char* shadow = nullptr;            // base of this net's shadow arena
-  int64_t sh_off[6] = {-1, -1, -1, -1, -1, -1};  // element offsets (weights only)
-  int ld_w1 = 0, ld_w2 = 0, ld_w3 = 0;
-  int64_t shadow_elems = 0;
-  // gradient partial slabs (workspace, learning nets only)
-  float* gp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  float* l1part = nullptr;
-  int32_t* t_ptr = nullptr;
-  int n_rows_blk = 0;
-};
-
-struct Acts {  // tc activations of one network application, [Bc, Hp]
-  char *h1 = nullptr, *h2 = nullptr;
-};
-
-}  // namespace
-
-struct recnn_engine {
-  recnn_engine_config cfg;
-  recnn_hyper hy;
-  // Hp / Ap / K1a / K1c / ldx are extents of compute-type rows in ELEMENTS: for the split-bf16 type (x3.h) twice the logical
-  // padded extents Hl / Al (weight-shadow row counts stay logical); ldx32 = row stride of the caller's fp32 packed rows
-  int S, A, H, Hp, Ap, K1a, K1c, ldx, Bc, esz;
-  int Hl, Al, ldx32;
-  bool bf16, td3;
-  recnn_engine_tuning tune;   // schedule / tile choices of THIS engine (recnn_engine_set_tuning)
-  GemmTune gtune;             // ... the part of it the GEMM launchers read (gemm.h)
-  bool x3 = false;     // compute type RECNN_BF16X3: split-bf16 rows through the layer-by-layer launches (gemm.hip / x3.hip)
-  bool twins = false;  // the compute type differs from the bound fp32 rows: the step reads twins of the packed rows (workspace)
-  int n_critic;
-  char* ws = nullptr;
-  int64_t ws_bytes = 0;
-  Net net[RECNN_NET_COUNT];
-  // batch
-  float *xs = nullptr, *xn = nullptr, *reward = nullptr, *done = nullptr;
-  const uint8_t* ext_masks = nullptr;
-  const float* ext_noise = nullptr;
-  // workspace buffers
-  Acts tp, tq[2], cv[2], pa, pc;           // target policy, target critics, critics, actor, policy-critic
-  char *dzc2[2], *dzc1[2];                 // critic backward
-  char *dze2, *dze1, *dag, *dzp2, *dzp1;   // policy backward chain
-  char *xcs = nullptr, *xcn = nullptr;     // packed rows in the compute type: the bound fp32 rows, or bf16 twins
-  char *xsh = nullptr, *xnh = nullptr;     // bf16 twins (workspace, bf16 mode only)
-  // second batch buffer set (bf16 sampler mode): inside a run graph the gather of step t+1 rides on the optimizer
-  // launch of step t and fills the set step t is not reading
-  char *xsh2 = nullptr, *xnh2 = nullptr;
-  float *reward2 = nullptr, *done2 = nullptr;
-  float *reward0 = nullptr, *done0 = nullptr;  // the bound reward / done arrays (set 0)
-  int cur_set = 0;
-  const GatherArgs* pregather = nullptr;   // set while the critic's optimizer launch should carry the next gather
-  // run graphs: the device counters (mask-key step, Adam steps, sampler cursor) are ticked ONCE, by the finalize of
-  // the run's last step; step i of the run is captured with these offsets on top of them
-  int run_off = 0;                         // steps of the run before this one
-  int run_t_off[RECNN_NET_COUNT] = {0};    // optimizer steps of each network earlier in the run
-  bool run_skip_finish = false;            // not the last step of a run: no finalize launch
-  int run_tick[3] = {1, 1, 1};             // increments applied by the finalize: steps, critic steps, actor steps
-  char* gen_action;                        // tc [Bc, Ap] of the current batch buffer set
-  char *gen_action0 = nullptr, *gen_action2 = nullptr;
-  // deferred policy-loss forward of the previous step: that step's packed state rows and actor output, its run offset / slot
-  struct PendingPc { bool on = false; const char* xs = nullptr; const char* ga = nullptr; int run_off = 0; int slot = 0; } pending_pc;
-  // ---- cycle mode (round 3, bf16 sampler engines): the batches of up to MSET_MAX consecutive steps live side by side
-  // (batch j = rows j * rows .. of every array), gathered by ONE launch and pushed through the FROZEN networks (target actor,
-  // target critics, actor: they only change at a policy step) by one set of cycle-batched launches; the per-step launches
-  // then carry the learning critics only (capture_run)
-  static constexpr int MSET_MAX = 16;
-  char *m_xs = nullptr, *m_xn = nullptr;           // bf16 [MSET_MAX * Bc, ldx]      (the CURRENT one of two copies: while a cycle
-  float *m_reward = nullptr, *m_done = nullptr;    // [MSET_MAX * Bc]                  steps on one, a side branch of the run graph
-  char *m_xs_b[2] = {nullptr, nullptr}, *m_xn_b[2] = {nullptr, nullptr};            //  gathers the next cycle's batches into the other)
-  float *m_reward_b[2] = {nullptr, nullptr}, *m_done_b[2] = {nullptr, nullptr};
-  char* m_ga = nullptr;                            // actor outputs, bf16 [MSET_MAX * Bc, Ap]
-  float* m_tq[2] = {nullptr, nullptr};             // Q'(s', pi'(s')) per target critic, fp32 [MSET_MAX * Bc]
-  float* m_noise = nullptr;                        // TD3 target-action noise, fp32 [MSET_MAX * Bc, A]
-  char *m_tp_h1 = nullptr, *m_tp_h2 = nullptr, *m_pa_h1 = nullptr, *m_pa_h2 = nullptr, *m_tq_h1[2] = {nullptr, nullptr};   // bf16 [MSET_MAX * Bc, Hp]
-  Acts pa0;                                        // the single-batch buffers the pointers below return to
-  float* tqv0[2] = {nullptr, nullptr};
-  float* noise_buf;                        // fp32 [Bc, A]
-  float *expected, *target_q, *q[2], *delta[2], *qpi;
-  bool panel_bwd_done = false;             // this step's critic head + dX ran in the bwd.hip launch
-  float* tc_part[2];                       // chained target critics: fp32 [Bc, 256] layer-1 state parts
-  int32_t* tc_flag[2];                     // ... their per-panel completion flags
-  float* tqv[2];
-  float* q_slot[2];                        // Q(s, a) hand-off slots (critic workgroup -> head in the target actor's workgroup)
-  bool unit_bwd = false;                   // this step's dzc2 / dzc1 hold UNIT backward tensors (to be scaled by delta)
-  float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
-  int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
-  float *loss_part[3];                     // value1, value2, policy  (per head block): the CURRENT step's slot of ...
-  float *loss_part_base[3];                // ... LOSS_HIST_MAX per-step slots (run graphs keep every step's partial sums)
-  int64_t loss_part_stride = 0;
-  float* pl_part_base = nullptr;
-  float* loss_ring = nullptr;              // [LOSS_RING][4] losses of the last LOSS_RING steps, indexed by the device step counter
-  int hist_pol_count[LOSS_HIST_MAX];       // capture-time description of the run being captured
-  unsigned char hist_pol_add[LOSS_HIST_MAX];
-  float* losses;                           // device float[4]
-  float* coef_out;                         // device float[1]
-  int32_t* counters;                       // device int32[8]: step, t_policy, t_value1, t_value2
-  float* l1_scratch;
-  // step scalars of the optimizers (bias corrections ...: fp64 chains, optim.h) for every step of the run being issued:
-  // [RUN_MAX][3] = {policy, value1, value2}; filled by one small launch at the start of a run graph / an eager step
-  float* h_stage = nullptr;                // pinned host words for the read-backs (a pageable destination is staged by the runtime: +30 us)
-  recnn_comm* comm = nullptr;              // data parallel: the gradient arenas are all-reduced in-stream (comm.hip)
-  float comm_scale = 1.0f;                 // 1 / world
-  bool comm_region = false;                // the arenas have regions of their own inside the communicator's buffers:
-  int64_t comm_off[RECNN_NET_COUNT] = {};  //   gradients are produced into in[] and the optimizers read out[] (no copies)
-  // device-resident sampler (optional)
-  recnn_sampler smp;
-  bool has_sampler = false;
-  // per-launch profiler (recnn_engine_profile)
-  bool prof_on = false;
-  int prof_n = 0;
-  int prof_repeat = 1;   // idempotent launches are issued this many times inside their event pair
-  static constexpr int PROF_MAX = 48;
-  hipEvent_t prof_ev[2 * PROF_MAX];
-  const char* prof_name[PROF_MAX];
-  double prof_flops[PROF_MAX];
-  int prof_reps[PROF_MAX];
-  bool prof_ready = false;
-  // graphs
-  // gexec[0] / gexec[1]: one ordinary step / one policy step.  Run graphs (several steps per graph launch):
-  //   grun_o[k]  k ordinary steps                      (k >= 2; k = 1 is gexec[0])
-  //   grun_p[k]  a policy step + k ordinary steps      (k >= 1; k = 0 is gexec[1]); k = policy_every-1 is a whole cycle
-  //   grun_multi whole policy cycles, grun_multi_len steps (starts on a policy step)
-  // graph_run() covers any (first_step, n_steps) with them: see recnn_engine_graph_run
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};
-  static constexpr int RUN_MAX = 64;       // = LOSS_HIST_MAX: steps per run graph
-  hipGraphExec_t grun_o[RUN_MAX + 1] = {};
-  hipGraphExec_t grun_p[RUN_MAX + 1] = {};
-  hipGraphExec_t grun_multi = nullptr;
-  int grun_multi_len = 0;
-  // run graphs made to order (recnn_engine_graph_prepare): one launch for a whole request (phase, n_steps)
-  static constexpr int CUSTOM_MAX = 8;
-  hipGraphExec_t grun_custom[CUSTOM_MAX] = {};
-  int grun_custom_phase[CUSTOM_MAX] = {}, grun_custom_len[CUSTOM_MAX] = {};
-  int grun_custom_next = 0;
-  bool grun_look = false;    // run graphs alternate the two batch buffer sets (look-ahead gather)
-  bool use_sampler = false;  // the step being issued / captured draws its batch from the bound sampler
-  bool sampler_eager = false;  // eager public calls (recnn_engine_step, value_grads) draw from the sampler too
-  hipGraphExec_t gdp[7][2] = {};           // data-parallel phase graphs [kind][batch buffer set]
-  int dp_sets = 1;                         // 2: merged tail+head graphs alternate the batch buffer sets (look-ahead gather)
-  int graph_rows = 0;
-  bool hyper_set = false;
-};
-
-static void sync_gemm_tune(recnn_engine* e) {
-  const recnn_engine_tuning& t = e->tune;
-  GemmTune& g = e->gtune;
-  g.variant = t.gemm_variant; g.v0_min_wg = t.gemm_v0_threshold; g.dma = t.gemm_dma; g.dma_deep = t.gemm_dma_depth;
-  g.dma_waves = t.gemm_dma_waves == 8 ? 8 : 4; g.waves = t.gemm_waves == 4 ? 4 : 8; g.dw_dma = t.dw_dma; g.x3_fwd = t.x3_fwd;
-}
-
-// Every kernel launch of the step goes through slot(): a no-op wrapper normally, a hipEvent pair in profile mode.
-template <class F> int slot(recnn_engine* e, const char* name, double flops, hipStream_t s, F&& launch, bool idempotent = true) {
-  if (!e->prof_on) return launch();
-  const int i = e->prof_n;
-  if (i >= recnn_engine::PROF_MAX) return launch();
-  e->prof_name[i] = name;
-  e->prof_flops[i] = flops;
-  const int reps = idempotent ? e->prof_repeat : 1;
-  e->prof_reps[i] = reps;
-  (void)hipEventRecord(e->prof_ev[2 * i], s);
-  int rc = 0;
-  for (int r = 0; r < reps && !rc; ++r) rc = launch();
-  (void)hipEventRecord(e->prof_ev[2 * i + 1], s);
-  e->prof_n = i + 1;
-  return rc;
-}
 
 // ------------------------------------------------------------------------------------ sizing
-namespace {
+namespace recnn_eng {
 
 struct Carver {
   char* base;
@@ -400,7 +203,7 @@ int setup_dims(recnn_engine* e, const recnn_engine_config* cfg) {
   return 0;
 }
 
-}  // namespace
+}  // namespace recnn_eng
 
 extern "C" int recnn_engine_query(const recnn_engine_config* cfg, recnn_engine_sizes* out) {
   RECNN_REQUIRE(out, "engine_query: null out");
@@ -447,7 +250,8 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   return 0;
 }
 
-static void drop_graphs(recnn_engine* e) {
+namespace recnn_eng {
+void drop_graphs(recnn_engine* e) {
   for (int i = 0; i < 2; ++i)
     if (e->gexec[i]) { (void)hipGraphExecDestroy(e->gexec[i]); e->gexec[i] = nullptr; }
   for (int i = 0; i <= recnn_engine::RUN_MAX; ++i) {
@@ -465,6 +269,7 @@ static void drop_graphs(recnn_engine* e) {
     for (int k = 0; k < 2; ++k)
       if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
 }
+}  // namespace recnn_eng
 
 extern "C" void recnn_engine_destroy(recnn_engine* e) {
   if (!e) return;
@@ -575,7 +380,7 @@ extern "C" int recnn_engine_set_counters(recnn_engine* e, int policy_t, int valu
 }
 
 // ------------------------------------------------------------------------------------ layouts
-namespace {
+namespace recnn_eng {
 
 bool value_panel_ok(const recnn_engine* e);
 
@@ -1637,7 +1442,7 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
 // Policy loss through the (updated) critic 1; optionally the gradient chain back into the actor.
 // need_rows: per-row Q(s, pi(s)) wanted (debug / learn=False logging) -> head kernel; otherwise, on the fused bf16 path,
 // the loss is summed in the layer-2 GEMM's epilogue and the backward seed comes from the row-panel kernel (bwd.hip).
-int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s, bool need_rows = true) {
+int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s, bool need_rows) {
   const int A = e->A, Hp = e->Hp, H = e->H, Ap = e->Ap;
   const int POL = RECNN_NET_POLICY, V1 = RECNN_NET_VALUE1;
   const int m0 = e->td3 ? 6 : 4;
@@ -1765,7 +1570,6 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
   return slot(e, "grad_reduce_actor", 0, s, [&] { return grad_reduce_launch(L, g_produce(e, RECNN_NET_POLICY), with_l1 ? pn.l1part : nullptr, s); });
 }
 
-int ph_policy_l1(recnn_engine* e, hipStream_t s);
 
 int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, hipStream_t s) {
   if (e->run_skip_finish) return 0;  // inside a run graph: the last step's finalize ticks the counters for the whole run
@@ -1813,9 +1617,9 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   return slot(e, "loss_finalize", 0, s, [&] { return loss_finalize_launch(a, s); }, false);
 }
 
-}  // namespace
+}  // namespace recnn_eng
 
-namespace {
+namespace recnn_eng {
 int ph_policy_l1(recnn_engine* e, hipStream_t s) {
   Net& pn = e->net[RECNN_NET_POLICY];
   NetLayout L = make_layout(e, RECNN_NET_POLICY, 0);
@@ -1825,7 +1629,7 @@ int ph_policy_l1(recnn_engine* e, hipStream_t s) {
 }
 
 // rows > 0: fused single-GPU path, Adam sums the gradient slabs itself (no separate reduction launch)
-int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int rows = 0) {
+int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int rows) {
   int rc;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
   for (int c = 0; c < e->n_critic; ++c)
@@ -1834,7 +1638,7 @@ int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int
   return 0;
 }
 
-int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bool have_l1 = false) {
+int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bool have_l1) {
   int rc;
   if (!have_l1 && (rc = ph_policy_l1(e, s))) return rc;
   // TD3 never soft-updates the target policy (td3.py:136-141); DDPG does (ddpg.py:98-100).
@@ -2129,8 +1933,8 @@ int net_allreduce(recnn_engine* e, int ni, const char* name, hipStream_t s) {
 // The whole step.  `policy_step` is decided by the caller (host counter), everything else is on-device.
 // pregathered: the batch of this step is already in the current buffer set (put there by the previous step's
 // optimizer launch); gather_next: this step's critic optimizer launch also gathers the NEXT batch into the other set.
-int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered = false,
-              bool gather_next = false, bool defer_policy_fwd = false, bool frozen_done = false) {
+int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered, bool gather_next,
+              bool defer_policy_fwd, bool frozen_done) {
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
   if (frozen_done) {   // cycle mode: the batch is in place and the frozen networks have been applied to it (ph_frozen_batched)
@@ -2180,7 +1984,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
   }
   return ph_finish(e, rows, learn, pol, s);
 }
-}  // namespace
+}  // namespace recnn_eng
 
 // ------------------------------------------------------------------------------------ public step API
 extern "C" int recnn_engine_refresh(recnn_engine* e, int ni, void* stream) {
@@ -2290,389 +2094,6 @@ extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* str
   return report_handoff_error(e, word, (hipStream_t)stream);
 }
 
-// ------------------------------------------------------------------------------------ per-launch profile
-extern "C" int recnn_engine_profile(recnn_engine* e, int rows, int policy_steps, int n_steps, void* stream, float* h_ms,
-                                    double* h_flops, const char** h_names, int* h_n) {
-  int rc = check_ready(e, rows);
-  if (rc) return rc;
-  // idempotent kernels run 8x back to back inside their event pair: amortises the ~3 us an event pair costs
-  e->prof_repeat = 8;
-  RECNN_REQUIRE(h_ms && h_flops && h_names && h_n && n_steps > 0, "profile: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  if (!e->prof_ready) {
-    for (int i = 0; i < 2 * recnn_engine::PROF_MAX; ++i) RECNN_HIP(hipEventCreate(&e->prof_ev[i]));
-    e->prof_ready = true;
-  }
-  double acc[recnn_engine::PROF_MAX];
-  for (int i = 0; i < recnn_engine::PROF_MAX; ++i) acc[i] = 0.0;
-  int nslots = 0;
-  for (int it = 0; it < n_steps; ++it) {
-    e->prof_on = true;
-    e->prof_n = 0;
-    e->use_sampler = e->has_sampler;
-    if (!rc && policy_steps == 2) {
-      // cycle mode, as the long run graphs issue it: one policy cycle's batches, the frozen networks on all of them, then
-      // the first step of the cycle (an ordinary step) on the split forward
-      RECNN_REQUIRE(cycle_ok(e, rows), "profile: cycle mode is not available for this engine / batch size");
-      const int n = e->hy.policy_every < recnn_engine::MSET_MAX ? e->hy.policy_every : recnn_engine::MSET_MAX;
-      select_mbuf(e, 0);
-      rc = ph_gather_cycle(e, rows, n, 0, 0, s);
-      if (!rc) rc = ph_frozen_batched(e, rows, n, 0, s);
-      if (!rc) {
-        use_mset(e, 0, rows);
-        rc = step_impl(e, rows, true, false, s, true, false, false, true);
-      }
-      leave_mset(e);
-    } else if (!rc) {
-      rc = step_impl(e, rows, true, policy_steps != 0, s);
-    }
-    e->use_sampler = false;
-    e->prof_on = false;
-    if (rc) return rc;
-    RECNN_HIP(hipStreamSynchronize(s));
-    nslots = e->prof_n;
-    for (int i = 0; i < nslots; ++i) {
-      float ms = 0.f;
-      RECNN_HIP(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
-      acc[i] += ms / e->prof_reps[i];
-    }
-  }
-  const int cap = *h_n;
-  const int n = nslots < cap ? nslots : cap;
-  for (int i = 0; i < n; ++i) {
-    h_ms[i] = (float)(acc[i] / n_steps);
-    h_flops[i] = e->prof_flops[i];
-    h_names[i] = e->prof_name[i];
-  }
-  *h_n = n;
-  return 0;
-}
-
-// ------------------------------------------------------------------------------------ graphs
-// tuning.graph_run: steps per run graph; -1 = whole policy cycles, up to 64 steps (policy_every > 32: 16 ordinary steps); 0 / 1 = off
-
-// Executable graphs: one ordinary step, one policy step, and a family of RUN graphs (several consecutive steps per
-// graph launch) -- between two graph launches the GPU idles for ~8 us (rocprofv3 kernel trace), inside a graph the
-// kernels are back to back, the sampler + gather of step t+1 rides on step t's optimizer launch and the policy-loss
-// forward of step t on step t+1's forward launch.  Which steps of a run are policy steps is frozen at capture time, so
-// the family holds every shape graph_run() needs to cover ANY (first_step, n_steps):
-//   grun_o[k]   k ordinary steps                  -- the stretch up to the next policy step / the end of the request
-//   grun_p[k]   a policy step + k ordinary steps  -- k = policy_every-1 is a whole cycle, smaller k the request's tail
-//   grun_multi  as many whole cycles as fit 64 steps
-// (policy_every <= 17: every k; larger: k in {1, 2, 4, 8, 16, 32} and greedy composition.)
-namespace {
-// One run of `len` steps captured into *out.  phase = (number of the run's first step) mod policy_every: step i of the run is
-// a policy step when (phase + i) is a multiple of policy_every; phase < 0: no policy step in the run.
-int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hipGraphExec_t* out) {
-  if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
-  const int pe = e->hy.policy_every;
-  const bool look = lookahead_ok(e) && len > 1;
-  hipGraph_t graph = nullptr;
-  int rc = 0;
-  RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  e->use_sampler = e->has_sampler;
-  int n_pol = 0;
-  const bool cyc = !rc && len > 1 && (e->tune.split_fwd >= 2 || len >= e->tune.cycle_min_len) && cycle_ok(e, rows);
-  auto is_pol = [&](int i) { return phase >= 0 && ((phase + i) % pe) == 0; };
-  if (cyc) {
-    // segments = the steps up to and including the next policy step (the frozen networks change right after it)
-    int seg0[recnn_engine::RUN_MAX + 1], seg1[recnn_engine::RUN_MAX + 1], nseg = 0;
-    for (int i0 = 0; i0 < len;) {
-      int i1 = i0;
-      while (i1 + 1 < len && !is_pol(i1) && i1 - i0 + 1 < recnn_engine::MSET_MAX) ++i1;
-      seg0[nseg] = i0; seg1[nseg] = i1; ++nseg;
-      i0 = i1 + 1;
-    }
-    rc = ph_gather_cycle(e, rows, seg1[0] - seg0[0] + 1, seg0[0], 0, s);
-    for (int k = 0; k < nseg && !rc; ++k) {
-      const int i0 = seg0[k], i1 = seg1[k], n = i1 - i0 + 1, buf = k & 1;
-      select_mbuf(e, buf);
-      e->run_off = i0;
-      // a one- or two-step segment (a graph that starts ON a policy step has one at its head) does not pay for the batched
-      // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays.
-      // (The driver's 20-step request in cycle mode, segments 6 + 10 + 4, with this threshold at 3 / 5 / 8: 67.7 / 67.1 / 67.6
-      // us/step against 67.8-68.3 all-fused -- inside the noise, so short graphs stay on the fused schedule: cycle_min_len 30.)
-      const bool batched = n >= e->tune.cycle_min_seg;
-      if (batched) rc = ph_frozen_batched(e, rows, n, i0, s);
-      for (int i = i0; i <= i1 && !rc; ++i) {
-        const bool pol = is_pol(i);
-        use_mset(e, i - i0, rows);
-        e->run_off = i;
-        use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
-        e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
-        for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
-        e->run_skip_finish = i + 1 < len;
-        if (pol) ++n_pol;
-        e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
-        // the policy-loss forward of an ordinary step rides on the next step's critic launches (its batch must survive until
-        // then: not across a segment boundary)
-        const bool defer = e->tune.defer_policy_fwd && i < i1;
-        rc = step_impl(e, rows, true, pol, s, true, false, defer, batched);
-      }
-      // (the next segment's batches go into the other copy of the cycle arrays: this segment's deferred forwards still read theirs)
-      if (!rc && k + 1 < nseg) rc = ph_gather_cycle(e, rows, seg1[k + 1] - seg0[k + 1] + 1, seg0[k + 1], buf ^ 1, s);
-    }
-    select_mbuf(e, 0);
-  }
-  if (cyc) leave_mset(e);
-  for (int i = 0; !cyc && i < len && !rc; ++i) {
-    const bool pol = phase >= 0 && ((phase + i) % pe) == 0;
-    use_set(e, look ? (i & 1) : 0);
-    // counters are ticked once, by the last step's finalize: step i runs `i` steps ahead of them
-    e->run_off = i;
-    use_hist_slot(e, i < LOSS_HIST_MAX ? i : 0);
-    e->hist_pol_count[i < LOSS_HIST_MAX ? i : 0] = 0;
-    for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = (ni == RECNN_NET_POLICY) ? n_pol : i;
-    e->run_skip_finish = i + 1 < len;
-    if (pol) ++n_pol;
-    e->run_tick[0] = len; e->run_tick[1] = len; e->run_tick[2] = n_pol;
-    // the policy-loss forward of an ordinary step rides on the next step's forward launch (needs the second
-    // buffer set)
-    const bool defer = look && e->tune.defer_policy_fwd && (value_chain_ok(e) || e->x3) && i + 1 < len;
-    rc = step_impl(e, rows, true, pol, s, look && i > 0, look && i + 1 < len, defer);
-  }
-  e->run_off = 0;
-  use_hist_slot(e, 0);
-  e->pending_pc.on = false;
-  for (int ni = 0; ni < RECNN_NET_COUNT; ++ni) e->run_t_off[ni] = 0;
-  e->run_skip_finish = false;
-  e->run_tick[0] = e->run_tick[1] = e->run_tick[2] = 1;
-  e->use_sampler = false;
-  use_set(e, 0);
-  hipError_t ce = hipStreamEndCapture(s, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  RECNN_HIP(ce);
-  hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  RECNN_HIP(ie);
-  // pay the one-time device-side set-up of the executable graph now, not inside somebody's timed first replay
-  if (hipGraphUpload(*out, s) != hipSuccess) (void)hipGetLastError();
-  return 0;
-}
-// the run lengths kept for `limit` (largest useful length): every length when the family stays small, else powers of two
-bool run_len_kept(int k, int limit) { return k >= 1 && k <= limit && (limit <= 16 || (k & (k - 1)) == 0); }
-}  // namespace
-
-extern "C" int recnn_engine_graph_build(recnn_engine* e, int rows, void* stream) {
-  int rc = check_ready(e, rows);
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  RECNN_REQUIRE(s != nullptr, "graph_build: capture needs a non-null stream");
-  drop_graphs(e);
-  const int pe = e->hy.policy_every;
-  int cap = e->tune.graph_run < 0 ? recnn_engine::RUN_MAX : e->tune.graph_run;   // longest run graph wanted
-  if (cap > recnn_engine::RUN_MAX) cap = recnn_engine::RUN_MAX;
-  if ((rc = capture_run(e, rows, s, -1, 1, &e->gexec[0]))) return rc;
-  if ((rc = capture_run(e, rows, s, 0, 1, &e->gexec[1]))) return rc;
-  if (cap >= 2) {
-    const int o_max = pe - 1 < cap ? pe - 1 : cap;            // ordinary stretch: never across a policy step
-    for (int k = 2; k <= o_max; ++k)
-      if (run_len_kept(k, o_max) && (rc = capture_run(e, rows, s, -1, k, &e->grun_o[k]))) return rc;
-    const int p_max = pe - 1 < cap - 1 ? pe - 1 : cap - 1;    // policy step + k ordinary ones
-    for (int k = 1; k <= p_max; ++k)
-      if (run_len_kept(k, p_max) && (rc = capture_run(e, rows, s, 0, k + 1, &e->grun_p[k]))) return rc;
-    const int cycles = cap / pe;
-    if (cycles >= 2) {
-      if ((rc = capture_run(e, rows, s, 0, cycles * pe, &e->grun_multi))) return rc;
-      e->grun_multi_len = cycles * pe;
-    }
-  }
-  e->grun_look = lookahead_ok(e);
-  e->graph_rows = rows;
-  return 0;
-}
-
-// A run graph made to order for requests of exactly n_steps steps starting at a step congruent to first_step modulo
-// policy_every: graph_run() then serves such a request with ONE launch instead of the [stretch][cycles][tail] composition
-// (each graph boundary costs ~45 us of GPU time plus a host launch).  Up to CUSTOM_MAX are kept, oldest replaced.
-extern "C" int recnn_engine_graph_prepare(recnn_engine* e, int first_step, int n_steps, void* stream) {
-  RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_prepare: build the graphs first (recnn_engine_graph_build)");
-  RECNN_REQUIRE(first_step >= 0 && n_steps >= 2 && n_steps <= recnn_engine::RUN_MAX, "graph_prepare: 2 <= n_steps <= %d",
-                recnn_engine::RUN_MAX);
-  hipStream_t s = (hipStream_t)stream;
-  RECNN_REQUIRE(s != nullptr, "graph_prepare: capture needs a non-null stream");
-  const int phase = first_step % e->hy.policy_every;
-  for (int i = 0; i < recnn_engine::CUSTOM_MAX; ++i)
-    if (e->grun_custom[i] && e->grun_custom_phase[i] == phase && e->grun_custom_len[i] == n_steps) return 0;
-  const int slot = e->grun_custom_next;
-  e->grun_custom_next = (slot + 1) % recnn_engine::CUSTOM_MAX;
-  e->grun_custom_len[slot] = 0;
-  const int rc = capture_run(e, e->graph_rows, s, phase, n_steps, &e->grun_custom[slot]);
-  if (rc) return rc;
-  e->grun_custom_phase[slot] = phase;
-  e->grun_custom_len[slot] = n_steps;
-  return 0;
-}
-
-// Replays n_steps consecutive steps starting at step number first_step with as few graph launches as the family allows:
-// [ordinary stretch up to the next policy step] [multi-cycle graphs] [whole cycles] [policy step + tail].
-extern "C" int recnn_engine_graph_run(recnn_engine* e, int first_step, int n_steps, void* stream) {
-  RECNN_REQUIRE(e && e->gexec[0] && e->gexec[1], "graph_run: graphs not built");
-  const int pe = e->hy.policy_every;
-  hipStream_t s = (hipStream_t)stream;
-  for (int c = 0; c < recnn_engine::CUSTOM_MAX; ++c)
-    if (e->grun_custom[c] && e->grun_custom_len[c] == n_steps && e->grun_custom_phase[c] == first_step % pe) {
-      RECNN_HIP(hipGraphLaunch(e->grun_custom[c], s));
-      use_set(e, e->grun_look ? ((n_steps - 1) & 1) : 0);
-      return 0;
-    }
-  int i = 0;
-  while (i < n_steps) {
-    const int step = first_step + i, rem = n_steps - i;
-    const bool pol = (step % pe) == 0;
-    hipGraphExec_t g = nullptr;
-    int len = 1;
-    if (pol) {
-      if (e->grun_multi && rem >= e->grun_multi_len) { g = e->grun_multi; len = e->grun_multi_len; }
-      else {
-        int k = (rem < pe ? rem : pe) - 1;                    // ordinary steps that may follow inside this cycle
-        if (k > recnn_engine::RUN_MAX) k = recnn_engine::RUN_MAX;
-        while (k >= 1 && !e->grun_p[k]) --k;
-        if (k >= 1) { g = e->grun_p[k]; len = k + 1; } else g = e->gexec[1];
-      }
-    } else {
-      int k = pe - (step % pe);                               // ordinary steps before the next policy step
-      if (k > rem) k = rem;
-      if (k > recnn_engine::RUN_MAX) k = recnn_engine::RUN_MAX;
-      while (k >= 2 && !e->grun_o[k]) --k;
-      if (k >= 2) { g = e->grun_o[k]; len = k; } else g = e->gexec[0];
-    }
-    RECNN_HIP(hipGraphLaunch(g, s));
-    use_set(e, (e->grun_look && len > 1) ? ((len - 1) & 1) : 0);   // where the debug views find the last batch
-    i += len;
-  }
-  return 0;
-}
-
-// Data-parallel phase graphs (see recnn_amd/parallel.py): the gradient all-reduces run between them.
-//   kind 0 H    batch + all forwards + critic backward + slab reduction            -> all-reduce critic grads
-//   kind 1 T1   [ordinary step] critic Adam, policy loss, finish
-//   kind 2 T2   [policy step]   critic Adam (+soft), policy loss + actor backward    -> all-reduce actor grads
-//   kind 3 T3   [policy step]   L1 clip + actor Adam (+soft), finish
-//   kind 4      (overlap mode)  actor forward alone: runs while the critic all-reduce is in flight; graph 0 then
-//                               leaves the actor out of its first group
-//   kind 5 T1H  T1 of step t followed by H of step t+1 in ONE graph (one graph launch per step instead of two: the GPU
-//               idles ~8 us between graph launches); with two batch buffer sets the sampler + gather of step t+1 rides
-//               on step t's critic optimizer launch, as in the single-GPU run graphs
-//   kind 6 T3H  T3 followed by H of the next step
-// `which` of recnn_engine_dp_graph_launch = kind + 8 * set (the buffer set step t's batch is in).
-static int dp_capture(recnn_engine* e, hipStream_t s, hipGraphExec_t* out, const std::function<int()>& body) {
-  if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
-  hipGraph_t graph = nullptr;
-  RECNN_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  const int rc = body();
-  hipError_t ce = hipStreamEndCapture(s, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  RECNN_HIP(ce);
-  hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  RECNN_HIP(ie);
-  (void)e;
-  return 0;
-}
-
-extern "C" int recnn_engine_dp_graph_build(recnn_engine* e, int rows, float grad_scale, int overlap_actor, void* stream) {
-  int rc = check_ready(e, rows);
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  RECNN_REQUIRE(s != nullptr, "dp_graph_build: capture needs a non-null stream");
-  for (int i = 0; i < 7; ++i)
-    for (int k = 0; k < 2; ++k)
-      if (e->gdp[i][k]) { (void)hipGraphExecDestroy(e->gdp[i][k]); e->gdp[i][k] = nullptr; }
-  const bool look = !overlap_actor && lookahead_ok(e);
-  e->dp_sets = look ? 2 : 1;
-  struct SamplerScope { recnn_engine* e; ~SamplerScope() { e->use_sampler = false; } } sampler_scope{e};
-  e->use_sampler = e->has_sampler;
-  auto head = [&](bool pregathered) -> int {
-    int r = pregathered ? 0 : stage_batch(e, rows, s);
-    if (!r && !(r = ph_forward(e, rows, true, !overlap_actor, true, s))) r = ph_value_backward(e, rows, true, s);
-    return r;
-  };
-  use_set(e, 0);
-  if ((rc = dp_capture(e, s, &e->gdp[0][0], [&] { return head(false); }))) return rc;
-  if (overlap_actor && (rc = dp_capture(e, s, &e->gdp[4][0], [&] { return ph_forward(e, rows, false, true, false, s); }))) return rc;
-  for (int set = 0; set < e->dp_sets && !rc; ++set) {
-    use_set(e, set);
-    use_hist_slot(e, set);   // loss partial sums of a step live in the slot of its batch buffer set
-    rc = dp_capture(e, s, &e->gdp[1][set], [&] {
-      int r;
-      if (!(r = value_apply(e, false, grad_scale, s)) && !(r = ph_policy(e, rows, false, false, s, false))) r = ph_finish(e, rows, true, false, s);
-      return r;
-    });
-    if (!rc) rc = dp_capture(e, s, &e->gdp[2][set], [&] {
-      int r;
-      if (!(r = value_apply(e, true, grad_scale, s))) r = ph_policy(e, rows, true, false, s, false);
-      return r;
-    });
-    const int pol_dots = e->pl_dot_parts;   // how the policy step's loss partials were produced (by graph 2's ph_policy)
-    if (!rc) rc = dp_capture(e, s, &e->gdp[3][set], [&] {
-      int r;
-      e->pl_dot_parts = pol_dots;
-      if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
-      return r;
-    });
-    if (overlap_actor) continue;   // the overlap variant keeps one graph per phase
-    if (!rc) rc = dp_capture(e, s, &e->gdp[5][set], [&] {
-      GatherArgs ga;
-      if (look) { ga = gather_args(e, rows, set ^ 1, 1); e->pregather = &ga; }
-      int r = value_apply(e, false, grad_scale, s);
-      e->pregather = nullptr;
-      // With two buffer sets the policy-loss forward of step t rides on step t+1's forward launch (as in the run
-      // graphs); step t's finalize then closes the graph: the head of step t+1 is captured one step ahead of the
-      // device counters and writes its loss partial sums into the other per-step slot.
-      const bool defer = look && e->tune.defer_policy_fwd && value_chain_ok(e);
-      if (!r) {
-        if (defer) {
-          e->pending_pc.on = true; e->pending_pc.xs = e->xcs; e->pending_pc.ga = e->gen_action; e->pending_pc.run_off = 0; e->pending_pc.slot = set;
-        } else if (!(r = ph_policy(e, rows, false, false, s, false))) {
-          r = ph_finish(e, rows, true, false, s);
-        }
-      }
-      if (!r) {
-        if (look) use_set(e, set ^ 1);
-        if (defer) { e->run_off = 1; use_hist_slot(e, set ^ 1); }
-        r = head(look);
-        if (defer) {
-          e->run_off = 0;
-          use_hist_slot(e, set);
-          e->pl_dot_parts = rows;   // Q per row (b3 included) in this step's policy slot
-          if (!r) r = ph_finish(e, rows, true, false, s);
-          e->pl_dot_parts = 0;
-        }
-        e->pending_pc.on = false;
-        use_set(e, set);
-      }
-      return r;
-    });
-    if (!rc) rc = dp_capture(e, s, &e->gdp[6][set], [&] {
-      int r;
-      e->pl_dot_parts = pol_dots;
-      if (!(r = policy_apply(e, true, grad_scale, s))) r = ph_finish(e, rows, true, true, s);
-      if (!r) {
-        if (look) { use_set(e, set ^ 1); use_hist_slot(e, set ^ 1); }
-        r = head(false);   // the policy step's tail does not look ahead: its own gather, after the cursor tick
-        use_set(e, set);
-        use_hist_slot(e, set);
-      }
-      return r;
-    });
-  }
-  use_set(e, 0);
-  use_hist_slot(e, 0);
-  return rc;
-}
-
-extern "C" int recnn_engine_dp_sets(recnn_engine* e) { return e ? e->dp_sets : 1; }
-
-extern "C" int recnn_engine_dp_graph_launch(recnn_engine* e, int which, void* stream) {
-  const int kind = which & 7, set = which >> 3;
-  RECNN_REQUIRE(e && which >= 0 && kind < 7 && set < 2 && e->gdp[kind][set], "dp_graph_launch: graph %d not built", which);
-  RECNN_HIP(hipGraphLaunch(e->gdp[kind][set], (hipStream_t)stream));
-  // where the debug views find the batch afterwards: merged graphs (kinds 5, 6) end in the other set's head
-  use_set(e, (kind >= 5 && e->dp_sets == 2) ? (set ^ 1) : set);
-  return 0;
-}
-
 // ------------------------------------------------------------------------------------ debug buffers
 extern "C" int recnn_engine_unit_backward(recnn_engine* e) { return e && e->unit_bwd ? 1 : 0; }
 
@@ -2706,3 +2127,4 @@ extern "C" const void* recnn_engine_buffer(recnn_engine* e, const char* name, in
     }
   return nullptr;
 }
+

@@ -209,11 +209,14 @@ _splitk_ws = {}
 
 
 def _splitk_scratch(device, floats):
-    """fp32 scratch of at least `floats` elements on `device`, kept for the process (one per device; stream-ordered reuse: every
-    product that uses it is launched on the current stream)."""
-    key = (device.type, device.index)
+    """fp32 scratch of at least `floats` elements on `device` for the library's split-K, one per (device, STREAM): products issued on
+    different streams never share a buffer.  A buffer that has to grow is REPLACED, never freed: a captured graph
+    (GraphedUpdate) has the old pointer baked in and may still replay into it, so retired buffers stay alive for the process."""
+    key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
     t = _splitk_ws.get(key)
     if t is None or t.numel() < floats:
+        if t is not None:
+            _splitk_ws.setdefault("_retired", []).append(t)
         t = torch.empty(floats, dtype=torch.float32, device=device)
         _splitk_ws[key] = t
     return t
@@ -694,9 +697,10 @@ class DiscretePolicyFunction(torch.autograd.Function):
         del scratch
         gdt = L.BF16 if bf16 else None
         h_op = h.to(torch.bfloat16) if bf16 else h       # [rows, hidden]: small next to the catalogue operands
-        if _episode["on"] and dprobs is None and ctx.w2_param.is_leaf:
-            gw2 = None                                   # ONE dW over the whole episode's rows at the end of the pass (episode_backward)
-        else:
+        need_w2 = bool(ctx.needs_input_grad[3])          # (a frozen head -- requires_grad False -- gets no gradient, deferred or not)
+        defer = need_w2 and _episode["on"] and dprobs is None and ctx.w2_param.is_leaf
+        gw2 = None                                       # deferred: ONE dW over the whole episode's rows at the end of the pass (episode_backward)
+        if need_w2 and not defer:
             gw2 = torch.empty(N, H, device=dev)
             _dw(dlog, N, h_op, H, gw2, dtype=gdt)
         dz1 = torch.zeros(B, Hp, device=dev)
@@ -707,8 +711,8 @@ class DiscretePolicyFunction(torch.autograd.Function):
             return transposed_rows(w, ldn, bf16)
         w2t = _derived_of(ctx.w2_param, "transposed_bf16" if bf16 else "transposed", transposed)
         _fwd(dlog, ldn, w2t, None, dz1, Hp, H, False, None, yref=h_op, scale=1.0, dtype=gdt)
-        if gw2 is None:
-            _episode["pending"].setdefault(id(ctx.w2_param), (ctx.w2_param, []))[1].append((dlog, h_op, gdt))
+        if defer:     # grouped by (parameter, operand type): set_catalogue_dtype may change between the steps of an episode
+            _episode["pending"].setdefault((id(ctx.w2_param), gdt), (ctx.w2_param, gdt, []))[2].append((dlog, h_op))
         del dlog
         gb1 = dz1[:, :H].sum(0)
         gw1 = torch.empty(H, K, device=dev)
@@ -751,11 +755,24 @@ class episode_backward:
         pending, _episode["pending"], _episode["on"] = _episode["pending"], {}, False
         if exc_type is not None:
             return False
-        for w2, terms in pending.values():
+        def gather(terms, i):
+            # the terms' tensors into one [rows, ld] operand, each released as soon as it is copied (torch.cat would hold the
+            # episode twice: ~2 x 1 GB of d logits at 10 x 256 x 100k)
+            if len(terms) == 1:
+                return terms[0][i]
+            first = terms[0][i]
+            out = torch.empty((sum(t[i].shape[0] for t in terms),) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            off = 0
+            for k in range(len(terms)):
+                t = terms[k][i]
+                out[off:off + t.shape[0]].copy_(t)
+                off += t.shape[0]
+                terms[k] = tuple(None if j == i else terms[k][j] for j in range(2))
+            return out
+        for w2, gdt, terms in pending.values():
             N, H = w2.shape
-            gdt = terms[0][2]
-            dlog = terms[0][0] if len(terms) == 1 else torch.cat([t[0] for t in terms], 0)
-            h_op = terms[0][1] if len(terms) == 1 else torch.cat([t[1] for t in terms], 0)
+            dlog = gather(terms, 0)
+            h_op = gather(terms, 1)
             gw2 = torch.empty(N, H, device=w2.device)
             _dw(dlog, N, h_op, H, gw2, dtype=gdt)
             del dlog, h_op

@@ -29,7 +29,11 @@ def beta_fn(fx, device=None):
     return beta
 
 
-def replay_oracle(fx):
+def replay_oracle(fx, learned_beta=False):
+    """learned_beta: the behaviour policy is the notebook's `Beta` net (oracle.reinforce_oracle.beta_step, pinned on the notebook's own
+    class by oracle/make_golden_beta.py), started from fx["g"]["beta_w0" / "beta_b0"] and TRAINED inside every step on the batch's
+    action, as `_select_action_with_TopK_correction(state, beta_net.forward, action, ...)` does (recnn/nn/models.py:143-184 +
+    notebook cell 3); returns its final parameters under "beta"."""
     from oracle import recnn_oracle as O
     from oracle import reinforce_oracle as R
     g = fx["g"]
@@ -38,6 +42,12 @@ def replay_oracle(fx):
     st = R.ReinforceState.create(pol, val, R.AdamDict(R.POLICY_ORDER, lr=fx["lr_p"], weight_decay=fx["wd_p"]),
                                  R.AdamDict(O.PARAM_ORDER, lr=fx["lr_v"], weight_decay=fx["wd_v"]), method=fx["method"], K=fx["K"])
     bs, beta = batches(fx), beta_fn(fx)
+    if learned_beta:
+        bp = {"w": torch.from_numpy(g["beta_w0"].copy()), "b": torch.from_numpy(g["beta_b0"].copy())}
+        bopt = R.AdamDict(("w", "b"), lr=fx["lr_b"], weight_decay=fx["wd_b"])
+
+        def beta(state, action=None, _bs=None):
+            return R.beta_step(bp, bopt, state, action.argmax(1))[0]
     pi_draws, beta_draws = torch.from_numpy(g["pi_draws"]), torch.from_numpy(g["beta_draws"])
     losses = []
     for t in range(fx["steps"]):
@@ -45,9 +55,11 @@ def replay_oracle(fx):
         masks = [torch.from_numpy(m) for m in g["masks"][t]]
         basic = fx["method"] == "basic"
         scored = pi_draws[t] if (basic or fx["pi_source"] == "pi") else beta_draws[t]
-        out = R.reinforce_step(st, b, scored, masks, step=t, beta_probs=None if basic else beta(b["state"]),
+        out = R.reinforce_step(st, b, scored, masks, step=t, beta_probs=None if basic else (beta(b["state"], b["action"]) if learned_beta else beta(b["state"])),
                                beta_action=None if basic else beta_draws[t])
         if out["policy"] is not None:
             losses.append([t, out["value"], out["policy"]])
     final = {"policy": st.policy, "value": st.value, "target_policy": st.target_policy, "target_value": st.target_value}
+    if learned_beta:
+        final["beta"] = bp
     return np.asarray(losses), final

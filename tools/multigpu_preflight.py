@@ -59,7 +59,12 @@ def make_engine(L, dev, rows, dtype, mask_mode, seed=0):
     return eng
 
 
-def main():
+LAST_SUMMARY = None     # {"ok": bool, "stages": {stage: ok}} of the latest main() in this process (bench.py embeds it)
+
+
+def main(keep_group=False):
+    """keep_group: leave the process group initialised (bench.py runs this in front of its timed regions and goes on with the group)."""
+    global LAST_SUMMARY
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,10 +105,11 @@ def main():
     # ---------------------------------------------------------------- process group
     def st_pg():
         backend = os.environ.get("RECNN_BENCH_BACKEND", "gloo" if single else "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        if not dist.is_initialized():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
         dist.barrier()
         x = torch.full((1024,), float(rank + 1), device=dev if backend == "nccl" else "cpu")
         t0 = time.perf_counter()
@@ -278,8 +284,12 @@ def main():
     stage("bench_rccl", lambda: bench_path(False))
 
     emit(rank, "summary", ok=all(v for v in summary.values()), stages=summary)
+    LAST_SUMMARY = {"ok": all(v for v in summary.values()), "stages": dict(summary)}
     dist.barrier()
-    dist.destroy_process_group()
+    if state["comm"] is not None:
+        state["comm"].close()
+    if not keep_group:
+        dist.destroy_process_group()
     return 0 if all(summary.values()) else 1
 
 
