@@ -108,6 +108,7 @@ def batch_tensor_embeddings(batch, item_embeddings_tensor, frame_size, *args, **
     done = torch.zeros(b, device=dev)
     if b:
         idx = torch.cumsum(torch.as_tensor(sizes_t).to(dev) - frame_size, dim=0) - 1
+        idx = idx[(idx >= 0) & (idx < b)]        # (a batch cut to rows_per_batch rows ends inside a user: the later users' last windows are not in it)
         done[idx.long()] = 1
     res = dict(out)
     res["done"] = done

@@ -60,6 +60,12 @@ BF16_BOUNDS = {
     "ddpg_vs_oracle/bf16/params/value": 5.0e-02,   # measured 2.41e-02
     "ddpg_vs_oracle/bf16/policy_grad": 1.3e-02,   # measured 5.15e-03
     "ddpg_vs_oracle/bf16/value_grad": 9.0e-03,   # measured 3.57e-03
+    "reinforce_beta_100k/bf16/loss": 3.9e-03,   # measured 1.55e-03 (round 5)
+    "reinforce_beta_100k/bf16/params/beta": 1.2e-03,   # measured 4.92e-04 (round 5)
+    "reinforce_beta_100k/bf16/params/policy": 9.2e-02,   # measured 3.68e-02 (round 5)
+    "reinforce_beta_100k/bf16/params/target_policy": 1.5e-04,   # measured 6.02e-05 (round 5)
+    "reinforce_beta_100k/bf16/params/target_value": 1.5e-05,   # measured 5.85e-06 (round 5)
+    "reinforce_beta_100k/bf16/params/value": 1.2e-03,   # measured 4.95e-04 (round 5)
     "td3_vs_oracle/bf16/loss": 6.7e-03,   # measured 2.64e-03
     "td3_vs_oracle/bf16/params/policy": 5.0e-02,   # measured 2.62e-02
     "td3_vs_oracle/bf16/params/target_policy": 1.0e-06,   # measured 0.00e+00

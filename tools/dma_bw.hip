@@ -5,6 +5,8 @@
 //   mode 2: global_load_dwordx4 into registers, 4 rows x 256 B per wave instruction
 //   mode 3: mode 2 with 1 KiB contiguous per wave instruction
 //   mode 4: global_load_lds_dwordx4, 8 rows x 128 B per wave instruction (64-k slabs of a 256-row matrix), row pitch = ld_bytes
+//   mode 5: waves 0-7 by LDS-DMA, waves 8-15 through registers (global_load_dwordx4 -> ds_write_b128), half the rows each (round 5)
+//   mode 6: all 16 waves through registers + ds_write_b128
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/_build/dma_bw tools/dma_bw.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -29,6 +31,51 @@ __global__ __launch_bounds__(1024) void stream_kernel(const char* w, int ld_byte
   u32x4 acc = {0, 0, 0, 0};
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (MODE == 5 || MODE == 6) {
+    // register path, software-pipelined two slabs deep (pa / pb): the loads of slab t + 1 are issued before slab t is written to LDS
+    const bool regw = MODE == 6 || wave >= 8;
+    u32x4 pa[NI], pb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pa[j] = pb[j] = acc;
+    auto src_of = [&](int t, int j) { return w + (int64_t)((j * 16 + wave) * 4 + q_row) * ld_bytes + t * 256 + q_pos * 16; };
+    for (int rep = 0; rep < reps; ++rep) {
+      if (regw) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa[j]) : "v"(src_of(0, j)) : "memory");
+      }
+      for (int t = 0; t < nslab; t += 2) {
+        if (regw) {
+          if (t + 1 < nslab) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pb[j]) : "v"(src_of(t + 1, j)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+          } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < NI; ++j) *(u32x4*)(lds + (t % DEPTH) * STAGE + (j * 16 + wave) * 1024 + lane * 16) = pa[j];
+          if (t + 2 < nslab) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa[j]) : "v"(src_of(t + 2, j)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+          } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (t + 1 < nslab) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) *(u32x4*)(lds + ((t + 1) % DEPTH) * STAGE + (j * 16 + wave) * 1024 + lane * 16) = pb[j];
+          }
+        } else {
+          for (int tt = t; tt < t + 2 && tt < nslab; ++tt) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) dma16(src_of(tt, j), lds0 + (tt % DEPTH) * STAGE + (j * 16 + wave) * 1024);
+            if (tt >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * NI) : "memory");
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+    if (pa[0].x == 0x12345678u || pb[0].y == 0x12345678u) sink[0] = 1.f;
+    return;
+  }
   for (int rep = 0; rep < reps; ++rep) {
     for (int t = 0; t < nslab; ++t) {
 #pragma unroll
@@ -91,27 +138,60 @@ void run(const char* name, const char* w, int ld_bytes, int nslab, int nwg) {
   hipFree(ticks); hipFree(sink);
 }
 
+static FILE* g_json = nullptr;
+static bool g_first = true;
+template <int MODE, int SLAB_ROWS, int DEPTH>
+void run_j(const char* name, const char* w, int ld_bytes, int nslab, int nwg) {
+  // (run() prints; the same numbers again as one JSON row)
+  unsigned long long* ticks;
+  float* sink;
+  hipMalloc(&ticks, nwg * sizeof(*ticks));
+  hipMalloc(&sink, 4);
+  const int reps = 8;
+  const int lds_bytes = DEPTH * SLAB_ROWS * 256;
+  hipFuncSetAttribute((const void*)stream_kernel<MODE, SLAB_ROWS, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((stream_kernel<MODE, SLAB_ROWS, DEPTH>), dim3(nwg), dim3(1024), lds_bytes, 0, w, ld_bytes, nslab, reps, ticks, sink);
+    hipEventRecord(e1);
+    if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s: FAILED\n", name); return; }
+  }
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(nwg);
+  hipMemcpy(h.data(), ticks, nwg * sizeof(*ticks), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto v : h) mean += (double)v;
+  mean /= nwg;
+  const double bytes = (double)reps * nslab * SLAB_ROWS * 256;
+  printf("%-64s slab %3d KB x %d in flight: %6.1f B/tick/CU, kernel %7.1f us, %6.1f GB/s per CU, %6.2f TB/s chip\n", name, SLAB_ROWS / 4, DEPTH,
+         bytes / mean, ms * 1e3, bytes / (ms * 1e-3) / 1e9, bytes * nwg / (ms * 1e-3) / 1e12);
+  if (g_json) {
+    fprintf(g_json, "%s\n  {\"variant\": \"%s\", \"slab_kb\": %d, \"slabs_in_flight\": %d, \"workgroups\": %d, \"B_per_clk_per_CU\": %.2f, \"GBs_per_CU\": %.1f, \"TBs_chip\": %.2f}",
+            g_first ? "" : ",", name, SLAB_ROWS / 4, DEPTH, nwg, bytes / mean, bytes / (ms * 1e-3) / 1e9, bytes * nwg / (ms * 1e-3) / 1e12);
+    g_first = false;
+  }
+  hipFree(ticks); hipFree(sink);
+}
+
 int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
   const int nwg = argc > 1 ? atoi(argv[1]) : 256;
+  if (argc > 2) { g_json = fopen(argv[2], "w"); if (g_json) fprintf(g_json, "{\"what\": \"one workgroup of 16 waves per CU streams an L2-resident [256 x 1408] bf16 matrix into LDS slab by slab (tools/dma_bw.hip): which issue path moves the most bytes per clock per CU\",\n \"rows\": ["); }
   const int K = 1408, rows = 256;
   char* w;
   hipMalloc(&w, (size_t)rows * K * 2 + 4096);
   hipMemset(w, 1, (size_t)rows * K * 2 + 4096);
   const int nslab = K / 128;
-  // mode 4: SLAB_ROWS = 128 -> 16 waves x 2 instructions x 8 rows = 256 image rows of 128 B = 32 KB per slab
-  run<4, 128, 4>("lds-dma 8x128B rows, pitch 2816 (W1)", w, 2816, 22, nwg);
-  run<4, 128, 4>("lds-dma 8x128B rows, pitch 512 (W2 as stored)", w, 512, 22, nwg);
-  run<4, 128, 4>("lds-dma 8x128B rows, pitch 640", w, 640, 22, nwg);
-  run<4, 128, 4>("lds-dma 8x128B rows, pitch 528", w, 528, 22, nwg);
-  run<4, 128, 4>("lds-dma 8x128B rows, pitch 1024", w, 1024, 22, nwg);
-  return 0;
-  run<0, 256, 2>("lds-dma 4x256B rows", w, K * 2, nslab, nwg);
-  run<1, 256, 2>("lds-dma 1KiB contiguous", w, K * 2, nslab, nwg);
-  run<0, 128, 4>("lds-dma 4x256B rows (half slabs)", w, K * 2, nslab, nwg);
-  run<0, 64, 8>("lds-dma 4x256B rows (quarter slabs)", w, K * 2, nslab, nwg);
-  run<2, 256, 2>("global_load->vgpr 4x256B rows", w, K * 2, nslab, nwg);
-  run<3, 256, 2>("global_load->vgpr 1KiB contiguous", w, K * 2, nslab, nwg);
-  run<2, 256, 4>("global_load->vgpr 4x256B rows, deeper", w, K * 2, nslab, nwg);
+  // round 5: the LDS-DMA path alone, the register path alone, and BOTH at once sharing the bytes
+  run_j<0, 128, 4>("lds-dma only (16 waves, 4 rows x 256 B per instruction)", w, K * 2, nslab, nwg);
+  run_j<6, 128, 4>("registers only (global_load_dwordx4 -> ds_write_b128, 16 waves)", w, K * 2, nslab, nwg);
+  run_j<5, 128, 4>("split: waves 0-7 lds-dma + waves 8-15 registers, half the rows each", w, K * 2, nslab, nwg);
+  run_j<0, 256, 2>("lds-dma only, 64 KB slabs x 2", w, K * 2, nslab / 2, nwg);
+  run_j<5, 256, 2>("split, 64 KB slabs x 2", w, K * 2, nslab / 2, nwg);
+  run_j<4, 128, 4>("lds-dma 8 rows x 128 B per instruction (mlps.hip's weight slabs)", w, 2816, 22, nwg);
+  if (g_json) { fprintf(g_json, "\n ]}\n"); fclose(g_json); }
   return 0;
 }
