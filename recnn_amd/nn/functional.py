@@ -363,7 +363,7 @@ class MLPFunction(torch.autograd.Function):
         scale = 2.0 if ctx.train else 1.0
         tiles = (B + 31) // 32
         need = ctx.needs_input_grad
-        d16 = torch.zeros(B, Op, dtype=torch.bfloat16, device=dev)
+        d16 = MLPFunction._buf16(B, Op, O, dev)
         d16[:, :O] = dout
         gw3 = gb3 = gw2 = gw1 = None
         if need[5]:
@@ -471,15 +471,25 @@ def mlp_candidates(state, x, n, w1, b1, w2, b2, w3, b3):
         f = lambda t: t.detach().float().contiguous()
         if _mlp_dtype == "bf16":
             Sp, Kp, Hp = _r128(S), _r128(Kx), _r128(H)
-            def to16(t, rows, cols):
-                o = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
+            buf16 = MLPFunction._buf16
+
+            def to16(t, rows, cols):       # only the padding is filled (whole-buffer zeros + copies were 11 % of the graphed BCQ step)
+                o = buf16(rows, cols, t.shape[1], dev)
+                if rows != t.shape[0]:
+                    o[t.shape[0]:].zero_()
                 o[: t.shape[0], : t.shape[1]] = t.detach()
                 return o
-            s1 = torch.zeros(B, Hp, device=dev)                 # the shared state part stays fp32 (it is an epilogue addend)
-            _fwd(to16(state, B, Sp), Sp, to16(w1[:, :S], Hp, Sp), f(b1), s1, Hp, H, False, None, dtype=L.BF16)
-            h1 = torch.zeros(R, Hp, dtype=torch.bfloat16, device=dev)
-            _fwd(to16(x, R, Kp), Kp, to16(w1[:, S:], Hp, Kp), None, h1, Hp, H, True, None, addend=s1, add_row_div=n, dtype=L.BF16, c_f32=0)
-            h2 = torch.zeros(R, Hp, dtype=torch.bfloat16, device=dev)
+
+            def w16(part, lo, hi, cols):   # bf16 copy of W1's columns [lo, hi), kept per weight version when W1 is a leaf
+                build = lambda w: to16(w[:, lo:hi], Hp, cols)
+                return _derived_of(w1, f"bf16_cols_{lo}_{hi}_{Hp}x{cols}", build) if w1.is_leaf else build(w1)
+            s1 = torch.empty(B, Hp, device=dev)                 # the shared state part stays fp32 (it is an epilogue addend)
+            if Hp != H:
+                s1[:, H:].zero_()
+            _fwd(to16(state, B, Sp), Sp, w16("state", 0, S, Sp), f(b1), s1, Hp, H, False, None, dtype=L.BF16)
+            h1 = buf16(R, Hp, H, dev)
+            _fwd(to16(x, R, Kp), Kp, w16("cand", S, S + Kx, Kp), None, h1, Hp, H, True, None, addend=s1, add_row_div=n, dtype=L.BF16, c_f32=0)
+            h2 = buf16(R, Hp, H, dev)
             _fwd(h1, Hp, MLPFunction._shadow16(w2, Hp, Hp), f(b2), h2, Hp, H, True, None, dtype=L.BF16, c_f32=0)
             out = torch.empty(R, O, device=dev)
             _fwd(h2, Hp, MLPFunction._shadow16(w3, Op, Hp), f(b3), out, O, O, False, None, dtype=L.BF16)
@@ -848,7 +858,12 @@ def beta_train_forward(state, target, weight, bias):
     L.call("recnn_softmax_bwd", L.ptr(p), ldn, B, N, L.ptr(dprobs), ldn, L.ptr(dlog), ldn, s)
     del dprobs
     gw = torch.empty(N, K, device=dev)
-    _dw(dlog, N, xp, K, gw)
+    if _catalogue_dtype == "bf16" and N >= 4096:
+        # the weight gradient d logits^T x state ([n_items, 256] x [256, 1290]: 66 GFLOP at 100k items) on the bf16 LDS-DMA dW kernel like the
+        # policy head's; the fp32 register-staged kernel it replaces was 17.5 % of the 100k bf16 step (profiles/r04_reinforce_100k_bf16_*)
+        _dw(dlog.to(torch.bfloat16), N, x16, K, gw, dtype=L.BF16)
+    else:
+        _dw(dlog, N, xp, K, gw)
     gb = torch.empty(N, device=dev)
     L.call("recnn_colsum_rows", L.ptr(dlog), ldn, B, N, L.ptr(gb), s)      # sum over the batch rows of d logits
     return p[:, :N], loss, gw, gb
