@@ -565,9 +565,7 @@ typedef struct recnn_engine_tuning {
                                that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
   int x3_fwd;               /* split-bf16 forward GEMM kernel: 2 (default) wave-specialised -- loader waves + consumer waves (csrc/gemm.hip
                                x3_fwd_ws_kernel), 11 only its 64 x 128-tile launches, 0 every wave loads and multiplies (round 4) */
-  int x3_head_dx;           /* split-bf16 DDPG engines (hidden 256, x3_tail): 1 the critic head (TD target, losses, dz2) runs as the prologue of the
-                               critic's layer-2 dX launch (csrc/x3.hip x3_dx_head_kernel), 0 a head launch of its own */
-  int reserved[6];
+  int reserved[7];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -640,7 +640,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->x3_head_dx = 1;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -1105,13 +1105,6 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
         h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
       }
     }
-    // DDPG + backward wanted: the head runs as the prologue of the critic's layer-2 dX launch (x3.hip x3_dx_head_kernel) -- ph_value_backward
-    // picks it up; one launch and one kernel boundary less on the step's chain
-    if (value_bwd && tails && nc == 1 && e->tune.x3_head_dx && e->H == 256 && Hp == 512) {
-      e->x3_head = h;
-      e->x3_head_pending = true;
-      return 0;
-    }
     if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
   }
   return 0;
@@ -1404,13 +1397,7 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   int rc;
-  if (e->x3_head_pending) {       // split bf16, DDPG: critic head + layer-2 dX in one launch (set up by ph_forward_x3)
-    e->x3_head_pending = false;
-    GemmProb p;
-    const double fl = fill_dx(e, &p, rows, e->dzc2[0], Hp, Hp, VAL[0], W2, 0, H, e->dzc1[0], Hp, e->cv[0].h1, Hp, e->net[VAL[0]].gp[B1]);
-    const HeadArgs hh = e->x3_head;
-    if ((rc = slot(e, "head+dx_critic_l2", fl, s, [&] { return x3_dx_head_launch(p, hh, s); }))) return rc;
-  } else if (!e->panel_bwd_done) {
+  if (!e->panel_bwd_done) {
     Group g(e, GEMM_DX, 0, 0);
     for (int c = 0; c < nc; ++c)
       g.flops += fill_dx(e, g.add(), rows, e->dzc2[c], Hp, Hp, VAL[c], W2, 0, H, e->dzc1[c], Hp, e->cv[c].h1, Hp, e->net[VAL[c]].gp[B1]);

@@ -179,8 +179,6 @@ struct recnn_engine {
   hipGraphExec_t gdp[7][2] = {};           // data-parallel phase graphs [kind][batch buffer set]
   int dp_sets = 1;                         // 2: merged tail+head graphs alternate the batch buffer sets (look-ahead gather)
   int graph_rows = 0;
-  HeadArgs x3_head;                // split bf16, DDPG: the critic head's arguments, handed from the forward phase to the dX launch that runs it
-  bool x3_head_pending = false;
   bool hyper_set = false;
 };
 

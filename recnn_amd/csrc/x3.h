@@ -58,8 +58,4 @@ struct GemmLaunch;
 int x3_gemm_launch(GemmLaunch* L, hipStream_t stream);   // RECNN_BF16X3 problems of gemm_launch (gemm.hip hands them over)
 int x3_fwd_launch(GemmLaunch* L, hipStream_t stream);    // defined in gemm.hip (the LDS-DMA forward kernel with the x3 pairing)
 int x3_init();
-struct GemmProb;
-struct HeadArgs;
-// the critic's layer-2 dX with the critic head as its prologue (x3.hip x3_dx_head_kernel; DDPG, hidden 256)
-int x3_dx_head_launch(const GemmProb& p, const HeadArgs& h, hipStream_t s);
 int rows_to_x3_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int cols, int64_t ld32, int64_t ldh, hipStream_t s);

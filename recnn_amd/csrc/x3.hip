@@ -11,7 +11,6 @@
 // the lo block of each operand and three MFMAs.  Tiles are staged through registers (two LDS buffers, one barrier per
 // 32-row k step): these launches are a small part of the step.
 #include "gemm.h"
-#include "head.h"
 #include "x3.h"
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -167,243 +166,6 @@ __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
     }
   }
   if (P.colsum) {   // a wave owns one 32-row slab: fixed tree over its rows (tm in the lane, then the 16 fr lanes of the column quad)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float c = cs[r];
-      c += __shfl_xor(c, 1, 64);
-      c += __shfl_xor(c, 2, 64);
-      c += __shfl_xor(c, 4, 64);
-      c += __shfl_xor(c, 8, 64);
-      if (fr == 0 && jb + r < P.N && m0 + wm0 < P.M) P.colsum[(int64_t)((m0 + wm0) >> 5) * P.N + jb + r] = c;
-    }
-  }
-}
-
-// ------------------------------------------------------------------ dX of the critic's layer 2 with the critic HEAD as its prologue (DDPG)
-// The head (head.hip: Q(s, a) = h2 . w3 + b3, TD target from Q', dQ, loss partials, dz2 = dQ w3 * gate(h2), partial sums of dW3 / db2 /
-// db3) reads exactly the rows this kernel stages: a 64-row workgroup loads the learning critic's h2 rows INSTEAD of dz2, evaluates the
-// head for them in LDS and overwrites them with dz2 in place, then runs the dX product unchanged.  The 8 column-tile workgroups of a row
-// tile repeat the (cheap) head; the one with tile_n == 0 also writes what other launches read: dz2 (the dW launch's operand), q, delta,
-// expected, target_q, the loss partials and the small tensors' partial sums -- one launch and one kernel boundary less on the step's chain
-// (recnn/nn/update/misc.py:33-39 + autograd through linear3 / linear2 of recnn/nn/models.py:207-213).  Partial sums keep head_kernel's
-// 16-row blocks (the optimizer pass sums them in block order either way).
-constexpr int DXH_RED = 8 * (256 + 8) * 4;
-constexpr int DXH_W3 = DX_LDS, DXH_ROW = DXH_W3 + 1024, DXH_REDW = DXH_ROW + 1024, DXH_REDB = DXH_REDW + DXH_RED, DXH_LDS = DXH_REDB + DXH_RED;
-
-__global__ __launch_bounds__(256) void x3_dx_head_kernel(const GemmBatch batch, const HeadArgs head) {
-  const GemmProb& P = batch.p[0];
-  const int nwg = P.tiles_m * P.tiles_n;
-  if ((int)blockIdx.x >= nwg) return;
-  const int tile_n = blockIdx.x % P.tiles_n, tile_m = blockIdx.x / P.tiles_n;
-  const int m0 = tile_m * DX_BM, n0 = tile_n * DX_BN;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int wm0 = (wave >> 1) * 32, wc0 = (wave & 1) * 16;
-  const GemmSeg& G = P.seg[0];
-  const int H = head.H;                     // = logical contraction length (256)
-  const int nt = (H + 31) / 32;
-  const bf16_t* A = (const bf16_t*)head.ch2[0];
-  const bf16_t* B = (const bf16_t*)G.B;
-  unsigned char* sa = smem;
-  unsigned char* sb = smem + DX_BM * DX_PA;
-  float* sw3 = (float*)(smem + DXH_W3);
-  float* stq = (float*)(smem + DXH_ROW);    // [64] Q', then [64] reward, [64] done, [64] dQ
-  float* srew = stq + 64;
-  float* sdn = srew + 64;
-  float* sd = sdn + 64;
-  float (*red_w)[256 + 8] = (float (*)[256 + 8])(smem + DXH_REDW);
-  float (*red_b)[256 + 8] = (float (*)[256 + 8])(smem + DXH_REDB);
-  const bool writer = tile_n == 0;          // (uniform per workgroup)
-
-  const int ca = 8 * nt;
-  const int na = DX_BM * ca, nb = 32 * nt * 8;
-  uint4 ra[16], rb[8];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int c = u * 256 + tid;
-    const int row = c / ca, kc = c - row * ca;
-    ra[u] = c < na ? *(const uint4*)(A + (int64_t)min(m0 + row, P.M - 1) * head.ld_h + kc * 8) : make_uint4(0, 0, 0, 0);
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int c = u * 256 + tid;
-    const int n = c >> 3, kc = c & 7;
-    rb[u] = (c < nb && n < H) ? *(const uint4*)(B + (int64_t)n * G.ldb + 2 * n0 + kc * 8) : make_uint4(0, 0, 0, 0);
-  }
-  const float w3v = tid < H ? head.cw3[0][tid] : 0.f;
-  float rin = 0.f;
-  if (tid < 192) {                          // threads 0..63: Q', 64..127: reward, 128..191: done of row m0 + (tid & 63)
-    const int r = min(m0 + (tid & 63), P.M - 1);
-    rin = tid < 64 ? head.tq_in[0][r] : (tid < 128 ? head.reward[r] : head.done[r]);
-  }
-  const float b3 = head.cb3[0][0];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int c = u * 256 + tid;
-    const int row = c / ca, kc = c - row * ca;
-    if (c < na) *(uint4*)(sa + row * DX_PA + kc * 16) = ra[u];
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int c = u * 256 + tid;
-    if (c < nb) *(uint4*)(sb + (c >> 3) * DX_PB + (c & 7) * 16) = rb[u];
-  }
-  sw3[tid] = w3v;
-  if (tid < 192) stq[tid] = rin;
-  const int jb = n0 + wc0 + fg * 4;
-  uint2 yq[2];
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = min(m0 + wm0 + tm * 16 + fr, P.M - 1);
-    yq[tm] = (P.yref && jb < P.N) ? *(const uint2*)((const bf16_t*)P.yref + (int64_t)m * P.ldy + x3_col(jb)) : make_uint2(0x3F803F80u, 0x3F803F80u);
-  }
-  __syncthreads();
-
-  // ---- head, phase 1: wave w owns rows 16 w .. 16 w + 15 = head block 4 tile_m + w; a lane's four logical columns 4 lane .. + 3
-  {
-    const float4 wv = lane * 4 < H ? *(const float4*)(sw3 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int xo = x3_col(lane * 4) * 2;
-    float loss = 0.f;
-    for (int i = 0; i < 16; ++i) {
-      const int row = wave * 16 + i, m = m0 + row;
-      float s = 0.f;
-      if (lane * 4 < H) {
-        const uint2 hv = *(const uint2*)(sa + row * DX_PA + xo), lv = *(const uint2*)(sa + row * DX_PA + xo + 64);
-        const float x0 = bf2f((bf16_t)(hv.x & 0xFFFF)) + bf2f((bf16_t)(lv.x & 0xFFFF)), x1 = bf2f((bf16_t)(hv.x >> 16)) + bf2f((bf16_t)(lv.x >> 16));
-        const float x2 = bf2f((bf16_t)(hv.y & 0xFFFF)) + bf2f((bf16_t)(lv.y & 0xFFFF)), x3 = bf2f((bf16_t)(hv.y >> 16)) + bf2f((bf16_t)(lv.y >> 16));
-        s = x0 * wv.x + x1 * wv.y + x2 * wv.z + x3 * wv.w;
-      }
-      const float q = wave_sum(s) + b3;
-      const bool valid = m < P.M;
-      const float tq = stq[row];
-      float y = srew[row] + (1.0f - sdn[row]) * head.gamma * tq;
-      y = fminf(fmaxf(y, head.lo), head.hi);
-      const float e = q - y;
-      const float d = e * (2.0f / (float)head.rows);
-      if (valid) loss += e * e;
-      if (lane == 0) {
-        sd[row] = valid ? d : 0.f;
-        if (writer && valid) {
-          if (head.expected) head.expected[m] = y;
-          if (head.target_q) head.target_q[m] = tq;
-          if (head.delta[0]) head.delta[0][m] = d;
-          if (head.q[0]) head.q[0][m] = q;
-        }
-      }
-    }
-    const int blk = 4 * tile_m + wave;
-    if (writer && lane == 0 && blk * HEAD_ROWS_PER_BLOCK < head.rows) head.loss_part[0][blk] = loss;
-  }
-  __syncthreads();
-
-  // ---- head, phase 2: h2 -> dz2 in place (thread = 8 logical columns x rows {rg, rg + 8} of each 16-row block); the writer also stores
-  // dz2 and reduces the blocks' partial sums of dW3 / db2 over the 8 row groups in a fixed order
-  {
-    const float scale = head.train ? 2.0f : 1.0f;
-    const int cg = tid & 31, rg = tid >> 5;
-    const int n = cg * 8;
-    const int xo = x3_col(n) * 2;
-    float w[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = n + j < H ? sw3[n + j] * scale : 0.f;
-    bf16_t* dz2 = (bf16_t*)head.dz2[0];
-    for (int b = 0; b < 4; ++b) {
-      float sw[8], sbb[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sw[j] = sbb[j] = 0.f;
-      if (n < H) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int row = b * 16 + rg + half * 8;
-          unsigned char* p = sa + row * DX_PA + xo;
-          const uint4 rh = *(const uint4*)p, rl = *(const uint4*)(p + 64);
-          const uint32_t uh[4] = {rh.x, rh.y, rh.z, rh.w}, ul[4] = {rl.x, rl.y, rl.z, rl.w};
-          float hv[8], dz[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            hv[2 * j] = bf2f((bf16_t)(uh[j] & 0xFFFF)) + bf2f((bf16_t)(ul[j] & 0xFFFF));
-            hv[2 * j + 1] = bf2f((bf16_t)(uh[j] >> 16)) + bf2f((bf16_t)(ul[j] >> 16));
-          }
-          const float d = sd[row];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            dz[j] = hv[j] > 0.f ? d * w[j] : 0.f;
-            sw[j] += d * hv[j];
-            sbb[j] += dz[j];
-          }
-          uint2 h0, l0, h1, l1;
-          const float d0[4] = {dz[0], dz[1], dz[2], dz[3]}, d1[4] = {dz[4], dz[5], dz[6], dz[7]};
-          x3_split4(d0, h0, l0);
-          x3_split4(d1, h1, l1);
-          const uint4 oh = make_uint4(h0.x, h0.y, h1.x, h1.y), ol = make_uint4(l0.x, l0.y, l1.x, l1.y);
-          *(uint4*)p = oh;
-          *(uint4*)(p + 64) = ol;
-          if (writer && m0 + row < P.M && dz2) {
-            bf16_t* g = dz2 + (int64_t)(m0 + row) * head.ld_h + x3_col(n);
-            *(uint4*)g = oh;
-            *(uint4*)(g + 32) = ol;
-          }
-        }
-      }
-      if (writer && head.do_bwd && head.dw3_part[0]) {      // (uniform per workgroup)
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { red_w[rg][cg * 8 + j] = sw[j]; red_b[rg][cg * 8 + j] = sbb[j]; }
-        __syncthreads();
-        const int blk = 4 * tile_m + b;
-        if (tid < H && blk * HEAD_ROWS_PER_BLOCK < head.rows) {
-          float tw = 0.f, tb = 0.f;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) { tw += red_w[g][tid]; tb += red_b[g][tid]; }
-          head.dw3_part[0][(int64_t)blk * H + tid] = tw;
-          head.db2_part[0][(int64_t)blk * H + tid] = tb;
-        }
-        if (tid == 0 && head.db3_part[0] && blk * HEAD_ROWS_PER_BLOCK < head.rows) {
-          float t = 0.f;
-          for (int i = 0; i < 16; ++i) t += sd[b * 16 + i];
-          head.db3_part[0][blk] = t;
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- the dX product on the dz2 rows now in LDS (as x3_dx_kernel)
-  f32x4 acc[2];
-  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < nt; ++t) {
-    const unsigned char* sbt = sb + t * 32 * DX_PB;
-    const bf16x8 bh = tr_frag(sbt, DX_PB, wc0, fr, fg), bl = tr_frag(sbt, DX_PB, 32 + wc0, fr, fg);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const unsigned char* ar = sa + (wm0 + tm * 16 + fr) * DX_PA + t * 128;
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + fg * 16));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(ar + 64 + fg * 16));
-      acc[tm] = mfma3(bh, bl, ah, al, acc[tm]);
-    }
-  }
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = m0 + wm0 + tm * 16 + fr;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = acc[tm][r] * P.dx_scale;
-      const float y = bf2f((bf16_t)((r < 2 ? yq[tm].x : yq[tm].y) >> ((r & 1) * 16)));
-      if (!(y > 0.f) || m >= P.M || jb + r >= P.N) v[r] = 0.f;
-      cs[r] += v[r];
-    }
-    if (m < P.M && jb + 3 < P.N) {
-      uint2 hi, lo;
-      x3_split4(v, hi, lo);
-      bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(jb);
-      *(uint2*)dst = hi;
-      *(uint2*)(dst + 32) = lo;
-    }
-  }
-  if (P.colsum) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float c = cs[r];
@@ -608,26 +370,9 @@ int launch_dw(GemmLaunch* L, hipStream_t s) {
 
 }  // namespace
 
-int x3_dx_head_launch(const GemmProb& p0, const HeadArgs& h, hipStream_t s) {
-  GemmBatch b;
-  memset(&b, 0, sizeof(b));
-  b.p[0] = p0;
-  GemmProb& p = b.p[0];
-  p.tiles_m = (p.M + DX_BM - 1) / DX_BM;
-  p.tiles_n = (p.N + DX_BN - 1) / DX_BN;
-  if (h.H != 256 || p.N != 256 || p.seg[0].K != 512 || h.rows != p.M || h.n_target != 1 || h.n_critic != 1 || h.tc_bf16 != RECNN_BF16X3 || h.policy_mode ||
-      !h.tq_in[0] || !h.do_bwd || !h.dz2[0] || p.c_f32 || p.ldc < 512 || h.ld_h < 512 || p.seg[0].ldb < 512 || !h.loss_part[0]) {
-    recnn_set_error("x3 dx + head: needs a DDPG critic of hidden 256 in split rows with Q' precomputed and the backward enabled");
-    return RECNN_E_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL(x3_dx_head_kernel, dim3(p.tiles_m * p.tiles_n, 1, 1), dim3(256), DXH_LDS, s, b, h);
-  return recnn_check_hip(hipGetLastError(), "x3_dx_head_kernel launch");
-}
-
 int x3_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS), "x3 dx attr");
   if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DW_STAGE), "x3 dw attr");
-  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_dx_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DXH_LDS), "x3 dx + head attr");
   return rc;
 }
 
