@@ -2,8 +2,8 @@
 step is evaluated in a reduced operand format instead of fp32?
 
 Formats: "bf16" (operands rounded to bf16, fp32 accumulation: the MFMA-bf16 path), "x3" (split bf16: x = hi + lo with
-hi = bf16(x), lo = bf16(x - hi); products hi*hi + hi*lo + lo*hi, fp32 accumulation), "x2" (hi*hi + lo*hi + hi*lo
-without ... see code).  The oracle's own arithmetic (fp32) is the reference curve.
+hi = bf16(x), lo = bf16(x - hi); products hi*hi + hi*lo + lo*hi, fp32 accumulation), "x2a" / "x2w" (two products: only the first / only the second operand
+split), "x4" (+ lo*lo), "x6" (three-way split); "a/b/c" = forward / dX / dW formats.  The oracle's own arithmetic (fp32) is the reference curve.
 
     python tests/x3_numerics.py [steps] [rows]
 """
@@ -39,6 +39,10 @@ def mm_fmt(fmt):
         bh, bl = split(b)
         if fmt == "x3":
             return (al @ bh + ah @ bl) + ah @ bh
+        if fmt == "x2a":     # two MFMAs per product: activations split, weights rounded to bf16
+            return al @ bh + ah @ bh
+        if fmt == "x2w":     # two MFMAs per product: weights split, activations rounded to bf16
+            return ah @ bl + ah @ bh
         if fmt == "x4":
             return (al @ bl + al @ bh + ah @ bl) + ah @ bh
         raise ValueError(fmt)
