@@ -117,7 +117,7 @@ KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_fwd_critic": "mlps_fwd
                   "frozen_actors": "mlp_frozen_kernel", "frozen_target_critics": "mlp_frozen_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",
-                  "fwd_l1": "_fwd_", "x3_tail": "x3_tail_kernel"}
+                  "fwd_l1": "x3_fwd_ws_kernel<2, 2, 2, 4, 4, 3", "x3_tail": "x3_tail_kernel"}   # (the 64 x 128-tile instance: the grouped layer-1 launch)
 
 
 def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):

@@ -83,6 +83,38 @@ def test_gemm_fwd(cuda, M, N, K):
     assert torch.equal(got, x3_value(out32.cpu()))                  # the split store of the same accumulators
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 1536), (2048, 256, 1536), (333, 256, 256), (20480, 256, 128)])
+def test_gemm_fwd_kernel_variants_are_bit_identical(cuda, M, N, K):
+    """Every split-bf16 forward GEMM kernel -- round 4's all-waves kernel (x3_fwd = 0), the wave-specialised kernel (2, the default: loader
+    waves + consumer waves) with its three tile / ring choices, only-big-launches (11), and the 128 x 128 / 128 x 256 tiles on 128-byte stage
+    rows (7, 8) -- computes the same bits: same LDS image, same k order, same epilogue (hash dropout, bias, relu, split store, the policy
+    loss's partial dots up to their grouping).  The variant is picked through the private debug hook (csrc/recnn_hip_debug.h)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    X, W, bd = x3_pack_ref(x).to(cuda), x3_pack_ref(w).to(cuda), b.to(cuda)
+    ldc = 2 * ((N + 31) // 32 * 32)
+    outs = {}
+    try:
+        for var in (0, 2, 11, 7, 8):
+            L.load().recnn_debug_x3_fwd(var)
+            out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=cuda)
+            a = _args(L, M, N)
+            a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), 2 * K, 2 * K, 2 * K
+            a.C, a.ldc, a.c_f32 = out.data_ptr(), ldc, 0
+            a.bias, a.relu, a.mask_mode, a.seed, a.stream_id = bd.data_ptr(), 1, L.MASK_HASH, 77, 3
+            L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+            torch.cuda.synchronize()
+            outs[var] = out.view(torch.int16).clone()
+    finally:
+        L.load().recnn_debug_x3_fwd(-1)
+    assert bool((outs[0] != 0).any())
+    for var, o in outs.items():
+        assert torch.equal(o, outs[0]), var
+
+
 def test_gemm_fwd_two_segments(cuda):
     """critic layer 1 on [gen_action | state]: two contraction segments into one accumulator."""
     L = _lib()
