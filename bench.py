@@ -397,11 +397,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import multigpu_preflight
             try:
-                multigpu_preflight.main(keep_group=True)
+                multigpu_preflight.main(keep_group=True, quick=True)
                 preflight = multigpu_preflight.LAST_SUMMARY
             except Exception as ex:       # diagnostic only: the benchmark still runs
                 preflight = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
-            if preflight and not preflight.get("ok") and not all(preflight.get("stages", {}).get(k, True) for k in ("peer_connect", "peer_self_test", "bench_peer")):
+            if preflight and not preflight.get("ok") and not all(preflight.get("stages", {}).get(k, True) for k in ("peer_connect", "peer_self_test")):
                 args.collective = "rccl"          # the device collective did not pass on this machine: host-issued RCCL all-reduces
         if not dist.is_initialized():
             if backend == "nccl":

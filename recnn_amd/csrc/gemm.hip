@@ -245,8 +245,14 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
 // i.e. a lane owns FOUR NEIGHBOURING COLUMNS of one row -- one 8-byte store for their hi halves and one for the lo halves (the
 // generic layout, four rows of one column, would take eight 2-byte stores), one 16-byte load of the bias / addend, one dropout
 // word per 4 x 4 block.  Same arithmetic, element by element, as epilogue_fwd.
+// lds_tile != nullptr (wave-specialised kernel, full tiles of split output): the hi / lo halves go into an LDS image of the tile -- row
+// r = m - m0 at r * X3_TILE_PITCH, physical column x3_col(n - n0) -- instead of global memory; the caller then writes the tile out as whole
+// 16-byte x 64-lane rows (a lane's two 8-byte stores per block hit 16 rows x 32 bytes per wave instruction: the store tail was 5 of the
+// layer-1 launch's 24 us, profiles/r05_x3_ws_probe_fixed.txt).
+constexpr int X3_TILE_PITCH_PAD = 16;
 template <int TM, int TN>
-__device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane, int part_idx) {
+__device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane, int part_idx,
+                                       unsigned char* lds_tile = nullptr, int tile_pitch = 0) {
   const int fr = lane & 15, fg = lane >> 4;
   float sdot = 0.f;
   uint32_t key = 0;
@@ -307,7 +313,11 @@ __device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], 
         uint2 hi, lo;
         x3_split4(v, hi, lo);
         bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + x3_col(nb);
-        if (full) {
+        if (lds_tile) {
+          unsigned char* t = lds_tile + (m - m0) * tile_pitch + x3_col(nb - n0) * 2;
+          *(uint2*)t = hi;
+          *(uint2*)(t + 64) = lo;
+        } else if (full) {
           *(uint2*)dst = hi;
           *(uint2*)(dst + 32) = lo;
         } else {
@@ -648,7 +658,7 @@ template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256>
 __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
   // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
-  // bit 4 no epilogue, bit 5 exit at entry
+  // bit 4 no epilogue, bit 5 exit at entry, bit 6 epilogue stores straight to global memory (round 5's first form)
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
   constexpr int KB = SR / 2;                      // physical k elements per stage
   constexpr int NG = SR / 128;                    // logical 32-k groups per stage
@@ -660,6 +670,17 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   static_assert(NINST % NL == 0, "loader waves must divide the stage");
   constexpr int PER = NINST / NL;
   static_assert(PER * (D - 1 > 3 ? 3 : D - 1) <= 60, "vmcnt range");
+  // pull the kernel-argument cache lines of this workgroup's problem into the scalar cache NOW, all in flight together: the epilogue reads
+  // a dozen fields of it 20 us from here, and each first touch of a 64-byte line there is a dependent scalar-cache miss (l1gemm.hip's idiom)
+  if (!(probe & 256)) {
+    unsigned touch = 0;
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    const char __attribute__((address_space(4)))* pa = ka + blockIdx.y * sizeof(GemmProb);
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(GemmProb) + 63) / 64); ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"((int)sizeof(GemmProb) - 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
+  }
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n;
   if ((int)blockIdx.x >= nwg) return;
@@ -772,11 +793,37 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
     }
   }
   if (probe && (sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x9E3779B9u) acc[0][0][0] += 1.f;
-  if (probe & 16) {   // no epilogue (one store keeps the accumulators alive)
-    if (acc[0][0][0] == 12345.678f) ((float*)P.C)[0] = acc[TM - 1][TN - 1][3];
+  if (probe & 16) {   // no epilogue (a never-taken store keeps EVERY accumulator alive)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    if (t == 12345.678f) ((float*)P.C)[0] = t;
     return;
   }
-  epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave);
+  // full tiles of split output leave through an LDS image of the tile (the ring is idle: every loader waited for its last DMA before
+  // the last barrier): whole 1 KB wave stores instead of 8-byte ones.  Uniform per workgroup; the loaders have left (or are leaving:
+  // a terminated wave does not take part in s_barrier).
+  constexpr int TP = BN * 4 + X3_TILE_PITCH_PAD;            // bytes per tile row: 2 BN bf16 + a 16-byte skew against bank conflicts
+  const bool staged = !P.c_f32 && !P.yref && m0 + BM <= P.M && n0 + BN <= P.N && !(P.ldc & 7) && !((uintptr_t)P.C & 15) && BM * TP <= NS * STAGE_BYTES &&
+                      !(probe & 64);
+  if (staged) __builtin_amdgcn_s_barrier();                 // every consumer is done reading the last k stage: the tile image may overwrite it
+  epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave, staged ? dsmem : nullptr, TP);
+  if (staged) {
+    __builtin_amdgcn_s_barrier();
+    constexpr int CPR2 = BN * 4 / 16;                          // 16-byte chunks per tile row
+    bf16_t* C = (bf16_t*)P.C + (int64_t)m0 * P.ldc + x3_col(n0);
+    for (int idx = wave * 64 + lane; idx < BM * CPR2; idx += NC * 64) {
+      const int row = idx / CPR2, ch = idx - row * CPR2;
+      const uint4 v = *(const uint4*)(dsmem + row * TP + ch * 16);
+      uint4* dst = (uint4*)(C + (int64_t)row * P.ldc + ch * 8);
+      if (probe & 128) *dst = v;
+      else { typedef unsigned u32x4_t __attribute__((ext_vector_type(4))); const u32x4_t vv = {v.x, v.y, v.z, v.w};
+             asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory"); }   // write-through: the tile drains while the
+                                                                                                 // launch runs, not at its end (guide: publish-large)
+    }
+  }
 }
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)

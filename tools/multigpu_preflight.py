@@ -62,8 +62,9 @@ def make_engine(L, dev, rows, dtype, mask_mode, seed=0):
 LAST_SUMMARY = None     # {"ok": bool, "stages": {stage: ok}} of the latest main() in this process (bench.py embeds it)
 
 
-def main(keep_group=False):
-    """keep_group: leave the process group initialised (bench.py runs this in front of its timed regions and goes on with the group)."""
+def main(keep_group=False, quick=False):
+    """keep_group: leave the process group initialised (bench.py runs this in front of its timed regions and goes on with the group).
+    quick: stop after the replica check -- no latency table, no 25-step runs of the two data-parallel paths (bench.py does those itself)."""
     global LAST_SUMMARY
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -179,7 +180,8 @@ def main(keep_group=False):
         if have_peer:
             state["comm"].check()
         return {"floats": out, "note": "host-timed, 20 back-to-back collectives, includes launch overhead"}
-    stage("collective_latency", st_latency)
+    if not quick:
+        stage("collective_latency", st_latency)
 
     # ---------------------------------------------------------------- N ranks x B/N rows == 1 rank x B rows (real engine, fp32)
     gen = torch.Generator().manual_seed(7)
@@ -237,6 +239,15 @@ def main(keep_group=False):
     stage("replicas", st_replicas)
     summary.pop("_gaps", None)
 
+    if quick:
+        emit(rank, "summary", ok=all(v for v in summary.values()), stages=summary, quick=True)
+        LAST_SUMMARY = {"ok": all(v for v in summary.values()), "stages": dict(summary), "quick": True}
+        dist.barrier()
+        if state["comm"] is not None:
+            state["comm"].close()
+        if not keep_group:
+            dist.destroy_process_group()
+        return 0 if all(summary.values()) else 1
     # ---------------------------------------------------------------- 5 + 20 steps of the benchmark's data-parallel paths
     import bench as B
     items, ratings, off, lens = B.synthetic_store(0)
