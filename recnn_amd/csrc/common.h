@@ -111,6 +111,22 @@ __device__ inline float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Pull `BYTES` bytes of the kernel-argument segment, starting `dyn_offset` bytes in, into the scalar cache -- every 64-byte line touched
+// by one s_load_dword, all in flight together, waited for once.  A kernel that reads the fields of a by-value argument block one dependent
+// batch after the other pays a scalar-cache miss (~0.5 us) per first touch of a line; after this they are hits (measured: l1gemm.hip, round
+// 3; x3_fwd_ws_kernel -0.5 us, round 5).
+#if defined(__HIPCC__)
+template <int BYTES> __device__ __forceinline__ void kernarg_prefetch(int dyn_offset = 0) {
+  unsigned touch = 0;
+  const char __attribute__((address_space(4)))* pa =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + dyn_offset;
+#pragma unroll
+  for (int i = 0; i < (BYTES + 63) / 64; ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
+  asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(BYTES - 4));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
+}
+#endif
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on one XCD
 // (hardware places block b on XCD b % 8), so tiles that share an operand panel share an L2.
 __device__ inline int xcd_remap(int bid, int nwg) {

@@ -672,15 +672,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   static_assert(PER * (D - 1 > 3 ? 3 : D - 1) <= 60, "vmcnt range");
   // pull the kernel-argument cache lines of this workgroup's problem into the scalar cache NOW, all in flight together: the epilogue reads
   // a dozen fields of it 20 us from here, and each first touch of a 64-byte line there is a dependent scalar-cache miss (l1gemm.hip's idiom)
-  if (!(probe & 256)) {
-    unsigned touch = 0;
-    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    const char __attribute__((address_space(4)))* pa = ka + blockIdx.y * sizeof(GemmProb);
-#pragma unroll
-    for (int i = 0; i < (int)((sizeof(GemmProb) + 63) / 64); ++i) asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"(i * 64));
-    asm volatile("s_load_dword %0, %1, %2" : "+s"(touch) : "s"(pa), "n"((int)sizeof(GemmProb) - 4));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch));
-  }
+  if (!(probe & 256)) kernarg_prefetch<(int)sizeof(GemmProb)>((int)(blockIdx.y * sizeof(GemmProb)));
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n;
   if ((int)blockIdx.x >= nwg) return;
@@ -863,6 +855,7 @@ __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {
 
 // SUB = batch rows per stage, NS = ring slots (all filled before the first MFMA).
 template <int SUB, int NS> __global__ __launch_bounds__(256) void gemm_dw_dma_kernel(const GemmBatch batch, const DwVec vec, const int nprob) {
+  // (no kernarg prefetch here: measured +0.4 us on this launch -- 736 short workgroups each paying the wait; round 5)
   // extra workgroups, first in the launch order (their chain of row loads is the longest single-workgroup path):
   // row-vector partial sums for the bias / last-layer gradients
   const int y0 = vec.n > 0 ? 1 : 0;

@@ -44,6 +44,7 @@ template <class TC> __device__ inline float dot4(const typename HeadStore<TC>::t
 // is a chain of memory latencies, not bandwidth.  TD target, Q, dQ, loss partial.  Phase 2 (do_bwd): dz2 and the
 // partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
 template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+  kernarg_prefetch<(int)sizeof(HeadArgs)>();
   using ST = typename HeadStore<TC>::type;
   constexpr bool X3 = std::is_same<TC, x3_t>::value;
   __shared__ float part[4][HEAD_MAX_CRITIC];

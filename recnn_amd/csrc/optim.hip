@@ -375,6 +375,7 @@ __device__ __forceinline__ void apply_body(const NetLayout& L, const ApplyArgs& 
 }
 
 __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const ApplyArgs a) {
+  kernarg_prefetch<(int)(sizeof(NetLayout) + sizeof(ApplyArgs))>();
   __shared__ float red[4];
   __shared__ float sp[4][OPT_SMALL_ELEMS];
   apply_body(L, a, blockIdx.x, red, sp);
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const NetLayout L, const App
 // The gather workgroups come first in the launch order: their latency chain starts at once and the optimizer
 // workgroups stream underneath it.
 __global__ __launch_bounds__(256) void apply_gather_kernel(const NetLayout L, const ApplyArgs a, const GatherArgs g, const int n_gather) {
+  kernarg_prefetch<(int)(sizeof(NetLayout) + sizeof(ApplyArgs) + sizeof(GatherArgs))>();
   __shared__ float red[4];
   __shared__ float sp[4][OPT_SMALL_ELEMS];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

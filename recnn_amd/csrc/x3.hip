@@ -67,6 +67,7 @@ constexpr int DX_PA = 2 * DX_KMAX * 2 + 16, DX_PB = 144;             // row pitc
 constexpr int DX_LDS = DX_BM * DX_PA + DX_KMAX * DX_PB;
 
 __global__ __launch_bounds__(256) void x3_dx_kernel(const GemmBatch batch) {
+  kernarg_prefetch<(int)sizeof(GemmProb)>((int)(blockIdx.y * sizeof(GemmProb)));
   const GemmProb& P = batch.p[blockIdx.y];
   const int nwg = P.tiles_m * P.tiles_n;
   if ((int)blockIdx.x >= nwg) return;

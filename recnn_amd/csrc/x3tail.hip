@@ -66,6 +66,7 @@ __device__ __forceinline__ void panel_get4(const unsigned char* panel, int row, 
 }  // namespace
 
 __global__ __launch_bounds__(NW * 64) void x3_tail_kernel(const X3TailBatch batch) {
+  kernarg_prefetch<(int)sizeof(X3TailProb)>((int)(blockIdx.y * sizeof(X3TailProb)));
   const int by = __builtin_amdgcn_readfirstlane((int)blockIdx.y), bx = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
   const X3TailProb& P = batch.p[by];
   const int m0 = bx * BM;
