@@ -1,5 +1,6 @@
 // engine_internal.h -- the step engine's state (struct recnn_engine) and the internal interface between its translation units:
-//   engine.hip        workspace layout, bind / hyper / tuning entry points, the launch plans of a step (ph_*), step_impl, eager API
+//   engine.hip        workspace layout, create / bind / hyper entry points, the eager step API, read-backs, debug views
+//   engine_plan.hip   optimizer layouts, problem builders, tuning entry points, the launch plans of a step (ph_*), step_impl
 //   engine_graph.hip  per-launch profile, hipGraph capture (run-graph family, made-to-order graphs, cycle segments), graph replay,
 //                     data-parallel phase graphs
 // Internal names live in namespace recnn_eng (external linkage, so both units see ONE definition); nothing here is part of the
@@ -206,9 +207,12 @@ template <class F> int slot(recnn_engine* e, const char* name, double flops, hip
   return rc;
 }
 
-// ---- defined in engine.hip, used by engine_graph.hip
+// ---- the internal interface (defined in engine.hip / engine_plan.hip)
 namespace recnn_eng {
 int check_ready(recnn_engine* e, int rows);
+NetLayout make_layout(const recnn_engine* e, int ni, int rows);
+int apply_net(recnn_engine* e, int ni, int rows, bool do_adam, int opt_idx, float grad_scale, bool clip, int target_ni, float tau, hipStream_t s,
+              bool from_slabs = false);
 void drop_graphs(recnn_engine* e);
 bool net_used(const recnn_engine* e, int ni);
 bool lookahead_ok(const recnn_engine* e);
