@@ -579,9 +579,9 @@ def main():
         # ---- per-launch times, measured live with HIP events around every launch (eager replays of the same steps on the stream
         # the kernels run on), and the rooflines they imply.  Two schedules exist and agree bit for bit:
         #   "fused": one row-panel launch for all networks of a step (csrc/mlps.hip) -- eager steps and run graphs shorter than
-        #            the cycle-mode threshold (30 steps: the driver's `--steps 20` replays THIS one);
+        #            the cycle-mode threshold (20 steps since round 5; 30 before, when the driver's `--steps 20` replayed THIS one);
         #   "cycle": a policy cycle's batches gathered at once, the frozen networks applied to all of them (csrc/mlpf.hip), the
-        #            per-step launches carry the learning critics only (csrc/l1gemm.hip + csrc/mlpt.hip) -- run graphs >= 30 steps.
+        #            per-step launches carry the learning critics only (csrc/l1gemm.hip + csrc/mlpt.hip) -- run graphs >= 20 steps (the driver's command).
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         pe = int(eng.policy_every)
         with torch.cuda.stream(stream):
@@ -591,7 +591,7 @@ def main():
                 prof_cyc = eng.profile(rows, policy=2, n_steps=20) if args.dtype == "bf16" else None
             except L.RecnnHipError:
                 prof_cyc = None
-        cyc_min = int(os.environ.get("RECNN_CYCLE_MIN_LEN", "30"))
+        cyc_min = int(os.environ.get("RECNN_CYCLE_MIN_LEN", "20"))       # (the library default, include/recnn_hip.h)
         split_knob = int(os.environ.get("RECNN_SPLIT_FWD", "1"))
         # (data parallel with the device collective replays the same run graphs; the host-collective path steps phase graphs on
         # the fused forward)

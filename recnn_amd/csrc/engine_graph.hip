@@ -104,7 +104,9 @@ int capture_run(recnn_engine* e, int rows, hipStream_t s, int phase, int len, hi
       // a one- or two-step segment (a graph that starts ON a policy step has one at its head) does not pay for the batched
       // launches (two 128-row-panel launches cost ~60 us whatever n is): its steps run the fused forward on the cycle arrays.
       // (The driver's 20-step request in cycle mode, segments 6 + 10 + 4, with this threshold at 3 / 5 / 8: 67.7 / 67.1 / 67.6
-      // us/step against 67.8-68.3 all-fused -- inside the noise, so short graphs stay on the fused schedule: cycle_min_len 30.)
+      // us/step against 67.8-68.3 all-fused -- inside the noise, so short graphs stayed on the fused schedule: cycle_min_len 30.
+      //  Round 5, after the kernel-argument prefetches: the same command 67.6-68.2 in cycle mode against 69.3-69.4 fused, A/B inside one
+      //  call -- cycle_min_len is 20 now.)
       const bool batched = n >= e->tune.cycle_min_seg;
       if (batched) rc = ph_frozen_batched(e, rows, n, i0, s);
       for (int i = i0; i <= i1 && !rc; ++i) {
