@@ -608,7 +608,13 @@ def main():
         used = prof_cyc if schedule == "cycle" else prof
         share = lambda r: r[1] / pe if r[0] in FROZEN else r[1]          # per-step time share (cycle launches serve `pe` steps)
         cand = [r for r in used if r[2] > 0]
-        dom = max(cand, key=share) if cand else max(used, key=lambda r: r[1])
+        # The dominant kernel of an MFMA roofline = the launch that carries the largest share of the step's ALGORITHMIC FLOPS (fused
+        # schedule: the row-panel forward of all networks, which is also the longest launch -- rounds 1-4's choice; cycle schedule: the
+        # batched frozen-network launch, 2/3 of the step's flops).  By TIME per step the cycle schedule's longest MFMA launch is the
+        # learning critic's tail (a dependent latency chain of 0.5 GFLOP): reported beside it as `roofline_time_dominant`.
+        flops_per_step = lambda r: r[2] / pe if r[0] in FROZEN else r[2]
+        dom = max(cand, key=flops_per_step) if cand else max(used, key=lambda r: r[1])
+        dom_time = max(cand, key=share) if cand else dom
         # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
         traffic, traffic_note = None, "skipped"
         gather_traffic, gather_note = None, "skipped"
@@ -629,7 +635,18 @@ def main():
                                       "note": "north_star asks >= 0.40 MFMA utilisation; this is flops / wall time of the whole step"}
         if dom[2] > 0:
             out["roofline"] = dict(roof(dom[0], dom[1], dom[2], 1.0 / pe if dom[0] in FROZEN else 1.0), traffic=traffic,
-                                   traffic_source=traffic_note)
+                                   traffic_source=traffic_note,
+                                   dominant_by="algorithmic flops per step: %.0f %% of the schedule's MFMA flops, %.0f %% of its MFMA launch time"
+                                               % (100 * flops_per_step(dom) / sum(flops_per_step(r) for r in cand),
+                                                  100 * share(dom) / sum(share(r) for r in cand)))
+            if dom[0] in ("frozen_actors", "frozen_target_critics"):
+                out["roofline"]["traffic_covers"] = "mean over the two launches of mlp_frozen_kernel per policy cycle (actors; target critics)"
+            if dom_time[0] != dom[0]:
+                out["roofline_time_dominant"] = dict(roof(dom_time[0], dom_time[1], dom_time[2], 1.0 / pe if dom_time[0] in FROZEN else 1.0),
+                                                     note="the MFMA launch with the largest TIME share of a step (%.0f %% of the MFMA launch time, "
+                                                          "%.0f %% of the flops): a latency chain, bound by neither roof"
+                                                          % (100 * share(dom_time) / sum(share(r) for r in cand),
+                                                             100 * flops_per_step(dom_time) / sum(flops_per_step(r) for r in cand)))
             # avg_ms / frac above: HIP events around EAGER launches of the kernel.  Inside the replayed run graphs the same launch
             # also carries the previous step's policy-loss forward (fused schedule: one more problem of the launch), so it does
             # more flops in more time: mean duration from the child run's kernel trace, flops = this launch + that forward
@@ -637,8 +654,13 @@ def main():
                 extra = 0.0
                 if dom[0] == "mlp_fwd_nets":
                     extra = sum(r[2] for r in prof if r[0] in ("mlp_fwd_pcritic", "fwd_l1_pcritic", "fwd_l2_pcritic"))
-                ach = (dom[2] + extra) / (graph_ms * 1e-3) / 1e12
-                out["roofline"]["in_graph"] = {"avg_ms": graph_ms, "flops_per_launch": dom[2] + extra, "achieved": ach, "frac": ach / peak,
+                base = dom[2]
+                if dom[0] in ("frozen_actors", "frozen_target_critics"):
+                    # the trace's mean covers BOTH launches of mlp_frozen_kernel (actors; target critics): their mean flops with it
+                    fz = [r[2] for r in used if r[0] in ("frozen_actors", "frozen_target_critics")]
+                    base = sum(fz) / len(fz)
+                ach = (base + extra) / (graph_ms * 1e-3) / 1e12
+                out["roofline"]["in_graph"] = {"avg_ms": graph_ms, "flops_per_launch": base + extra, "achieved": ach, "frac": ach / peak,
                                                "source": "kernel trace of the PMC child run (graph replays, counter collection on)"}
         else:
             out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

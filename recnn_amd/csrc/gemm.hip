@@ -658,7 +658,8 @@ template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256>
 __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
   // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
-  // bit 4 no epilogue, bit 5 exit at entry, bit 6 epilogue stores straight to global memory (round 5's first form)
+  // bit 4 no epilogue, bit 5 exit at entry, bit 6 epilogue stores straight to global memory (round 5's first form),
+  // bit 7 plain (not write-through) tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop (round 5's first form)
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
   constexpr int KB = SR / 2;                      // physical k elements per stage
   constexpr int NG = SR / 128;                    // logical 32-k groups per stage
@@ -742,6 +743,77 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint4 sink = make_uint4(0, 0, 0, 0);
+  if (SR == 256 && !(probe & (512 | 4 | 8))) {   // (the read-only / MFMA-only probes time the unpipelined loop: a branch inside this one
+                                                 // would make the compiler wait for ALL outstanding reads in front of every MFMA group)
+    // Software-pipelined over the 32-k groups (two per 256-byte stage, fragment sets F[0] / F[1]): the reads of the NEXT group are in
+    // flight while the 12 MFMAs of the current one issue, across the stage barrier too.  (Round 5's first form read a group, waited,
+    // multiplied: the two consumer waves of a SIMD leave every barrier in step, wait ~250 clk for their reads together and then queue
+    // 2 x 192 clk of MFMAs -- the matrix pipe ran at 60 % inside the loop.)  Same MFMAs in the same order per accumulator: same bits.
+    struct Frag { uint4 ah[TM], al[TM], bh[TN], bl[TN]; };
+    Frag F[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) F[s].ah[i] = F[s].al[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) F[s].bh[i] = F[s].bl[i] = make_uint4(0, 0, 0, 0);
+    }
+    auto load = [&](Frag& f, int t, int g) {
+      const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
+      const unsigned char* sb = sa + BM * SR;
+      const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        f.ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + ph);
+        f.al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + pl);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        f.bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + ph);
+        f.bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + pl);
+      }
+    };
+    auto mult = [&](const Frag& f) {
+      // x3_mfma's three products (lo.hi, hi.lo, hi.hi: x3.h) product-major, so that consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {   // (weights first: a lane owns 4 columns of one row)
+            const bf16x8 w = __builtin_bit_cast(bf16x8, p == 0 ? f.bl[tn] : f.bh[tn]);
+            const bf16x8 x = __builtin_bit_cast(bf16x8, p == 1 ? f.al[tm] : f.ah[tm]);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[tm][tn], 0, 0, 0);
+          }
+    };
+    __builtin_amdgcn_s_barrier();       // every loader's part of tile 0 is in LDS
+    if (probe & 1) {
+      for (int t = 1; t < nt; ++t) __builtin_amdgcn_s_barrier();
+    } else {
+      // (sched_barrier: the compiler's scheduler otherwise sinks every read to just in front of its first use to save registers)
+      load(F[0], 0, 0);
+      for (int t = 0; t + 1 < nt; ++t) {
+        load(F[1], t, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(F[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's reads of tile t have all returned (they were issued a group of MFMAs ago): the loaders may overwrite its slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile t + 1 is in LDS
+        asm volatile("" ::: "memory");
+        load(F[0], t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(F[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (the last tile on its own: a conditional barrier inside the loop joins two paths in front of mult(F[1]) and the compiler then
+      // waits for the reads just issued instead of the ones it needs)
+      load(F[1], nt - 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(F[0]);
+      mult(F[1]);
+    }
+  } else {
   uint4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) ah[i] = al[i] = make_uint4(0, 0, 0, 0);
@@ -783,6 +855,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
           acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
                                 __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);   // (weights first: a lane owns 4 columns of one row)
     }
+  }
   }
   if (probe && (sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x9E3779B9u) acc[0][0][0] += 1.f;
   if (probe & 16) {   // no epilogue (a never-taken store keeps EVERY accumulator alive)

@@ -52,7 +52,7 @@ if has dma; then
   mkdir -p tools/_build
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/_build/dma_bw tools/dma_bw.hip 2>/dev/null
   timeout 120 tools/_build/dma_bw 256 gpurun_out/${T}_dma_paths_microbench.json
-  VARIANTS=0,2 PROBES=0,1,2,4,8,16 OUT=gpurun_out/${T}_x3_fwd_probe_8192.json timeout 300 python tools/x3_fwd_probe.py 2>&1 | grep variant
+  VARIANTS=0,2 PROBES=0,512,1,2,4,8,16 OUT=gpurun_out/${T}_x3_fwd_probe_8192.json timeout 300 python tools/x3_fwd_probe.py 2>&1 | grep variant
 fi
 if has reinforce; then
   for D in bf16; do
