@@ -461,37 +461,100 @@ extern "C" int recnn_soft_update_flat(float* target, const float* net, int64_t n
 // A row-padded copy of a 2-D parameter in another leading dimension / type (recnn_shadow_out: what the GEMM kernels read in place of
 // a [rows, cols] weight whose rows are not 16-byte aligned or not in the compute type), rewritten by the optimizer pass that has the
 // new value in a register anyway: element i of the flat array is (i / cols, i % cols) of the copy.
-struct ShadowDst { void* dst; int cols; int64_t ld; int bf16; };
+struct ShadowDst { void* dst; int cols; int64_t ld; int bf16; int quad; };
 __device__ __forceinline__ void shadow_put(const ShadowDst& sh, int64_t i, float v) {
   const int64_t r = i / sh.cols;
   const int c = (int)(i - r * sh.cols);
   if (sh.bf16) ((bf16_t*)sh.dst)[r * sh.ld + c] = f2bf(v);
   else ((float*)sh.dst)[r * sh.ld + c] = v;
 }
+// Four consecutive flat elements i .. i + 3 (i a multiple of 4) with ONE division.  sh.quad (shadow_arg): 4 = the quad lies in one row and
+// its destination is 8- / 16-byte aligned (cols and ld multiples of 4): one store; 2 = cols and ld even: a PAIR never straddles a row and is
+// 4- / 8-byte aligned (the catalogue-sized weights of REINFORCE: [2048, 101290], [100000, 1290]): two stores; 1 = element by element.
+__device__ __forceinline__ void shadow_put4(const ShadowDst& sh, int64_t i, const float (&x)[4]) {
+  int64_t r;
+  if (i < (int64_t)0x7fffffff) r = (uint32_t)i / (uint32_t)sh.cols;   // (a 64-bit division is ~100 instructions)
+  else r = i / sh.cols;
+  int c = (int)(i - r * sh.cols);
+  if (sh.quad == 4) {
+    if (sh.bf16) *(uint2*)((bf16_t*)sh.dst + r * sh.ld + c) = make_uint2(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]));
+    else *(float4*)((float*)sh.dst + r * sh.ld + c) = make_float4(x[0], x[1], x[2], x[3]);
+  } else if (sh.quad == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (sh.bf16) *(uint32_t*)((bf16_t*)sh.dst + r * sh.ld + c) = pack_bf2(x[2 * h], x[2 * h + 1]);
+      else *(float2*)((float*)sh.dst + r * sh.ld + c) = make_float2(x[2 * h], x[2 * h + 1]);
+      c += 2;
+      if (c >= sh.cols) { c = 0; ++r; }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (sh.bf16) ((bf16_t*)sh.dst)[r * sh.ld + c] = f2bf(x[j]);
+      else ((float*)sh.dst)[r * sh.ld + c] = x[j];
+      if (++c == sh.cols) { c = 0; ++r; }
+    }
+  }
+}
+// whether the flat passes may take 16 bytes per lane and instruction (the flat arrays 16-byte aligned; the copy is handled by sh.quad)
+static bool flat_vec4(std::initializer_list<const void*> ptrs) {
+  for (const void* q : ptrs)
+    if ((uintptr_t)q & 15) return false;
+  return true;
+}
 static int shadow_arg(const recnn_shadow_out* h, int64_t n, ShadowDst* out) {
-  out->dst = nullptr; out->cols = 1; out->ld = 0; out->bf16 = 0;
+  out->dst = nullptr; out->cols = 1; out->ld = 0; out->bf16 = 0; out->quad = 1;
   if (!h || !h->dst) return 0;
   RECNN_REQUIRE(h->cols > 0 && h->ld >= h->cols && n % h->cols == 0, "optimizer shadow: the flat length %lld is not rows x cols = . x %d (ld %lld)",
                 (long long)n, h->cols, (long long)h->ld);
   out->dst = h->dst; out->cols = h->cols; out->ld = h->ld; out->bf16 = h->bf16 ? 1 : 0;
+  const uintptr_t d = (uintptr_t)h->dst;
+  const int esz = out->bf16 ? 2 : 4;
+  if (!(h->cols & 3) && !(h->ld & 3) && !(d & (uintptr_t)(4 * esz - 1))) out->quad = 4;
+  else if (!(h->cols & 1) && !(h->ld & 1) && !(d & (uintptr_t)(2 * esz - 1))) out->quad = 2;
+  else out->quad = 1;
   return 0;
 }
 
-template <bool SH>
+// One element of the flat Adam pass (torch.optim.Adam's arithmetic, fp contraction off: every instantiation rounds alike).
+__device__ __forceinline__ void adam_elem(float& pi, float& mi, float& vi, float graw, float beta2, float eps, float wd, float step_size,
+                                          float bc2_sqrt, float gs, float omb1, float omb2) {
+#pragma clang fp contract(off)
+  float gi = graw * gs;
+  if (wd != 0.f) gi += wd * pi;
+  mi += omb1 * (gi - mi);
+  vi = beta2 * vi + omb2 * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi -= step_size * (mi / denom);
+}
+// VEC = 4: 16 bytes per lane and load (catalogue-sized tensors -- REINFORCE at 100k items -- are bound by bytes in flight, not by HBM, with
+// 4-byte lanes); the n % 4 tail and unaligned callers take the scalar form.  Element by element the same arithmetic.
+template <bool SH, int VEC>
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float lr, float beta1, float beta2,
                                                         float eps, float wd, float step_size, float bc2_sqrt, float gs, float omb1,
                                                         float omb2, const ShadowDst sh) {
 #pragma clang fp contract(off)      // (both instantiations must round alike: which products fuse into FMAs is the compiler's choice per body)
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float pi = p[i];
-    float gi = g[i] * gs;
-    if (wd != 0.f) gi += wd * pi;
-    float mi = m[i], vi = v[i];
-    mi += omb1 * (gi - mi);
-    vi = beta2 * vi + omb2 * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi -= step_size * (mi / denom);
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  int64_t done = 0;
+  if (VEC == 4) {
+    const int64_t n4 = n >> 2;
+    for (int64_t q = gid; q < n4; q += stride) {
+      const float4 P = ((const float4*)p)[q], G = ((const float4*)g)[q], M = ((const float4*)m)[q], V = ((const float4*)v)[q];
+      float x[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+      const float gg[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_elem(x[j], mm[j], vv[j], gg[j], beta2, eps, wd, step_size, bc2_sqrt, gs, omb1, omb2);
+      ((float4*)p)[q] = make_float4(x[0], x[1], x[2], x[3]);
+      ((float4*)m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      ((float4*)v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (SH) shadow_put4(sh, q << 2, x);
+    }
+    done = n4 << 2;
+  }
+  for (int64_t i = done + gid; i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_elem(pi, mi, vi, g[i], beta2, eps, wd, step_size, bc2_sqrt, gs, omb1, omb2);
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (SH) shadow_put(sh, i, pi);
   }
@@ -506,14 +569,15 @@ extern "C" int recnn_adam_flat_shadow(float* p, const float* g, float* m, float*
   if (rc) return rc;
   const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
   const double bc1 = 1.0 - pow(b1, (double)step_t), bc2 = 1.0 - pow(b2, (double)step_t);
-  int grid = (int)((n + 255) / 256);
+  const bool v4 = flat_vec4({p, g, m, v});
+  int grid = (int)(((v4 ? (n + 3) / 4 : n) + 255) / 256);
   if (grid > 2048) grid = 2048;
-  if (sh.dst)
-    hipLaunchKernelGGL(adam_flat_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
-  else
-    hipLaunchKernelGGL(adam_flat_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
+#define ADAM_FLAT_GO(SH, VEC)                                                                                                             \
+  hipLaunchKernelGGL((adam_flat_kernel<SH, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,  \
+                     weight_decay, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh)
+  if (sh.dst) { if (v4) ADAM_FLAT_GO(true, 4); else ADAM_FLAT_GO(true, 1); }
+  else { if (v4) ADAM_FLAT_GO(false, 4); else ADAM_FLAT_GO(false, 1); }
+#undef ADAM_FLAT_GO
   return recnn_check_hip(hipGetLastError(), "adam_flat");
 }
 extern "C" int recnn_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
@@ -579,21 +643,52 @@ extern "C" int recnn_l1_norm_flat(const float* g, int64_t n, float* scratch, flo
   return recnn_check_hip(hipGetLastError(), "l1_norm_flat");
 }
 
-template <bool SH>
+// One element of the flat Ranger pass (RAdam + Lookahead: torch_optimizer.Ranger, the third-party optimizer recnn/nn/algo.py:84-90 constructs;
+// its published step restated in oracle/), fp contraction off.
+__device__ __forceinline__ void ranger_elem(float& pi, float& mi, float& vi, float graw, float lr, float beta1, float beta2, float eps, float wd,
+                                            int rect, float sl_lr, float gs, float omb1, float omb2) {
+#pragma clang fp contract(off)
+  const float gi = graw * gs;
+  vi = beta2 * vi + omb2 * gi * gi;
+  mi = beta1 * mi + omb1 * gi;
+  if (wd != 0.f) pi += (-wd * lr) * pi;
+  if (rect) pi += -sl_lr * (mi / (sqrtf(vi) + eps));
+  else pi += -sl_lr * mi;
+}
+template <bool SH, int VEC>
 __global__ __launch_bounds__(256) void ranger_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, float* __restrict__ slow, int64_t n, float lr,
                                                           float beta1, float beta2, float eps, float wd, float la_alpha, int la_sync,
                                                           int rect, float step, float gs, float omb1, float omb2, const ShadowDst sh) {
 #pragma clang fp contract(off)
   const float sl_lr = step * lr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  int64_t done = 0;
+  if (VEC == 4) {      // (see adam_flat_kernel)
+    const int64_t n4 = n >> 2;
+    for (int64_t q = gid; q < n4; q += stride) {
+      const float4 P = ((const float4*)p)[q], G = ((const float4*)g)[q], M = ((const float4*)m)[q], V = ((const float4*)v)[q];
+      float x[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+      const float gg[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ranger_elem(x[j], mm[j], vv[j], gg[j], lr, beta1, beta2, eps, wd, rect, sl_lr, gs, omb1, omb2);
+      if (la_sync) {
+        const float4 S = ((const float4*)slow)[q];
+        float ss[4] = {S.x, S.y, S.z, S.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ss[j] += la_alpha * (x[j] - ss[j]); x[j] = ss[j]; }
+        ((float4*)slow)[q] = make_float4(ss[0], ss[1], ss[2], ss[3]);
+      }
+      ((float4*)p)[q] = make_float4(x[0], x[1], x[2], x[3]);
+      ((float4*)m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      ((float4*)v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (SH) shadow_put4(sh, q << 2, x);
+    }
+    done = n4 << 2;
+  }
+  for (int64_t i = done + gid; i < n; i += stride) {
     float pi = p[i], mi = m[i], vi = v[i];
-    const float gi = g[i] * gs;
-    vi = beta2 * vi + omb2 * gi * gi;
-    mi = beta1 * mi + omb1 * gi;
-    if (wd != 0.f) pi += (-wd * lr) * pi;
-    if (rect) pi += -sl_lr * (mi / (sqrtf(vi) + eps));
-    else pi += -sl_lr * mi;
+    ranger_elem(pi, mi, vi, g[i], lr, beta1, beta2, eps, wd, rect, sl_lr, gs, omb1, omb2);
     if (la_sync) {
       float si = slow[i];
       si += la_alpha * (pi - si);
@@ -614,15 +709,16 @@ extern "C" int recnn_ranger_flat_shadow(float* p, const float* g, float* m, floa
   if (rc) return rc;
   const double b1 = recnn_snap7(beta1), b2 = recnn_snap7(beta2);
   const RadamScalars rs = radam_scalars(step_t, log(b1), log(b2), b2, (double)nsma_threshold);
-  int grid = (int)((n + 255) / 256);
-  if (grid > 2048) grid = 2048;
+  const bool v4 = flat_vec4({p, g, m, v, slow});
+  int grid = (int)(((v4 ? (n + 3) / 4 : n) + 255) / 256);
+  if (grid > 2048) grid = 2048;     // (measured: 4096 / 8192 workgroups and non-temporal loads / stores are all 4-10 % slower)
   const int sync = (la_k > 0 && step_t % la_k == 0) ? 1 : 0;
-  if (sh.dst)
-    hipLaunchKernelGGL(ranger_flat_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
-                       weight_decay, la_alpha, sync, rs.rect, rs.step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
-  else
-    hipLaunchKernelGGL(ranger_flat_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, eps,
-                       weight_decay, la_alpha, sync, rs.rect, rs.step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh);
+#define RANGER_FLAT_GO(SH, VEC)                                                                                                             \
+  hipLaunchKernelGGL((ranger_flat_kernel<SH, VEC>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, lr, beta1, beta2, \
+                     eps, weight_decay, la_alpha, sync, rs.rect, rs.step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2), sh)
+  if (sh.dst) { if (v4) RANGER_FLAT_GO(true, 4); else RANGER_FLAT_GO(true, 1); }
+  else { if (v4) RANGER_FLAT_GO(false, 4); else RANGER_FLAT_GO(false, 1); }
+#undef RANGER_FLAT_GO
   return recnn_check_hip(hipGetLastError(), "ranger_flat");
 }
 extern "C" int recnn_ranger_flat(float* p, const float* g, float* m, float* v, float* slow, int64_t n, float lr, float beta1,

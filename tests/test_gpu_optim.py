@@ -160,7 +160,8 @@ def test_run_graphs_with_default_ranger(cuda):
 
 @pytest.mark.parametrize("opt_name", ["ranger", "adam"])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_optimizer_rewrites_the_cached_compute_layout_in_the_same_pass(cuda, opt_name, bf16):
+@pytest.mark.parametrize("cols", [2049, 2050, 2052])
+def test_optimizer_rewrites_the_cached_compute_layout_in_the_same_pass(cuda, opt_name, bf16, cols):
     """recnn_*_flat_shadow: the optimizer kernel also writes the row-padded (optionally bf16) copy of a catalogue-sized weight that
     the GEMM kernels read (recnn_amd.nn.functional `_derived_of` layouts), so the next forward does not spend a conversion pass over
     it.  The parameter and optimizer state equal the plain step bit for bit; the copy equals a rebuild from the new parameter, bit
@@ -168,7 +169,10 @@ def test_optimizer_rewrites_the_cached_compute_layout_in_the_same_pass(cuda, opt
     import recnn_amd
     from recnn_amd.nn import functional as Fh
     torch.manual_seed(1)
-    rows, cols, ld = 2050, 2049, 2112                       # > 4M elements; odd column count: flat quads straddle rows
+    # > 4M elements; the flat pass takes 16 bytes per lane and writes the copy per quad: element by element (odd column count: quads
+    # straddle rows and a two-element tail is left), as two pairs (2050: the catalogue-sized weights of REINFORCE are of this kind) or
+    # as one store (2052).
+    rows, ld = 2050, 2112
     w0 = torch.randn(rows, cols, device=cuda)
     make = (lambda ps: recnn_amd.optim.Ranger(ps, lr=1e-3, weight_decay=1e-2)) if opt_name == "ranger" else \
         (lambda ps: recnn_amd.optim.Adam(ps, lr=1e-3, weight_decay=1e-2))
@@ -195,5 +199,30 @@ def test_optimizer_rewrites_the_cached_compute_layout_in_the_same_pass(cuda, opt
         assert hit is shadow
         assert torch.equal(hit[:rows, :cols], pa.detach().to(dt)), it
         assert bool((hit[:rows, cols:] == 7).all()) and bool((hit[rows:] == 7).all())
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(oa.state[pa][k], ob.state[pb][k]), k
+
+
+@pytest.mark.parametrize("opt_name", ["ranger", "adam"])
+def test_flat_pass_with_16_byte_lanes_equals_the_4_byte_form(cuda, opt_name):
+    """The flat optimizer kernels take 16 bytes per lane when every array is 16-byte aligned and 4 bytes otherwise (a parameter that is a
+    view at an odd offset): element by element the same arithmetic, so the same bits -- parameter and state, through a Lookahead sync."""
+    import recnn_amd
+    torch.manual_seed(2)
+    n = 1_000_003                                            # (n % 4 = 3: the 16-byte form leaves a tail)
+    w0 = torch.randn(n, device=cuda)
+    base = torch.zeros(n + 1, device=cuda)
+    base[1:] = w0
+    pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(base[1:])
+    assert pa.data_ptr() % 16 == 0 and pb.data_ptr() % 16 == 4
+    make = (lambda ps: recnn_amd.optim.Ranger(ps, lr=1e-3, weight_decay=1e-2)) if opt_name == "ranger" else \
+        (lambda ps: recnn_amd.optim.Adam(ps, lr=1e-3, weight_decay=1e-2))
+    oa, ob = make([pa]), make([pb])
+    for it in range(7):
+        g = torch.randn(n, device=cuda) * 1e-2
+        pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        assert torch.equal(pa.detach(), pb.detach()), it
     for k in ("exp_avg", "exp_avg_sq"):
         assert torch.equal(oa.state[pa][k], ob.state[pb][k]), k
