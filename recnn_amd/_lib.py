@@ -202,6 +202,8 @@ DEBUG_SIGNATURES = {
     "recnn_debug_l1_trace": (None, [_P]),
     "recnn_debug_x3_fwd": (None, [_I]),
     "recnn_debug_x3_ws_probe": (None, [_I]),
+    "recnn_debug_wide_ws": (None, [_I]),
+    "recnn_debug_ws_trace": (None, [_P]),
 }
 
 _lib = None

@@ -21,7 +21,8 @@ ENV_FIELDS = {
 }
 # process-level settings of the peer communicators (shared by engines: not part of an engine's tuning) and debug hooks
 ENV_CALLS = {"RECNN_COMM_MEMORY": "recnn_tune_comm_memory", "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",
-             "RECNN_MLP_PROBE": "recnn_debug_mlp_probe", "RECNN_X3_FWD_DEBUG": "recnn_debug_x3_fwd", "RECNN_X3_WS_PROBE": "recnn_debug_x3_ws_probe"}
+             "RECNN_MLP_PROBE": "recnn_debug_mlp_probe", "RECNN_X3_FWD_DEBUG": "recnn_debug_x3_fwd", "RECNN_X3_WS_PROBE": "recnn_debug_x3_ws_probe",
+             "RECNN_WIDE_WS": "recnn_debug_wide_ws"}
 
 _overrides = {}
 

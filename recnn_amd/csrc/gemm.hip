@@ -250,7 +250,10 @@ __device__ inline void epilogue_fwd(const GemmProb& P, f32x4 (&acc)[TM][TN], int
 // 16-byte x 64-lane rows (a lane's two 8-byte stores per block hit 16 rows x 32 bytes per wave instruction: the store tail was 5 of the
 // layer-1 launch's 24 us, profiles/r05_x3_ws_probe_fixed.txt).
 constexpr int X3_TILE_PITCH_PAD = 16;
-template <int TM, int TN>
+// SPLIT = false (round 5, the wave-specialised kernel on PLAIN bf16 operands: catalogue-wide products): the same lane layout and arithmetic,
+// plain fp32 / bf16 output (16- / 8-byte stores of four neighbouring columns), yref a plain bf16 matrix; the LDS tile image is then
+// [row][BN outputs] in the output type.
+template <int TM, int TN, bool SPLIT = true>
 __device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane, int part_idx,
                                        unsigned char* lds_tile = nullptr, int tile_pitch = 0) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -283,7 +286,18 @@ __device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], 
         if (full && !(P.ld_add & 3) && !((uintptr_t)P.addend & 15)) { const float4 t = *(const float4*)ap; ad[0] = t.x; ad[1] = t.y; ad[2] = t.z; ad[3] = t.w; }
         else for (int r = 0; r < 4; ++r) if (nb + r < P.N) ad[r] = ap[r];
       }
-      if (P.yref) yh = *(const uint2*)((const bf16_t*)P.yref + (int64_t)m * P.ldy + x3_col(nb));
+      if (P.yref) {
+        if constexpr (SPLIT) yh = *(const uint2*)((const bf16_t*)P.yref + (int64_t)m * P.ldy + x3_col(nb));
+        else {
+          const bf16_t* yp = (const bf16_t*)P.yref + (int64_t)m * P.ldy + nb;
+          if (full && !(P.ldy & 3) && !((uintptr_t)P.yref & 7)) yh = *(const uint2*)yp;
+          else {
+            uint32_t e[4] = {0x3F80u, 0x3F80u, 0x3F80u, 0x3F80u};
+            for (int r = 0; r < 4; ++r) if (nb + r < P.N) e[r] = yp[r];
+            yh = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+          }
+        }
+      }
       if (P.mask_mode == RECNN_MASK_EXTERNAL) {
         const uint8_t* mp = P.mask + (int64_t)m * P.ld_mask + nb;
         if (full && !(P.ld_mask & 3) && !((uintptr_t)P.mask & 3)) mk = *(const uint32_t*)mp;
@@ -307,8 +321,17 @@ __device__ inline void epilogue_fwd_x3(const GemmProb& P, f32x4 (&acc)[TM][TN], 
       }
       if (P.c_f32) {
         float* dst = (float*)P.C + (int64_t)m * P.ldc + nb;
-        if (full && !(P.ldc & 3) && !((uintptr_t)P.C & 15)) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        if (!SPLIT && lds_tile) *(float4*)(lds_tile + (m - m0) * tile_pitch + (nb - n0) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        else if (full && !(P.ldc & 3) && !((uintptr_t)P.C & 15)) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
         else for (int r = 0; r < 4; ++r) if (nb + r < P.N) dst[r] = v[r];
+      } else if constexpr (!SPLIT) {
+        const uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        bf16_t* dst = (bf16_t*)P.C + (int64_t)m * P.ldc + nb;
+        if (lds_tile) *(uint2*)(lds_tile + (m - m0) * tile_pitch + (nb - n0) * 2) = pk;
+        else if (full && !(P.ldc & 3) && !((uintptr_t)P.C & 7)) *(uint2*)dst = pk;
+        else for (int r = 0; r < 4; ++r) if (nb + r < P.N) dst[r] = (bf16_t)((r < 2 ? pk.x : pk.y) >> ((r & 1) * 16));
+        // the values a consumer of C would read
+        v[0] = bf2f((bf16_t)(pk.x & 0xFFFFu)); v[1] = bf2f((bf16_t)(pk.x >> 16)); v[2] = bf2f((bf16_t)(pk.y & 0xFFFFu)); v[3] = bf2f((bf16_t)(pk.y >> 16));
       } else {
         uint2 hi, lo;
         x3_split4(v, hi, lo);
@@ -654,8 +677,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 // SR = bytes per stage row: 256 (two logical 32-k groups per stage, chunk c of row r at position c ^ (r & 15)) or 128 (one group per
 // stage -- tiles of 128 x 128 / 128 x 256 then fit a 3-4 deep ring; chunk c of row r at position c ^ ((r >> 1) & 7): rows r, r + 1 sit in
 // the two halves of one 256-byte bank row, so the 16 rows x 16 bytes of a fragment read still cover all 64 banks exactly once).
-template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256>
-__global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe) {
+template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256, bool X3 = true>
+__global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const GemmBatch batch, const int probe, unsigned long long* trace) {
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
   // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
   // bit 4 no epilogue, bit 5 exit at entry, bit 6 epilogue stores straight to global memory (round 5's first form),
@@ -679,7 +702,8 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   if ((int)blockIdx.x >= nwg) return;
   if (probe & 32) return;
   const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  // (plain bf16 = the catalogue-wide products: few rows, 100k columns -- the row tiles of one weight panel side by side on one XCD)
+  const int tile_n = X3 ? lid % P.tiles_n : lid / P.tiles_m, tile_m = X3 ? lid / P.tiles_n : lid % P.tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
@@ -743,13 +767,65 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint4 sink = make_uint4(0, 0, 0, 0);
-  if (SR == 256 && !(probe & (512 | 4 | 8))) {   // (the read-only / MFMA-only probes time the unpipelined loop: a branch inside this one
-                                                 // would make the compiler wait for ALL outstanding reads in front of every MFMA group)
-    // Software-pipelined over the 32-k groups (two per 256-byte stage, fragment sets F[0] / F[1]): the reads of the NEXT group are in
-    // flight while the 12 MFMAs of the current one issue, across the stage barrier too.  (Round 5's first form read a group, waited,
-    // multiplied: the two consumer waves of a SIMD leave every barrier in step, wait ~250 clk for their reads together and then queue
-    // 2 x 192 clk of MFMAs -- the matrix pipe ran at 60 % inside the loop.)  Same MFMAs in the same order per accumulator: same bits.
-    struct Frag { uint4 ah[TM], al[TM], bh[TN], bl[TN]; };
+  // One fragment set: split bf16 -- one logical 32-k group = 64 physical k of every tile row of the wave (hi at chunk fg, lo at chunk
+  // 4 + fg; three products); plain bf16 -- one 32-k group (chunk 4 g + fg; "l" unused; one product).
+  static_assert(X3 || SR == 128, "the plain bf16 form is built for 128-byte stage rows");
+  constexpr int SETS = X3 ? SR / 128 : SR / 64;   // fragment sets per k stage
+  struct Frag { uint4 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto load = [&](Frag& f, int t, int g) {
+    const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
+    const unsigned char* sb = sa + BM * SR;
+    int ph, pl;
+    if constexpr (SR == 256) { ph = ((g * 8 + fg) ^ fr) * 16; pl = ((g * 8 + 4 + fg) ^ fr) * 16; }
+    else { const int sw = (fr >> 1) & 7; ph = (((X3 ? 0 : 4 * g) + fg) ^ sw) * 16; pl = ((4 + fg) ^ sw) * 16; }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      f.ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + ph);
+      if constexpr (X3) f.al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + pl);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      f.bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + ph);
+      if constexpr (X3) f.bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + pl);
+    }
+  };
+  auto mult = [&](const Frag& f) {
+    // product-major, so that consecutive MFMAs never share an accumulator.  Split bf16: x3_mfma's three products (lo.hi, hi.lo, hi.hi: x3.h),
+    // plain bf16: the one product; weights first in both (a lane owns 4 columns of one row: epilogue_fwd_x3).
+#pragma unroll
+    for (int p = 0; p < (X3 ? 3 : 1); ++p)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if constexpr (X3) {
+            const bf16x8 w = __builtin_bit_cast(bf16x8, p == 0 ? f.bl[tn] : f.bh[tn]);
+            const bf16x8 x = __builtin_bit_cast(bf16x8, p == 1 ? f.al[tm] : f.ah[tm]);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[tm][tn], 0, 0, 0);
+          } else {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f.bh[tn]), __builtin_bit_cast(bf16x8, f.ah[tm]),
+                                                                  acc[tm][tn], 0, 0, 0);
+          }
+        }
+  };
+  // the stage barrier of the pipelined loops: this wave's reads of the tile before have all returned (they were issued a group of MFMAs
+  // ago), so the loaders may overwrite its slot; behind the barrier the next tile is in LDS
+  auto next_tile = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // two fragment sets + the accumulators must fit the 170 registers a wave of a 768-thread workgroup may have (the 128 x 256 probe tile: no)
+  constexpr bool PIPE = (TM + TN) * (X3 ? 16 : 8) + TM * TN * 4 <= 150;
+  if (PIPE && !(probe & (512 | 4 | 8))) {   // (the read-only / MFMA-only probes time the unpipelined loop: a branch inside this one would
+                                            // make the compiler wait for ALL outstanding reads in front of every MFMA group)
+    // Software-pipelined over the fragment sets F[0] / F[1]: the reads of the NEXT set are in flight while the MFMAs of the current one
+    // issue, across the stage barrier too.  (Round 5's first form read a group, waited, multiplied: the two consumer waves of a SIMD leave
+    // every barrier in step, wait ~250 clk for their reads together and then queue 2 x 192 clk of MFMAs -- the matrix pipe ran at 60 %
+    // inside the loop.)  Same MFMAs in the same order per accumulator: same bits.  sched_barrier: the compiler's scheduler otherwise
+    // sinks every read to just in front of its first use to save registers.  The last tile(s) stand on their own: a conditional
+    // barrier inside the loop joins two paths in front of a mult() and the compiler then waits for the reads just issued instead of the
+    // ones it needs.
     Frag F[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -758,57 +834,43 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
 #pragma unroll
       for (int i = 0; i < TN; ++i) F[s].bh[i] = F[s].bl[i] = make_uint4(0, 0, 0, 0);
     }
-    auto load = [&](Frag& f, int t, int g) {
-      const unsigned char* sa = dsmem + (t % NS) * STAGE_BYTES;
-      const unsigned char* sb = sa + BM * SR;
-      const int ph = ((g * 8 + fg) ^ fr) * 16, pl = ((g * 8 + 4 + fg) ^ fr) * 16;
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        f.ah[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + ph);
-        f.al[tm] = *(const uint4*)(sa + (wm0 + tm * 16 + fr) * SR + pl);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        f.bh[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + ph);
-        f.bl[tn] = *(const uint4*)(sb + (wn0 + tn * 16 + fr) * SR + pl);
-      }
-    };
-    auto mult = [&](const Frag& f) {
-      // x3_mfma's three products (lo.hi, hi.lo, hi.hi: x3.h) product-major, so that consecutive MFMAs never share an accumulator
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {   // (weights first: a lane owns 4 columns of one row)
-            const bf16x8 w = __builtin_bit_cast(bf16x8, p == 0 ? f.bl[tn] : f.bh[tn]);
-            const bf16x8 x = __builtin_bit_cast(bf16x8, p == 1 ? f.al[tm] : f.ah[tm]);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[tm][tn], 0, 0, 0);
-          }
-    };
     __builtin_amdgcn_s_barrier();       // every loader's part of tile 0 is in LDS
     if (probe & 1) {
       for (int t = 1; t < nt; ++t) __builtin_amdgcn_s_barrier();
-    } else {
-      // (sched_barrier: the compiler's scheduler otherwise sinks every read to just in front of its first use to save registers)
+    } else if constexpr (SETS == 2) {   // two sets per tile
       load(F[0], 0, 0);
       for (int t = 0; t + 1 < nt; ++t) {
         load(F[1], t, 1);
         __builtin_amdgcn_sched_barrier(0);
         mult(F[0]);
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's reads of tile t have all returned (they were issued a group of MFMAs ago): the loaders may overwrite its slot
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // tile t + 1 is in LDS
-        asm volatile("" ::: "memory");
+        next_tile();
         load(F[0], t + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mult(F[1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // (the last tile on its own: a conditional barrier inside the loop joins two paths in front of mult(F[1]) and the compiler then
-      // waits for the reads just issued instead of the ones it needs)
       load(F[1], nt - 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(F[0]);
+      mult(F[1]);
+    } else {                            // one set per tile; nt is even (K is a multiple of 128 physical k)
+      static_assert(SETS == 1, "one or two fragment sets per stage");
+      load(F[0], 0, 0);
+      for (int t = 0; t + 2 < nt; t += 2) {
+        next_tile();
+        load(F[1], t + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(F[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        next_tile();
+        load(F[0], t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(F[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      next_tile();
+      load(F[1], nt - 1, 0);
       __builtin_amdgcn_sched_barrier(0);
       mult(F[0]);
       mult(F[1]);
@@ -851,9 +913,15 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
-                                __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);   // (weights first: a lane owns 4 columns of one row)
+        for (int tn = 0; tn < TN; ++tn) {
+          if constexpr (X3) {
+            acc[tm][tn] = x3_mfma(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, ah[tm]),
+                                  __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn]);   // (weights first: a lane owns 4 columns of one row)
+          } else {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[tn]), __builtin_bit_cast(bf16x8, ah[tm]), acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[tn]), __builtin_bit_cast(bf16x8, al[tm]), acc[tm][tn], 0, 0, 0);
+          }
+        }
     }
   }
   }
@@ -870,6 +938,95 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   // full tiles of split output leave through an LDS image of the tile (the ring is idle: every loader waited for its last DMA before
   // the last barrier): whole 1 KB wave stores instead of 8-byte ones.  Uniform per workgroup; the loaders have left (or are leaving:
   // a terminated wave does not take part in s_barrier).
+  if constexpr (!X3) {
+    // Plain output.  Full tiles: the RAW accumulators go into an fp32 LDS image of the tile (16 tight 16-byte stores per lane), then
+    // the waves walk the image row-wise -- a lane takes four neighbouring columns of one row per step (its column group never changes:
+    // bias loaded once), applies the forward epilogue element by element (the arithmetic of epilogue_fwd) and stores 16 (fp32) / 8
+    // (bf16) bytes: a wave instruction covers two whole 512- / 256-byte tile rows.  The first form ran epilogue_fwd_x3's fully
+    // unrolled body per (tm, tn) block here: 16 blocks x ~800 instructions, 12.5 of the 14.7 us a workgroup spent behind its k loop
+    // (recnn_debug_ws_trace; 72 of the catalogue-wide product's 206 us).  Ragged tiles keep the direct form.
+    constexpr int TPF = BN * 4 + 16;       // image row pitch: + 16 bytes against bank conflicts
+    const int es = P.c_f32 ? 4 : 2;
+    const bool st = m0 + BM <= P.M && n0 + BN <= P.N && !(((int64_t)P.ldc * es) & 15) && !((uintptr_t)P.C & 15) && !((uintptr_t)P.bias & 15) &&
+                    BM * TPF <= NS * STAGE_BYTES && !P.dot_part && !(probe & 64);
+    unsigned long long* trow = (trace && tid == 0) ? trace + (int64_t)blockIdx.x * 8 : nullptr;
+    if (trow) trow[0] = __builtin_amdgcn_s_memtime();
+    if (!st) {
+      epilogue_fwd_x3<TM, TN, false>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave);
+      return;
+    }
+    __builtin_amdgcn_s_barrier();          // every consumer is done reading the last k stage
+    if (trow) trow[1] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        *(f32x4*)(dsmem + (wm0 + tm * 16 + fr) * TPF + (wn0 + tn * 16 + fg * 4) * 4) = acc[tm][tn];
+    if (trow) trow[2] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    if (trow) trow[3] = __builtin_amdgcn_s_memtime();
+    constexpr int CPR = BN / 4;            // 4-column groups per tile row
+    static_assert((NC * 64) % CPR == 0, "a lane keeps its column group");
+    const int ch = (wave * 64 + lane) % CPR;
+    const int nb = n0 + ch * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bv = *(const f32x4*)(P.bias + nb);
+    uint32_t key = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
+    // the problem's fields in registers (the kernel-argument loads would otherwise repeat in every step of the walk), and no memory
+    // clobber on the stores (nothing in this kernel reads the output): the steps overlap
+    const float* const addend = P.addend;
+    const bf16_t* const yref = (const bf16_t*)P.yref;
+    const uint8_t* const mask = P.mask;
+    const int mask_mode = P.mask_mode, relu = P.relu, add_row_div = P.add_row_div, c_f32 = P.c_f32;
+    const int64_t ld_add = P.ld_add, ldy = P.ldy, ld_mask = P.ld_mask, ldc = P.ldc;
+    const float add_clip = P.add_clip, dx_scale = P.dx_scale;
+    char* const Cb = (char*)P.C;
+#pragma unroll 2
+    for (int row = (wave * 64 + lane) / CPR; row < BM; row += NC * 64 / CPR) {
+      const int m = m0 + row;
+      const f32x4 a4 = *(const f32x4*)(dsmem + row * TPF + ch * 16);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = a4[r] + bv[r];
+      if (addend) {
+        const int ma = add_row_div > 1 ? m / add_row_div : m;
+        const float* ap = addend + (int64_t)ma * ld_add + nb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += fminf(fmaxf(ap[r], -add_clip), add_clip);
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (yref) {
+        const bf16_t* yp = yref + (int64_t)m * ldy + nb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = bf2f(yp[r]) > 0.f ? v[r] * dx_scale : 0.f;
+      }
+      if (mask_mode == RECNN_MASK_EXTERNAL) {
+        const uint8_t* mp = mask + (int64_t)m * ld_mask + nb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mp[r] ? v[r] * 2.f : 0.f;
+      } else if (mask_mode == RECNN_MASK_HASH) {
+        const uint32_t word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(nb >> 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mask_keep(word, m & 3, r) ? v[r] * 2.f : 0.f;
+      }
+      char* dst = Cb + ((int64_t)m * ldc + nb) * es;
+      if (c_f32) {
+        const f32x4 o = {v[0], v[1], v[2], v[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(o));   // write-through: the tile drains while the launch runs,
+                                                                                  // not at its end (guide: publish-large)
+      } else {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(o));
+      }
+    }
+    if (trow) { trow[4] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trow[5] = __builtin_amdgcn_s_memtime(); }
+    return;
+  }
   constexpr int TP = BN * 4 + X3_TILE_PITCH_PAD;            // bytes per tile row: 2 BN bf16 + a 16-byte skew against bank conflicts
   const bool staged = !P.c_f32 && !P.yref && m0 + BM <= P.M && n0 + BN <= P.N && !(P.ldc & 7) && !((uintptr_t)P.C & 15) && BM * TP <= NS * STAGE_BYTES &&
                       !(probe & 64);
@@ -1128,14 +1285,16 @@ template <int TM, int TN, int NS, int NW = 8> static int launch_dma_x3(GemmLaunc
   hipLaunchKernelGGL((gemm_fwd_dma_kernel<bf16_t, TM, TN, NS, NW, true>), dim3(maxwg, L->nprob, 1), dim3(NW * 64, 1, 1), LDS, stream, L->batch);
   return recnn_check_hip(hipGetLastError(), "gemm_fwd_dma_kernel (x3) launch");
 }
+static unsigned long long* g_ws_trace = nullptr;   // recnn_debug_ws_trace: [workgroup][8] shader-clock stamps of the plain-bf16 epilogue
+extern "C" void recnn_debug_ws_trace(void* p) { g_ws_trace = (unsigned long long*)p; }
 static int g_x3_ws_probe = 0;    // recnn_debug_x3_ws_probe (csrc/recnn_hip_debug.h)
 extern "C" void recnn_debug_x3_ws_probe(int bits) { g_x3_ws_probe = bits; }
-template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
+template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256, bool X3 = true> static int launch_x3_ws(GemmLaunch* L, hipStream_t stream) {
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
   constexpr int LDS = NS * (BM + BN) * SR;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR>,
+    int rc = recnn_check_hip(hipFuncSetAttribute((const void*)x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR, X3>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS), "gemm x3 ws attr");
     if (rc) return rc;
     attr_done = true;
@@ -1150,7 +1309,7 @@ template <int TM, int TN, int WR, int WC, int NL, int NS, int SR = 256> static i
     if (nwg > maxwg) maxwg = nwg;
   }
   if (maxwg == 0) return 0;
-  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe);
+  hipLaunchKernelGGL((x3_fwd_ws_kernel<TM, TN, WR, WC, NL, NS, SR, X3>), dim3(maxwg, L->nprob, 1), dim3((NC + NL) * 64, 1, 1), LDS, stream, L->batch, g_x3_ws_probe, g_ws_trace);
   return recnn_check_hip(hipGetLastError(), "x3_fwd_ws_kernel launch");
 }
 static int g_x3_fwd_debug = -1;   // recnn_debug_x3_fwd (csrc/recnn_hip_debug.h): overrides GemmTune::x3_fwd, probes only
@@ -1201,7 +1360,24 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
 // Catalogue-wide forward products ([256, 2048] x [2048, 100k], recnn/nn/models.py:93-95 at a 100k-item catalogue): 128 x 128
 // tiles (wave tile 64 x 32: 6 fragment reads per 8 MFMAs), two 64 KB ring stages, row tiles fastest.  The 32 x 64 tile tuned
 // for the 256-wide MLPs streams 4.5 GB through L2 -> LDS for this shape (0.093 of the bf16 peak, round 3); this one 1.6 GB.
+// Round 5: in bf16 with more than 128 rows (REINFORCE's 256-row batches) the wave-specialised kernel takes them as 256 x 128 tiles -- the
+// whole batch against one weight panel: the panel goes L2 -> LDS once instead of twice (1.2 GB per product instead of 1.6), 4 loader waves
+// stream 48 KB stages of 128-byte rows through a 3-slot ring, 8 consumer waves (wave tile 64 x 64: 8 fragment reads per 16 MFMAs) multiply,
+// software-pipelined.  Same products in the same k order: bit-identical to the 128 x 128 form (tests/test_gpu_reinforce.py).
+static int g_wide_ws = 1;   // recnn_debug_wide_ws (csrc/recnn_hip_debug.h): 0 = the 128 x 128 kernel everywhere (A/B runs)
+extern "C" void recnn_debug_wide_ws(int on) { g_wide_ws = on; }
 template <class TC> static int launch_dma_wide(GemmLaunch* L, hipStream_t stream) {
+  if constexpr (sizeof(TC) == 2) {
+    bool tall = g_wide_ws != 0 && L->nprob > 0;
+    for (int i = 0; i < L->nprob; ++i) tall = tall && L->batch.p[i].M > 128 && !L->batch.p[i].dot_part;
+    if (tall) switch (g_wide_ws) {
+      case 2: return launch_x3_ws<4, 2, 2, 4, 4, 4, 128, false>(L, stream);   // 128 x 128, 4 stages
+      case 3: return launch_x3_ws<2, 4, 2, 4, 4, 4, 128, false>(L, stream);   //  64 x 256, 4 stages
+      case 4: return launch_x3_ws<4, 4, 2, 4, 4, 3, 128, false>(L, stream);   // 128 x 256, 3 stages
+      case 5: return launch_x3_ws<2, 2, 2, 4, 4, 6, 128, false>(L, stream);   //  64 x 128, 6 stages
+      default: return launch_x3_ws<4, 4, 4, 2, 4, 3, 128, false>(L, stream);  // 256 x 128, 3 stages
+    }
+  }
   constexpr int TM = 4, TN = 2, NS = 2, NW = 8, BM = 128, BN = 128;
   constexpr int LDS = NS * (BM + BN) * 256;
   static bool attr_done = false;

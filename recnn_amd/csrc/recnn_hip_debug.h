@@ -19,8 +19,15 @@ void recnn_debug_l1_trace(void* device_u64_wg16);
  * recnn_engine_tuning::x3_fwd); -1 = off */
 void recnn_debug_x3_fwd(int variant);
 /* timing experiments on the wave-specialised split-bf16 forward GEMM (results garbage): bit 0 consumers idle, bit 1 no DMA, bit 2 fragment
- * reads without MFMAs, bit 3 MFMAs without fragment reads */
+ * reads without MFMAs, bit 3 MFMAs without fragment reads, bit 4 no epilogue, bit 5 exit at entry, bit 6 direct epilogue stores, bit 7 plain
+ * tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop */
 void recnn_debug_x3_ws_probe(int bits);
+/* catalogue-wide bf16 forward products of more than 128 rows: 1 (default) = 256 x 128 tiles on the wave-specialised kernel, 0 = round 3's
+ * 128 x 128 kernel (A/B runs; the results are bit-identical); 2..5 = other tile / ring shapes (tools/wide_fwd_probe.py) */
+void recnn_debug_wide_ws(int on);
+/* shader-clock stamps of the plain-bf16 wave-specialised kernel's epilogue: device uint64 [workgroup][8] (loop end, barrier, image written,
+ * barrier, stores issued, stores acknowledged); NULL = off */
+void recnn_debug_ws_trace(void* device_u64_wg8);
 #ifdef __cplusplus
 }
 #endif

@@ -207,6 +207,37 @@ def test_gemm_fwd_split_k(cuda, dtype, M, N, K, tc_out):
     assert rel_err(outs[0], outs[2]) < (1e-5 if not (tc_out and dtype == "bf16") else 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,tc_out", [(256, 9000, 2048, False), (300, 8200, 1344, True), (129, 8192, 128, False)])
+def test_gemm_fwd_catalogue_wide_tall_tile_equals_the_square_tile(cuda, M, N, K, tc_out):
+    """Catalogue-wide bf16 products of more than 128 rows (REINFORCE: [256, 2048] x [2048, 100k]) run as 256 x 128 tiles on the
+    wave-specialised kernel (gemm.hip launch_dma_wide, round 5); `recnn_debug_wide_ws(0)` keeps round 3's 128 x 128 kernel.  Same products
+    in the same k order: the two must agree BIT FOR BIT (ragged last row / column tiles included), and with the float64 product."""
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g)
+    X, W, bd = _tc(x, "bf16").to(cuda), _tc(w, "bf16").to(cuda), b.to(cuda)
+    outs = []
+    try:
+        for tall in (1, 0):
+            lib.recnn_debug_wide_ws(tall)
+            out = torch.zeros(M, N, device=cuda, dtype=torch.bfloat16 if tc_out else torch.float32)
+            a = _args(L, "bf16", M, N)
+            a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), K, K, K
+            a.C, a.ldc, a.c_f32 = out.data_ptr(), N, 0 if tc_out else 1
+            a.bias, a.relu = bd.data_ptr(), 1
+            L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+            torch.cuda.synchronize()
+            outs.append(out.float().cpu())
+    finally:
+        lib.recnn_debug_wide_ws(1)
+    ref = torch.relu(X.double().cpu() @ W.double().cpu().t() + b.double())
+    assert rel_err(outs[0], ref) < (1e-2 if tc_out else 2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gemm_fwd_two_segments_f32_inputs_tc_output(cuda, dtype):
     """critic layer 1 on [gen_action | state]: 2 contraction segments, fp32 packed inputs, tc output."""

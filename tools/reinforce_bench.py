@@ -108,6 +108,8 @@ def _measure(a):
             else:
                 dist.init_process_group(backend)
     dev = torch.device("cuda", local)
+    from recnn_amd._tune import apply_env_knobs
+    apply_env_knobs()                                     # RECNN_* debug / tuning knobs for A/B runs from the shell
     recnn_amd.nn.algo.set_default_optimizer(a.optimizer)
     F_hip.set_catalogue_dtype(a.dtype)
     N, S, H, B = a.items, 1290, a.hidden, a.rows
