@@ -667,6 +667,62 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
   else epilogue_fwd<TC, TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NW + wave);
 }
 
+// The same epilogue for a FULL tile of split output that leaves through the LDS image (the wave-specialised kernel's common case), written
+// lean: the problem's fields in registers once, the bias of a lane's column groups loaded once, no ragged-edge / dot-product / backward-gate
+// code.  epilogue_fwd_x3's general body costs ~1900 clk per (tm, tn) block even with everything switched off (3.2 of the layer-1 launch's
+// 23.3 us: recnn_debug_ws_trace) -- kernel-argument loads and branches, not arithmetic.  Element by element the same arithmetic.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_x3_full_tile(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
+                                                      unsigned char* lds_tile, int tile_pitch) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* const bias = P.bias;
+  const float* const addend = P.addend;
+  const uint8_t* const mask = P.mask;
+  const int relu = P.relu, mask_mode = P.mask_mode, add_row_div = P.add_row_div;
+  const int64_t ld_add = P.ld_add, ld_mask = P.ld_mask;
+  const float add_clip = P.add_clip;
+  uint32_t key = 0;
+  if (mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
+  f32x4 bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) bv[tn] = bias ? *(const f32x4*)(bias + n0 + wn0 + tn * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + fr;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int nb = n0 + wn0 + tn * 16 + fg * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] + bv[tn][r];
+      if (addend) {
+        const int ma = add_row_div > 1 ? m / add_row_div : m;
+        const float* ap = addend + (int64_t)ma * ld_add + nb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += fminf(fmaxf(ap[r], -add_clip), add_clip);
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (mask_mode == RECNN_MASK_EXTERNAL) {
+        const uint8_t* mp = mask + (int64_t)m * ld_mask + nb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mp[r] ? v[r] * 2.f : 0.f;
+      } else if (mask_mode == RECNN_MASK_HASH) {
+        const uint32_t word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(nb >> 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mask_keep(word, m & 3, r) ? v[r] * 2.f : 0.f;
+      }
+      uint2 hi, lo;
+      x3_split4(v, hi, lo);
+      unsigned char* t = lds_tile + (m - m0) * tile_pitch + x3_col(nb - n0) * 2;
+      *(uint2*)t = hi;
+      *(uint2*)(t + 64) = lo;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ split-bf16 forward GEMM, wave-specialised (round 5)
 // Same tile image, arithmetic and epilogue as gemm_fwd_dma_kernel<.., X3>, different division of labour: NL LOADER waves do nothing
 // but issue the LDS-DMA of the ring (tile t + D while tile t is multiplied), WR x WC CONSUMER waves do nothing but read fragments and
@@ -682,7 +738,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   // probe (recnn_debug_x3_ws_probe, timing experiments only, results garbage): bit 0 consumers do nothing but the barriers, bit 1 loaders
   // issue nothing, bit 2 consumers read their fragments but issue no MFMA, bit 3 consumers issue the MFMAs on stale registers (no reads),
   // bit 4 no epilogue, bit 5 exit at entry, bit 6 epilogue stores straight to global memory (round 5's first form),
-  // bit 7 plain (not write-through) tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop (round 5's first form)
+  // bit 7 plain (not write-through) tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop (round 5's first form), bit 10 the general epilogue on full tiles
   constexpr int NC = WR * WC, BM = 16 * TM * WR, BN = 16 * TN * WC;
   constexpr int KB = SR / 2;                      // physical k elements per stage
   constexpr int NG = SR / 128;                    // logical 32-k groups per stage
@@ -963,6 +1019,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
       for (int tn = 0; tn < TN; ++tn)
         *(f32x4*)(dsmem + (wm0 + tm * 16 + fr) * TPF + (wn0 + tn * 16 + fg * 4) * 4) = acc[tm][tn];
     if (trow) trow[2] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of the image is IN LDS (s_barrier alone does not wait for LDS writes)
     __builtin_amdgcn_s_barrier();
     if (trow) trow[3] = __builtin_amdgcn_s_memtime();
     constexpr int CPR = BN / 4;            // 4-column groups per tile row
@@ -1030,10 +1087,17 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   constexpr int TP = BN * 4 + X3_TILE_PITCH_PAD;            // bytes per tile row: 2 BN bf16 + a 16-byte skew against bank conflicts
   const bool staged = !P.c_f32 && !P.yref && m0 + BM <= P.M && n0 + BN <= P.N && !(P.ldc & 7) && !((uintptr_t)P.C & 15) && BM * TP <= NS * STAGE_BYTES &&
                       !(probe & 64);
+  unsigned long long* trow = (trace && tid == 0) ? trace + (int64_t)blockIdx.x * 8 : nullptr;
+  if (trow) trow[0] = __builtin_amdgcn_s_memtime();
   if (staged) __builtin_amdgcn_s_barrier();                 // every consumer is done reading the last k stage: the tile image may overwrite it
-  epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave, staged ? dsmem : nullptr, TP);
+  if (trow) trow[1] = __builtin_amdgcn_s_memtime();
+  if (staged && !P.dot_part && !P.dot_w && !((uintptr_t)P.bias & 15) && !(probe & 1024)) epilogue_x3_full_tile<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, dsmem, TP);
+  else epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave, staged ? dsmem : nullptr, TP);
+  if (trow) trow[2] = __builtin_amdgcn_s_memtime();
   if (staged) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of the image is IN LDS (s_barrier alone does not wait for LDS writes)
     __builtin_amdgcn_s_barrier();
+    if (trow) trow[3] = __builtin_amdgcn_s_memtime();
     constexpr int CPR2 = BN * 4 / 16;                          // 16-byte chunks per tile row
     bf16_t* C = (bf16_t*)P.C + (int64_t)m0 * P.ldc + x3_col(n0);
     for (int idx = wave * 64 + lane; idx < BM * CPR2; idx += NC * 64) {
@@ -1045,6 +1109,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
              asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory"); }   // write-through: the tile drains while the
                                                                                                  // launch runs, not at its end (guide: publish-large)
     }
+    if (trow) { trow[4] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trow[5] = __builtin_amdgcn_s_memtime(); }
   }
 }
 

@@ -115,6 +115,49 @@ def test_gemm_fwd_kernel_variants_are_bit_identical(cuda, M, N, K):
         assert torch.equal(o, outs[0]), var
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (8192, 256, 256), (2048, 128, 128)])
+def test_gemm_fwd_lean_full_tile_epilogue_equals_the_general_one(cuda, M, N, K):
+    """Full tiles of split output leave the wave-specialised kernel through `epilogue_x3_full_tile` (gemm.hip, round 5: the problem's
+    fields in registers, no ragged / dot-product / backward-gate code); probe bit 10 (csrc/recnn_hip_debug.h) keeps the general epilogue.
+    Element by element the same arithmetic: the same bits under every option the lean form handles (bias, relu, hash / external dropout,
+    clamped and unclamped addends), on the 32 x 64 tiles with 3- and 5-stage rings and on 64 x 128 tiles."""
+    import itertools
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    X, W = x3_pack_ref(x).to(cuda), x3_pack_ref(w).to(cuda)
+    bd = torch.randn(N, generator=g).to(cuda)
+    ad = (torch.randn(M, N, generator=g) * 3).to(cuda)
+    md = (torch.rand(M, N, generator=g) < 0.5).to(torch.uint8).to(cuda)
+    ldc = 2 * ((N + 31) // 32 * 32)
+    try:
+        for use_b, relu, mm, use_add in itertools.product((0, 1), (0, 1), (0, 1, 2), (0, 1, 2)):
+            outs = []
+            for probe in (0, 1024):
+                lib.recnn_debug_x3_ws_probe(probe)
+                out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=cuda)
+                a = _args(L, M, N)
+                a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), 2 * K, 2 * K, 2 * K
+                a.C, a.ldc, a.c_f32, a.relu = out.data_ptr(), ldc, 0, relu
+                if use_b:
+                    a.bias = bd.data_ptr()
+                if mm == 1:
+                    a.mask_mode, a.seed, a.stream_id = L.MASK_HASH, 77, 3
+                elif mm == 2:
+                    a.mask_mode, a.mask, a.ld_mask = L.MASK_EXTERNAL, md.data_ptr(), N
+                if use_add:
+                    a.addend, a.ld_add, a.add_clip = ad.data_ptr(), N, (1.5 if use_add == 2 else float("inf"))
+                L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+                torch.cuda.synchronize()
+                outs.append(out.view(torch.int16).clone())
+            assert bool((outs[0] != 0).any())
+            assert torch.equal(outs[0], outs[1]), (use_b, relu, mm, use_add)
+    finally:
+        lib.recnn_debug_x3_ws_probe(0)
+
+
 def test_gemm_fwd_two_segments(cuda):
     """critic layer 1 on [gen_action | state]: two contraction segments into one accumulator."""
     L = _lib()

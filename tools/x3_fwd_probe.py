@@ -56,6 +56,32 @@ for var, probe in [(v, p) for v in VARIANTS for p in PROBES]:
         print(f"variant {var:2d} M={M:5d} {name:18s} {us:7.2f} us   {tiles} tiles, {gb / (us * 1e-6) / 1e3:.1f} TB/s of LDS-DMA bytes, "
               f"{bclk:.1f} B/clk/CU at 2.4 GHz, {2.0 * M * N * K * 3 / (us * 1e-6) / 1e12:.0f} TFLOP/s executed")
         res[f"v{var}_{name.replace(' ', '_')}"] = {"us": us, "tiles": tiles, "dma_bytes": gb * 1e9, "B_per_clk_per_CU": bclk}
+if os.environ.get("TRACE"):
+    import numpy as np
+    lib = L.load()
+    lib.recnn_debug_x3_fwd(2)
+    lib.recnn_debug_x3_ws_probe(0)
+    RELU_MASK = int(os.environ.get("HASH", "1"))
+    tr = torch.zeros(4096, 8, dtype=torch.int64, device=dev)
+    bias = torch.randn(N, device=dev)
+    a = L.GemmArgs()
+    C.memset(C.byref(a), 0, C.sizeof(a))
+    a.dtype, a.M, a.N = L.BF16X3, M, N
+    a.A[0], a.B[0], a.lda[0], a.ldb[0], a.K[0] = X.data_ptr(), W.data_ptr(), 2 * K, 2 * K, 2 * K
+    a.C, a.ldc, a.c_f32, a.relu = out.data_ptr(), 2 * N, 0, 1
+    a.bias = bias.data_ptr()
+    if RELU_MASK:
+        a.mask_mode, a.seed, a.stream_id = L.MASK_HASH, 1234, 3
+    a.dx_scale, a.dw_splits = 1.0, 1
+    L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+    lib.recnn_debug_ws_trace(tr.data_ptr())
+    L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
+    torch.cuda.synchronize()
+    lib.recnn_debug_ws_trace(None)
+    t = tr.cpu().numpy()[: (M // 64) * (N // 128)]
+    d = (t[:, 1:6] - t[:, 0:5]) / 2400.0
+    print("x3 epilogue phases, us at 2.4 GHz (median / max over workgroups): barrier, epilogue -> LDS image, barrier, copy-out issue, stores acknowledged")
+    print(np.round(np.median(d, 0), 2), np.round(d.max(0), 2))
 L.load().recnn_debug_x3_fwd(-1)
 L.load().recnn_debug_x3_ws_probe(0)
 out_path = os.environ.get("OUT")
