@@ -636,9 +636,14 @@ def main():
         if dom[2] > 0:
             out["roofline"] = dict(roof(dom[0], dom[1], dom[2], 1.0 / pe if dom[0] in FROZEN else 1.0), traffic=traffic,
                                    traffic_source=traffic_note,
-                                   dominant_by="algorithmic flops per step: %.0f %% of the schedule's MFMA flops, %.0f %% of its MFMA launch time"
+                                   dominant_by="algorithmic flops per step: this launch %.0f %% of the schedule's MFMA flops in %.0f %% of its MFMA launch "
+                                               "time; its kernel (all launches of it) %.0f %% in %.0f %%"
                                                % (100 * flops_per_step(dom) / sum(flops_per_step(r) for r in cand),
-                                                  100 * share(dom) / sum(share(r) for r in cand)))
+                                                  100 * share(dom) / sum(share(r) for r in cand),
+                                                  100 * sum(flops_per_step(r) for r in cand if KERNEL_OF_SLOT.get(r[0], r[0]) == KERNEL_OF_SLOT.get(dom[0], dom[0]))
+                                                  / sum(flops_per_step(r) for r in cand),
+                                                  100 * sum(share(r) for r in cand if KERNEL_OF_SLOT.get(r[0], r[0]) == KERNEL_OF_SLOT.get(dom[0], dom[0]))
+                                                  / sum(share(r) for r in cand)))
             if dom[0] in ("frozen_actors", "frozen_target_critics"):
                 out["roofline"]["traffic_covers"] = "mean over the two launches of mlp_frozen_kernel per policy cycle (actors; target critics)"
             if dom_time[0] != dom[0]:
