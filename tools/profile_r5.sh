@@ -52,7 +52,10 @@ if has dma; then
   mkdir -p tools/_build
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/_build/dma_bw tools/dma_bw.hip 2>/dev/null
   timeout 120 tools/_build/dma_bw 256 gpurun_out/${T}_dma_paths_microbench.json
-  VARIANTS=0,2 PROBES=0,512,1,2,4,8,16 OUT=gpurun_out/${T}_x3_fwd_probe_8192.json timeout 300 python tools/x3_fwd_probe.py 2>&1 | grep variant
+  VARIANTS=0,2 PROBES=0,512,1024,1,2,4,8,16 TRACE=1 OUT=gpurun_out/${T}_x3_fwd_probe_8192.json timeout 300 python tools/x3_fwd_probe.py 2>&1 | grep -v aliased | tee gpurun_out/${T}_x3_fwd_probe_8192.txt
+  TRACE=1 TILES=1,2,3,4,5,0 PADS=0,128 PROBES=0 OUT=gpurun_out/${T}_wide_fwd_pitch.json timeout 300 python tools/wide_fwd_probe.py 2>&1 | tee gpurun_out/${T}_wide_fwd_probe.txt
+  TILES=1 PADS=0 PROBES=16,1,17 timeout 300 python tools/wide_fwd_probe.py 2>&1 | tee -a gpurun_out/${T}_wide_fwd_probe.txt
+  OUT=gpurun_out/${T}_ranger_bw.json timeout 200 python tools/ranger_bw.py | tee gpurun_out/${T}_ranger_bw.txt
 fi
 if has reinforce; then
   for D in bf16; do
