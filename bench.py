@@ -120,6 +120,28 @@ KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_fwd_critic": "mlps_fwd
                   "fwd_l1": "x3_fwd_ws_kernel<2, 2, 2, 4, 4, 3", "x3_tail": "x3_tail_kernel"}   # (the 64 x 128-tile instance: the grouped layer-1 launch)
 
 
+FROZEN_SLOTS = ("frame_gather_cycle", "td3_noise", "frozen_actors", "frozen_target_critics", "l1_frozen_actors", "l2_frozen_actors",
+                "l3_frozen_actors", "tail_frozen_actors", "l1_frozen_target_critic", "l2_frozen_target_critic",
+                "q_frozen_target_critic", "tail_frozen_target_critic")    # launches of the cycle schedule that serve a whole policy cycle
+
+
+def pick_dominant(launches, policy_every):
+    """launches: [(slot name, mean ms per launch, algorithmic flops per launch)] of the schedule the timed region replayed.
+    Returns (flop-dominant launch, time-dominant launch, per-step flops of a launch, per-step ms of a launch): the dominant kernel of an
+    MFMA roofline is the launch that carries the largest share of the step's ALGORITHMIC FLOPS -- fused schedule: the row-panel forward of
+    all networks (also the longest launch: rounds 1-4's choice); cycle schedule: the batched frozen-network launch.  By TIME per step the
+    cycle schedule's longest MFMA launch is the learning critic's tail (a dependent latency chain of 0.5 GFLOP): reported beside it.
+    Launches in FROZEN_SLOTS run once per policy cycle and count 1 / policy_every per step.  No MFMA launch at all: the longest launch."""
+    per_step = lambda r, v: v / policy_every if r[0] in FROZEN_SLOTS else v
+    flops_per_step = lambda r: per_step(r, r[2])
+    share = lambda r: per_step(r, r[1])
+    cand = [r for r in launches if r[2] > 0]
+    if not cand:
+        dom = max(launches, key=lambda r: r[1])
+        return dom, dom, flops_per_step, share
+    return max(cand, key=flops_per_step), max(cand, key=share), flops_per_step, share
+
+
 def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):
     """HBM bytes per launch of the named kernels from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3
     sections) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a child
@@ -602,19 +624,10 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "avg_ms": ms, "flops_per_launch": fl, "launches_per_step": per_step}
-        FROZEN = ("frame_gather_cycle", "td3_noise", "frozen_actors", "frozen_target_critics", "l1_frozen_actors", "l2_frozen_actors",
-                  "l3_frozen_actors", "tail_frozen_actors", "l1_frozen_target_critic", "l2_frozen_target_critic",
-                  "q_frozen_target_critic", "tail_frozen_target_critic")
+        FROZEN = FROZEN_SLOTS
         used = prof_cyc if schedule == "cycle" else prof
-        share = lambda r: r[1] / pe if r[0] in FROZEN else r[1]          # per-step time share (cycle launches serve `pe` steps)
         cand = [r for r in used if r[2] > 0]
-        # The dominant kernel of an MFMA roofline = the launch that carries the largest share of the step's ALGORITHMIC FLOPS (fused
-        # schedule: the row-panel forward of all networks, which is also the longest launch -- rounds 1-4's choice; cycle schedule: the
-        # batched frozen-network launch, 2/3 of the step's flops).  By TIME per step the cycle schedule's longest MFMA launch is the
-        # learning critic's tail (a dependent latency chain of 0.5 GFLOP): reported beside it as `roofline_time_dominant`.
-        flops_per_step = lambda r: r[2] / pe if r[0] in FROZEN else r[2]
-        dom = max(cand, key=flops_per_step) if cand else max(used, key=lambda r: r[1])
-        dom_time = max(cand, key=share) if cand else dom
+        dom, dom_time, flops_per_step, share = pick_dominant(used, pe)
         # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
         traffic, traffic_note = None, "skipped"
         gather_traffic, gather_note = None, "skipped"
