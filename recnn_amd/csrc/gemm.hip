@@ -668,12 +668,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_fwd_dma_kernel(const GemmBatch b
 }
 
 // The same epilogue for a FULL tile of split output that leaves through the LDS image (the wave-specialised kernel's common case), written
-// lean: the problem's fields in registers once, the bias of a lane's column groups loaded once, no ragged-edge / dot-product / backward-gate
-// code.  epilogue_fwd_x3's general body costs ~1900 clk per (tm, tn) block even with everything switched off (3.2 of the layer-1 launch's
+// lean: the problem's fields in registers once, the bias (and last-layer weights) of a lane's column groups loaded once, no ragged-edge /
+// backward-gate code.  epilogue_fwd_x3's general body costs ~1900 clk per (tm, tn) block even with everything switched off (3.2 of the layer-1 launch's
 // 23.3 us: recnn_debug_ws_trace) -- kernel-argument loads and branches, not arithmetic.  Element by element the same arithmetic.
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_x3_full_tile(const GemmProb& P, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
-                                                      unsigned char* lds_tile, int tile_pitch) {
+                                                      int part_idx, unsigned char* lds_tile, int tile_pitch) {
   const int fr = lane & 15, fg = lane >> 4;
   const float* const bias = P.bias;
   const float* const addend = P.addend;
@@ -683,9 +683,18 @@ __device__ __forceinline__ void epilogue_x3_full_tile(const GemmProb& P, f32x4 (
   const float add_clip = P.add_clip;
   uint32_t key = 0;
   if (mask_mode == RECNN_MASK_HASH) key = mask_key(P.seed, (P.step_ptr ? *P.step_ptr : 0) + P.step_add, P.stream_id);
-  f32x4 bv[TN];
+  // the last layer's dot product riding on this GEMM (the policy loss: -Q(s, pi(s)) summed from these partials): per lane in the general
+  // epilogue's block order, over the values a consumer of C would read (hi + lo), one partial per wave
+  float* const dot_part = P.dot_part;
+  const float* const dot_w = dot_part ? P.dot_w : nullptr;
+  const float* const dot_bias = dot_part ? P.dot_bias : nullptr;
+  float sdot = 0.f;
+  f32x4 bv[TN], dwv[TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) bv[tn] = bias ? *(const f32x4*)(bias + n0 + wn0 + tn * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tn = 0; tn < TN; ++tn) {
+    bv[tn] = bias ? *(const f32x4*)(bias + n0 + wn0 + tn * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dwv[tn] = dot_w ? *(const f32x4*)(dot_w + n0 + wn0 + tn * 16 + fg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m0 + wm0 + tm * 16 + fr;
@@ -719,7 +728,20 @@ __device__ __forceinline__ void epilogue_x3_full_tile(const GemmProb& P, f32x4 (
       unsigned char* t = lds_tile + (m - m0) * tile_pitch + x3_col(nb - n0) * 2;
       *(uint2*)t = hi;
       *(uint2*)(t + 64) = lo;
+      if (dot_part) {
+        const float c0 = bf2f((bf16_t)(hi.x & 0xFFFFu)) + bf2f((bf16_t)(lo.x & 0xFFFFu)), c1 = bf2f((bf16_t)(hi.x >> 16)) + bf2f((bf16_t)(lo.x >> 16));
+        const float c2 = bf2f((bf16_t)(hi.y & 0xFFFFu)) + bf2f((bf16_t)(lo.y & 0xFFFFu)), c3 = bf2f((bf16_t)(hi.y >> 16)) + bf2f((bf16_t)(lo.y >> 16));
+        sdot += c0 * dwv[tn][0];
+        sdot += c1 * dwv[tn][1];
+        sdot += c2 * dwv[tn][2];
+        sdot += c3 * dwv[tn][3];
+        if (nb == 0 && dot_bias) sdot += dot_bias[0];
+      }
     }
+  }
+  if (dot_part) {  // uniform
+    sdot = wave_sum(sdot);
+    if (lane == 0) dot_part[part_idx] = sdot;
   }
 }
 
@@ -1091,7 +1113,7 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
   if (trow) trow[0] = __builtin_amdgcn_s_memtime();
   if (staged) __builtin_amdgcn_s_barrier();                 // every consumer is done reading the last k stage: the tile image may overwrite it
   if (trow) trow[1] = __builtin_amdgcn_s_memtime();
-  if (staged && !P.dot_part && !P.dot_w && !((uintptr_t)P.bias & 15) && !(probe & 1024)) epilogue_x3_full_tile<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, dsmem, TP);
+  if (staged && !((uintptr_t)P.bias & 15) && !((uintptr_t)P.dot_w & 15) && !(probe & 1024)) epilogue_x3_full_tile<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave, dsmem, TP);
   else epilogue_fwd_x3<TM, TN>(P, acc, m0, n0, wm0, wn0, lane, lid * NC + wave, staged ? dsmem : nullptr, TP);
   if (trow) trow[2] = __builtin_amdgcn_s_memtime();
   if (staged) {
