@@ -20,7 +20,8 @@ void recnn_debug_l1_trace(void* device_u64_wg16);
 void recnn_debug_x3_fwd(int variant);
 /* timing experiments on the wave-specialised split-bf16 forward GEMM (results garbage): bit 0 consumers idle, bit 1 no DMA, bit 2 fragment
  * reads without MFMAs, bit 3 MFMAs without fragment reads, bit 4 no epilogue, bit 5 exit at entry, bit 6 direct epilogue stores, bit 7 plain
- * tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop */
+ * tile stores, bit 8 no kernel-argument prefetch, bit 9 the unpipelined consumer loop, bit 10 the general epilogue on full tiles (bits 9 and 10
+ * leave the results intact: A/B runs of the step, RECNN_X3_WS_PROBE) */
 void recnn_debug_x3_ws_probe(int bits);
 /* catalogue-wide bf16 forward products of more than 128 rows: 1 (default) = 256 x 128 tiles on the wave-specialised kernel, 0 = round 3's
  * 128 x 128 kernel (A/B runs; the results are bit-identical); 2..5 = other tile / ring shapes (tools/wide_fwd_probe.py) */
