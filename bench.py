@@ -92,7 +92,8 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
         torch.set_num_threads(nt)
         one(0)
         t0 = time.perf_counter()
-        one(1)
+        for k in range(3):               # three steps per candidate: one step's time moves by more than the candidates differ
+            one(1 + k)
         dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best, best_t = nt, dt
@@ -100,7 +101,7 @@ def cpu_baseline(items, ratings, off, table, budget_s=12.0):
     t0 = time.perf_counter()
     n = 0
     while True:
-        one(n + 2)
+        one(n + 4)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s and n >= 3:
@@ -117,7 +118,12 @@ KERNEL_OF_SLOT = {"mlp_fwd_nets": "mlps_fwd_kernel", "mlp_fwd_critic": "mlps_fwd
                   "frozen_actors": "mlp_frozen_kernel", "frozen_target_critics": "mlp_frozen_kernel",
                   "frame_gather": "frame_gather_kernel", "dw_critic": "gemm_dw_dma_kernel",
                   "adam_critic": "apply_kernel", "adam_critic+gather": "apply_gather_kernel",
-                  "fwd_l1": "x3_fwd_ws_kernel<2, 2, 2, 4, 4, 3", "x3_tail": "x3_tail_kernel"}   # (the 64 x 128-tile instance: the grouped layer-1 launch)
+                  "fwd_l1": "x3_fwd_ws_kernel<2, 2, 2, 4, 4, 3", "x3_tail": "x3_tail_kernel",   # (the 64 x 128-tile instance: the grouped layer-1 launch)
+                  "dwadam_critic": "dw_adam_kernel", "dw_actor": "gemm_dw_dma_kernel", "adam_actor": "apply_kernel",
+                  "frame_gather_cycle": "frame_gather_multi_kernel", "bwd_chain_policy": "bwd_chain_kernel",
+                  "grad_reduce_actor": "grad_reduce_kernel", "grad_reduce_critic": "grad_reduce_kernel",
+                  "fwd_l1_pcritic": "gemm_fwd_dma_kernel", "fwd_l2_pcritic": "gemm_fwd_dma_kernel"}
+PARAMS = {"critic": 429_313, "actor": 429_184}      # parameters per network
 
 
 FROZEN_SLOTS = ("frame_gather_cycle", "td3_noise", "frozen_actors", "frozen_target_critics", "l1_frozen_actors", "l2_frozen_actors",
@@ -140,6 +146,40 @@ def pick_dominant(launches, policy_every):
         dom = max(launches, key=lambda r: r[1])
         return dom, dom, flops_per_step, share
     return max(cand, key=flops_per_step), max(cand, key=share), flops_per_step, share
+
+
+def kernel_table(used, prof, prof_pol, policy_every):
+    """Per KERNEL SYMBOL of the schedule the timed region replayed: us per step summed over all its launches -- what
+    `rocprofv3 --kernel-trace --stats` of the same command lists (profiles/rNN_cycle_stats.txt), so that `roofline` can be re-derived
+    from that file: flops per launch / average duration / peak for the kernel at its top.
+    used: [(slot, ms per launch, flops per launch)] of an ordinary step of that schedule (cycle schedule: + the launches that serve a whole
+    policy cycle, FROZEN_SLOTS, counted 1 / policy_every per step); a policy step's EXTRA launches (prof_pol minus prof, as multisets of
+    slot names: the actor's backward chain, dW, L1 norm, optimizer) are counted 1 / policy_every per step as well."""
+    rows = [(n, ms, fl, (1.0 / policy_every) if n in FROZEN_SLOTS else 1.0) for n, ms, fl in used]
+    left = {}
+    for n, _, _ in (prof or []):
+        left[n] = left.get(n, 0) + 1
+    for n, ms, fl in (prof_pol or []):
+        if left.get(n, 0) > 0:
+            left[n] -= 1
+        else:
+            rows.append((n, ms, fl, 1.0 / policy_every))
+    tab = {}
+    for n, ms, fl, w in rows:
+        k = KERNEL_OF_SLOT.get(n, n)
+        t = tab.setdefault(k, {"kernel": k, "slots": [], "ms_per_step": 0.0, "flops_per_step": 0.0, "launches_per_step": 0.0})
+        if n not in t["slots"]:
+            t["slots"].append(n)
+        t["ms_per_step"] += ms * w
+        t["flops_per_step"] += fl * w
+        t["launches_per_step"] += w
+    out = sorted(tab.values(), key=lambda t: -t["ms_per_step"])
+    total = sum(t["ms_per_step"] for t in out) or 1.0
+    for t in out:
+        t["avg_ms"] = t["ms_per_step"] / t["launches_per_step"]
+        t["flops_per_launch"] = t["flops_per_step"] / t["launches_per_step"]
+        t["share_of_step_time"] = t["ms_per_step"] / total
+    return out
 
 
 def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):
@@ -423,13 +463,20 @@ def main():
                 preflight = multigpu_preflight.LAST_SUMMARY
             except Exception as ex:       # diagnostic only: the benchmark still runs
                 preflight = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
-            if preflight and not preflight.get("ok") and not all(preflight.get("stages", {}).get(k, True) for k in ("peer_connect", "peer_self_test")):
-                args.collective = "rccl"          # the device collective did not pass on this machine: host-issued RCCL all-reduces
         if not dist.is_initialized():
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group(backend)
+        if preflight is not None:
+            # the choice of collective is made by ALL ranks together: a preflight that failed, or raised, on one rank only
+            # must not send that rank down the RCCL path while its peers enter PeerComm.create's gathers
+            peer_ok = bool(preflight.get("ok")) or all(preflight.get("stages", {}).get(k, False) for k in ("peer_connect", "peer_self_test"))
+            votes = [None] * world
+            dist.all_gather_object(votes, int(peer_ok and "error" not in preflight))
+            preflight["peer_votes"] = votes
+            if not min(votes):
+                args.collective = "rccl"          # the device collective did not pass on every rank: host-issued RCCL all-reduces
 
     from recnn_amd import _lib as L
     from recnn_amd._tune import apply_env_knobs
@@ -545,6 +592,20 @@ def main():
             run(args.warmup + r * args.steps, args.steps)
             barrier()
             samples.append(time.perf_counter() - t0)
+    # the same path over ONE long region (whole policy cycles per run graph): the short timed regions above carry ~100 us of fixed cost each
+    # (graph launch, loss read-back), which a 20-step region does not amortise -- both figures go into the line
+    sustained = None
+    if not use_dp and args.steps < 2000:
+        with torch.cuda.stream(stream):
+            first = args.warmup + reps * args.steps
+            run(first, 200)
+            barrier()
+            t0 = time.perf_counter()
+            run(first + 200, 2000)
+            barrier()
+            el_s = time.perf_counter() - t0
+        sustained = {"steps": 2000, "ms_per_step": el_s / 2000 * 1e3, "value": 2000 / el_s, "unit": "steps/s",
+                     "note": "one 2000-step region after the timed regions (not `value`: the contract times exactly --steps steps)"}
     if use_dp:
         t = torch.tensor(samples, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -571,6 +632,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "repeats": reps, "ms_per_step_samples": [round(x / args.steps * 1e3, 6) for x in samples], "graph_setup": graph_setup,
             "spread": (max(samples) - min(samples)) / elapsed,     # (slowest - fastest region) / median region
+            "sustained": sustained,
             "scaling": args.scaling,
             # synchronised optimizer updates per second (one per step whatever N is) and transition rows consumed per second
             "global_updates_per_s": args.steps / elapsed, "rows_per_s": world * rows * args.steps / elapsed,
@@ -627,70 +689,76 @@ def main():
         FROZEN = FROZEN_SLOTS
         used = prof_cyc if schedule == "cycle" else prof
         cand = [r for r in used if r[2] > 0]
-        dom, dom_time, flops_per_step, share = pick_dominant(used, pe)
-        # HBM bytes per launch of the dominant kernel: PMC counters over a child run of this very command (N=1 only)
-        traffic, traffic_note = None, "skipped"
+        # `roofline` = the kernel with the largest us per step in the schedule the timed region replayed (all its launches summed, as a
+        # `rocprofv3 --stats` listing of this command ranks them); the launch with the largest share of the algorithmic flops is
+        # reported beside it as `roofline_flop_dominant` (rounds 1-4 and 6: the time-dominant one is `roofline`; round 5 had them swapped)
+        ktab = kernel_table(used, prof, prof_pol, pe)
+        top = ktab[0]
+        dom, _, flops_per_step, share = pick_dominant(used, pe)
+        dom_k = KERNEL_OF_SLOT.get(dom[0], dom[0])
+        # HBM bytes per launch of both kernels: PMC counters over a child run of this very command (N=1 only)
+        tr = None
         gather_traffic, gather_note = None, "skipped"
-        gather_multi_traffic, graph_ms = None, None
+        gather_multi_traffic = None
         if world == 1 and not args.no_traffic and not use_dp:
             tail = ["--steps", str(max(40, cyc_min) if schedule == "cycle" else 20), "--warmup", "20", "--repeats", "1", "--no-cpu-baseline",
                     "--no-traffic", "--no-extras", "--dtype", args.dtype, "--algo", args.algo, "--rows", str(args.rows)]
-            dom_k = KERNEL_OF_SLOT.get(dom[0], dom[0])
-            tr = measure_traffic(tail, [dom_k, "frame_gather_kernel", "frame_gather_multi_kernel"])
-            traffic, traffic_note = tr[dom_k]
+            tr = measure_traffic(tail, sorted({top["kernel"], dom_k, "frame_gather_kernel", "frame_gather_multi_kernel"}))
             gather_traffic, gather_note = tr["frame_gather_kernel"]
             gather_multi_traffic = tr["frame_gather_multi_kernel"][0]
-            graph_ms = tr["_graph_ms"].get(dom_k)
+        traffic_of = lambda k: tr[k] if tr else (None, "skipped")
+        graph_ms_of = lambda k: tr["_graph_ms"].get(k) if tr else None
         out["schedule"] = schedule
         # SURVEY.md 8(d)'s end-to-end figure: algorithmic MLP flops of a step / measured time per step / dense MFMA peak
         e2e = FLOP_PER_ROW[args.algo] * rows / (ms_per_step * 1e-3) / 1e12
         out["roofline_end_to_end"] = {"flops_per_step": FLOP_PER_ROW[args.algo] * rows, "tflops": e2e, "peak": peak, "frac": e2e / peak,
                                       "note": "north_star asks >= 0.40 MFMA utilisation; this is flops / wall time of the whole step"}
+        # algorithmic HBM bytes per launch of the kernels that do no matrix work: optimizer 28 B / parameter, gather per row
+        f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
+        per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else args.dtype]
+        hbm_bytes = {"apply_kernel": 28.0 * PARAMS["critic"], "apply_gather_kernel": 28.0 * PARAMS["critic"] + per_row * rows,
+                     "frame_gather_kernel": float(per_row * rows), "frame_gather_multi_kernel": float(per_row * rows * pe),
+                     "grad_reduce_kernel": 8.0 * PARAMS["actor"]}
+        sel = ("largest us per step of the replayed schedule, all launches of the kernel summed: %.2f us/step = %.0f %% of the step's kernel "
+               "time (%.2f launches per step)" % (top["ms_per_step"] * 1e3, 100 * top["share_of_step_time"], top["launches_per_step"]))
+        t_traffic, t_note = traffic_of(top["kernel"])
+        if top["flops_per_launch"] > 0:
+            ach = top["flops_per_launch"] / (top["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "avg_ms": top["avg_ms"], "flops_per_launch": top["flops_per_launch"],
+                               "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
+                               "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
+        else:
+            nbytes = hbm_bytes.get(top["kernel"])
+            gbs = nbytes / (top["avg_ms"] * 1e-3) / 1e9 if nbytes else None
+            out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS if gbs else None, "avg_ms": top["avg_ms"], "bytes_per_launch": nbytes,
+                               "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
+                               "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
+        g_ms = graph_ms_of(top["kernel"])
+        if g_ms and top["flops_per_launch"] > 0:
+            # avg_ms above: HIP events around EAGER launches.  Inside the replayed run graphs: mean duration from the child run's kernel trace
+            ach = top["flops_per_launch"] / (g_ms * 1e-3) / 1e12
+            out["roofline"]["in_graph"] = {"avg_ms": g_ms, "achieved": ach, "frac": ach / peak,
+                                           "source": "kernel trace of the PMC child run (graph replays, counter collection on)"}
+        out["kernel_time_table"] = [{"kernel": t["kernel"], "us_per_step": round(t["ms_per_step"] * 1e3, 3), "avg_us": round(t["avg_ms"] * 1e3, 3),
+                                     "launches_per_step": round(t["launches_per_step"], 3), "gflop_per_launch": round(t["flops_per_launch"] / 1e9, 4),
+                                     "share_of_step_time": round(t["share_of_step_time"], 4)} for t in ktab]
         if dom[2] > 0:
-            out["roofline"] = dict(roof(dom[0], dom[1], dom[2], 1.0 / pe if dom[0] in FROZEN else 1.0), traffic=traffic,
+            traffic, traffic_note = traffic_of(dom_k)
+            out["roofline_flop_dominant"] = dict(roof(dom[0], dom[1], dom[2], 1.0 / pe if dom[0] in FROZEN else 1.0), traffic=traffic,
                                    traffic_source=traffic_note,
                                    dominant_by="algorithmic flops per step: this launch %.0f %% of the schedule's MFMA flops in %.0f %% of its MFMA launch "
-                                               "time; its kernel (all launches of it) %.0f %% in %.0f %%"
-                                               % (100 * flops_per_step(dom) / sum(flops_per_step(r) for r in cand),
-                                                  100 * share(dom) / sum(share(r) for r in cand),
-                                                  100 * sum(flops_per_step(r) for r in cand if KERNEL_OF_SLOT.get(r[0], r[0]) == KERNEL_OF_SLOT.get(dom[0], dom[0]))
-                                                  / sum(flops_per_step(r) for r in cand),
-                                                  100 * sum(share(r) for r in cand if KERNEL_OF_SLOT.get(r[0], r[0]) == KERNEL_OF_SLOT.get(dom[0], dom[0]))
-                                                  / sum(share(r) for r in cand)))
+                                               "time" % (100 * flops_per_step(dom) / sum(flops_per_step(r) for r in cand),
+                                                         100 * share(dom) / sum(share(r) for r in cand)))
             if dom[0] in ("frozen_actors", "frozen_target_critics"):
-                out["roofline"]["traffic_covers"] = "mean over the two launches of mlp_frozen_kernel per policy cycle (actors; target critics)"
-            if dom_time[0] != dom[0]:
-                out["roofline_time_dominant"] = dict(roof(dom_time[0], dom_time[1], dom_time[2], 1.0 / pe if dom_time[0] in FROZEN else 1.0),
-                                                     note="the MFMA launch with the largest TIME share of a step (%.0f %% of the MFMA launch time, "
-                                                          "%.0f %% of the flops): a latency chain, bound by neither roof"
-                                                          % (100 * share(dom_time) / sum(share(r) for r in cand),
-                                                             100 * flops_per_step(dom_time) / sum(flops_per_step(r) for r in cand)))
-            # avg_ms / frac above: HIP events around EAGER launches of the kernel.  Inside the replayed run graphs the same launch
-            # also carries the previous step's policy-loss forward (fused schedule: one more problem of the launch), so it does
-            # more flops in more time: mean duration from the child run's kernel trace, flops = this launch + that forward
-            if graph_ms:
-                extra = 0.0
-                if dom[0] == "mlp_fwd_nets":
-                    extra = sum(r[2] for r in prof if r[0] in ("mlp_fwd_pcritic", "fwd_l1_pcritic", "fwd_l2_pcritic"))
-                base = dom[2]
-                if dom[0] in ("frozen_actors", "frozen_target_critics"):
-                    # the trace's mean covers BOTH launches of mlp_frozen_kernel (actors; target critics): their mean flops with it
-                    fz = [r[2] for r in used if r[0] in ("frozen_actors", "frozen_target_critics")]
-                    base = sum(fz) / len(fz)
-                ach = (base + extra) / (graph_ms * 1e-3) / 1e12
-                out["roofline"]["in_graph"] = {"avg_ms": graph_ms, "flops_per_launch": base + extra, "achieved": ach, "frac": ach / peak,
-                                               "source": "kernel trace of the PMC child run (graph replays, counter collection on)"}
-        else:
-            out["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": None, "traffic": traffic, "traffic_source": traffic_note, "avg_ms": dom[1]}
+                out["roofline_flop_dominant"]["traffic_covers"] = "mean over the two launches of mlp_frozen_kernel per policy cycle (actors; target critics)"
         # every MFMA launch of both schedules (the per-step forward AND the cycle-batched frozen-network launch)
         out["roofline_kernels"] = {
             "fused": [roof(n, ms, fl) for n, ms, fl in prof if fl > 0],
             "cycle": [roof(n, ms, fl, 1.0 / pe if n in FROZEN else 1.0) for n, ms, fl in (prof_cyc or []) if fl > 0]}
         g = [r for r in prof if r[0] == "frame_gather"]
         if g:
-            f32_rows = args.dtype == "fp32" or os.environ.get("RECNN_SAMPLER_F32") == "1"
-            per_row = GATHER_BYTES_PER_ROW["fp32" if f32_rows else args.dtype]
             gbs = per_row * rows / (g[0][1] * 1e-3) / 1e9
             # the fraction is taken on MEASURED HBM bytes (PMC) when there are any: consecutive windows of a user share embedding
             # lines, so the algorithmic byte count (every line counted per use) over-states what the kernel has to move

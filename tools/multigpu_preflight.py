@@ -144,6 +144,14 @@ def main(keep_group=False, quick=False):
         state["comm"] = comm
         return {"floats": floats, "world": comm.world}
     have_peer = stage("peer_connect", st_connect)
+    # AGREE on the outcome before any stage that only some ranks would enter: a connect that failed on ONE rank must
+    # take every rank down the same path -- the self-test below is a collective
+    votes = [None] * world
+    dist.all_gather_object(votes, int(have_peer))
+    if have_peer and not min(votes):
+        summary["peer_connect"] = False
+        emit(rank, "peer_connect", event="vote", ok=False, per_rank=votes)
+    have_peer = bool(min(votes))
 
     def st_selftest():
         ok = state["comm"].self_test()
