@@ -565,7 +565,10 @@ typedef struct recnn_engine_tuning {
                                that keep h2 on chip (csrc/x3tail.hip), 0 grouped GEMM launches per layer */
   int x3_fwd;               /* split-bf16 forward GEMM kernel: 2 (default) wave-specialised -- loader waves + consumer waves (csrc/gemm.hip
                                x3_fwd_ws_kernel), 11 only its 64 x 128-tile launches, 0 every wave loads and multiplies (round 4) */
-  int reserved[7];
+  int dw_fuse;              /* 1 (default): on the single-GPU bf16 step whose backward tensors come from the split forward (cycle mode), the critics'
+                               weight-gradient GEMMs carry the optimizer in their epilogue -- ONE launch, no gradient slabs (csrc/dwadam.hip);
+                               0: dW launch + optimizer launch.  Bit-identical results */
+  int reserved[6];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -230,6 +230,7 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   if ((rc = bwd_init())) { delete e; return rc; }
   if ((rc = l1gemm_init())) { delete e; return rc; }
   if ((rc = mlpt_init())) { delete e; return rc; }
+  if ((rc = dwadam_init())) { delete e; return rc; }
   if ((rc = mlpf_init())) { delete e; return rc; }
   if ((rc = x3tail_init())) { delete e; return rc; }
   recnn_engine_tuning_init(&e->tune);

@@ -15,6 +15,7 @@
 #include "mlp.h"
 #include "bwd.h"
 #include "optim.h"
+#include "dwadam.h"
 #include "comm.h"
 #include "split.h"
 #include "x3.h"
@@ -235,6 +236,8 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
 int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, hipStream_t s);
 int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int rows = 0);
+bool dwadam_ok(const recnn_engine* e, int rows);
+int ph_value_dwadam(recnn_engine* e, int rows, bool soft, hipStream_t s);
 int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bool have_l1 = false);
 int net_allreduce(recnn_engine* e, int ni, const char* name, hipStream_t s);
 int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream_t s, bool pregathered = false,

@@ -266,7 +266,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -1264,6 +1264,41 @@ int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int
   return 0;
 }
 
+// The critics' weight gradients with the optimizer step in the epilogue (dwadam.hip): ONE launch instead of ph_value_backward +
+// value_apply, no gradient slabs.  Taken when the step's backward tensors came from the split forward's tail (mlpt.hip: dz2 / dz1
+// already carry the per-row loss seed, the small tensors' panel sums exist) on the single-GPU bf16 step; bit-identical to the two launches.
+bool dwadam_ok(const recnn_engine* e, int rows) {
+  if (!e->tune.dw_fuse || e->comm || e->cfg.dtype != RECNN_BF16 || !e->panel_bwd_done || e->unit_bwd || e->H != 256 || e->Hp != 256) return false;
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
+  for (int c = 0; c < e->n_critic; ++c) {
+    const Net& n = e->net[VAL[c]];
+    if (!n.g || !n.m || !n.v || !n.critic) return false;
+    const NetLayout L = make_layout(e, VAL[c], rows);
+    if (!dwadam_tensor_ok(L, W1, rows) || !dwadam_tensor_ok(L, W2, rows)) return false;
+    if (!L.t[B1].small || !L.t[B2].small || !L.t[W3].small || !L.t[B3].small) return false;
+  }
+  return true;
+}
+
+int ph_value_dwadam(recnn_engine* e, int rows, bool soft, hipStream_t s) {
+  const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2}, TVAL[2] = {RECNN_NET_TARGET_VALUE1, RECNN_NET_TARGET_VALUE2};
+  DwAdamBatch b;
+  memset(&b, 0, sizeof(b));
+  double fl = 0;
+  int rc;
+  for (int c = 0; c < e->n_critic; ++c) {
+    DwAdamNet& n = b.n[c];
+    n.L = make_layout(e, VAL[c], rows);
+    if ((rc = fill_apply_args(e, VAL[c], n.L, true, 1, 1.0f, false, soft ? TVAL[c] : -1, e->hy.soft_tau, &n.a))) return rc;
+    n.a.from_slabs = 1;
+    n.rows = rows;
+    n.w[0].dz = e->dzc2[c]; n.w[0].ldz = e->Hp; n.w[0].x = e->cv[c].h1; n.w[0].ldx = e->Hp; n.w[0].tensor = W2;
+    n.w[1].dz = e->dzc1[c]; n.w[1].ldz = e->Hp; n.w[1].x = e->xcs; n.w[1].ldx = e->ldx; n.w[1].tensor = W1;
+    fl += 2.0 * rows * (double)e->H * (e->H + e->S + e->A);
+  }
+  return slot(e, "dwadam_critic", fl, s, [&] { return dwadam_launch(b, e->n_critic, s); }, false);
+}
+
 int policy_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, bool have_l1) {
   int rc;
   if (!have_l1 && (rc = ph_policy_l1(e, s))) return rc;
@@ -1586,6 +1621,8 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
         for (int c = 0; c < e->n_critic && !rc; ++c) rc = net_allreduce(e, VAL[c], "allreduce_critic", s);
         if (!rc) rc = value_apply(e, policy_step, e->comm_scale, s);
       }
+    } else if (!gather_next && dwadam_ok(e, rows)) {
+      rc = ph_value_dwadam(e, rows, policy_step, s);
     } else {
       rc = ph_value_backward(e, rows, false, s);
       if (!rc) rc = value_apply(e, policy_step, 1.0f, s, rows);

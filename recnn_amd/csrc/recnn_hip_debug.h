@@ -29,6 +29,9 @@ void recnn_debug_wide_ws(int on);
 /* shader-clock stamps of the plain-bf16 wave-specialised kernel's epilogue: device uint64 [workgroup][8] (loop end, barrier, image written,
  * barrier, stores issued, stores acknowledged); NULL = off */
 void recnn_debug_ws_trace(void* device_u64_wg8);
+/* shader-clock stamps of dw_adam_kernel's tile workgroups (csrc/dwadam.hip): device uint64 [workgroup][8] (entry, state requested, first stage
+ * landed, contraction done, partial tiles in LDS, optimizer arithmetic done, stores issued, stores acknowledged); NULL = off */
+void recnn_debug_dwadam_trace(void* device_u64_wg8);
 #ifdef __cplusplus
 }
 #endif
