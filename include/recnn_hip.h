@@ -568,7 +568,9 @@ typedef struct recnn_engine_tuning {
   int dw_fuse;              /* 1 (default): on the single-GPU bf16 step whose backward tensors come from the split forward (cycle mode), the critics'
                                weight-gradient GEMMs carry the optimizer in their epilogue -- ONE launch, no gradient slabs (csrc/dwadam.hip);
                                0: dW launch + optimizer launch.  Bit-identical results */
-  int reserved[6];
+  int tail_half;            /* 1 (default): the learning critic's tail launch (csrc/mlpt.hip) runs 16-row panels -- twice the workgroups, half the
+                               per-workgroup epilogue work (its phases are bound by the CU's vector issue); 0: 32-row panels.  Bit-identical */
+  int reserved[5];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -153,7 +153,7 @@ int64_t carve(recnn_engine* e, char* base) {
     Net& n = e->net[ni];
     n.gp[W1] = (float*)c.take((int64_t)SP_W1_MAX * H * n.in_dim * 4);
     n.gp[W2] = (float*)c.take((int64_t)SP_W2 * H * H * 4);
-    n.gp[B1] = (float*)c.take(tiles_m * H * 4);
+    n.gp[B1] = (float*)c.take((n.critic ? 2 : 1) * tiles_m * H * 4);   // (critics: one entry per 16 rows when the tail runs half panels)
     if (n.critic) {
       n.gp[W3] = (float*)c.take(nblk_hb * H * 4);
       n.gp[B2] = (float*)c.take(nblk_hb * H * 4);

@@ -125,6 +125,9 @@ struct recnn_engine {
   float* tqv[2];
   float* q_slot[2];                        // Q(s, a) hand-off slots (critic workgroup -> head in the target actor's workgroup)
   bool unit_bwd = false;                   // this step's dzc2 / dzc1 hold UNIT backward tensors (to be scaled by delta)
+  bool half_panels = false;                // this step's tail launch ran 16-row panels: the small tensors' panel sums and the value-loss
+                                           // partials are HALF-panel sums, consumed in pairs (TensorSeg.pair, LossFinalizeArgs.pair)
+  bool hist_half[LOSS_HIST_MAX] = {};      // ... per step of the run being captured (loss history)
   float* pl_part;                          // policy loss: per-wave partial dots of the policy-critic's layer-2 GEMM
   int pl_cap = 0, pl_dot_parts = 0;        // capacity / number written by this step (0: the head kernel produced the loss)                           // ... their outputs, fp32 [Bc]
   float *loss_part[3];                     // value1, value2, policy  (per head block): the CURRENT step's slot of ...

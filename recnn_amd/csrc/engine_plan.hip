@@ -44,10 +44,12 @@ NetLayout make_layout(const recnn_engine* e, int ni, int rows) {
     L.t[W2].nslab = sp(SP_W2); L.t[W2].slab_stride = (int64_t)H * H;
     L.t[B1].nslab = tiles_m; L.t[B1].slab_stride = H;
     if (n.critic) {
-      const int nhead = value_panel_ok(e) ? tiles_m : nblk_hb;  // bwd.hip emits one partial per 32 rows, head.hip per 16
+      const bool half = e->half_panels && e->panel_bwd_done && !e->unit_bwd;   // mlpt.hip ran 16-row panels: half-panel sums, taken in pairs
+      const int nhead = (value_panel_ok(e) || half) ? tiles_m : nblk_hb;  // bwd.hip emits one partial per 32 rows, head.hip per 16
       L.t[W3].nslab = nhead; L.t[W3].slab_stride = H;
       L.t[B2].nslab = nhead; L.t[B2].slab_stride = H;
       L.t[B3].nslab = nhead; L.t[B3].slab_stride = 1;
+      if (half) L.t[B1].pair = L.t[W3].pair = L.t[B2].pair = L.t[B3].pair = 1;
     } else {
       L.t[W3].nslab = sp(SP_W3); L.t[W3].slab_stride = (int64_t)e->A * H;
       L.t[B2].nslab = tiles_m; L.t[B2].slab_stride = H;
@@ -266,7 +268,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1; t->tail_half = 1;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -426,7 +428,11 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
   }
   e->panel_bwd_done = false;
   e->unit_bwd = false;
+  e->half_panels = false;
   if (!value_side) return 0;
+  // 16-row panels for the learning critics' tail (tuning.tail_half): whole 32-row pairs only, and the consumers of its panel sums must
+  // be the pair-aware ones (the optimizer launches; not grad_reduce's callers that read gp[] directly -- there are none)
+  const bool half = e->tune.tail_half && value_bwd && rows % 32 == 0;
   if (!frozen_done) {  // ---- target critics on [next_state | next_action]: state part first, then the action columns (mlps.hip's chained order)
     L1Batch lb;
     TailBatch tb;
@@ -461,6 +467,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
       if (c == 0) { p->expected = e->expected; p->target_q = e->target_q; }
       p->delta_out = e->delta[c]; p->loss_part = e->loss_part[c];
       p->scale = train ? 2.0f : 1.0f;
+      p->half_panels = half;
       p->dz2 = e->dzc2[c]; p->dz1 = e->dzc1[c];
       if (value_bwd) {
         RECNN_REQUIRE(v.g, "value backward: network %d has no gradient arena bound", VAL[c]);
@@ -483,6 +490,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
     if ((rc = slot(e, "tail_critic", tfl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
   }
   e->panel_bwd_done = true;     // dz2 / dz1 (already times the per-row loss seed) and the small tensors' panel sums exist
+  e->half_panels = half;
   return 0;
 }
 
@@ -670,6 +678,7 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
   }
   }
   e->panel_bwd_done = false;
+  e->half_panels = false;
   e->unit_bwd = false;
   if (!value_side) return 0;
   {  // ---- target critics: the action part on top of the state part
@@ -947,6 +956,7 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
     }
   }
   e->panel_bwd_done = false;
+  e->half_panels = false;
   e->unit_bwd = false;
   if (value_side && fwd_did_bwd) {
     // nothing left to launch here: losses, the per-row seed and the UNIT dz2 / dz1 came out of the forward launch; the dW
@@ -1198,13 +1208,14 @@ int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_
 
 
 int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, hipStream_t s) {
+  if (e->run_off >= 0 && e->run_off < LOSS_HIST_MAX) e->hist_half[e->run_off] = e->half_panels;
   if (e->run_skip_finish) return 0;  // inside a run graph: the last step's finalize ticks the counters for the whole run
   LossFinalizeArgs a;
   memset(&a, 0, sizeof(a));
   const int nblk = (rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
   const int nc = e->n_critic;
-  const int nval = value_panel_ok(e) ? (rows + BWD_ROWS - 1) / BWD_ROWS : nblk;
-  for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nval; a.scale[c] = 1.0f / (float)rows; }
+  const int nval = (value_panel_ok(e) || e->half_panels) ? (rows + BWD_ROWS - 1) / BWD_ROWS : nblk;
+  for (int c = 0; c < nc; ++c) { a.part[c] = e->loss_part[c]; a.n_part[c] = nval; a.scale[c] = 1.0f / (float)rows; a.pair[c] = e->half_panels; }
   a.part[nc] = e->loss_part[2]; a.n_part[nc] = nblk; a.scale[nc] = -1.0f / (float)rows;
   if (e->pl_dot_parts > 0) {  // policy loss = -(sum of the layer-2 epilogue's partial dots, b3 included) / B
     a.part[nc] = e->pl_part; a.n_part[nc] = e->pl_dot_parts;
@@ -1226,6 +1237,7 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
     LossHistoryArgs h;
     memset(&h, 0, sizeof(h));
     h.n_steps = e->run_off; h.n = nc + 1;
+    for (int i = 0; i < e->run_off; ++i) h.pair_steps |= (unsigned long long)(e->hist_half[i] ? 1 : 0) << i;
     for (int c = 0; c < nc; ++c) { h.part[c] = e->loss_part_base[c]; h.stride[c] = e->loss_part_stride; h.n_part[c] = nval; h.scale[c] = 1.0f / (float)rows; }
     h.scale[nc] = -1.0f / (float)rows;
     if (value_panel_ok(e) || e->x3) {   // policy loss from the layer-2 epilogue's partial dots / the deferred forward's per-row Q

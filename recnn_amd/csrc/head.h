@@ -54,6 +54,7 @@ struct LossFinalizeArgs {
   int wrap_mod, wrap_inc;
   float* ring;        // optional loss history ring [ring_mask + 1][4]: entry (old *tick[0] + tick_inc[0] - 1) & ring_mask
   int ring_mask;
+  int pair[4];        // 1: part[c] holds 2 n_part[c] half-panel sums (mlpt.hip, 16-row panels): partial i = part[2 i] + part[2 i + 1]
 };
 
 // Losses of the earlier steps of a run graph (their partial sums were kept per step; the run's last step is
@@ -72,6 +73,7 @@ struct LossHistoryArgs {
   const int32_t* step_ctr;     // device step counter, not yet ticked for this run
   float* ring;
   int ring_mask;
+  unsigned long long pair_steps;   // bit j: step j's value-loss partials are half-panel sums (LossFinalizeArgs.pair)
 };
 int loss_history_launch(const LossHistoryArgs& a, hipStream_t s);
 

@@ -287,10 +287,18 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
       const int n = a.n_part[c];
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int i = threadIdx.x;
-      for (; i + 768 < n; i += 1024) {
-        s0 += part[i]; s1 += part[i + 256]; s2 += part[i + 512]; s3 += part[i + 768];
+      if (a.pair[c]) {   // half-panel sums: the two halves of a 32-row panel first (the panel's own wave_sum order: rows 0..15 + rows 16..31)
+        for (; i + 768 < n; i += 1024) {
+          s0 += part[2 * i] + part[2 * i + 1]; s1 += part[2 * (i + 256)] + part[2 * (i + 256) + 1];
+          s2 += part[2 * (i + 512)] + part[2 * (i + 512) + 1]; s3 += part[2 * (i + 768)] + part[2 * (i + 768) + 1];
+        }
+        for (; i < n; i += 256) s0 += part[2 * i] + part[2 * i + 1];
+      } else {
+        for (; i + 768 < n; i += 1024) {
+          s0 += part[i]; s1 += part[i + 256]; s2 += part[i + 512]; s3 += part[i + 768];
+        }
+        for (; i < n; i += 256) s0 += part[i];
       }
-      for (; i < n; i += 256) s0 += part[i];
       acc[c] = (s0 + s1) + (s2 + s3);
     }
   }
@@ -330,7 +338,11 @@ __global__ __launch_bounds__(256) void loss_history_kernel(const LossHistoryArgs
       const float* __restrict__ part = a.part[c] + (int64_t)j * a.stride[c];
       const int n = c == a.n - 1 ? a.pol_count[j] : a.n_part[c];
       float s0 = 0.f;
-      for (int i = threadIdx.x; i < n; i += 256) s0 += part[i];
+      if (c < a.n - 1 && ((a.pair_steps >> j) & 1ull)) {
+        for (int i = threadIdx.x; i < n; i += 256) s0 += part[2 * i] + part[2 * i + 1];
+      } else {
+        for (int i = threadIdx.x; i < n; i += 256) s0 += part[i];
+      }
       acc[c] = s0;
     }
   }

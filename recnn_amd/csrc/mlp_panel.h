@@ -25,7 +25,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
 template <int TNH>
 __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x4 (&bias_v)[TNH], int H, int rows, int m0, int wave, int fr,
                                                 int fg, int mask_mode, const uint8_t* mask, int64_t ld_mask, uint32_t key,
-                                                unsigned char* panel, uint32_t* gbits = nullptr) {
+                                                unsigned char* panel, uint32_t* gbits = nullptr, const bool two = true) {   // two = false: 16-row panel
   uint32_t bits = 0;
 #pragma unroll
   for (int tn = 0; tn < TNH; ++tn) {
@@ -35,6 +35,7 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x
     const int c = (n0 & 127) >> 3;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+      if (tm == 1 && !two) break;
       const int row = tm * 16 + fr, m = m0 + row;
       uint32_t word = 0;
       if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n0 >> 2));

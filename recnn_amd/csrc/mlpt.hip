@@ -38,7 +38,8 @@ __device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned
 
 // acc += panel(k quarter q: columns 64 q .. 64 q + 63 of the 32 x 256 activation panel) * W(rows wrow0 + fr, 64 k)^T; operands
 // swapped as in mlps.hip: acc[tm][0][r] = C[row 16 tm + fr][column wrow0 + 4 fg + r]
-__device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, const unsigned char* sb, f32x4 (&acc)[2][1], int wrow0, int fr, int fg) {
+__device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, const unsigned char* sb, f32x4 (&acc)[2][1], int wrow0, int fr, int fg,
+                                          const bool two = true) {   // two = false: 16-row panel, only the first row block exists
   const int sw = (fr >> 1) & 7;
   const unsigned char* sa = panel + (q >> 1) * PANEL_HALF;
 #pragma unroll
@@ -46,12 +47,11 @@ __device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, con
     const int posa = ((((q & 1) * 8) + ks * 4 + fg) ^ fr) * 16;
     const int posb = ((ks * 4 + fg) ^ sw) * 16;
     uint4 a[2], b;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + posa);
+    a[0] = *(const uint4*)(sa + fr * 256 + posa);
+    if (two) a[1] = *(const uint4*)(sa + (16 + fr) * 256 + posa);
     b = *(const uint4*)(sb + (wrow0 + fr) * 128 + posb);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-      acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a[tm]), acc[tm][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a[0]), acc[0][0], 0, 0, 0);
+    if (two) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a[1]), acc[1][0], 0, 0, 0);
   }
 }
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -66,7 +66,11 @@ __device__ __forceinline__ float panel_at(const unsigned char* panel, int row, i
 #define MLPT_STAMP(i) do { if (trow) trow[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch, unsigned long long* trace) {
   const TailProb& P = batch.p[blockIdx.y];
-  const int m0 = blockIdx.x * BM;
+  // rows per workgroup: 32, or 16 for a learning critic with P.half_panels (round 6: every phase behind layer 2 is bound by the VALU
+  // issue of the CU's 16 waves, and 64 learning panels of 32 rows leave half the machine idle -- 128 half panels halve each phase)
+  const bool two = !P.half_panels;
+  const int PR = two ? BM : BM / 2;
+  const int m0 = blockIdx.x * PR;
   if (m0 >= P.rows) return;
   unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
   asm volatile("" : "+v"(trow));
@@ -112,20 +116,27 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   // (raw loads only up here: arithmetic on a loaded value would make the compiler wait for it before the stream is issued)
   float h_rew = 0.f, h_done = 0.f, h_tq0 = 0.f, h_tq1 = 0.f;
   if (learn && wave == 0) {
-    const int mc = min(m0 + (lane & 31), P.rows - 1);
+    const int mc = min(m0 + (lane & (PR - 1)), P.rows - 1);
     h_rew = P.reward[mc];
     h_done = P.done[mc];
     h_tq0 = P.tq[0][mc];
     h_tq1 = P.n_target > 1 ? P.tq[1][mc] : 0.f;
   }
   // the learning critic's w3 for this thread's u2 cell (columns n8 .. n8 + 7 of row lane & 31)
-  const int n8 = (2 * wave + (lane >> 5)) * 8;
+  // (32-row panel: row lane & 31, 32 cells of 8 columns per row over the 16 waves; 16-row panel: row lane & 15, waves 0..7)
+  const int crow = two ? (lane & 31) : (lane & 15);
+  const int n8 = two ? (2 * wave + (lane >> 5)) * 8 : ((4 * wave + (lane >> 4)) & 31) * 8;
+  const bool cell_on = two || wave < NW / 2;
   float4 w3a = make_float4(0.f, 0.f, 0.f, 0.f), w3b = w3a;
   if (learn) {
     const int nb = min(n8, P.H - 8);
     w3a = *(const float4*)(P.w3row + nb);
     w3b = *(const float4*)(P.w3row + nb + 4);
   }
+  // ... and for its column of the panel's column sums (dw3 / db2: thread = (row chunk, column)); raw load, used after the head
+  const int ck = tid & 255, cc = tid >> 8;
+  float w3c = 0.f;
+  if (learn && P.dw3_part && ck < P.H) w3c = P.w3row[ck];
   int mrow0 = m0, mset = 0;                     // first row of the panel inside its batch, the batch's index
   if (P.rows_per_set > 0) { mset = m0 / P.rows_per_set; mrow0 = m0 - mset * P.rows_per_set; }
   // the device step counter through the SCALAR cache (hipcc turns a plain load of this uniform global into a vector load + an
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     const int half = wave >> 3, r = (wave & 7) * 4 + (lane >> 4), pos = lane & 15;
     const int gr = min(m0 + r, P.rows - 1);
     const unsigned voff = (unsigned)((gr * (int)P.ldh + half * 128) * 2 + ((pos ^ (r & 15)) << 4));
-    dma_s(voff, P.h1, lds0 + PANEL_OFF + half * PANEL_HALF + (wave & 7) * 1024);
+    if (two || (wave & 7) < 4) dma_s(voff, P.h1, lds0 + PANEL_OFF + half * PANEL_HALF + (wave & 7) * 1024);
   }
   const int l_row = wave * 8 + (lane >> 3);
   const int l_c = ((lane & 7) ^ ((l_row >> 1) & 7)) * 16;
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     if (q == 0 && learn) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
+        if (tm == 1 && !two) break;
         const int row = tm * 16 + fr;
         const uint2 hv = *(const uint2*)(panel + (n0 >> 7) * PANEL_HALF + row * 256 + ((((n0 & 127) >> 3) ^ (row & 15)) << 4) + (n0 & 7) * 2);
         if (hv.x & 0x7FFFu) gate1 |= 1u << (tm * 4 + 0);
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
         if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
       }
     }
-    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg);
+    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg, two);
   }
   MLPT_STAMP(2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(step_now));
   const uint32_t key2 = P.mask_mode == RECNN_MASK_HASH ? mask_key(P.seed, step_now + P.step_add + mset, P.stream2) : 0u;
   hidden_epilogue<1>(acc, b2v, P.H, P.rows - (m0 - mrow0), mrow0, wave, fr, fg, P.mask_mode,
-                     P.mask2 ? P.mask2 + (int64_t)(m0 - mrow0) * P.ld_mask : nullptr, P.ld_mask, key2, panel);
+                     P.mask2 ? P.mask2 + (int64_t)(m0 - mrow0) * P.ld_mask : nullptr, P.ld_mask, key2, panel, nullptr, two);
 
   if (actor) {
     // ---------------------------------------------------------------- layer 3 (actor): 32 x 128 outputs on waves 0..7
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   // The TD target needs nothing this workgroup computes (Q' came with the kernel's inputs): wave 0 evaluates it while the
   // h2 panel is being completed, so a row's TD error and loss seed are one subtraction away from its q dot.
   const float h_tq = P.n_target > 1 ? fminf(h_tq0, h_tq1) : h_tq0;
-  if (learn && wave == 0 && lane < BM) {
+  if (learn && wave == 0 && lane < PR) {
     float y = h_rew + (1.0f - h_done) * P.gamma * h_tq;
     y = fminf(fmaxf(y, P.lo), P.hi);
     ys[lane] = y;
@@ -268,49 +280,77 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   MLPT_STAMP(3);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // h2 panel complete (and the TD targets are in LDS)
-  if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, P.rows, tid);
-  {
+  if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, min(P.rows, m0 + PR), tid);
+  // ---- everything that reads h2 happens HERE, in one burst of LDS reads behind one barrier (round 6; before: q dots -> barrier -> column
+  // sums and u2 cells -> barrier, each phase a latency chain of its own): the q dots' operands, the 8 values of this thread's column for the
+  // d-weighted column sums (kept in registers until d exists), and the thread's u2 cell, which needs no d at all -- u2 = w3 scale [h2 > 0]
+  // and U = (u2 W2) scale gate(h1) are UNIT tensors, only their d multiples and the column sums wait for the head.
+  float sdot[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
     // both rows of the wave side by side (two independent load -> dot -> reduction chains); Q and the loss seed reach global
     // memory after the rendezvous below, as two 128-byte stores, instead of one 4-byte store per row from here
-    float sdot[RW];
+    // (16-row panel: one row per wave)
+    if (i == 1 && !two) { sdot[1] = 0.f; break; }
+    const int row = two ? wave * RW + i : wave;
+    const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
+    const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
+    const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
+    float sd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sd += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
+    sdot[i] = sd;
+  }
+  float hc[8];                                  // h2[rows 8 cc .. 8 cc + 7][column ck]
+  uint4 packed = make_uint4(0u, 0u, 0u, 0u);    // this thread's u2 cell (row lane & 31, columns n8 .. n8 + 7), rounded to bf16
+  unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + crow * 256 + ((((n8 & 127) >> 3) ^ (crow & 15)) * 16);
+  const bool col_on = two || cc < 2;            // the panel's row chunks of 8: four, or two
+  if (learn && col_on) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hc[j] = panel_at(panel, cc * 8 + j, ck);
+  }
+  if (learn && cell_on) {
+    const uint4 raw = *(const uint4*)cell;
+    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float wsc = n8 < P.H ? P.scale : 0.f;
+    const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
+    float uz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
+      uz[j] = hv > 0.f ? w3s[j] : 0.f;
+    }
+    packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
+  }
+  sdot[0] = wave_sum(sdot[0]);
+  if (two) sdot[1] = wave_sum(sdot[1]);
+  if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      const int row = wave * RW + i;
-      const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
-      const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
-      const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
-      sdot[i] = s;
-    }
-#pragma unroll
-    for (int i = 0; i < RW; ++i) sdot[i] = wave_sum(sdot[i]);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        const int row = wave * RW + i;
-        const float qv = sdot[i] + b3s;
-        const bool valid = m0 + row < P.rows;
-        qs[row] = qv;
-        if (learn) {
-          const float e = valid ? qv - ys[row] : 0.f;
-          es[row] = e;
-          ds[row] = e * (2.0f / (float)P.rows);
-        }
+      if (i == 1 && !two) break;
+      const int row = two ? wave * RW + i : wave;
+      const float qv = sdot[i] + b3s;
+      const bool valid = m0 + row < P.rows;
+      qs[row] = qv;
+      if (learn) {
+        const float e = valid ? qv - ys[row] : 0.f;
+        es[row] = e;
+        ds[row] = e * (2.0f / (float)P.rows);
       }
     }
   }
   if (!learn) {
     __syncthreads();
-    if (tid < BM && m0 + tid < P.rows && P.q) P.q[m0 + tid] = qs[tid];
+    if (tid < PR && m0 + tid < P.rows && P.q) P.q[m0 + tid] = qs[tid];
     MLPT_STAMP(4);
     return;
   }
   MLPT_STAMP(4);
-  __syncthreads();                              // e and d of all 32 rows are in LDS; every wave is done with its q dots
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // e and d of all 32 rows are in LDS; every thread has read the h2 values it needs
   MLPT_STAMP(5);
-  if (wave == 1 && lane < BM && m0 + lane < P.rows) {       // (wave 0 has the loss sums)
+  if (cell_on) *(uint4*)cell = packed;          // the u2 panel (the A operand of the next product) takes h2's place
+  if (wave == 1 && lane < PR && m0 + lane < P.rows) {       // (wave 0 has the loss sums)
     if (P.q) P.q[m0 + lane] = qs[lane];
     if (P.delta_out) P.delta_out[m0 + lane] = ds[lane];
   }
@@ -318,9 +358,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   // ---- loss partial sums (wave 0, off everybody else's path): sum (q - y)^2 and sum d over the panel, lanes 0..31 = rows
   if (wave == 0) {
     const int r = lane & 31, m = m0 + r;
-    const bool valid = lane < 32 && m < P.rows;
-    const float e = lane < 32 ? es[r] : 0.f;
-    const float d = lane < 32 ? ds[r] : 0.f;
+    const bool valid = lane < PR && m < P.rows;
+    const float e = lane < PR ? es[r] : 0.f;
+    const float d = lane < PR ? ds[r] : 0.f;
     if (valid) {
       if (P.expected) P.expected[m] = ys[r];
       if (P.target_q) P.target_q[m] = h_tq;
@@ -332,56 +372,39 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
       if (P.db3_part) P.db3_part[blockIdx.x] = dsum;
     }
   }
-
+  // ---- dz2 = d * u2 to global (the ROUNDED unit value times d)
+  if (cell_on) {
+    const int row = crow, m = m0 + row;
+    const float d = ds[row];
+    const uint32_t pu[4] = {packed.x, packed.y, packed.z, packed.w};
+    float dz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[j] = bf2f((bf16_t)((pu[j >> 1] >> ((j & 1) * 16)) & 0xFFFF)) * d;
+    if (m < P.rows)
+      *(uint4*)((bf16_t*)P.dz2 + (int64_t)m * P.ldh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+  }
   // ---- column sums over the panel's rows, four row chunks of 8 per column (thread = (chunk, column)), fma chains upwards:
   //   dw3[k] = sum_r d_r h2[r][k]         db2[k] = sum_r d_r u2[r][k],  u2 = bf16(w3[k] scale) where h2 > 0
-  const int ck = tid & 255, cc = tid >> 8;
-  if (P.dw3_part && ck < P.H) {
-    const float u = bf2f(f2bf(P.w3row[ck] * P.scale));
+  if (P.dw3_part && ck < P.H && col_on) {
+    const float u = bf2f(f2bf(w3c * P.scale));
     float s3 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = cc * 8; r < cc * 8 + 8; ++r) {
-      const float h = panel_at(panel, r, ck);
-      s3 = fmaf(ds[r], h, s3);
-      s2 = fmaf(ds[r], h > 0.f ? u : 0.f, s2);
+    for (int j = 0; j < 8; ++j) {
+      const float d = ds[cc * 8 + j];
+      s3 = fmaf(d, hc[j], s3);
+      s2 = fmaf(d, hc[j] > 0.f ? u : 0.f, s2);
     }
     colp[cc * 256 + ck] = s3;
     colp[1024 + cc * 256 + ck] = s2;
-  }
-  // ---- u2 = w3 * scale * [h2 > 0] for this thread's cell (row lane & 31, columns n8 .. n8 + 7), dz2 = d * u2 to global; the
-  // cell goes back into the panel (the A operand of the next product) once every thread has read the h2 it needs
-  uint4 packed;
-  {
-    const int row = lane & 31, m = m0 + row;
-    unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + row * 256 + ((((n8 & 127) >> 3) ^ (row & 15)) * 16);
-    const uint4 raw = *(const uint4*)cell;
-    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-    const float d = ds[row];
-    const float wsc = n8 < P.H ? P.scale : 0.f;
-    const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
-    float uz[8], dz[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float hv = bf2f((bf16_t)((u[j >> 1] >> ((j & 1) * 16)) & 0xFFFF));
-      uz[j] = hv > 0.f ? w3s[j] : 0.f;
-    }
-    packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
-    const uint32_t pu[4] = {packed.x, packed.y, packed.z, packed.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dz[j] = bf2f((bf16_t)((pu[j >> 1] >> ((j & 1) * 16)) & 0xFFFF)) * d;   // (the ROUNDED unit value times d)
-    if (m < P.rows)
-      *(uint4*)((bf16_t*)P.dz2 + (int64_t)m * P.ldh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // every thread has read its h2 values (column sums, cells)
-    *(uint4*)cell = packed;
   }
   MLPT_STAMP(6);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // u2 panel complete, the column partials are in LDS
   MLPT_STAMP(7);
   if (P.dw3_part && tid < P.H) {
-    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]);
-    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = (colp[1024 + tid] + colp[1280 + tid]) + (colp[1536 + tid] + colp[1792 + tid]);
+    // (16-row panel: the sum of ITS two chunks; the consumer adds the two halves of a 32-row panel first -- optim_dev.h slab_grads, pair)
+    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
+    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[1024 + tid] + colp[1280 + tid]) + (colp[1536 + tid] + colp[1792 + tid]) : colp[1024 + tid] + colp[1280 + tid];
   }
 
   // ---- U = (u2 W2) * scale * gate(h1): W2's four k-slabs are still in stages 0..3: k-slab q holds in-columns 64 q .. 64 q + 63,
@@ -397,8 +420,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
       const unsigned char* sa = panel + (ks >> 2) * PANEL_HALF;
       const int pos = ((((ks & 3) * 4) + fg) ^ fr) * 16;
       uint4 a[2];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + pos);
+      a[0] = *(const uint4*)(sa + fr * 256 + pos);
+      if (two) a[1] = *(const uint4*)(sa + (16 + fr) * 256 + pos);
       v4s16 b[2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -407,9 +430,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
             (__attribute__((address_space(3))) v4s16*)(wslab + k * 128 + (((cpair + ((fr & 3) >> 1)) ^ ((k >> 1) & 7)) * 16) + (fr & 1) * 8));
       }
       struct { v4s16 lo, hi; } bv = {b[0], b[1]};
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-        dacc[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[tm]), dacc[tm], 0, 0, 0);
+      dacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[0]), dacc[0], 0, 0, 0);
+      if (two) dacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[1]), dacc[1], 0, 0, 0);
     }
   }
   // (operands swapped: dacc[tm][r] = U[row 16 tm + fr][column 16 wave + 4 fg + r], the layout of gate1)
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     const int c = (n0 & 127) >> 3;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+      if (tm == 1 && !two) break;
       const int row = tm * 16 + fr, mm = m0 + row;
       float v[4];
 #pragma unroll
@@ -435,14 +458,14 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   MLPT_STAMP(9);
   if (P.db1_part) {                             // db1[k] = sum_r d_r U[r][k], same four-chunk order
     __syncthreads();                            // U panel complete
-    if (ck < P.H) {
+    if (ck < P.H && col_on) {
       float s1 = 0.f;
 #pragma unroll
       for (int r = cc * 8; r < cc * 8 + 8; ++r) s1 = fmaf(ds[r], panel_at(panel, r, ck), s1);
       colp[cc * 256 + ck] = s1;
     }
     __syncthreads();
-    if (tid < P.H) P.db1_part[(int64_t)blockIdx.x * P.H + tid] = (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]);
+    if (tid < P.H) P.db1_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
   }
   MLPT_STAMP(10);
 }
@@ -482,10 +505,12 @@ int mlpt_init() {
 
 int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s) {
   RECNN_REQUIRE(nprob >= 1 && nprob <= TAIL_MAX_GROUP, "mlp_tail: 1..%d problems per launch", TAIL_MAX_GROUP);
-  int rows = 0;
+  int panels = 0;
   for (int i = 0; i < nprob; ++i) {
     const TailProb& p = b.p[i];
-    if (p.rows > rows) rows = p.rows;
+    const int pr = p.half_panels ? BM / 2 : BM;
+    if ((p.rows + pr - 1) / pr > panels) panels = (p.rows + pr - 1) / pr;
+    RECNN_REQUIRE(!p.half_panels || (p.kind == TAIL_CRITIC_LEARN && p.rows % BM == 0), "mlp_tail: 16-row panels are the learning critic's, whole 32-row pairs only");
     RECNN_REQUIRE(p.rows > 0 && p.H >= 8 && p.H <= HP && (p.H & 7) == 0 && p.out_dim <= 128, "mlp_tail: hidden <= 256 (multiple of 8), out_dim <= 128");
     RECNN_REQUIRE(p.h1 && p.W2 && p.b2 && p.b3 && p.ldh % 8 == 0 && p.ldw2 % 8 == 0 && (((uintptr_t)p.h1 | (uintptr_t)p.W2) & 15) == 0, "mlp_tail: bad operands");
     RECNN_REQUIRE(p.rows_per_set == 0 || p.rows_per_set % BM == 0, "mlp_tail: batches must be multiples of %d rows", BM);
@@ -498,6 +523,6 @@ int mlpt_launch(const TailBatch& b, int nprob, hipStream_t s) {
                       "mlp_tail: the learning critic needs Q', reward, done and its backward buffers");
     }
   }
-  hipLaunchKernelGGL(mlp_tail_kernel, dim3((rows + BM - 1) / BM, nprob), dim3(NW * 64), LDS_TOTAL, s, b, g_mlpt_trace);
+  hipLaunchKernelGGL(mlp_tail_kernel, dim3(panels, nprob), dim3(NW * 64), LDS_TOTAL, s, b, g_mlpt_trace);
   return recnn_check_hip(hipGetLastError(), "mlp_tail_kernel");
 }

@@ -16,6 +16,7 @@ struct TensorSeg {
   int blk0;             // first workgroup of this tensor
   int small;            // 1: OPT_SMALL_ELEMS elements per workgroup (slabs split over the 4 waves), 0: OPT_BLOCK_ELEMS
   int vec4;             // offsets / sizes allow 16-byte accesses
+  int pair;             // small tensors only: gpart holds 2 nslab HALF slabs (mlpt.hip's 16-row panels); slab s = half[2 s] + half[2 s + 1]
 };
 struct NetLayout {
   TensorSeg t[6];

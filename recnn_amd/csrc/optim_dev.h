@@ -77,10 +77,16 @@ __device__ inline void slab_grads(const TensorSeg& T, int bt, const Own& o, floa
     const int s_end = min(s + q, T.nslab);
     float acc = 0.f;
     if (in) {
+      // slab s of this element; half slabs (mlpt.hip's 16-row panels, T.pair): a 32-row panel's sum is (its first half) + (its second
+      // half) = (c0 + c1) + (c2 + c3), what the 32-row panel kernels write -- then the slabs combine exactly as the whole ones do
+      const float* gp = T.gpart + e;
+      const int64_t st = T.slab_stride;
+      const bool pair = T.pair != 0;
+      auto ld = [&](int k) -> float { return pair ? gp[(int64_t)(2 * k) * st] + gp[(int64_t)(2 * k + 1) * st] : gp[(int64_t)k * st]; };
       for (; s + 32 <= s_end; s += 32) {
         float v[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+        for (int j = 0; j < 32; ++j) v[j] = ld(s + j);
 #pragma unroll
         for (int w = 16; w > 0; w >>= 1)
 #pragma unroll
@@ -90,10 +96,10 @@ __device__ inline void slab_grads(const TensorSeg& T, int bt, const Own& o, floa
       for (; s + 8 <= s_end; s += 8) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = T.gpart[(int64_t)(s + j) * T.slab_stride + e];
+        for (int j = 0; j < 8; ++j) v[j] = ld(s + j);
         acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       }
-      for (; s < s_end; ++s) acc += T.gpart[(int64_t)s * T.slab_stride + e];
+      for (; s < s_end; ++s) acc += ld(s);
     }
     sp[wave][lane] = acc;
     __syncthreads();

@@ -93,6 +93,9 @@ struct TailProb {
   float* db2_part;                // [panels][H] sum_r d_r u2[r][.]
   float* db1_part;                // [panels][H] sum_r d_r U[r][.]
   float* db3_part;                // [panels]    sum_r d_r
+  int half_panels;                // TAIL_CRITIC_LEARN: 16-row workgroups; every *_part array (and loss_part) then holds one entry per 16 rows =
+                                  // the sum of that half panel's two 8-row chunks, and the consumers add entries 2 i and 2 i + 1 first -- the
+                                  // (c0 + c1) + (c2 + c3) of a 32-row panel, bit for bit (optim_dev.h slab_grads, head.hip loss kernels)
 };
 constexpr int TAIL_MAX_GROUP = 4;
 struct TailBatch { TailProb p[TAIL_MAX_GROUP]; };

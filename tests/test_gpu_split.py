@@ -90,3 +90,28 @@ def test_two_engines_with_different_schedules_coexist(cuda):
     got = L.EngineTuning()
     L.call("recnn_engine_get_tuning", engs[1].handle, got)
     assert got.split_fwd == 2 and got.dw_dma == 3
+
+
+@pytest.mark.parametrize("algo,B", [("ddpg", 2048), ("td3", 1024), ("ddpg", 96), ("ddpg", 333)])
+def test_half_panel_tail_equals_whole_panel_tail(cuda, algo, B):
+    """tuning.tail_half (round 6): the learning critic's tail launch on 16-row panels -- the small tensors' panel sums and the value-loss
+    partials then arrive as HALF-panel sums and are consumed in pairs ((c0 + c1) + (c2 + c3), optim_dev.h / head.hip) -- against
+    32-row panels: every buffer, gradient and parameter bit for bit (333 rows: not whole pairs, the engine keeps 32-row panels)."""
+    from recnn_amd import _lib as L
+
+    def run(half):
+        from recnn_amd._tune import set_default_tuning
+        set_default_tuning(tail_half=half)
+        try:
+            return _run(algo, B, 2, "hash", 4, L)
+        finally:
+            set_default_tuning(tail_half=None)
+    ref, new = run(0), run(1)
+    for t, (a, b) in enumerate(zip(ref, new)):
+        for n in a["bufs"]:
+            assert torch.equal(a["bufs"][n], b["bufs"][n]), (t, n, (a["bufs"][n] - b["bufs"][n]).abs().max().item())
+        assert a["loss"] == b["loss"], (t, a["loss"], b["loss"])
+        for ni in a["g"]:
+            assert torch.equal(a["g"][ni], b["g"][ni]), (t, "grad", ni, (a["g"][ni] - b["g"][ni]).abs().max().item())
+        for ni in a["p"]:
+            assert torch.equal(a["p"][ni], b["p"][ni]), (t, "param", ni, (a["p"][ni] - b["p"][ni]).abs().max().item())
