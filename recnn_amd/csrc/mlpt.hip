@@ -56,6 +56,66 @@ __device__ __forceinline__ void mma_panel(const unsigned char* panel, int q, con
 }
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
+// The critics' layer 2 once ALL four W2 slabs have landed: the same eight 32-k steps in the same order per accumulator as four
+// mma_panel calls, but the fragment reads of four steps are issued together, ahead of their MFMAs (round 6: the step-by-step form read,
+// waited for the LDS latency and multiplied eight times in a row -- 1.7-2.1k cycles for 8-16 MFMAs; straight-line code, no branch
+// inside: hipcc then counts lgkmcnt down instead of waiting for every read in front of every MFMA).
+template <bool TWO>
+__device__ __forceinline__ void mma_panel_all(const unsigned char* panel, const unsigned char* w, f32x4 (&acc)[2][1], int wrow0, int fr, int fg) {
+  const int sw = (fr >> 1) & 7;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                  // k steps 4 h .. 4 h + 3 = slabs 2 h, 2 h + 1
+    uint4 a0[4], a1[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 2 * h + (j >> 1), ks = j & 1;
+      const unsigned char* sa = panel + (q >> 1) * PANEL_HALF;
+      const int posa = ((((q & 1) * 8) + ks * 4 + fg) ^ fr) * 16;
+      const int posb = ((ks * 4 + fg) ^ sw) * 16;
+      a0[j] = *(const uint4*)(sa + fr * 256 + posa);
+      if (TWO) a1[j] = *(const uint4*)(sa + (16 + fr) * 256 + posa);
+      b[j] = *(const uint4*)(w + q * W_BYTES + (wrow0 + fr) * 128 + posb);
+    }
+    __builtin_amdgcn_sched_barrier(0);           // (without it the scheduler sinks every read to just in front of its first use)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a0[j]), acc[0][0], 0, 0, 0);
+      if (TWO) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a1[j]), acc[1][0], 0, 0, 0);
+    }
+  }
+}
+
+// U = u2 W2 for the wave's 16 in-columns: k = the 256 out indices, W2's slabs k-strided (transpose reads); same batching
+template <bool TWO>
+__device__ __forceinline__ void mma_u_all(const unsigned char* panel, const unsigned char* wslab, int cpair, f32x4 (&dacc)[2], int fr, int fg) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint4 a0[4], a1[4];
+    v4s16 b[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ks = 4 * h + j;
+      const unsigned char* sa = panel + (ks >> 2) * PANEL_HALF;
+      const int pos = ((((ks & 3) * 4) + fg) ^ fr) * 16;
+      a0[j] = *(const uint4*)(sa + fr * 256 + pos);
+      if (TWO) a1[j] = *(const uint4*)(sa + (16 + fr) * 256 + pos);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int k = ks * 32 + fg * 8 + half * 4 + (fr >> 2);
+        b[j][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s16*)(wslab + k * 128 + (((cpair + ((fr & 3) >> 1)) ^ ((k >> 1) & 7)) * 16) + (fr & 1) * 8));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      struct { v4s16 lo, hi; } bv = {b[j][0], b[j][1]};
+      dacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a0[j]), dacc[0], 0, 0, 0);
+      if (TWO) dacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a1[j]), dacc[1], 0, 0, 0);
+    }
+  }
+}
+
 // element (row, column n) of the panel image as float
 __device__ __forceinline__ float panel_at(const unsigned char* panel, int row, int n) {
   const bf16_t v = *(const bf16_t*)(panel + (n >> 7) * PANEL_HALF + row * 256 + ((((n & 127) >> 3) ^ (row & 15)) << 4) + (n & 7) * 2);
@@ -205,7 +265,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
         if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
       }
     }
-    mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg, two);
+    if (actor) mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg, true);
+  }
+  if (!actor) {
+    if (two) mma_panel_all<true>(panel, lds, acc, wave * 16, fr, fg);
+    else mma_panel_all<false>(panel, lds, acc, wave * 16, fr, fg);
   }
   MLPT_STAMP(2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -415,24 +479,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   {
     const unsigned char* wslab = lds + (wave >> 2) * W_BYTES;     // in-columns 16 wave .. 16 wave + 15
     const int cpair = (wave & 3) * 2;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const unsigned char* sa = panel + (ks >> 2) * PANEL_HALF;
-      const int pos = ((((ks & 3) * 4) + fg) ^ fr) * 16;
-      uint4 a[2];
-      a[0] = *(const uint4*)(sa + fr * 256 + pos);
-      if (two) a[1] = *(const uint4*)(sa + (16 + fr) * 256 + pos);
-      v4s16 b[2];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int k = ks * 32 + fg * 8 + half * 4 + (fr >> 2);
-        b[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) v4s16*)(wslab + k * 128 + (((cpair + ((fr & 3) >> 1)) ^ ((k >> 1) & 7)) * 16) + (fr & 1) * 8));
-      }
-      struct { v4s16 lo, hi; } bv = {b[0], b[1]};
-      dacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[0]), dacc[0], 0, 0, 0);
-      if (two) dacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, a[1]), dacc[1], 0, 0, 0);
-    }
+    if (two) mma_u_all<true>(panel, wslab, cpair, dacc, fr, fg);
+    else mma_u_all<false>(panel, wslab, cpair, dacc, fr, fg);
   }
   // (operands swapped: dacc[tm][r] = U[row 16 tm + fr][column 16 wave + 4 fg + r], the layout of gate1)
   MLPT_STAMP(8);
