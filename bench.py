@@ -148,14 +148,30 @@ def pick_dominant(launches, policy_every):
     return max(cand, key=flops_per_step), max(cand, key=share), flops_per_step, share
 
 
-def kernel_table(used, prof, prof_pol, policy_every):
+PCRITIC_SLOTS = ("fwd_l1_pcritic", "fwd_l2_pcritic", "mlp_fwd_pcritic")     # the policy-loss forward through the updated critic
+PCRITIC_HOST = {"fwd_l1_pcritic": ("l1_critic", "mlp_fwd_nets"), "fwd_l2_pcritic": ("tail_critic", "mlp_fwd_nets"),
+                "mlp_fwd_pcritic": ("mlp_fwd_nets",)}
+
+
+def kernel_table(used, prof, prof_pol, policy_every, deferred=False):
     """Per KERNEL SYMBOL of the schedule the timed region replayed: us per step summed over all its launches -- what
     `rocprofv3 --kernel-trace --stats` of the same command lists (profiles/rNN_cycle_stats.txt), so that `roofline` can be re-derived
     from that file: flops per launch / average duration / peak for the kernel at its top.
     used: [(slot, ms per launch, flops per launch)] of an ordinary step of that schedule (cycle schedule: + the launches that serve a whole
     policy cycle, FROZEN_SLOTS, counted 1 / policy_every per step); a policy step's EXTRA launches (prof_pol minus prof, as multisets of
-    slot names: the actor's backward chain, dW, L1 norm, optimizer) are counted 1 / policy_every per step as well."""
-    rows = [(n, ms, fl, (1.0 / policy_every) if n in FROZEN_SLOTS else 1.0) for n, ms, fl in used]
+    slot names: the actor's backward chain, dW, L1 norm, optimizer) are counted 1 / policy_every per step as well.
+    deferred (run graphs): the policy-loss forward of an ordinary step rides as one more problem on the NEXT step's forward launch(es) --
+    its own launches then run on policy steps only (1 / policy_every per step) and its flops are credited to the launch that carries it."""
+    names = {n for n, _, _ in used}
+    rows = []
+    for n, ms, fl in used:
+        w = (1.0 / policy_every) if n in FROZEN_SLOTS else 1.0
+        if deferred and n in PCRITIC_SLOTS:
+            host = next((h for h in PCRITIC_HOST[n] if h in names), None)
+            if host:
+                rows.append((host, 0.0, fl * (1.0 - 1.0 / policy_every), 0.0))   # flops only: the host launch's time already has it in-graph
+                w = 1.0 / policy_every
+        rows.append((n, ms, fl, w))
     left = {}
     for n, _, _ in (prof or []):
         left[n] = left.get(n, 0) + 1
@@ -171,7 +187,7 @@ def kernel_table(used, prof, prof_pol, policy_every):
         if n not in t["slots"]:
             t["slots"].append(n)
         t["ms_per_step"] += ms * w
-        t["flops_per_step"] += fl * w
+        t["flops_per_step"] += fl * (w if w > 0 else 1.0)
         t["launches_per_step"] += w
     out = sorted(tab.values(), key=lambda t: -t["ms_per_step"])
     total = sum(t["ms_per_step"] for t in out) or 1.0
@@ -182,23 +198,60 @@ def kernel_table(used, prof, prof_pol, policy_every):
     return out
 
 
-def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):
-    """HBM bytes per launch of the named kernels from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3
-    sections) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a child
-    run of this same benchmark, counter unit KB, FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B),
-    WRITE_SIZE as is.  Returns {substr: (bytes or None, note)}."""
+class ChildTrace:
+    """What the two `rocprofv3 --pmc X --kernel-trace` child runs of this benchmark saw, per kernel symbol: launches, total duration, and the
+    mean FETCH_SIZE / WRITE_SIZE counter values (KB).  Kernels are looked up by a substring of their symbol."""
+
+    def __init__(self, note=None):
+        self.calls, self.total_ns, self.ctr = {}, {}, {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
+        self.note = note
+
+    def names(self, sub):
+        return [k for k in self.calls if sub in k]
+
+    def graph_ms(self, sub):
+        ks = self.names(sub)
+        n = sum(self.calls[k] for k in ks)
+        return sum(self.total_ns[k] for k in ks) / n * 1e-6 if n else None
+
+    def traffic(self, sub):
+        """(HBM bytes per launch or None, note): FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B), WRITE_SIZE as is."""
+        if self.note:
+            return None, self.note
+        m = {}
+        for ctr, d in self.ctr.items():
+            v = [x for k, xs in d.items() if sub in k for x in xs]
+            if v:
+                m[ctr] = sum(v) / len(v)
+        if len(m) < 2:
+            return None, f"no counter rows for {sub}"
+        return (m["FETCH_SIZE"] * 1024.0 * 2.0 + m["WRITE_SIZE"] * 1024.0,
+                "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on a child run of this command, mean per "
+                f"launch of {sub}: fetch 2 x {m['FETCH_SIZE'] * 1024:.0f} B + write {m['WRITE_SIZE'] * 1024:.0f} B")
+
+    def table(self, steps):
+        """[(short symbol, us per step, calls per step, average us)] of every kernel, by time per step: the `--stats` ranking."""
+        rows = []
+        for k, n in self.calls.items():
+            short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            rows.append((short, k, self.total_ns[k] / 1e3 / steps, n / steps, self.total_ns[k] / 1e3 / n))
+        return sorted(rows, key=lambda r: -r[2])
+
+
+def measure_traffic(argv_tail, timeout_s=300):
+    """HBM bytes per launch from the PMC counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3 sections) prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE `rocprofv3 --pmc X --kernel-trace` passes over a child run of this same benchmark (`--child-trace`: the timed
+    regions only), counter unit KB; the FETCH pass's kernel trace is also the in-graph duration of every kernel.  Returns a ChildTrace."""
     import csv
     import shutil
     import subprocess
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    fail = lambda note: dict({k: (None, note) for k in kernel_substrs}, _graph_ms={k: None for k in kernel_substrs})
     if not os.path.isfile(rocprof):
-        return fail("rocprofv3 not found")
+        return ChildTrace("rocprofv3 not found")
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return fail("already running under a profiler")
-    means = {k: {} for k in kernel_substrs}
-    durs = {k: [] for k in kernel_substrs}      # in-graph durations (ns) of the same kernels, from the passes' kernel traces
+        return ChildTrace("already running under a profiler")
+    ct = ChildTrace()
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix=f"recnn_pmc_{ctr}_", dir="/tmp")
         cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
@@ -206,44 +259,29 @@ def measure_traffic(argv_tail, kernel_substrs, timeout_s=240):
         try:
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
                            env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
-            vals = {k: [] for k in kernel_substrs}
             for root, _, files in os.walk(d):
                 for f in files:
-                    if f.endswith("kernel_trace.csv"):
+                    if f.endswith("kernel_trace.csv") and ctr == "FETCH_SIZE":
                         for r in csv.DictReader(open(os.path.join(root, f))):
                             try:
                                 dt = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                             except (KeyError, ValueError):
                                 continue
-                            for k in kernel_substrs:
-                                if k in r.get("Kernel_Name", ""):
-                                    durs[k].append(dt)
+                            k = r.get("Kernel_Name", "?")
+                            ct.calls[k] = ct.calls.get(k, 0) + 1
+                            ct.total_ns[k] = ct.total_ns.get(k, 0.0) + dt
                     if f.endswith("counter_collection.csv"):
                         for r in csv.DictReader(open(os.path.join(root, f))):
                             if r.get("Counter_Name", ctr) != ctr:
                                 continue
-                            for k in kernel_substrs:
-                                if k in r["Kernel_Name"]:
-                                    vals[k].append(float(r["Counter_Value"]))
-            for k in kernel_substrs:
-                if vals[k]:
-                    means[k][ctr] = sum(vals[k]) / len(vals[k])
+                            ct.ctr[ctr].setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
         except Exception as ex:                                    # profiler unavailable on this box: report null
-            return fail(f"{ctr} pass failed: {type(ex).__name__}")
+            return ChildTrace(f"{ctr} pass failed: {type(ex).__name__}")
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    out = {}
-    for k in kernel_substrs:
-        m = means[k]
-        if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
-            out[k] = (None, f"no counter rows for {k}")
-            continue
-        out[k] = (m["FETCH_SIZE"] * 1024.0 * 2.0 + m["WRITE_SIZE"] * 1024.0,
-                  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on a child run of this command, mean per "
-                  f"launch of {k}: fetch 2 x {m['FETCH_SIZE'] * 1024:.0f} B + write {m['WRITE_SIZE'] * 1024:.0f} B")
-    # mean duration (ms) of each kernel as it ran inside the child's replayed graphs (under counter collection)
-    out["_graph_ms"] = {k: (sum(v) / len(v) * 1e-6 if v else None) for k, v in durs.items()}
-    return out
+    if not ct.calls:
+        ct.note = "the child run left no kernel trace"
+    return ct
 
 
 FLOP_PER_ROW = {"ddpg": 5.401e6, "td3": 8.106e6}    # algorithmic MLP flops per transition row, averaged over a policy cycle
@@ -411,6 +449,9 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel stepper even with one rank (tests the N>1 path)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of `--steps` steps each; value = their median")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-records (parity_mode, other_configs, loss-curve deviation)")
+    ap.add_argument("--child-trace", action="store_true",
+                    help="(internal: the rocprofv3 child runs behind roofline.traffic) the timed regions only -- no eager per-launch profile, no "
+                         "sustained region, no sub-records: the child's kernel trace then holds the replayed schedule and nothing else")
     ap.add_argument("--preflight", action="store_true",
                     help="N > 1 diagnostics instead of the benchmark: one JSON object per stage (tools/multigpu_preflight.py)")
     args = ap.parse_args()
@@ -595,7 +636,7 @@ def main():
     # the same path over ONE long region (whole policy cycles per run graph): the short timed regions above carry ~100 us of fixed cost each
     # (graph launch, loss read-back), which a 20-step region does not amortise -- both figures go into the line
     sustained = None
-    if not use_dp and args.steps < 2000:
+    if not use_dp and args.steps < 2000 and not args.child_trace:
         with torch.cuda.stream(stream):
             first = args.warmup + reps * args.steps
             run(first, 200)
@@ -621,6 +662,10 @@ def main():
         eng.set_comm(None)
     assert os.environ.get("RECNN_MLP_PROBE") or all(np.isfinite(v) for v in losses.values()), losses
 
+    if args.child_trace:
+        if rank == 0:
+            print(json.dumps({"child_trace": True, "ms_per_step": elapsed / args.steps * 1e3}), flush=True)
+        return
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -692,22 +737,22 @@ def main():
         # `roofline` = the kernel with the largest us per step in the schedule the timed region replayed (all its launches summed, as a
         # `rocprofv3 --stats` listing of this command ranks them); the launch with the largest share of the algorithmic flops is
         # reported beside it as `roofline_flop_dominant` (rounds 1-4 and 6: the time-dominant one is `roofline`; round 5 had them swapped)
-        ktab = kernel_table(used, prof, prof_pol, pe)
+        ktab = kernel_table(used, prof, prof_pol, pe, deferred=run_graphs)
         top = ktab[0]
         dom, _, flops_per_step, share = pick_dominant(used, pe)
         dom_k = KERNEL_OF_SLOT.get(dom[0], dom[0])
-        # HBM bytes per launch of both kernels: PMC counters over a child run of this very command (N=1 only)
+        # A child run of this very command under rocprofv3 (N = 1 only; two passes, one counter each): HBM bytes per launch from the PMC
+        # counters, and -- from its kernel trace -- what every kernel of the REPLAYED schedule took inside the run graphs
         tr = None
-        gather_traffic, gather_note = None, "skipped"
-        gather_multi_traffic = None
         if world == 1 and not args.no_traffic and not use_dp:
-            tail = ["--steps", str(max(40, cyc_min) if schedule == "cycle" else 20), "--warmup", "20", "--repeats", "1", "--no-cpu-baseline",
+            c_steps, c_reps = min(args.steps, 2000), (reps if args.steps <= 200 else 1)
+            tail = ["--steps", str(c_steps), "--warmup", str(min(args.warmup, 200)), "--repeats", str(c_reps), "--child-trace", "--no-cpu-baseline",
                     "--no-traffic", "--no-extras", "--dtype", args.dtype, "--algo", args.algo, "--rows", str(args.rows)]
-            tr = measure_traffic(tail, sorted({top["kernel"], dom_k, "frame_gather_kernel", "frame_gather_multi_kernel"}))
-            gather_traffic, gather_note = tr["frame_gather_kernel"]
-            gather_multi_traffic = tr["frame_gather_multi_kernel"][0]
-        traffic_of = lambda k: tr[k] if tr else (None, "skipped")
-        graph_ms_of = lambda k: tr["_graph_ms"].get(k) if tr else None
+            tr = measure_traffic(tail)
+            child_steps = min(args.warmup, 200) + c_reps * c_steps
+        traffic_of = lambda k: tr.traffic(k) if tr else (None, "skipped")
+        gather_traffic, gather_note = traffic_of("frame_gather_kernel")
+        gather_multi_traffic = traffic_of("frame_gather_multi_kernel")[0]
         out["schedule"] = schedule
         # SURVEY.md 8(d)'s end-to-end figure: algorithmic MLP flops of a step / measured time per step / dense MFMA peak
         e2e = FLOP_PER_ROW[args.algo] * rows / (ms_per_step * 1e-3) / 1e12
@@ -719,28 +764,49 @@ def main():
         hbm_bytes = {"apply_kernel": 28.0 * PARAMS["critic"], "apply_gather_kernel": 28.0 * PARAMS["critic"] + per_row * rows,
                      "frame_gather_kernel": float(per_row * rows), "frame_gather_multi_kernel": float(per_row * rows * pe),
                      "grad_reduce_kernel": 8.0 * PARAMS["actor"]}
-        sel = ("largest us per step of the replayed schedule, all launches of the kernel summed: %.2f us/step = %.0f %% of the step's kernel "
-               "time (%.2f launches per step)" % (top["ms_per_step"] * 1e3, 100 * top["share_of_step_time"], top["launches_per_step"]))
-        t_traffic, t_note = traffic_of(top["kernel"])
-        if top["flops_per_launch"] > 0:
-            ach = top["flops_per_launch"] / (top["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "avg_ms": top["avg_ms"], "flops_per_launch": top["flops_per_launch"],
-                               "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
-                               "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
+        # `roofline`: the kernel at the top of the replayed schedule's time ranking.  With the child trace: ranked by what the kernels took
+        # INSIDE the run graphs (the `rocprofv3 --stats` order of this command); else by HIP events around eager launches of the same steps
+        gtab = tr.table(child_steps) if tr and tr.calls else []
+        if gtab:
+            g_short, g_full, g_us, g_lps, g_avg = gtab[0]
+            kt = next((t for t in ktab if t["kernel"] in g_full), None)
+            g_total = sum(r[2] for r in gtab)
+            src = (f"kernel trace of a child run of this command under rocprofv3 ({child_steps} replayed steps, counter pass): all launches of "
+                   f"the kernel summed = {g_us:.2f} us/step of {g_total:.2f} us/step of kernel time")
+            rec = {"kernel": g_short, "avg_ms": g_avg * 1e-3, "launches_per_step": g_lps, "us_per_step": g_us, "share_of_step_time": g_us / g_total,
+                   "selected_by": src}
+            t_traffic, t_note = tr.traffic(g_short)
+            fl_step = kt["flops_per_step"] if kt else 0.0
+            if fl_step > 0:
+                ach = fl_step / (g_us * 1e-6) / 1e12
+                rec.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, flops_per_launch=fl_step / g_lps, slots=kt["slots"],
+                           eager={"avg_ms": kt["avg_ms"], "launches_per_step": kt["launches_per_step"]})
+            else:
+                nbytes = next((v for k, v in hbm_bytes.items() if k in g_full), None)
+                gbs = nbytes / (g_avg * 1e-6) / 1e9 if nbytes else None
+                rec.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS if gbs else None, bytes_per_launch=nbytes)
+            rec.update(traffic=t_traffic, traffic_source=t_note)
+            out["roofline"] = rec
+            out["kernel_time_table_in_graph"] = [{"kernel": r[0], "us_per_step": round(r[2], 3), "launches_per_step": round(r[3], 3),
+                                                  "avg_us": round(r[4], 3)} for r in gtab if r[2] > 0.05]
         else:
-            nbytes = hbm_bytes.get(top["kernel"])
-            gbs = nbytes / (top["avg_ms"] * 1e-3) / 1e9 if nbytes else None
-            out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": gbs / HBM_PEAK_GBS if gbs else None, "avg_ms": top["avg_ms"], "bytes_per_launch": nbytes,
-                               "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
-                               "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
-        g_ms = graph_ms_of(top["kernel"])
-        if g_ms and top["flops_per_launch"] > 0:
-            # avg_ms above: HIP events around EAGER launches.  Inside the replayed run graphs: mean duration from the child run's kernel trace
-            ach = top["flops_per_launch"] / (g_ms * 1e-3) / 1e12
-            out["roofline"]["in_graph"] = {"avg_ms": g_ms, "achieved": ach, "frac": ach / peak,
-                                           "source": "kernel trace of the PMC child run (graph replays, counter collection on)"}
+            sel = ("largest us per step of the replayed schedule, all launches of the kernel summed (HIP events around eager launches): %.2f "
+                   "us/step = %.0f %% of the step's kernel time (%.2f launches per step)"
+                   % (top["ms_per_step"] * 1e3, 100 * top["share_of_step_time"], top["launches_per_step"]))
+            t_traffic, t_note = traffic_of(top["kernel"])
+            if top["flops_per_launch"] > 0:
+                ach = top["flops_per_launch"] / (top["avg_ms"] * 1e-3) / 1e12
+                out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": ach / peak, "avg_ms": top["avg_ms"], "flops_per_launch": top["flops_per_launch"],
+                                   "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
+                                   "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
+            else:
+                nbytes = hbm_bytes.get(top["kernel"])
+                gbs = nbytes / (top["avg_ms"] * 1e-3) / 1e9 if nbytes else None
+                out["roofline"] = {"kernel": top["kernel"], "slots": top["slots"], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs / HBM_PEAK_GBS if gbs else None, "avg_ms": top["avg_ms"], "bytes_per_launch": nbytes,
+                                   "launches_per_step": top["launches_per_step"], "share_of_step_time": top["share_of_step_time"],
+                                   "traffic": t_traffic, "traffic_source": t_note, "selected_by": sel}
         out["kernel_time_table"] = [{"kernel": t["kernel"], "us_per_step": round(t["ms_per_step"] * 1e3, 3), "avg_us": round(t["avg_ms"] * 1e3, 3),
                                      "launches_per_step": round(t["launches_per_step"], 3), "gflop_per_launch": round(t["flops_per_launch"] / 1e9, 4),
                                      "share_of_step_time": round(t["share_of_step_time"], 4)} for t in ktab]

@@ -543,7 +543,7 @@ typedef struct recnn_engine_tuning {
                                batches gathered at once, frozen networks applied to all of them: mlpf.hip; per-step launches = split
                                forward of the learning critics: l1gemm.hip + mlpt.hip); 2: split forward and cycle mode everywhere */
   int cycle_min_len;        /* default 20 (round 5; 30 before) */
-  int cycle_min_seg;        /* cycle mode: segments shorter than this step through the fused forward (default 5; 3 before round 5) */
+  int cycle_min_seg;        /* cycle mode: segments shorter than this step through the fused forward (default 4 since round 6: the per-step launches of cycle mode got cheaper; 5 in round 5, 3 before) */
   int frozen_fused;         /* cycle mode: 1 each frozen network as one launch of 128-row panels, 0 tiled layer 1 + later layers */
   int frozen_gemm;          /* ... whose later layers run as tiled GEMMs (1) or row-panel tails (0) */
   int graph_run;            /* steps per run graph: -1 as many whole policy cycles as fit 64 steps, 0 single-step graphs only */

@@ -264,7 +264,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   if (!t) return;
   memset(t, 0, sizeof(*t));
   t->fused_mlp = 1; t->chain_target_critic = 1; t->bwd_panel = 2; t->policy_chain = 1;
-  t->split_fwd = 1; t->cycle_min_len = 20; t->cycle_min_seg = 5; t->frozen_fused = 1; t->frozen_gemm = 1;
+  t->split_fwd = 1; t->cycle_min_len = 20; t->cycle_min_seg = 4; t->frozen_fused = 1; t->frozen_gemm = 1;
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
