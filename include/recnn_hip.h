@@ -311,6 +311,15 @@ int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t l
 /* out[c] = sum over rows of x[r, c], c < n (rows added in order; x rows 16-byte aligned, ld % 4 == 0, padded to 4 floats): the bias
  * gradient of a catalogue-wide Linear from d logits. */
 int recnn_colsum_rows(const float* x, int64_t ld, int rows, int n, float* out, void* stream);
+/* The softmax of rows whose columns are SHARDED over ranks (the vocabulary-parallel policy head, recnn_amd/parallel.py; replaces the
+ * F.softmax of recnn/nn/models.py:95-99 on a shard): three passes over this rank's float[rows, ld] logits x, the all-reduces between
+ * them are the caller's.  pass 0: rowval[r] = max_j x[r, j].  pass 1: x = exp(x - rowval[r]) in place (rowval = the max over ALL shards),
+ * pa[r] = the row's sum.  pass 2: x /= rowval[r] in place (rowval = the sum over all shards) -> this shard's probabilities, pa[r] =
+ * x[r, local[r]] if 0 <= local[r] < n else 0 (local = the row's action minus the shard's first item). */
+int recnn_shard_softmax_pass(float* x, int64_t ld, int rows, int n, int pass, float* rowval, const int64_t* local, float* pa, void* stream);
+/* dlogits[r, j] = -g[r] p[r, j] (+ g[r] at j = local[r] when the shard owns it): backward of log(clamp(p_a)) through the sharded softmax */
+int recnn_shard_logprob_bwd(const float* p, int64_t ldp, int rows, int n, const int64_t* local, const float* g, float* dlogits, int64_t ldd,
+                            void* stream);
 /* dst[c, r] = src[r, c]: float [rows, cols] (row stride ld) -> float or bfloat16 [cols, ldt] (ldt >= rows; columns [rows, ldt) are
  * not touched).  The transposed copy of the policy head's W2 [n_items, hidden] that puts the catalogue on the contiguous axis
  * for the backward product d logits x W2 (made once per weight version). */
@@ -521,11 +530,12 @@ int recnn_comm_set_timeout_ms(recnn_comm* c, int ms);
 int recnn_comm_clear_status(recnn_comm* c);
 void recnn_comm_destroy(recnn_comm* c);
 int recnn_engine_set_comm(recnn_engine* e, recnn_comm* comm, float grad_scale);
-/* Process-level settings of the peer communicators created afterwards (a communicator is shared by engines, so these are not part
- * of an engine's tuning): memory kind of the peer buffers, 0 fine-grained (default), 1 uncached, 2 ordinary; workgroups per
- * collective launch (default 128; ranks that share ONE GPU in tests need all of them resident at once: 32). */
-void recnn_tune_comm_memory(int kind);
-void recnn_tune_comm_workgroups(int n);
+/* Settings of ONE communicator (round 6: no process-wide communicator state is left): recnn_comm_create_ex takes the memory kind of the
+ * peer buffers -- 0 fine-grained (default, = recnn_comm_create), 1 uncached, 2 ordinary device memory; recnn_comm_set_workgroups the
+ * workgroups per collective launch made or captured afterwards (default 128; ranks that share ONE GPU in tests need every rank's
+ * collective resident at once: 32). */
+int recnn_comm_create_ex(int world, int rank, int64_t max_floats, int memory_kind, recnn_comm** out);
+int recnn_comm_set_workgroups(recnn_comm* c, int n);
 
 /* ---- per-engine tuning.  Every field selects among schedules / kernel tilings that produce the SAME numbers (the GPU suite runs
  * under several of them); nothing here is process-wide: two engines of one process can run different schedules.

@@ -145,6 +145,8 @@ SIGNATURES = {
     "recnn_softmax_bwd": (_I, [_P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_onehot_rows": (_I, [_P, _I, _I, _P, _L, _P]),
     "recnn_colsum_rows": (_I, [_P, _L, _I, _I, _P, _P]),
+    "recnn_shard_softmax_pass": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "recnn_shard_logprob_bwd": (_I, [_P, _L, _I, _I, _P, _P, _P, _L, _P]),
     "recnn_transpose_rows": (_I, [_P, _L, _I, _I, _P, _L, _I, _P]),
     "recnn_vae_latent_fwd": (_I, [_P, _L, _P, _L, _I, _I, _P, _L, _P, _L, _P]),
     "recnn_vae_latent_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
@@ -184,8 +186,8 @@ SIGNATURES = {
     "recnn_comm_clear_status": (_I, [_P]),
     "recnn_comm_destroy": (None, [_P]),
     "recnn_engine_set_comm": (_I, [_P, _P, _F]),
-    "recnn_tune_comm_memory": (None, [_I]),
-    "recnn_tune_comm_workgroups": (None, [_I]),
+    "recnn_comm_create_ex": (_I, [_I, _I, _L, _I, C.POINTER(_P)]),
+    "recnn_comm_set_workgroups": (_I, [_P, _I]),
     "recnn_engine_read_losses": (_I, [_P, _P, _P]),
     "recnn_topk_item_aux": (_I, [_P, _I, _I, _I, _P, _P]),
     "recnn_topk_workspace_bytes": (_I, [_I, _I, C.POINTER(_L)]),

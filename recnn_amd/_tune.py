@@ -5,6 +5,7 @@ shapes that produce the same numbers.  The C ABI keeps NO process-wide tuning st
 (`recnn_engine_set_tuning`), made here from the library defaults, then the environment, then `set_default_tuning(...)` overrides
 (tests that run a whole facade under another schedule), then the engine's own `set_tuning(...)` keywords."""
 import os
+import warnings
 
 from . import _lib as L
 
@@ -20,9 +21,13 @@ ENV_FIELDS = {
     "RECNN_X3_TAIL": "x3_tail", "RECNN_X3_FWD": "x3_fwd", "RECNN_DW_FUSE": "dw_fuse", "RECNN_TAIL_HALF": "tail_half",
 }
 # process-level settings of the peer communicators (shared by engines: not part of an engine's tuning) and debug hooks
-ENV_CALLS = {"RECNN_COMM_MEMORY": "recnn_tune_comm_memory", "RECNN_COMM_WORKGROUPS": "recnn_tune_comm_workgroups",
-             "RECNN_MLP_PROBE": "recnn_debug_mlp_probe", "RECNN_X3_FWD_DEBUG": "recnn_debug_x3_fwd", "RECNN_X3_WS_PROBE": "recnn_debug_x3_ws_probe",
+# (RECNN_COMM_MEMORY / RECNN_COMM_WORKGROUPS are read by each PeerComm for ITSELF: recnn_amd/parallel.py)
+ENV_CALLS = {"RECNN_MLP_PROBE": "recnn_debug_mlp_probe", "RECNN_X3_FWD_DEBUG": "recnn_debug_x3_fwd", "RECNN_X3_WS_PROBE": "recnn_debug_x3_ws_probe",
              "RECNN_WIDE_WS": "recnn_debug_wide_ws"}
+
+# debug hooks that make kernels compute garbage (timing probes): variable -> the bits that leave results intact
+RESULT_CORRUPTING = {"RECNN_MLP_PROBE": 0, "RECNN_X3_WS_PROBE": (1 << 8) | (1 << 9) | (1 << 10)}
+OVERRIDES_ENGINE_TUNING = {"RECNN_X3_FWD_DEBUG": "x3_fwd"}
 
 _overrides = {}
 
@@ -60,8 +65,23 @@ def apply_env_knobs():
     for var, fn in ENV_CALLS.items():
         v = os.environ.get(var)
         if v not in (None, ""):
-            getattr(lib, fn)(int(v))
-            done[var] = int(v)
+            val = int(v)
+            if var in RESULT_CORRUPTING:
+                # timing probes whose results are garbage by design: never from a stray variable alone
+                keep = RESULT_CORRUPTING[var]
+                if (val & ~keep) and os.environ.get("RECNN_ALLOW_GARBAGE_PROBES") != "1":
+                    warnings.warn(f"{var}={val}: bits {val & ~keep:#x} make the kernels compute GARBAGE (timing probes); ignored -- set "
+                                  "RECNN_ALLOW_GARBAGE_PROBES=1 to apply them", RuntimeWarning, stacklevel=2)
+                    val &= keep
+                elif val & ~keep:
+                    warnings.warn(f"{var}={val}: timing probe active, results of the probed kernels are GARBAGE", RuntimeWarning, stacklevel=2)
+                if val == 0:
+                    continue
+            elif var in OVERRIDES_ENGINE_TUNING:
+                warnings.warn(f"{var}={val}: process-wide debug override of every engine's `{OVERRIDES_ENGINE_TUNING[var]}` tuning", RuntimeWarning,
+                              stacklevel=2)
+            getattr(lib, fn)(val)
+            done[var] = val
     for var in ENV_FIELDS:
         v = os.environ.get(var)
         if v not in (None, ""):

@@ -148,16 +148,19 @@ struct recnn_comm {
   unsigned long long timeout = 0;
   int khz = 100000;              // wall_clock64 rate
   unsigned timeout_ms = COMM_TIMEOUT_MS;
+  int memory = 0;                // 0 fine-grained device memory (default), 1 uncached, 2 ordinary hipMalloc (system-scope fences alone)
+  int max_wg = 128;              // workgroups per collective (x 256 threads x 4 groups in flight = 2 MB per pass)
 };
-
-// 0 (default) fine-grained device memory, 1 uncached, 2 ordinary hipMalloc (relies on the system-scope fences alone)
-static int g_comm_memory = 0;
-extern "C" void recnn_tune_comm_memory(int kind) { g_comm_memory = kind; }
 
 int comm_world(const recnn_comm* c) { return c ? c->world : 1; }
 
-static int g_comm_wg = 128;   // workgroups per collective (x 256 threads x 4 groups in flight = 2 MB per pass)
-extern "C" void recnn_tune_comm_workgroups(int n) { g_comm_wg = n < 1 ? 1 : (n > COMM_MAX_WG ? COMM_MAX_WG : n); }
+// Workgroups per collective launch of THIS communicator, for launches made or captured afterwards (round 6: was a process-wide setting).
+// Ranks that share one GPU in tests need every rank's collective resident at once: 32.
+extern "C" int recnn_comm_set_workgroups(recnn_comm* c, int n) {
+  RECNN_REQUIRE(c, "comm_set_workgroups: null communicator");
+  c->max_wg = n < 1 ? 1 : (n > COMM_MAX_WG ? COMM_MAX_WG : n);
+  return 0;
+}
 
 int comm_port(const recnn_comm* c, int64_t off, CommPort* out) {
   RECNN_REQUIRE(c && c->connected && out && off >= 0 && (off & 3) == 0 && off < c->cap, "comm_port: communicator not connected / bad region offset");
@@ -175,7 +178,7 @@ static int launch(recnn_comm* c, const float* src, float* dst, int64_t off, int6
   a.src = src; a.dst = dst; a.n = n;
   int64_t wg = ((n + 3) / 4 + COMM_THREADS * 4 - 1) / (COMM_THREADS * 4);
   if (wg < 1) wg = 1;
-  if (wg > g_comm_wg) wg = g_comm_wg;
+  if (wg > c->max_wg) wg = c->max_wg;
   hipLaunchKernelGGL(allreduce_kernel, dim3((unsigned)wg), dim3(COMM_THREADS), 0, s, a);
   return recnn_check_hip(hipGetLastError(), "allreduce_kernel");
 }
@@ -197,19 +200,25 @@ int comm_allreduce_region(recnn_comm* c, int64_t off, const float* src, float* d
   return launch(c, src, dst, off, n, s);
 }
 
+extern "C" int recnn_comm_create_ex(int world, int rank, int64_t max_floats, int memory_kind, recnn_comm** out);
 extern "C" int recnn_comm_create(int world, int rank, int64_t max_floats, recnn_comm** out) {
+  return recnn_comm_create_ex(world, rank, max_floats, 0, out);
+}
+// memory_kind of the peer buffers: 0 fine-grained (default), 1 uncached, 2 ordinary device memory
+extern "C" int recnn_comm_create_ex(int world, int rank, int64_t max_floats, int memory_kind, recnn_comm** out) {
   RECNN_REQUIRE(out, "comm_create: null output");
+  RECNN_REQUIRE(memory_kind >= 0 && memory_kind <= 2, "comm_create: memory kind 0 (fine-grained), 1 (uncached) or 2 (ordinary)");
   *out = nullptr;
   RECNN_REQUIRE(world >= 1 && world <= COMM_MAX_WORLD && rank >= 0 && rank < world, "comm_create: world %d (max %d), rank %d", world, COMM_MAX_WORLD, rank);
   RECNN_REQUIRE(max_floats > 0, "comm_create: capacity must be positive");
   recnn_comm* c = new recnn_comm();
-  c->world = world; c->rank = rank;
+  c->world = world; c->rank = rank; c->memory = memory_kind;
   c->cap = (max_floats + 63) & ~(int64_t)63;
   c->bytes = (size_t)(COMM_HDR + 2 * c->cap * (int64_t)sizeof(float));
   // fine-grained device memory: stores of one agent become visible to the others inside a running kernel (system-scope
   // release / acquire), which ordinary (coarse-grained) device memory only promises at kernel boundaries
-  hipError_t e = g_comm_memory == 2 ? hipMalloc((void**)&c->base, c->bytes)
-                                    : hipExtMallocWithFlags((void**)&c->base, c->bytes, g_comm_memory == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+  hipError_t e = c->memory == 2 ? hipMalloc((void**)&c->base, c->bytes)
+                                : hipExtMallocWithFlags((void**)&c->base, c->bytes, c->memory == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
   if (e != hipSuccess) { (void)hipGetLastError(); delete c; return recnn_check_hip(e, "comm_create: peer buffer allocation"); }
   e = hipMalloc((void**)&c->ctl, 8 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(c->base, 0, c->bytes);

@@ -1,5 +1,6 @@
-// dw_tile.h -- the 64 x 64 output tile of a weight-gradient GEMM dW[m][n] = sum_b dZ[b][m] * X[b][n] (bf16, gfx950), shared by
-// gemm_dw_dma_kernel (gemm.hip: split-batch slabs) and dw_opt_kernel (dwopt.hip: whole batch per tile, optimizer in the epilogue).
+// dw_tile.h -- the 64 x 64 output tile of a weight-gradient GEMM dW[m][n] = sum_b dZ[b][m] * X[b][n] (bf16, gfx950) of
+// gemm_dw_dma_kernel (gemm.hip: split-batch slabs; NWK > 1 = k-groups inside the workgroup, the round-3 experiment).  dwadam.hip
+// (round 6: 32 x 64 tiles, whole batch per workgroup, optimizer in the epilogue) shares the LDS image and the transpose reads.
 //
 // BOTH operands are k-strided (k = batch row), i.e. stored with the tile dimension contiguous.  The rows go global -> LDS
 // untouched (`global_load_lds_dwordx4`) and the MFMA fragments are read with gfx950's `ds_read_b64_tr_b16`, which hands lane i

@@ -1137,8 +1137,8 @@ __global__ __launch_bounds__((WR * WC + NL) * 64) void x3_fwd_ws_kernel(const Ge
 
 // ------------------------------------------------------------------ dW GEMM, LDS-DMA + transpose reads (bf16)
 // dW[m][n] = sum_b dZ[b][m] * X[b][n], batch split into slabs (deterministic): the 64 x 64 tile itself is dw_tile.h; here the
-// split-batch driver that writes one fp32 slab per batch slice (summed later by grad_reduce / the Adam pass).  The fused
-// single-GPU step uses dwopt.hip instead (whole batch per tile, optimizer in the epilogue: no slabs at all).
+// split-batch driver that writes one fp32 slab per batch slice (summed later by grad_reduce / the Adam pass).  The single-GPU step
+// whose backward tensors come from mlpt.hip takes dwadam.hip instead (whole batch per tile, optimizer in the epilogue: no slabs).
 constexpr int DW_SCALE_ROWS = 512;    // per-row scales of a workgroup's k range are staged in LDS up to this many rows
 // one 32-row panel of one critic: per-column sums over the rows of d_r * {h2, u2, U}; thread = column
 __device__ __forceinline__ void dw_vec_role(const DwVecProb& V, int panel) {

@@ -329,6 +329,77 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const float* __rest
   }
 }
 
+
+// ---- the softmax of a row whose columns are SHARDED over ranks (recnn_amd/parallel.py VocabParallelPolicyFunction; round 6: these were
+// ATen amax / exp / sum / div / gather calls between the all-reduces).  Three passes, one workgroup per row, the all-reduces of the row
+// maxima / sums / chosen probabilities between them stay with torch.distributed:
+//   rowmax        m[r] = max_j x[r, j]
+//   exp_rowsum    x[r, j] = exp(x[r, j] - m[r]) in place (m: the max over ALL shards), s[r] = sum_j of it
+//   norm_pick     x[r, j] /= s[r] (s: the sum over all shards) in place -> this shard's probabilities; pa[r] = x[r, a_r] when this shard
+//                 owns the row's action (0 <= a_r < n), else 0
+__global__ __launch_bounds__(PT) void shard_rowmax_kernel(const float* __restrict__ x, int64_t ld, int n, float* __restrict__ m) {
+  __shared__ float red[NWAVE];
+  const float* xr = x + (int64_t)blockIdx.x * ld;
+  const int n4 = (n + 3) >> 2;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n4; i += PT) {
+    const float4 v = load4_tail(xr, i, n, -INFINITY);
+    mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  }
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) m[blockIdx.x] = mx;
+}
+__global__ __launch_bounds__(PT) void shard_exp_rowsum_kernel(float* __restrict__ x, int64_t ld, int n, const float* __restrict__ m,
+                                                              float* __restrict__ ssum) {
+  __shared__ float red[NWAVE];
+  float* xr = x + (int64_t)blockIdx.x * ld;
+  const int n4 = (n + 3) >> 2;
+  const float mx = m[blockIdx.x];
+  float mine = 0.f;
+  for (int i = threadIdx.x; i < n4; i += PT) {
+    float4 v = load4_tail(xr, i, n, -INFINITY);
+    v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);   // padding columns: exp(-inf) = 0
+    *(float4*)(xr + 4 * (int64_t)i) = v;
+    mine += (v.x + v.y) + (v.z + v.w);
+  }
+  const float tot = block_sum(mine, red);
+  if (threadIdx.x == 0) ssum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PT) void shard_norm_pick_kernel(float* __restrict__ x, int64_t ld, int n, const float* __restrict__ ssum,
+                                                             const int64_t* __restrict__ local, float* __restrict__ pa) {
+  float* xr = x + (int64_t)blockIdx.x * ld;
+  const int n4 = (n + 3) >> 2;
+  const float s = ssum[blockIdx.x];
+  for (int i = threadIdx.x; i < n4; i += PT) {
+    float4 v = *(const float4*)(xr + 4 * (int64_t)i);
+    v.x = v.x / s; v.y = v.y / s; v.z = v.z / s; v.w = v.w / s;          // (a true division, like torch's div_)
+    *(float4*)(xr + 4 * (int64_t)i) = v;
+  }
+  __syncthreads();                                                         // the row's stores are visible to thread 0's read below
+  if (threadIdx.x == 0) {
+    const int64_t a = local[blockIdx.x];
+    pa[blockIdx.x] = (a >= 0 && a < n) ? xr[a] : 0.f;
+  }
+}
+// d logits of this shard for d loss / d log(clamp(p_a)) = g:  dlog[r, j] = -g[r] p[r, j]  (+ g[r] at j = a_r when the shard owns it)
+__global__ __launch_bounds__(256) void shard_logprob_bwd_kernel(const float* __restrict__ p, int64_t ldp, int rows, int n,
+                                                                const int64_t* __restrict__ local, const float* __restrict__ g,
+                                                                float* __restrict__ dlog, int64_t ldd) {
+  const int n4 = (n + 3) >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float gr = g[r];
+    const int64_t a = local[r];
+    float4 v = *(const float4*)(p + (int64_t)r * ldp + 4 * (int64_t)i);
+    v.x = v.x * -gr; v.y = v.y * -gr; v.z = v.z * -gr; v.w = v.w * -gr;
+    if (a >= 0 && a < n && (a >> 2) == i) {
+      const int c = (int)(a & 3);
+      if (c == 0) v.x += gr; else if (c == 1) v.y += gr; else if (c == 2) v.z += gr; else v.w += gr;
+    }
+    *(float4*)(dlog + (int64_t)r * ldd + 4 * (int64_t)i) = v;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -384,6 +455,30 @@ int recnn_onehot_rows(const int64_t* idx, int rows, int n, float* out, int64_t l
   const int l4 = (int)(ld / 4);
   hipLaunchKernelGGL(onehot_kernel, dim3((l4 + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, (hipStream_t)stream, idx, rows, n, out, ld);
   return recnn_check_hip(hipGetLastError(), "onehot_kernel launch");
+}
+
+int recnn_shard_softmax_pass(float* x, int64_t ld, int rows, int n, int pass, float* rowval, const int64_t* local, float* pa, void* stream) {
+  RECNN_REQUIRE(x && rowval && rows >= 0 && n > 0 && pass >= 0 && pass <= 2, "shard_softmax_pass: bad arguments");
+  RECNN_REQUIRE(aligned16(x) && ld % 4 == 0 && ld >= ((n + 3) & ~3), "shard_softmax_pass: rows must be 16-byte aligned and padded to 4 floats");
+  RECNN_REQUIRE(pass != 2 || (local && pa), "shard_softmax_pass: the last pass needs the local action indices and the output");
+  if (rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (pass == 0) hipLaunchKernelGGL(shard_rowmax_kernel, dim3(rows), dim3(PT), 0, s, x, ld, n, rowval);
+  else if (pass == 1) hipLaunchKernelGGL(shard_exp_rowsum_kernel, dim3(rows), dim3(PT), 0, s, x, ld, n, rowval, pa);
+  else hipLaunchKernelGGL(shard_norm_pick_kernel, dim3(rows), dim3(PT), 0, s, x, ld, n, rowval, local, pa);
+  return recnn_check_hip(hipGetLastError(), "shard_softmax_pass launch");
+}
+
+int recnn_shard_logprob_bwd(const float* p, int64_t ldp, int rows, int n, const int64_t* local, const float* g, float* dlogits, int64_t ldd,
+                            void* stream) {
+  RECNN_REQUIRE(p && local && g && dlogits && rows >= 0 && n > 0, "shard_logprob_bwd: bad arguments");
+  RECNN_REQUIRE(aligned16(p) && aligned16(dlogits) && ldp % 4 == 0 && ldd % 4 == 0 && ldp >= ((n + 3) & ~3) && ldd >= ((n + 3) & ~3),
+                "shard_logprob_bwd: rows must be 16-byte aligned and padded to 4 floats");
+  if (rows == 0) return 0;
+  const int n4 = (n + 3) >> 2;
+  hipLaunchKernelGGL(shard_logprob_bwd_kernel, dim3((n4 + 255) / 256, rows < 256 ? rows : 256), dim3(256), 0, (hipStream_t)stream, p, ldp, rows, n,
+                     local, g, dlogits, ldd);
+  return recnn_check_hip(hipGetLastError(), "shard_logprob_bwd launch");
 }
 
 int recnn_colsum_rows(const float* x, int64_t ld, int rows, int n, float* out, void* stream) {

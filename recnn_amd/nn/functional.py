@@ -205,21 +205,30 @@ def _fwd(x, K, w, bias, out, ldc, N, relu, mask, addend=None, yref=None, scale=1
     L.call("recnn_gemm_fwd", C.byref(a), L.current_stream())
 
 
-_splitk_ws = {}
+_splitk_ws = {}          # (device type, index, stream) -> [tensor, handed out during a stream capture?]
+_splitk_retired = []     # outgrown buffers a captured graph may still replay into: alive for the process, nothing else is kept
+_SPLITK_MAX_STREAMS = 8  # eager scratch buffers kept (least recently used first out); captured ones are never dropped
 
 
 def _splitk_scratch(device, floats):
     """fp32 scratch of at least `floats` elements on `device` for the library's split-K, one per (device, STREAM): products issued on
-    different streams never share a buffer.  A buffer that has to grow is REPLACED, never freed: a captured graph
-    (GraphedUpdate) has the old pointer baked in and may still replay into it, so retired buffers stay alive for the process."""
+    different streams never share a buffer.  A buffer that was handed out DURING A STREAM CAPTURE has its pointer baked into a
+    graph (GraphedUpdate) that may replay into it for the life of the process: when it has to grow it is retired, not freed, and its
+    stream's entry is never evicted.  Buffers only ever used eagerly are plain cache entries: replaced when they grow, and at most
+    _SPLITK_MAX_STREAMS of them are kept (every stream used to pin its buffer, and the outgrown ones, forever)."""
     key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
-    t = _splitk_ws.get(key)
-    if t is None or t.numel() < floats:
-        if t is not None:
-            _splitk_ws.setdefault("_retired", []).append(t)
-        t = torch.empty(floats, dtype=torch.float32, device=device)
-        _splitk_ws[key] = t
-    return t
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = _splitk_ws.pop(key, None)               # (re-inserted below: dict order = recency)
+    if ent is None or ent[0].numel() < floats:
+        if ent is not None and ent[1]:
+            _splitk_retired.append(ent[0])
+        ent = [torch.empty(floats, dtype=torch.float32, device=device), False]
+    ent[1] = ent[1] or capturing
+    _splitk_ws[key] = ent
+    eager = [k for k, e in _splitk_ws.items() if not e[1]]
+    for k in eager[:max(0, len(eager) - _SPLITK_MAX_STREAMS)]:
+        del _splitk_ws[k]
+    return ent[0]
 
 
 def _dx(dz, Kc, w, N, out, yref, scale, colsum, dtype=None, c_f32=1):

@@ -11,6 +11,8 @@ N ranks x B/N rows with the matching slices of the dropout masks == 1 rank x B r
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,8 +34,9 @@ class PeerComm:
     group is not used again.  `PeerComm.create` returns None on every rank when any rank cannot map its peers (another node,
     IPC unavailable): the caller then stays on RCCL (`dist.all_reduce`)."""
 
-    def __init__(self, max_floats: int, group=None, _state=None):
+    def __init__(self, max_floats: int, group=None, _state=None, memory_kind=None, workgroups=None):
         self.group = group
+        self.memory_kind, self.workgroups = memory_kind, workgroups
         ready = dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
         self.rank = dist.get_rank(group) if ready else 0
@@ -71,8 +74,14 @@ class PeerComm:
         import ctypes as C
         self.lib = L.load()
         h = C.c_void_p()
-        L.call("recnn_comm_create", self.world, self.rank, self.max_floats, C.byref(h))
+        # settings of THIS communicator (the library keeps no process-wide communicator state): memory kind of the peer buffers and
+        # workgroups per collective, from the constructor's keywords or, for A/B runs from the shell, the environment
+        mem = self.memory_kind if self.memory_kind is not None else int(os.environ.get("RECNN_COMM_MEMORY", "0") or 0)
+        L.call("recnn_comm_create_ex", self.world, self.rank, self.max_floats, mem, C.byref(h))
         self.handle = h
+        wg = self.workgroups if self.workgroups is not None else os.environ.get("RECNN_COMM_WORKGROUPS")
+        if wg not in (None, ""):
+            L.call("recnn_comm_set_workgroups", self.handle, int(wg))
 
     def _export(self) -> bytes:
         import ctypes as C
@@ -366,6 +375,44 @@ class _HipOps:
         Fh._fwd(xp, Kp, wp, b.detach().float().contiguous(), out, ldn, N, relu, None)
         return out[:, :N]
 
+    # ---- the sharded softmax's row passes (csrc/policy.hip); x = this rank's [B, ns] logits, rows 16-byte aligned, pitch % 4 == 0
+    @staticmethod
+    def _rows(x):
+        if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+            raise L.RecnnHipError("sharded softmax: logits rows must be contiguous, 16-byte aligned, pitch a multiple of 4 floats")
+        return L.ptr(x), x.stride(0), x.shape[0], x.shape[1]
+
+    @staticmethod
+    def rowmax(x):
+        p, ld, B, n = _HipOps._rows(x)
+        m = torch.empty(B, device=x.device)
+        L.call("recnn_shard_softmax_pass", p, ld, B, n, 0, L.ptr(m), None, None, L.current_stream())
+        return m
+
+    @staticmethod
+    def exp_rowsum_(x, m):
+        p, ld, B, n = _HipOps._rows(x)
+        s = torch.empty(B, device=x.device)
+        L.call("recnn_shard_softmax_pass", p, ld, B, n, 1, L.ptr(m), None, L.ptr(s), L.current_stream())
+        return s
+
+    @staticmethod
+    def norm_pick_(x, ssum, local):
+        p, ld, B, n = _HipOps._rows(x)
+        pa = torch.empty(B, device=x.device)
+        L.call("recnn_shard_softmax_pass", p, ld, B, n, 2, L.ptr(ssum), L.ptr(local), L.ptr(pa), L.current_stream())
+        return pa
+
+    @staticmethod
+    def logprob_bwd(probs, local, g):
+        p, ld, B, n = _HipOps._rows(probs)
+        ldd = (n + 63) // 64 * 64
+        buf = torch.empty(B, ldd, device=probs.device)
+        if ldd != n:
+            buf[:, n:].zero_()
+        L.call("recnn_shard_logprob_bwd", p, ld, B, n, L.ptr(local), L.ptr(g), L.ptr(buf), ldd, L.current_stream())
+        return buf[:, :n]
+
     @staticmethod
     def grad_w(dz, x):          # dz^T x : [N, K]
         from .nn import functional as Fh
@@ -391,12 +438,6 @@ class _HipOps:
         return out[:, :K]
 
 
-class _TorchOps:
-    linear = staticmethod(lambda x, w, b, relu: torch.relu(x @ w.t() + b) if relu else x @ w.t() + b)
-    grad_w = staticmethod(lambda dz, x: dz.t() @ x)
-    grad_x = staticmethod(lambda dz, w: dz @ w)
-
-
 class VocabParallelPolicyFunction(torch.autograd.Function):
     """(log_prob [B], probs_shard [B, n1 - n0]) of actions under softmax over the WHOLE catalogue; see the section header."""
 
@@ -404,16 +445,17 @@ class VocabParallelPolicyFunction(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2s, b2s, actions, n0, group, ops):
         h = ops.linear(x, w1, b1, True)
         logits = ops.linear(h, w2s, b2s, False)
-        m = logits.amax(1)
+        # the softmax over the WHOLE catalogue in three passes over this rank's shard (policy.hip shard_* kernels through `ops`; round 6:
+        # these were ATen amax / exp / sum / div / gather calls), the all-reduces between them are RCCL's
+        m = ops.rowmax(logits)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-        e = (logits - m[:, None]).exp_()
-        ssum = e.sum(1)
+        ssum = ops.exp_rowsum_(logits, m)                       # logits -> exp(logits - m), in place
         dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=group)
-        probs = e.div_(ssum[:, None])
         ns = w2s.shape[0]
-        local = actions.to(torch.int64) - n0
+        local = (actions.to(torch.int64) - n0).contiguous()
         own = (local >= 0) & (local < ns)
-        pa = torch.where(own, probs.gather(1, local.clamp(0, ns - 1)[:, None])[:, 0], torch.zeros_like(ssum))
+        pa = ops.norm_pick_(logits, ssum, local)                # ... -> this shard's probabilities, in place; p of the action if owned
+        probs = logits
         dist.all_reduce(pa, op=dist.ReduceOp.SUM, group=group)
         eps = torch.finfo(torch.float32).eps
         lp = pa.clamp(eps, 1 - eps).log()
@@ -427,10 +469,8 @@ class VocabParallelPolicyFunction(torch.autograd.Function):
     def backward(ctx, dlp, _dprobs):
         x, h, w1, w2s, probs, local, own, inside = ctx.saved_tensors
         ops = ctx.ops
-        g = dlp.float() * inside                                  # d log(clamp(p_a)) / d logit_j = [p_a inside] (delta_ja - p_j)
-        dlog = probs * (-g)[:, None]
-        rows = own.nonzero()[:, 0]
-        dlog[rows, local[rows]] += g[rows]
+        g = (dlp.float() * inside).contiguous()                   # d log(clamp(p_a)) / d logit_j = [p_a inside] (delta_ja - p_j)
+        dlog = ops.logprob_bwd(probs, local, g)                   # -g p (+ g at the owned action): policy.hip shard_logprob_bwd_kernel
         gw2 = ops.grad_w(dlog, h)
         gb2 = dlog.sum(0)
         dh = ops.grad_x(dlog, w2s).contiguous()

@@ -119,3 +119,34 @@ def x3_value(x):
     """what a split row holds for x: hi + lo (fp32)"""
     hi = x.float().bfloat16().float()
     return hi + (x.float() - hi).bfloat16().float()
+
+
+class TorchOps:
+    """Stand-in for recnn_amd.parallel._HipOps in the gloo tests on CPU (the vocab-parallel modules take `ops=`): the three
+    products in torch.  Test infrastructure -- the product package has no CPU implementation of its ops."""
+    import torch as _t
+    linear = staticmethod(lambda x, w, b, relu: TorchOps._t.relu(x @ w.t() + b) if relu else x @ w.t() + b)
+    grad_w = staticmethod(lambda dz, x: dz.t() @ x)
+    grad_x = staticmethod(lambda dz, w: dz @ w)
+    rowmax = staticmethod(lambda x: x.amax(1))
+
+    @staticmethod
+    def exp_rowsum_(x, m):
+        x.sub_(m[:, None]).exp_()
+        return x.sum(1)
+
+    @staticmethod
+    def norm_pick_(x, ssum, local):
+        x.div_(ssum[:, None])
+        ns = x.shape[1]
+        own = (local >= 0) & (local < ns)
+        t = TorchOps._t
+        return t.where(own, x.gather(1, local.clamp(0, ns - 1)[:, None])[:, 0], t.zeros_like(ssum))
+
+    @staticmethod
+    def logprob_bwd(probs, local, g):
+        dlog = probs * (-g)[:, None]
+        ns = probs.shape[1]
+        rows = ((local >= 0) & (local < ns)).nonzero()[:, 0]
+        dlog[rows, local[rows]] += g[rows]
+        return dlog

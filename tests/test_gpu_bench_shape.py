@@ -375,8 +375,13 @@ def test_td3_b4096_loss_curve_and_parameters_vs_oracle(cuda, dtype):
     # 1 % bound stays for BOTH types on everything that is not an Adam sign flip (measured: none -- every deviation is within 3.0 lr);
     # the flips are counted on their own: at most 1 % in fp32 (as before), 2 % in split bf16, whose pre-activations carry ~1e-5
     # instead of ~1e-7 of relative error and whose two critics train on min(Q1', Q2'), an argmin that flips with them.
+    # (in fp32 the two buckets share ONE 1 % budget -- a regression that moves many elements by < 3.5 lr must not pass on the
+    #  flip allowance; the separate 2 % flip budget is split bf16's only.)
     assert failed <= 0.01 * total, report
-    assert flips <= (0.01 if dtype == "fp32" else 0.02) * total, report
+    if dtype == "fp32":
+        assert failed + flips <= 0.01 * total, report
+    else:
+        assert flips <= 0.02 * total, report
     assert excluded <= 0.05 * total, report
     assert max_dev <= 20 * lr, report
     assert fro <= 1e-4, report

@@ -41,7 +41,8 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    from recnn_amd.parallel import VocabParallelDiscreteActor, _TorchOps
+    from recnn_amd.parallel import VocabParallelDiscreteActor
+    from tests.helpers import TorchOps as _TorchOps
     w1, b1, w2, b2, x, act, coef = _full()
     m = VocabParallelDiscreteActor(S, N, H, ops=_TorchOps)
     with torch.no_grad():
@@ -131,7 +132,8 @@ def _reinforce_worker(rank, world, port, q):
     import recnn_amd
     from recnn_amd.nn.update import reinforce as RU
     from recnn_amd.nn.update.reinforce import ChooseREINFORCE, reinforce_update
-    from recnn_amd.parallel import VocabParallelCritic, VocabParallelDiscreteActor, _TorchOps
+    from recnn_amd.parallel import VocabParallelCritic, VocabParallelDiscreteActor
+    from tests.helpers import TorchOps as _TorchOps
 
     def torch_soft_update(net, target, soft_tau=1e-2):       # the HIP soft-update kernel is GPU-only; this test checks the sharding
         with torch.no_grad():
