@@ -653,6 +653,61 @@ def main():
         samples = [float(x) for x in t.tolist()]
     elapsed = float(np.median(samples))
     losses = eng.losses()
+    collective_ab = None
+    if use_dp and world > 1 and not args.child_trace:
+        # ---- ONE run decides between the collectives: per-collective latency at the two gradient sizes, and the
+        # same data-parallel steps with the OTHER exchange (host-issued RCCL all-reduces between phase graphs), timed like the headline
+        single = bool(os.environ.get("RECNN_BENCH_SINGLE_DEVICE"))
+        n_ab = 6 if single else 200
+        collective_ab = {"steps": n_ab, "latency_us": {}}
+        with torch.cuda.stream(stream):
+            gpu_backend = dist.get_backend() == "nccl"
+
+            def rccl_all_reduce(t):
+                if gpu_backend:
+                    dist.all_reduce(t)
+                else:                       # gloo stand-in on a 1-GPU box: through the host
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+            for n_fl in (429_312, 858_496):              # ~ one network's gradient arena; two (the communicator's capacity for DDPG)
+                row = {}
+                for name, fn in (("peer", comm.all_reduce if comm is not None else None), ("rccl", rccl_all_reduce)):
+                    if fn is None:
+                        continue
+                    x = torch.randn((n_fl + 3) // 4 * 4, device=dev)
+                    for _ in range(2):
+                        fn(x)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3 if single else 20):
+                        fn(x)
+                    torch.cuda.synchronize(dev)
+                    row[name] = round((time.perf_counter() - t0) / (3 if single else 20) * 1e6, 2)
+                collective_ab["latency_us"][str(n_fl)] = row
+            if comm is not None:
+                comm.check()
+                # the other exchange: detach the device communicator, step the same engine through the host-collective path
+                eng.set_comm(None)
+                dp_b = DataParallelStepper(eng, rows, always_reduce=args.force_dp, overlap=False)
+                first = args.warmup + reps * args.steps
+                dp_b.run(first, 2)
+                barrier()
+                t0 = time.perf_counter()
+                dp_b.run(first + 2, n_ab)
+                barrier()
+                tb = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                collective_ab["rccl"] = {"ms_per_step": float(tb[0]) / n_ab * 1e3, "rank_steps_per_s": world * n_ab / float(tb[0])}
+                collective_ab["peer"] = {"ms_per_step": elapsed / args.steps * 1e3, "rank_steps_per_s": world * args.steps / elapsed,
+                                         "note": f"the headline's {args.steps}-step regions"}
+                collective_ab["faster"] = "peer" if collective_ab["peer"]["ms_per_step"] <= collective_ab["rccl"]["ms_per_step"] else "rccl"
+                comm = None
+            else:
+                collective_ab["rccl"] = {"ms_per_step": elapsed / args.steps * 1e3, "rank_steps_per_s": world * args.steps / elapsed,
+                                         "note": "the headline's regions (the peer collective was not available on every rank)"}
+        collective_ab["note"] = ("latency: host-timed back-to-back collectives incl. launch overhead; rates: weak scaling, MAX over ranks"
+                                 + ("; ranks share ONE GPU: functional only" if single else ""))
     if use_dp and comm is not None:
         # the per-launch profile below replays steps on rank 0 ONLY: with the communicator attached its collectives would wait
         # (4 s each, then report) for peers that are not stepping
@@ -701,7 +756,7 @@ def main():
                                              "host-issued all-reduces between phase graphs (torch.distributed backend above)"),
                                 "ranks_share_one_gpu": bool(os.environ.get("RECNN_BENCH_SINGLE_DEVICE")),
                                 "global_updates_per_s": args.steps / elapsed, "rank_steps_per_s": world * args.steps / elapsed,
-                                "preflight": preflight}
+                                "preflight": preflight, "collective_ab": collective_ab}
             if world > 1:
                 out["config"]["workload"] += (f"; N = {world}: value = rank-steps/s (every rank steps on its own {rows}-row batch, one gradient "
                                               "all-reduce per optimizer step), global_updates_per_s = synchronised updates/s")

@@ -39,6 +39,17 @@ def test_bench_two_ranks_on_one_gpu_prints_the_multi_gpu_record(cuda):
     assert pf is not None and set(pf["stages"]) >= {"devices", "process_group", "identity", "replicas"}, pf
     assert pf["stages"]["identity"] and pf["stages"]["replicas"], pf
     assert any('"stage": "summary"' in ln for ln in lines[:-1])
+    # round 6: the same run times BOTH exchanges -- per-collective latency at the critic's / TD3's gradient sizes and the data-parallel
+    # steps with the device collective (headline) and with host-issued all-reduces -- so that one SCALE run yields the decision
+    ab = mg["collective_ab"]
+    assert ab is not None and set(ab["latency_us"]) == {"429312", "858496"}, ab
+    for row in ab["latency_us"].values():
+        assert row["rccl"] > 0 and (mg["collective"].split()[0] != "peer" or row["peer"] > 0), ab
+    assert ab["rccl"]["ms_per_step"] > 0 and ab["rccl"]["rank_steps_per_s"] > 0
+    if mg["collective"].split()[0] == "peer":
+        assert ab["peer"]["ms_per_step"] > 0 and ab["faster"] in ("peer", "rccl") and ab["steps"] == 6
+    pf_votes = pf.get("peer_votes")
+    assert pf_votes is not None and len(pf_votes) == 2, pf            # the collective was chosen by a vote over the ranks
     assert all(abs(v) < 1e6 for v in out["config"]["final_losses"].values())
 
 
