@@ -761,7 +761,7 @@ def main():
                 out["config"]["workload"] += (f"; N = {world}: value = rank-steps/s (every rank steps on its own {rows}-row batch, one gradient "
                                               "all-reduce per optimizer step), global_updates_per_s = synchronised updates/s")
         # ---- per-launch times, measured live with HIP events around every launch (eager replays of the same steps on the stream
-        # the kernels run on), and the rooflines they imply.  Two schedules exist and agree bit for bit:
+        # the kernels run on), and the rooflines they imply.  Two schedules exist and agree bit for bit (profiles/NOTES_r01_r05.md 5c):
         #   "fused": one row-panel launch for all networks of a step (csrc/mlps.hip) -- eager steps and run graphs shorter than
         #            the cycle-mode threshold (20 steps since round 5; 30 before, when the driver's `--steps 20` replayed THIS one);
         #   "cycle": a policy cycle's batches gathered at once, the frozen networks applied to all of them (csrc/mlpf.hip), the

@@ -248,7 +248,7 @@ int check_ready(recnn_engine* e, int rows) {
 }
 
 // ---- per-engine tuning (include/recnn_hip.h recnn_engine_tuning): every field selects among schedules / tile shapes that
-// produce the same numbers.  What the measured-slower variants of earlier rounds taught is recorded in DESIGN.md 5c, not kept in
+// produce the same numbers.  What the measured-slower variants of earlier rounds taught is recorded in profiles/NOTES_r01_r05.md 5c, not kept in
 // the binary: the optimizer in the dW launch's epilogue (26.7 vs 18.7 us), an XCD-affine workgroup map of the fused forward
 // (-11 MB of HBM traffic, +6 us), the cycle gather on a side branch of the run graph (67.5 vs 61.5 us/step), the learning
 // critic's step forward as one fused launch in cycle mode (67.4 vs 65.1 us/step), padded leading dimensions (no effect).

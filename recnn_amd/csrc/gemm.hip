@@ -1416,7 +1416,7 @@ int x3_fwd_launch(GemmLaunch* L, hipStream_t stream) {
   }
   // Measured (DDPG, 2048 rows, 4 networks' layer 1 = 256 tiles of 64 x 128): 27.9 us with 16 waves, 29.4 with 8 (wave tile 32 x 32),
   // 31.5 as 1024 tiles of 32 x 64, 42.5 as 128 tiles of 128 x 128 -- the launch moves 290 MB (590 MB in the small tiling) through
-  // L2 -> LDS at 10-19 TB/s whatever the tile: what is left is the memory system, not the tile shape.
+  // L2 -> LDS at 10-19 TB/s whatever the tile: what is left is the memory system, not the tile shape (profiles/NOTES_r01_r05.md 5d).
   // Counters (profiles/r04_x3_pmc.txt): matrix cores 25 % busy, LDS array 25 % busy, no bank conflicts -- the time goes into ISSUING
   // the LDS-DMA (one 1 KB global_load_lds_dwordx4 ~ 60 clk of CU-serial issue: 48 per 64-k stage of this tile = 1440 clk per 32
   // logical k, 1680 observed).  Tried instead: every wave loading its own MFMA fragments straight from L2 into registers (16-byte

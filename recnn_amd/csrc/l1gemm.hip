@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
 template <int TM, int TN, int WM, int WN, int NS> constexpr int lds_bytes() { return NS * (16 * TM * WM + 16 * TN * WN) * 256; }
 }  // namespace
 
-// 16 waves as 4 x 4 everywhere (the more waves issue the DMAs, the closer a CU gets to its ~45 B/clk: DESIGN.md 5):
+// 16 waves as 4 x 4 everywhere (the more waves issue the DMAs, the closer a CU gets to its ~45 B/clk: profiles/NOTES_r01_r05.md 5):
 //   SMALL  64 x  64, wave tile 16 x 16, 4-slot ring (128 KB)      per-step launches
 //   BIG   128 x 128, wave tile 32 x 32, 2-slot ring (128 KB)      cycle-batched launches
 //   MID   128 x  64, wave tile 32 x 16, 3-slot ring (144 KB)      cycle-batched launches (tuning.l1_big = 2): no 2.5-round tail

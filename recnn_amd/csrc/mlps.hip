@@ -4,7 +4,7 @@
 // network application and all 256 hidden columns; recnn/nn/models.py:66-73 / :207-213 (cat + 3 x (addmm, relu, dropout)),
 // the chained target critics, the TD head and the critic's layer-2 backward tail (mlp.h).
 //
-// What differs is the SCHEDULE.  In-kernel traces of mlp.hip (tools/mlp_trace.py) showed a workgroup spending
+// What differs is the SCHEDULE.  In-kernel traces of mlp.hip (tools/mlp_trace.py, profiles/NOTES_r01_r05.md 5b) showed a workgroup spending
 // 7.6 us of its 30 in the layer-1 k loop and 18 us in the phases after it: every later phase issued its weights (64-128 KB)
 // as a burst when it began and then waited for the whole burst (0.6-1.2 us each, six of them on the target actor's chain),
 // although the weights of ALL phases are known at launch and a CU streams 102-111 GB/s back to back but only 70 GB/s as

@@ -1,7 +1,7 @@
 // split.h -- the split forward of the Actor / Critic MLPs (round 3): layer 1 as a full-machine tiled GEMM (l1gemm.hip), layers
 // 2 / 3, the TD head and the critic's layer-2 backward as a lean row-panel "tail" kernel (mlpt.hip).
 //
-// Why split: layer 1 is 84-87 % of a network's weight bytes.  The fused row-panel kernel (mlps.hip) streams ALL
+// Why split (profiles/NOTES_r01_r05.md 5c): layer 1 is 84-87 % of a network's weight bytes.  The fused row-panel kernel (mlps.hip) streams ALL
 // of them through every 32-row workgroup (1.0-1.2 MB per workgroup at ~45 B/clk per CU = the whole launch time), and at 2048
 // rows only a quarter to a half of the CUs have a workgroup of a given network.  A tiled layer-1 GEMM cuts N as well (64 x 64
 // tiles: 393 KB per workgroup, every CU busy), and what remains per 32-row panel is 128-192 KB of weights.  The frozen networks

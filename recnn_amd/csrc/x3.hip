@@ -9,7 +9,7 @@
 // fragments are read with gfx950's ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of a [4 k][16 cols]
 // block): a 16-column block of physical columns is all-hi or all-lo, so one logical 16 x 16 output block takes the hi and
 // the lo block of each operand and three MFMAs.  Tiles are staged through registers (two LDS buffers, one barrier per
-// 32-row k step): these launches are a small part of the step.
+// 32-row k step): these launches are a small part of the step (profiles/NOTES_r01_r05.md 5d).
 #include "gemm.h"
 #include "x3.h"
 
