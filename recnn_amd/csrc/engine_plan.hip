@@ -432,7 +432,10 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
   if (!value_side) return 0;
   // 16-row panels for the learning critics' tail (tuning.tail_half): whole 32-row pairs only, and the consumers of its panel sums must
   // be the pair-aware ones (the optimizer launches; not grad_reduce's callers that read gp[] directly -- there are none)
-  const bool half = e->tune.tail_half && value_bwd && rows % 32 == 0;
+  // ... and only while the launch still fits the machine in ONE round of workgroups (one 152 KB workgroup per CU): 2 nc (rows / 32) half panels
+  // + rows / 32 panels of the deferred policy-loss critic <= 256.  DDPG at 2048 rows: 192 (53.9 vs 57.3 us/step); TD3 at 4096 rows would be
+  // 640 -- measured 130.5 vs 124.1 us/step with 32-row panels (profiles/NOTES_r06.md)
+  const bool half = e->tune.tail_half && value_bwd && rows % 32 == 0 && (2 * nc + 1) * (rows / 32) <= 256;
   if (!frozen_done) {  // ---- target critics on [next_state | next_action]: state part first, then the action columns (mlps.hip's chained order)
     L1Batch lb;
     TailBatch tb;
