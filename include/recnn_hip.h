@@ -580,7 +580,9 @@ typedef struct recnn_engine_tuning {
                                0: dW launch + optimizer launch.  Bit-identical results */
   int tail_half;            /* 1 (default): the learning critic's tail launch (csrc/mlpt.hip) runs 16-row panels -- twice the workgroups, half the
                                per-workgroup epilogue work (its phases are bound by the CU's vector issue); 0: 32-row panels.  Bit-identical */
-  int reserved[5];
+  int l1_ws;                /* 1: the per-step layer-1 GEMM (csrc/l1gemm.hip, 64 x 64 tiles) runs with 4 loader + 8 consumer waves; 0: all 16 waves
+                               load and multiply.  Bit-identical */
+  int reserved[4];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -268,7 +268,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1; t->tail_half = 1;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1; t->tail_half = 1; t->l1_ws = 1;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -408,7 +408,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
     double fl = 0;
     if (value_side) { fill_l1(e, &lb.p[np++], TPOL, rows, e->xcn + aoff, e->ldx, e->K1a, 0, e->tp.h1, -1, e->run_off); fl += l1_fl_a; }
     if (actor_side) { fill_l1(e, &lb.p[np++], POL, rows, e->xcs + aoff, e->ldx, e->K1a, 0, e->pa.h1, actor_m1, e->run_off); fl += l1_fl_a; }
-    if (np && (rc = slot(e, "l1_actors", fl, s, [&] { return l1gemm_launch(lb, np, 0, s); }))) return rc;
+    if (np && (rc = slot(e, "l1_actors", fl, s, [&] { return l1gemm_launch(lb, np, 0, s, e->tune.l1_ws); }))) return rc;
     TailBatch tb;
     np = 0; fl = 0;
     if (value_side) {   // next_action into the action slot of the packed next rows (+ TD3's clipped noise, td3.py:74-78)
@@ -447,7 +447,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
       tb.p[c].q = e->tqv[c];
       fl += l1_fl_c; tfl += t_fl_c;
     }
-    if ((rc = slot(e, "l1_target_critic", fl, s, [&] { return l1gemm_launch(lb, nc, 0, s); }))) return rc;
+    if ((rc = slot(e, "l1_target_critic", fl, s, [&] { return l1gemm_launch(lb, nc, 0, s, e->tune.l1_ws); }))) return rc;
     if ((rc = slot(e, "tail_target_critic", tfl, s, [&] { return mlpt_launch(tb, nc, s); }))) return rc;
   }
   {  // ---- learning critics (+ the previous step's policy-loss forward riding along: same weights, the previous batch)
@@ -489,7 +489,7 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
       fl += l1_fl_c; tfl += t_fl_c;
       e->pending_pc.on = false;
     }
-    if ((rc = slot(e, "l1_critic", fl, s, [&] { return l1gemm_launch(lb, np, 0, s); }))) return rc;
+    if ((rc = slot(e, "l1_critic", fl, s, [&] { return l1gemm_launch(lb, np, 0, s, e->tune.l1_ws); }))) return rc;
     if ((rc = slot(e, "tail_critic", tfl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
   }
   e->panel_bwd_done = true;     // dz2 / dz1 (already times the per-row loss seed) and the small tensors' panel sums exist

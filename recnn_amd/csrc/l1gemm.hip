@@ -194,6 +194,140 @@ __global__ __launch_bounds__(WM * WN * 64) void l1_gemm_kernel(const L1Batch bat
 }
 
 template <int TM, int TN, int WM, int WN, int NS> constexpr int lds_bytes() { return NS * (16 * TM * WM + 16 * TN * WN) * 256; }
+
+// ---- the 64 x 64 per-step tile with the waves' roles split (round 6; gemm.hip x3_fwd_ws_kernel's scheme): NL = 4 LOADER waves do nothing
+// but issue the ring's LDS-DMA (8 instructions of 1 KB per 32 KB stage each, lane offsets precomputed, vmcnt-counted), 8 CONSUMER waves
+// (2 x 4, wave tile 32 x 16) read fragments and multiply -- the fragment reads of a whole 128-k stage are issued ahead of its MFMAs.
+// One s_barrier per stage for all twelve waves; loaders leave after the last.  Same LDS image, same k order per accumulator, same
+// epilogue as l1_gemm_kernel<L1_SMALL>: bit-identical (tests/test_gpu_split.py runs under both).
+constexpr int WS_NL = 4, WS_NC = 8, WS_NS = 4, WS_BM = 64, WS_BN = 64, WS_STAGE = (WS_BM + WS_BN) * 256;
+__global__ __launch_bounds__((WS_NL + WS_NC) * 64) void l1_gemm_ws_kernel(const L1Batch batch) {
+  kernarg_prefetch<(int)sizeof(L1Prob)>((int)(blockIdx.y * sizeof(L1Prob)));
+  constexpr int KB = 128, D = WS_NS - 1;
+  constexpr int PER = (WS_BM + WS_BN) / 4 / WS_NL;         // DMA instructions per loader wave and stage (4 rows each): 8
+  const L1Prob& P = batch.p[blockIdx.y];
+  const int nwg = P.tiles_m * P.tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tile_n = lid % P.tiles_n, tile_m = lid / P.tiles_n;
+  const int m0 = tile_m * WS_BM, n0 = tile_n * WS_BN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+  const unsigned lds0 = (unsigned)(size_t)dsmem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt0 = P.K[0] / KB;
+  const int nt = nt0 + (P.nseg > 1 ? P.K[1] / KB : 0);
+
+  if (wave >= WS_NC) {
+    // ------------------------------------------------------------ loader wave lw: stage rows (j * NL + lw) * 4 .. + 3, j < PER
+    const int lw = wave - WS_NC;
+    const int q_row = lane >> 4, q_pos = lane & 15;
+    unsigned voff[PER];
+    auto lane_offsets = [&](int sidx) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int srow = (j * WS_NL + lw) * 4 + q_row;     // row of the [A tile | W tile] stage image
+        const bool isa = srow < WS_BM;
+        const int row = isa ? srow : srow - WS_BM;
+        voff[j] = isa ? (unsigned)(min(m0 + row, P.rows - 1) * (int)P.lda[sidx] * 2 + ((q_pos ^ (row & 15)) << 4))
+                      : (unsigned)((n0 + row) * (int)P.ldw1 * 2 + ((q_pos ^ (row & 15)) << 4));
+      }
+    };
+    lane_offsets(0);
+    const char* sa_ptr = (const char*)P.A[0];
+    const char* sw_ptr = (const char*)P.W1 + (int64_t)P.w1_col[0] * 2;
+    int issued = 0;
+    auto issue = [&](int stage) {
+      if (issued == nt0) {
+        lane_offsets(1);
+        sa_ptr = (const char*)P.A[1];
+        sw_ptr = (const char*)P.W1 + (int64_t)P.w1_col[1] * 2;
+      }
+      ++issued;
+      const unsigned sbase = lds0 + stage * WS_STAGE + lw * 1024;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const bool isa = (j * WS_NL + lw) * 4 < WS_BM;      // (uniform per instruction: 4-row groups never straddle the A / W boundary)
+        dma_s(voff[j], isa ? sa_ptr : sw_ptr, sbase + j * (WS_NL * 1024));
+      }
+      sa_ptr += 256;
+      sw_ptr += 256;
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < nt) issue(i);
+    for (int t = 0; t < nt; ++t) {
+      const int younger = min(D - 1, nt - 1 - t);
+      if (younger >= 2) wait_vm_const<2 * PER>();
+      else if (younger == 1) wait_vm_const<PER>();
+      else wait_vm_const<0>();
+      __builtin_amdgcn_s_barrier();                // this wave's part of stage t has landed; the consumers are done with stage t - 1
+      if (t + D < nt) issue((t + D) % WS_NS);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------- consumer wave: rows 32 (wave / 4) .. + 31, columns 16 (wave % 4) .. + 15
+  const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 16;
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // everything the epilogue reads from global memory is requested now (consumers issue no DMA: no vmcnt bookkeeping to disturb)
+  const int nb = n0 + wn0 + fg * 4;
+  const f32x4 bias = (nb + 3 < P.H) ? *(const f32x4*)(P.b1 + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+  int32_t step_now = 0;
+  if (P.mask_mode == RECNN_MASK_HASH && P.step_ptr) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(step_now) : "s"(P.step_ptr));
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's reads of stage t - 1 have returned: its slot may be refilled)
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sa = dsmem + (t % WS_NS) * WS_STAGE;
+    const unsigned char* sb = sa + WS_BM * 256;
+    uint4 a0[4], a1[4], b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int pos = ((ks * 4 + fg) ^ fr) * 16;
+      a0[ks] = *(const uint4*)(sa + (wm0 + fr) * 256 + pos);
+      a1[ks] = *(const uint4*)(sa + (wm0 + 16 + fr) * 256 + pos);
+      b[ks] = *(const uint4*)(sb + (wn0 + fr) * 256 + pos);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[ks]), __builtin_bit_cast(bf16x8, a0[ks]), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[ks]), __builtin_bit_cast(bf16x8, a1[ks]), acc[1], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(step_now));
+  const int32_t step0 = step_now + P.step_add;
+  // ---- epilogue (l1_gemm_kernel's, per 16 x 16 block): acc[tm][r] = C[row m0 + wm0 + 16 tm + fr][column nb + r]
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int m = m0 + wm0 + tm * 16 + fr;
+    int mrow = m;
+    uint32_t key = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) {
+      int set = 0;
+      if (P.rows_per_set > 0) { set = m / P.rows_per_set; mrow = m - set * P.rows_per_set; }
+      key = mask_key(P.seed, step0 + set, P.stream);
+    }
+    uint32_t word = 0;
+    if (P.mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(mrow >> 2), (uint32_t)(nb >> 2));
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = acc[tm][r] + bias[r];
+      if (!P.no_relu) v[r] = fmaxf(v[r], 0.f);
+      if (P.addend && m < P.rows && nb + r < P.H) {
+        const float z = P.addend[(int64_t)m * P.ld_add + nb + r];
+        v[r] += fminf(fmaxf(z, -P.add_clip), P.add_clip);
+      }
+      if (P.mask_mode == RECNN_MASK_EXTERNAL) v[r] = (m < P.rows && nb + r < P.H && P.mask[(int64_t)m * P.ld_mask + nb + r]) ? v[r] * 2.f : 0.f;
+      else if (P.mask_mode == RECNN_MASK_HASH) v[r] = mask_keep(word, mrow & 3, r) ? v[r] * 2.f : 0.f;
+      if (nb + r >= P.H) v[r] = 0.f;
+    }
+    if (m < P.rows) *(uint2*)((bf16_t*)P.h1 + (int64_t)m * P.ldh + nb) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
 }  // namespace
 
 // 16 waves as 4 x 4 everywhere (the more waves issue the DMAs, the closer a CU gets to its ~45 B/clk: profiles/NOTES_r01_r05.md 5):
@@ -211,10 +345,11 @@ int l1gemm_init() {
   int rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_SMALL>()), "l1gemm attr");
   if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_BIG>()), "l1gemm attr");
   if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_kernel<L1_MID>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<L1_MID>()), "l1gemm attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)l1_gemm_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_NS * WS_STAGE), "l1gemm ws attr");
   return rc;
 }
 
-int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s) {
+int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s, int ws) {
   RECNN_REQUIRE(nprob >= 1 && nprob <= L1_MAX_GROUP, "l1gemm: 1..%d problems per launch", L1_MAX_GROUP);
   const int shape = big == 2 ? 2 : (big ? 1 : 0);   // 0: 64 x 64 per-step tiles, 1: 128 x 128, 2: 128 x 64 (cycle-batched launches)
   const int BM = shape ? 128 : 64, BN = shape == 1 ? 128 : 64;
@@ -237,6 +372,7 @@ int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s) {
   const dim3 grid(maxwg, nprob), block(1024);
   if (shape == 1) hipLaunchKernelGGL((l1_gemm_kernel<L1_BIG>), grid, block, (lds_bytes<L1_BIG>()), s, b, g_l1_trace);
   else if (shape == 2) hipLaunchKernelGGL((l1_gemm_kernel<L1_MID>), grid, block, (lds_bytes<L1_MID>()), s, b, g_l1_trace);
+  else if (ws && !g_l1_trace) hipLaunchKernelGGL(l1_gemm_ws_kernel, grid, dim3((WS_NL + WS_NC) * 64), WS_NS * WS_STAGE, s, b);
   else hipLaunchKernelGGL((l1_gemm_kernel<L1_SMALL>), grid, block, (lds_bytes<L1_SMALL>()), s, b, g_l1_trace);
   return recnn_check_hip(hipGetLastError(), "l1_gemm_kernel");
 }

@@ -49,7 +49,7 @@ struct L1Batch { L1Prob p[L1_MAX_GROUP]; };
 
 int l1gemm_init();
 // big = 0: 64 x 64 tiles (per-step launches, M ~ 2048-8192); 1: 128 x 128 tiles (cycle-batched launches, M >= 16k)
-int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s);
+int l1gemm_launch(L1Batch& b, int nprob, int big, hipStream_t s, int ws = 0);   // ws: the 64 x 64 tile with loader / consumer waves
 
 // ---------------------------------------------------------------------------------------------- tail
 enum { TAIL_ACTOR = 0, TAIL_CRITIC_Q = 1, TAIL_CRITIC_LEARN = 2 };
