@@ -1,6 +1,7 @@
 // mlp_panel.h -- pieces shared by the fused row-panel forward kernels (mlp.hip, mlps.hip): the LDS-DMA primitive, the
 // 32 x 256 bf16 activation panel (the next layer's A operand) and the hidden-layer epilogue that fills it.
 #pragma once
+#include <type_traits>
 #include "mlp.h"
 
 namespace {
@@ -33,9 +34,10 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x
     // panel image: k half (n / 128), row, chunk ((n % 128) / 8) ^ (row & 15), element n % 8
     unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
     const int c = (n0 & 127) >> 3;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      if (tm == 1 && !two) break;
+    // (row blocks as compile-time constants; the second one under a uniform branch: a loop that breaks on the run-time flag would not
+    //  be unrolled and its accumulator indexing would turn into select chains)
+    auto row_block = [&](auto TMc) {
+      constexpr int tm = decltype(TMc)::value;
       const int row = tm * 16 + fr, m = m0 + row;
       uint32_t word = 0;
       if (mask_mode == RECNN_MASK_HASH) word = mask_word(key, (uint32_t)(m >> 2), (uint32_t)(n0 >> 2));
@@ -54,7 +56,9 @@ __device__ __forceinline__ void hidden_epilogue(f32x4 (&acc)[2][TNH], const f32x
       if (hi & 0x7FFFu) bits |= 1u << (tn * 8 + tm * 4 + 2);
       if (hi & 0x7FFF0000u) bits |= 1u << (tn * 8 + tm * 4 + 3);
       *(uint2*)(col + row * 256 + ((c ^ fr) << 4)) = make_uint2(lo, hi);   // row & 15 == fr
-    }
+    };
+    row_block(std::integral_constant<int, 0>{});
+    if (two) row_block(std::integral_constant<int, 1>{});
   }
   if (gbits) *gbits = bits;
 }

@@ -17,6 +17,7 @@
 // Rounding matches the path it replaces (unit tensor rounded to bf16, times d, rounded again), so the weight gradients of
 // W1 / W2 are bit-identical to mlps.hip + the scaling dW kernel (tests/test_gpu_split.py).
 #include <cstddef>
+#include <type_traits>
 #include "mlp_panel.h"
 #include "split.h"
 
@@ -132,7 +133,15 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   const int PR = two ? BM : BM / 2;
   const int m0 = blockIdx.x * PR;
   if (m0 >= P.rows) return;
-  unsigned long long* trow = (trace && threadIdx.x == 0) ? trace + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  // (bit 0 of the trace pointer: stamps from lane 0 of EVERY wave -- [workgroup][16 waves][16] -- to see the skew the barriers absorb)
+  const bool tr_waves = ((uintptr_t)trace & 1) != 0;
+  unsigned long long* const tbase = (unsigned long long*)((uintptr_t)trace & ~(uintptr_t)1);
+  unsigned long long* trow = nullptr;
+  if (tbase) {
+    const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (tr_waves) { if ((threadIdx.x & 63) == 0) trow = tbase + (wg * 16 + (threadIdx.x >> 6)) * 16; }
+    else if (threadIdx.x == 0) trow = tbase + wg * 16;
+  }
   asm volatile("" : "+v"(trow));
   MLPT_STAMP(0);
   // pull the kernel-argument cache lines of this workgroup's problem into the scalar cache NOW, all in flight together (a first
@@ -254,16 +263,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     if (q == 0) MLPT_STAMP(1);
     if (actor && q >= 1 && q <= 2) issue_w3(q - 1);   // W2's slab q - 1 is done with: W3's slab q - 1 takes its stage
     if (q == 0 && learn) {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        if (tm == 1 && !two) break;
+      // (row blocks as compile-time constants: a loop that BREAKS on a run-time flag is not unrolled, and indexing registers with its
+      //  counter becomes select chains -- the U epilogue below spent 2-3k clocks that way until it was written like this)
+      auto gate_block = [&](auto TMc) {
+        constexpr int tm = decltype(TMc)::value;
         const int row = tm * 16 + fr;
         const uint2 hv = *(const uint2*)(panel + (n0 >> 7) * PANEL_HALF + row * 256 + ((((n0 & 127) >> 3) ^ (row & 15)) << 4) + (n0 & 7) * 2);
         if (hv.x & 0x7FFFu) gate1 |= 1u << (tm * 4 + 0);
         if (hv.x & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 1);
         if (hv.y & 0x7FFFu) gate1 |= 1u << (tm * 4 + 2);
         if (hv.y & 0x7FFF0000u) gate1 |= 1u << (tm * 4 + 3);
-      }
+      };
+      gate_block(std::integral_constant<int, 0>{});
+      if (two) gate_block(std::integral_constant<int, 1>{});
     }
     if (actor) mma_panel(panel, q, lds + q * W_BYTES, acc, wave * 16, fr, fg, true);
   }
@@ -349,22 +361,20 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   // sums and u2 cells -> barrier, each phase a latency chain of its own): the q dots' operands, the 8 values of this thread's column for the
   // d-weighted column sums (kept in registers until d exists), and the thread's u2 cell, which needs no d at all -- u2 = w3 scale [h2 > 0]
   // and U = (u2 W2) scale gate(h1) are UNIT tensors, only their d multiples and the column sums wait for the head.
-  float sdot[RW];
-#pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    // both rows of the wave side by side (two independent load -> dot -> reduction chains); Q and the loss seed reach global
-    // memory after the rendezvous below, as two 128-byte stores, instead of one 4-byte store per row from here
-    // (16-row panel: one row per wave)
-    if (i == 1 && !two) { sdot[1] = 0.f; break; }
-    const int row = two ? wave * RW + i : wave;
+  // both rows of the wave side by side (two independent load -> dot -> reduction chains); Q and the loss seed reach global
+  // memory after the rendezvous below, as two 128-byte stores, instead of one 4-byte store per row from here
+  // (16-row panel: one row per wave)
+  auto qdot_row = [&](const int row) -> float {
     const int c = ((((lane * 4) & 127) >> 3) ^ (row & 15));
     const uint2 hv = *(const uint2*)(panel + ((lane * 4) >> 7) * PANEL_HALF + row * 256 + c * 16 + ((lane * 4) & 7) * 2);
     const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
     float sd = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) sd += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
-    sdot[i] = sd;
-  }
+    return sd;
+  };
+  float sdot0 = qdot_row(two ? wave * RW : wave), sdot1 = 0.f;
+  if (two) sdot1 = qdot_row(wave * RW + 1);
   float hc[8];                                  // h2[rows 8 cc .. 8 cc + 7][column ck]
   uint4 packed = make_uint4(0u, 0u, 0u, 0u);    // this thread's u2 cell (row lane & 31, columns n8 .. n8 + 7), rounded to bf16
   unsigned char* cell = panel + (n8 >> 7) * PANEL_HALF + crow * 256 + ((((n8 & 127) >> 3) ^ (crow & 15)) * 16);
@@ -386,14 +396,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     }
     packed = make_uint4(pack_bf2(uz[0], uz[1]), pack_bf2(uz[2], uz[3]), pack_bf2(uz[4], uz[5]), pack_bf2(uz[6], uz[7]));
   }
-  sdot[0] = wave_sum(sdot[0]);
-  if (two) sdot[1] = wave_sum(sdot[1]);
+  sdot0 = wave_sum(sdot0);
+  if (two) sdot1 = wave_sum(sdot1);
   if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      if (i == 1 && !two) break;
-      const int row = two ? wave * RW + i : wave;
-      const float qv = sdot[i] + b3s;
+    auto head_row = [&](const int row, const float sd) {
+      const float qv = sd + b3s;
       const bool valid = m0 + row < P.rows;
       qs[row] = qv;
       if (learn) {
@@ -401,7 +408,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
         es[row] = e;
         ds[row] = e * (2.0f / (float)P.rows);
       }
-    }
+    };
+    head_row(two ? wave * RW : wave, sdot0);
+    if (two) head_row(wave * RW + 1, sdot1);
   }
   if (!learn) {
     __syncthreads();
@@ -489,19 +498,24 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   {
     unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
     const int c = (n0 & 127) >> 3;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      if (tm == 1 && !two) break;
+    const float uscale = P.scale;
+    const int Hc = P.H, nrows = P.rows;
+    bf16_t* const dz1 = (bf16_t*)P.dz1;
+    const int64_t ldh = P.ldh;
+    auto u_block = [&](auto TMc) {
+      constexpr int tm = decltype(TMc)::value;
       const int row = tm * 16 + fr, mm = m0 + row;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (((gate1 >> (tm * 4 + r)) & 1u) && n0 + r < P.H) ? dacc[tm][r] * P.scale : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = (((gate1 >> (tm * 4 + r)) & 1u) && n0 + r < Hc) ? dacc[tm][r] * uscale : 0.f;
       const uint32_t lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);          // unit U, rounded to bf16
       *(uint2*)(col + row * 256 + ((c ^ fr) << 4)) = make_uint2(lo, hi);             // panel image (db1 sums)
       const float d = ds[row];
       const float z[4] = {bf2f((bf16_t)(lo & 0xFFFFu)) * d, bf2f((bf16_t)(lo >> 16)) * d, bf2f((bf16_t)(hi & 0xFFFFu)) * d, bf2f((bf16_t)(hi >> 16)) * d};
-      if (mm < P.rows) *(uint2*)((bf16_t*)P.dz1 + (int64_t)mm * P.ldh + n0) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
-    }
+      if (mm < nrows) *(uint2*)(dz1 + (int64_t)mm * ldh + n0) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
+    };
+    u_block(std::integral_constant<int, 0>{});
+    if (two) u_block(std::integral_constant<int, 1>{});
   }
   MLPT_STAMP(9);
   if (P.db1_part) {                             // db1[k] = sum_r d_r U[r][k], same four-chunk order
