@@ -344,19 +344,29 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     return;
   }
 
+  // ---- the problem's fields this path reads from here on, ONCE, into scalar registers (round 6: read at their use sites each was an
+  // s_load + s_waitcnt lgkmcnt(0) in the middle of a phase -- and lgkmcnt also counts the phase's LDS reads: 9 loads / 15 waits in the
+  // column-sum phase alone)
+  const int kH = P.H, kRows = P.rows, kNTarget = P.n_target;
+  const float kScale = P.scale, kGamma = P.gamma, kLo = P.lo, kHi = P.hi;
+  const int64_t kLdh = P.ldh;
+  float* const kQ = P.q; float* const kDelta = P.delta_out; float* const kExpected = P.expected; float* const kTargetQ = P.target_q;
+  float* const kLossPart = P.loss_part; float* const kDb3 = P.db3_part; float* const kDw3 = P.dw3_part; float* const kDb2 = P.db2_part;
+  float* const kDb1 = P.db1_part;
+  void* const kDz2 = P.dz2; void* const kDz1 = P.dz1; void* const kH2 = P.h2;
   // ------------------------------------------------------------------ critic head: q[m] = h2[m, :] . w3 + b3
   // The TD target needs nothing this workgroup computes (Q' came with the kernel's inputs): wave 0 evaluates it while the
   // h2 panel is being completed, so a row's TD error and loss seed are one subtraction away from its q dot.
-  const float h_tq = P.n_target > 1 ? fminf(h_tq0, h_tq1) : h_tq0;
+  const float h_tq = kNTarget > 1 ? fminf(h_tq0, h_tq1) : h_tq0;
   if (learn && wave == 0 && lane < PR) {
-    float y = h_rew + (1.0f - h_done) * P.gamma * h_tq;
-    y = fminf(fmaxf(y, P.lo), P.hi);
+    float y = h_rew + (1.0f - h_done) * kGamma * h_tq;
+    y = fminf(fmaxf(y, kLo), kHi);
     ys[lane] = y;
   }
   MLPT_STAMP(3);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // h2 panel complete (and the TD targets are in LDS)
-  if (P.h2) panel_to_global<NW>(panel, (bf16_t*)P.h2, P.ldh, m0, min(P.rows, m0 + PR), tid);
+  if (kH2) panel_to_global<NW>(panel, (bf16_t*)kH2, kLdh, m0, min(kRows, m0 + PR), tid);
   // ---- everything that reads h2 happens HERE, in one burst of LDS reads behind one barrier (round 6; before: q dots -> barrier -> column
   // sums and u2 cells -> barrier, each phase a latency chain of its own): the q dots' operands, the 8 values of this thread's column for the
   // d-weighted column sums (kept in registers until d exists), and the thread's u2 cell, which needs no d at all -- u2 = w3 scale [h2 > 0]
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     const float hf[4] = {bf2f((bf16_t)(hv.x & 0xFFFFu)), bf2f((bf16_t)(hv.x >> 16)), bf2f((bf16_t)(hv.y & 0xFFFFu)), bf2f((bf16_t)(hv.y >> 16))};
     float sd = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sd += lane * 4 + j < P.H ? hf[j] * v3[j] : 0.f;
+    for (int j = 0; j < 4; ++j) sd += lane * 4 + j < kH ? hf[j] * v3[j] : 0.f;
     return sd;
   };
   float sdot0 = qdot_row(two ? wave * RW : wave), sdot1 = 0.f;
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   if (learn && cell_on) {
     const uint4 raw = *(const uint4*)cell;
     const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-    const float wsc = n8 < P.H ? P.scale : 0.f;
+    const float wsc = n8 < kH ? kScale : 0.f;
     const float w3s[8] = {w3a.x * wsc, w3a.y * wsc, w3a.z * wsc, w3a.w * wsc, w3b.x * wsc, w3b.y * wsc, w3b.z * wsc, w3b.w * wsc};
     float uz[8];
 #pragma unroll
@@ -401,12 +411,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   if (lane == 0) {
     auto head_row = [&](const int row, const float sd) {
       const float qv = sd + b3s;
-      const bool valid = m0 + row < P.rows;
+      const bool valid = m0 + row < kRows;
       qs[row] = qv;
       if (learn) {
         const float e = valid ? qv - ys[row] : 0.f;
         es[row] = e;
-        ds[row] = e * (2.0f / (float)P.rows);
+        ds[row] = e * (2.0f / (float)kRows);
       }
     };
     head_row(two ? wave * RW : wave, sdot0);
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   }
   if (!learn) {
     __syncthreads();
-    if (tid < PR && m0 + tid < P.rows && P.q) P.q[m0 + tid] = qs[tid];
+    if (tid < PR && m0 + tid < kRows && kQ) kQ[m0 + tid] = qs[tid];
     MLPT_STAMP(4);
     return;
   }
@@ -423,26 +433,26 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   __builtin_amdgcn_s_barrier();                 // e and d of all 32 rows are in LDS; every thread has read the h2 values it needs
   MLPT_STAMP(5);
   if (cell_on) *(uint4*)cell = packed;          // the u2 panel (the A operand of the next product) takes h2's place
-  if (wave == 1 && lane < PR && m0 + lane < P.rows) {       // (wave 0 has the loss sums)
-    if (P.q) P.q[m0 + lane] = qs[lane];
-    if (P.delta_out) P.delta_out[m0 + lane] = ds[lane];
+  if (wave == 1 && lane < PR && m0 + lane < kRows) {       // (wave 0 has the loss sums)
+    if (kQ) kQ[m0 + lane] = qs[lane];
+    if (kDelta) kDelta[m0 + lane] = ds[lane];
   }
 
   // ---- loss partial sums (wave 0, off everybody else's path): sum (q - y)^2 and sum d over the panel, lanes 0..31 = rows
   if (wave == 0) {
     const int r = lane & 31, m = m0 + r;
-    const bool valid = lane < PR && m < P.rows;
+    const bool valid = lane < PR && m < kRows;
     const float e = lane < PR ? es[r] : 0.f;
     const float d = lane < PR ? ds[r] : 0.f;
     if (valid) {
-      if (P.expected) P.expected[m] = ys[r];
-      if (P.target_q) P.target_q[m] = h_tq;
+      if (kExpected) kExpected[m] = ys[r];
+      if (kTargetQ) kTargetQ[m] = h_tq;
     }
     const float tot = wave_sum(e * e);
     const float dsum = wave_sum(d);
     if (lane == 0) {
-      if (P.loss_part) P.loss_part[blockIdx.x] = tot;
-      if (P.db3_part) P.db3_part[blockIdx.x] = dsum;
+      if (kLossPart) kLossPart[blockIdx.x] = tot;
+      if (kDb3) kDb3[blockIdx.x] = dsum;
     }
   }
   // ---- dz2 = d * u2 to global (the ROUNDED unit value times d)
@@ -453,13 +463,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     float dz[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) dz[j] = bf2f((bf16_t)((pu[j >> 1] >> ((j & 1) * 16)) & 0xFFFF)) * d;
-    if (m < P.rows)
-      *(uint4*)((bf16_t*)P.dz2 + (int64_t)m * P.ldh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
+    if (m < kRows)
+      *(uint4*)((bf16_t*)kDz2 + (int64_t)m * kLdh + n8) = make_uint4(pack_bf2(dz[0], dz[1]), pack_bf2(dz[2], dz[3]), pack_bf2(dz[4], dz[5]), pack_bf2(dz[6], dz[7]));
   }
   // ---- column sums over the panel's rows, four row chunks of 8 per column (thread = (chunk, column)), fma chains upwards:
   //   dw3[k] = sum_r d_r h2[r][k]         db2[k] = sum_r d_r u2[r][k],  u2 = bf16(w3[k] scale) where h2 > 0
-  if (P.dw3_part && ck < P.H && col_on) {
-    const float u = bf2f(f2bf(w3c * P.scale));
+  if (kDw3 && ck < kH && col_on) {
+    const float u = bf2f(f2bf(w3c * kScale));
     float s3 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -474,10 +484,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                 // u2 panel complete, the column partials are in LDS
   MLPT_STAMP(7);
-  if (P.dw3_part && tid < P.H) {
+  if (kDw3 && tid < kH) {
     // (16-row panel: the sum of ITS two chunks; the consumer adds the two halves of a 32-row panel first -- optim_dev.h slab_grads, pair)
-    P.dw3_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
-    P.db2_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[1024 + tid] + colp[1280 + tid]) + (colp[1536 + tid] + colp[1792 + tid]) : colp[1024 + tid] + colp[1280 + tid];
+    kDw3[(int64_t)blockIdx.x * kH + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
+    kDb2[(int64_t)blockIdx.x * kH + tid] = two ? (colp[1024 + tid] + colp[1280 + tid]) + (colp[1536 + tid] + colp[1792 + tid]) : colp[1024 + tid] + colp[1280 + tid];
   }
 
   // ---- U = (u2 W2) * scale * gate(h1): W2's four k-slabs are still in stages 0..3: k-slab q holds in-columns 64 q .. 64 q + 63,
@@ -498,10 +508,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
   {
     unsigned char* col = panel + (n0 >> 7) * PANEL_HALF + (n0 & 7) * 2;
     const int c = (n0 & 127) >> 3;
-    const float uscale = P.scale;
-    const int Hc = P.H, nrows = P.rows;
-    bf16_t* const dz1 = (bf16_t*)P.dz1;
-    const int64_t ldh = P.ldh;
+    const float uscale = kScale;
+    const int Hc = kH, nrows = kRows;
+    bf16_t* const dz1 = (bf16_t*)kDz1;
+    const int64_t ldh = kLdh;
     auto u_block = [&](auto TMc) {
       constexpr int tm = decltype(TMc)::value;
       const int row = tm * 16 + fr, mm = m0 + row;
@@ -518,16 +528,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_tail_kernel(const TailBatch batch
     if (two) u_block(std::integral_constant<int, 1>{});
   }
   MLPT_STAMP(9);
-  if (P.db1_part) {                             // db1[k] = sum_r d_r U[r][k], same four-chunk order
+  if (kDb1) {                             // db1[k] = sum_r d_r U[r][k], same four-chunk order
     __syncthreads();                            // U panel complete
-    if (ck < P.H && col_on) {
+    if (ck < kH && col_on) {
       float s1 = 0.f;
 #pragma unroll
       for (int r = cc * 8; r < cc * 8 + 8; ++r) s1 = fmaf(ds[r], panel_at(panel, r, ck), s1);
       colp[cc * 256 + ck] = s1;
     }
     __syncthreads();
-    if (tid < P.H) P.db1_part[(int64_t)blockIdx.x * P.H + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
+    if (tid < kH) kDb1[(int64_t)blockIdx.x * kH + tid] = two ? (colp[tid] + colp[256 + tid]) + (colp[512 + tid] + colp[768 + tid]) : colp[tid] + colp[256 + tid];
   }
   MLPT_STAMP(10);
 }
