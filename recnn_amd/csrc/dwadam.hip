@@ -148,6 +148,24 @@ __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& 
     e[h].v = *(const float2*)(a.v + idx[h]);
     e[h].tp = *(const float2*)(tsrc + idx[h]);
   }
+  // everything the epilogue reads from the kernel-argument block, ONCE, into registers (read at their use sites these were 17 scalar
+  // loads + waits and the optimizer arithmetic's branches waited on them: in-kernel trace, 3.4k clocks for four elements per thread)
+  OptK ok_ = {a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.omb1, a.omb2, a.la_alpha};
+  asm volatile("" : "+s"(ok_.lr), "+s"(ok_.beta1), "+s"(ok_.beta2), "+s"(ok_.eps), "+s"(ok_.weight_decay), "+s"(ok_.omb1), "+s"(ok_.omb2), "+s"(ok_.la_alpha));
+  float* a_p = a.p; float* a_m = a.m; float* a_v = a.v; float* a_g = a.g_out; float* a_tp = a.tgt_p;
+  float* a_slow = a.slow;
+  bf16_t* a_sh = (bf16_t*)a.shadow; bf16_t* a_tsh = (bf16_t*)a.tgt_shadow;
+  float a_tau = a.tau, a_gs = a.grad_scale;
+  asm volatile("" : "+s"(a_tau), "+s"(a_gs));
+  int64_t t_sh_off = T.sh_off;
+  int t_sh_ld = T.sh_ld;
+  {  // (pinned: hipcc otherwise re-reads a kernel argument wherever it is used)
+    uint64_t q0 = (uint64_t)a_p, q1 = (uint64_t)a_m, q2 = (uint64_t)a_v, q3 = (uint64_t)a_g, q4 = (uint64_t)a_tp, q5 = (uint64_t)a_slow,
+             q6 = (uint64_t)a_sh, q7 = (uint64_t)a_tsh;
+    asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4), "+s"(q5), "+s"(q6), "+s"(q7), "+s"(t_sh_off), "+s"(t_sh_ld));
+    a_p = (float*)q0; a_m = (float*)q1; a_v = (float*)q2; a_g = (float*)q3; a_tp = (float*)q4; a_slow = (float*)q5;
+    a_sh = (bf16_t*)q6; a_tsh = (bf16_t*)q7;
+  }
   // the step's optimizer scalars (an fp64 chain, optim.h): ONE wave evaluates them under the launch's first memory latency
   if (cw == NC - 1) {
     const OptScalars S = opt_scalars(a);
@@ -243,39 +261,45 @@ __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& 
     }
   }
   const OptScalars S = *(const OptScalars*)(lds + SCAL_OFF);
-  const float gs = a.grad_scale;
+  const float gs = a_gs;
   float pn[4], tn4[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float p[2] = {e[h].p.x, e[h].p.y}, m[2] = {e[h].m.x, e[h].m.y}, v[2] = {e[h].v.x, e[h].v.y}, tp[2] = {e[h].tp.x, e[h].tp.y};
     float sl[2] = {0.f, 0.f};
-    if (S.la_sync && ok[h]) { const float2 x = *(const float2*)(a.slow + idx[h]); sl[0] = x.x; sl[1] = x.y; }
+    if (S.la_sync && ok[h]) { const float2 x = *(const float2*)(a_slow + idx[h]); sl[0] = x.x; sl[1] = x.y; }
+    // (the optimizer kind decided ONCE per pair: inside either branch opt_elem's own tests of the step scalars fold away)
+    if (S.ranger) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) opt_elem(a, S, g[2 * h + j], gs, p[j], m[j], v[j], sl[j]);
-    if (a.tgt_p) {
+      for (int j = 0; j < 2; ++j) opt_elem(ok_, S, g[2 * h + j], gs, p[j], m[j], v[j], sl[j]);
+    } else if (S.adam) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tp[j] = soft_elem(tp[j], p[j], a.tau);
+      for (int j = 0; j < 2; ++j) opt_elem(ok_, S, g[2 * h + j], gs, p[j], m[j], v[j], sl[j]);
+    }
+    if (a_tp) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tp[j] = soft_elem(tp[j], p[j], a_tau);
     }
     pn[2 * h] = p[0]; pn[2 * h + 1] = p[1];
     tn4[2 * h] = tp[0]; tn4[2 * h + 1] = tp[1];
     if (ok[h]) {
-      *(float2*)(a.m + idx[h]) = make_float2(m[0], m[1]);
-      *(float2*)(a.v + idx[h]) = make_float2(v[0], v[1]);
-      *(float2*)(a.p + idx[h]) = make_float2(p[0], p[1]);
-      if (S.la_sync) *(float2*)(a.slow + idx[h]) = make_float2(sl[0], sl[1]);
-      if (a.g_out) *(float2*)(a.g_out + idx[h]) = make_float2(g[2 * h], g[2 * h + 1]);
-      if (a.tgt_p) *(float2*)(a.tgt_p + idx[h]) = make_float2(tp[0], tp[1]);
+      *(float2*)(a_m + idx[h]) = make_float2(m[0], m[1]);
+      *(float2*)(a_v + idx[h]) = make_float2(v[0], v[1]);
+      *(float2*)(a_p + idx[h]) = make_float2(p[0], p[1]);
+      if (S.la_sync) *(float2*)(a_slow + idx[h]) = make_float2(sl[0], sl[1]);
+      if (a_g) *(float2*)(a_g + idx[h]) = make_float2(g[2 * h], g[2 * h + 1]);
+      if (a_tp) *(float2*)(a_tp + idx[h]) = make_float2(tp[0], tp[1]);
     }
   }
   DWA_STAMP(5);
-  if (T.sh_off >= 0) {                           // the bf16 compute shadow(s): 8 bytes per thread (4 when the row ends inside the quad)
-    const int64_t se = T.sh_off + (int64_t)row * T.sh_ld + n0 + enq;
+  if (t_sh_off >= 0) {                           // the bf16 compute shadow(s): 8 bytes per thread (4 when the row ends inside the quad)
+    const int64_t se = t_sh_off + (int64_t)row * t_sh_ld + n0 + enq;
     if (ok[1]) {
-      if (a.shadow) *(uint2*)((bf16_t*)a.shadow + se) = make_uint2(pack_bf2(pn[0], pn[1]), pack_bf2(pn[2], pn[3]));
-      if (a.tgt_p && a.tgt_shadow) *(uint2*)((bf16_t*)a.tgt_shadow + se) = make_uint2(pack_bf2(tn4[0], tn4[1]), pack_bf2(tn4[2], tn4[3]));
+      if (a_sh) *(uint2*)(a_sh + se) = make_uint2(pack_bf2(pn[0], pn[1]), pack_bf2(pn[2], pn[3]));
+      if (a_tp && a_tsh) *(uint2*)(a_tsh + se) = make_uint2(pack_bf2(tn4[0], tn4[1]), pack_bf2(tn4[2], tn4[3]));
     } else if (ok[0]) {
-      if (a.shadow) *(uint32_t*)((bf16_t*)a.shadow + se) = pack_bf2(pn[0], pn[1]);
-      if (a.tgt_p && a.tgt_shadow) *(uint32_t*)((bf16_t*)a.tgt_shadow + se) = pack_bf2(tn4[0], tn4[1]);
+      if (a_sh) *(uint32_t*)(a_sh + se) = pack_bf2(pn[0], pn[1]);
+      if (a_tp && a_tsh) *(uint32_t*)(a_tsh + se) = pack_bf2(tn4[0], tn4[1]);
     }
   }
   DWA_STAMP(6);

@@ -134,8 +134,12 @@ __device__ inline OptScalars opt_scalars(const ApplyArgs& a) {
   const int t = a.do_adam ? *a.t_ptr + 1 + a.t_add : 0;
   return opt_scalars_at(a.do_adam, a.opt_kind, t, a.lr, a.log_beta1, a.log_beta2, a.nsma_thr, a.la_k);
 }
+// the hyper-parameters opt_elem reads, as a register-resident copy (dwadam.hip: read from the kernel-argument block at their use sites they
+// were scalar loads + waits inside the optimizer arithmetic); same field names as ApplyArgs, opt_elem takes either
+struct OptK { float lr, beta1, beta2, eps, weight_decay, omb1, omb2, la_alpha; };
 // g: raw gradient, gs: gradient scale (1/world, clip coefficient); p, m, v, sl updated in place (sl only on Lookahead syncs)
-__device__ inline void opt_elem(const ApplyArgs& a, const OptScalars& S, float g, float gs, float& p, float& m, float& v, float& sl) {
+template <class A>
+__device__ inline void opt_elem(const A& a, const OptScalars& S, float g, float gs, float& p, float& m, float& v, float& sl) {
 #pragma clang fp contract(off)
   if (S.ranger) {
     const float gj = g * gs;
