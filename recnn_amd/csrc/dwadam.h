@@ -16,6 +16,7 @@ struct DwAdamNet {
   ApplyArgs a;           // finished by dwadam_launch (apply_args_finish)
   DwAdamProb w[2];       // launch order: the small contraction (W2) first
   int rows;
+  int x3;                // split-bf16 operands and shadows (filled by dwadam_launch from a.tc_bf16)
   int nsmall;            // optimizer workgroups of the tensors that are NOT weight tiles (biases, the last layer)
   int ntile[2];
 };
@@ -26,5 +27,5 @@ struct DwAdamBatch {
 
 int dwadam_init();
 // whether tensor `ti` of layout L can be a tile problem of this kernel at `rows` batch rows
-bool dwadam_tensor_ok(const NetLayout& L, int ti, int rows);
+bool dwadam_tensor_ok(const NetLayout& L, int ti, int rows, int x3 = 0);
 int dwadam_launch(DwAdamBatch& b, int nnet, hipStream_t s);

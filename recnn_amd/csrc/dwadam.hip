@@ -28,6 +28,7 @@
 // same launch, first in the launch order.
 #include "dwadam.h"
 #include "optim_dev.h"
+#include "x3.h"
 #include "recnn_hip_debug.h"
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -55,8 +56,45 @@ struct Pair { float2 p, m, v, tp; };
 
 #define DWA_STAMP(i) do { if (trow) trow[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-// SPW = slabs per consumer wave (nslab / 8)
-template <int SPW>
+// ---- split bf16 (x3.h): the tile's operands are 64 physical columns of dZ (one [hi 32 | lo 32] group = 32 logical) and 128 of X (two
+// groups = 64 logical); three MFMAs per 32-row k step and 16 x 16 block (x3_mfma: lo.hi, hi.lo, hi.hi -- x3.hip x3_dw_kernel's order).
+// A stage = 128 batch rows (four k steps) of both operands: X 128 x 256 B + dZ 128 x 128 B = 48 KB, the same 3-slot ring.  Consumer wave w
+// owns ONE 16 x 16 logical block (tm = w / 4, tn = w % 4) for ALL slabs (one accumulator per slab: the slabs are consecutive stage
+// ranges), so the slab sums need no exchange -- each lane adds its own accumulators in apply_kernel's order and the finished tile goes
+// through LDS only to reach the row-contiguous quads of the shared epilogue.
+constexpr int X3_ROWS = 128;                     // batch rows per stage
+constexpr int X3_XB = X3_ROWS * 256;             // 32 KB of X rows, then 16 KB of dZ rows
+__device__ __forceinline__ int swz32(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }   // (x3.hip: 32-byte chunk c of a 256-byte row at c ^ swz32)
+struct TrFrag { v4s16 lo, hi; };
+// transpose-read fragment of 16 physical columns [col0, col0 + 16) over the 32 rows of k step `ks` of the X image (256-byte rows)
+__device__ __forceinline__ bf16x8 x3_frag_x(const unsigned char* s, int col0, int fr, int fg) {
+  TrFrag f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = fg * 8 + half * 4 + (fr >> 2);
+    const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) v4s16*)(s + row * 256 + (((col0 >> 4) ^ swz32(row)) << 5) + (fr & 3) * 8));
+    if (half == 0) f.lo = v; else f.hi = v;
+  }
+  return __builtin_bit_cast(bf16x8, f);
+}
+// ... of the dZ image (128-byte rows, dw_tile.h's pair swizzle p ^ f(row))
+__device__ __forceinline__ bf16x8 x3_frag_z(const unsigned char* s, int col0, int fr, int fg) {
+  TrFrag f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = fg * 8 + half * 4 + (fr >> 2);
+    const int fs = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int c = (col0 >> 3) + ((fr & 3) >> 1);
+    const int slot = (((c >> 1) ^ fs) << 1) | (c & 1);
+    const v4s16 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(s + row * 128 + slot * 16 + (fr & 1) * 8));
+    if (half == 0) f.lo = v; else f.hi = v;
+  }
+  return __builtin_bit_cast(bf16x8, f);
+}
+
+// SPW = slabs per consumer wave (nslab / 8); X3: split-bf16 operands and shadows
+template <int SPW, bool X3>
 __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& P, const int tile, unsigned char* lds, unsigned long long* trow) {
   const unsigned lds0 = (unsigned)(size_t)lds;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -66,6 +104,51 @@ __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& 
   const int R = N.rows / NC;                     // batch rows per consumer wave
   const int nstep = R / 32;
 
+  if (X3 && wave >= NC) {
+    // ------------------------------------------------------------ loader wave lw (split bf16): instructions q = j * NL + lw, j < 12, of every
+    // 48-instruction stage -- q < 32: X rows 4 q .. + 3 (256 B each), else dZ rows 8 (q - 32) .. + 7 (128 B each)
+    const int lw = wave - NC;
+    const int nst = N.rows / X3_ROWS;
+    unsigned voff[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int q = j * NL + lw;
+      if (q < 32) {
+        const int r = 4 * q + (lane >> 4), ch = lane & 15;
+        const int src = ((((ch >> 1) ^ swz32(r)) << 1) | (ch & 1));
+        voff[j] = (unsigned)((r * (int)P.ldx + 2 * n0) * 2 + src * 16);
+      } else {
+        const int r = 8 * (q - 32) + (lane >> 3), ds = lane & 7;
+        const int fs = ((r >> 1) & 1) | (((r >> 3) & 1) << 1);
+        const int c = (((ds >> 1) ^ fs) << 1) | (ds & 1);
+        voff[j] = (unsigned)((r * (int)P.ldz + 2 * m0) * 2 + c * 16);
+      }
+    }
+    const int64_t xstep = (int64_t)X3_ROWS * P.ldx * 2, zstep = (int64_t)X3_ROWS * P.ldz * 2;
+    auto issue = [&](int t, int slot) {
+      const char* xs = (const char*)P.x + t * xstep;
+      const char* zs = (const char*)P.dz + t * zstep;
+      const unsigned sb = lds0 + slot * STAGE;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int q = j * NL + lw;
+        if (q < 32) dma_s(voff[j], xs, sb + q * 1024);
+        else dma_s(voff[j], zs, sb + X3_XB + (q - 32) * 1024);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < nst) issue(i, i);
+    int slot = D % NS;
+    for (int t = 0; t < nst; ++t) {
+      if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + D < nst) issue(t + D, slot);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    return;
+  }
   if (wave >= NC) {
     // ------------------------------------------------------------ loader wave lw: the chunks of consumers 2 lw, 2 lw + 1 of every stage
     const int lw = wave - NC;
@@ -173,91 +256,142 @@ __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& 
   }
   DWA_STAMP(1);
 
-  f32x4 acc[SPW][2][4];
-#pragma unroll
-  for (int s = 0; s < SPW; ++s)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[s][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addresses inside a chunk (constant over the stages): k row of the lane = fg * 8 + half * 4 + (fr >> 2)
-  int offa[2][2], offb[4][2];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int kr = fg * 8 + half * 4 + (fr >> 2);
-    const int f = ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int pos = tm ^ ((kr >> 3) & 1);
-      offa[tm][half] = CH_X + kr * 64 + (pos * 2 + ((fr & 3) >> 1)) * 16 + (fr & 1) * 8;
-    }
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int c = 2 * tn + ((fr & 3) >> 1);
-      const int sl = (((c >> 1) ^ f) << 1) | (c & 1);
-      offb[tn][half] = kr * 128 + sl * 16 + (fr & 1) * 8;
-    }
-  }
-  const int per_slab = nstep / SPW;
-  int slot = 0;
-#pragma unroll
-  for (int s = 0; s < SPW; ++s) {
-    for (int tt = 0; tt < per_slab; ++tt) {
-      __builtin_amdgcn_s_barrier();              // stage t is in LDS (every loader waited for its part)
-      if (s == 0 && tt == 0) DWA_STAMP(2);
-      const unsigned char* ch = lds + slot * STAGE + cw * CHUNK;
-      v4s16 fa[2][2], fb[4][2];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-          fa[tm][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ch + offa[tm][half]));
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-          fb[tn][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ch + offb[tn][half]));
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          struct { v4s16 lo, hi; } av = {fa[tm][0], fa[tm][1]}, bv = {fb[tn][0], fb[tn][1]};
-          acc[s][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[s][tm][tn], 0, 0, 0);
-        }
-      slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-  }
-  DWA_STAMP(3);
-  // ---- the partial tiles meet in LDS (the ring is idle once every consumer has read its last stage)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  {
-    float* part = (float*)lds;
-#pragma unroll
-    for (int s = 0; s < SPW; ++s) {
-      float* ps = part + (cw * SPW + s) * (PART / 4);
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ps[(tm * 16 + fg * 4 + r) * TP + tn * 16 + fr] = acc[s][tm][tn][r];
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  DWA_STAMP(4);
-  constexpr int NG = NC * SPW;
   float g[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    const float* pe = (const float*)lds + em * TP + enq;
+  if constexpr (X3) {
+    // ---- split bf16: this wave's 16 x 16 logical block over all slabs
+    constexpr int NSLAB = NC * SPW;
+    const int tm = cw >> 2, tn = cw & 3;
+    const int nst = N.rows / X3_ROWS, sps = nst / NSLAB;   // stages, stages per slab
+    f32x4 acc[NSLAB];
 #pragma unroll
-    for (int s0 = 0; s0 < NG; s0 += 8) {         // slab_grads' order: eight slabs as a balanced tree, added to the running sum
-      f32x4 v[8];
+    for (int i = 0; i < NSLAB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xcol = (tn >> 1) * 64 + (tn & 1) * 16;       // physical column of the block's hi part inside the X image (lo: + 32)
+    int slot = 0;
+    bool first = true;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(pe + (s0 + j) * (PART / 4));
+    for (int sl = 0; sl < NSLAB; ++sl) {
+      for (int st = 0; st < sps; ++st) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (first) { DWA_STAMP(2); first = false; }
+        const unsigned char* sx = lds + slot * STAGE;
+        const unsigned char* sz = sx + X3_XB;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] += ((v[0][k] + v[1][k]) + (v[2][k] + v[3][k])) + ((v[4][k] + v[5][k]) + (v[6][k] + v[7][k]));
+        for (int kk = 0; kk < X3_ROWS / 32; ++kk) {
+          const bf16x8 ah = x3_frag_z(sz + kk * 32 * 128, tm * 16, fr, fg), al = x3_frag_z(sz + kk * 32 * 128, 32 + tm * 16, fr, fg);
+          const bf16x8 bh = x3_frag_x(sx + kk * 32 * 256, xcol, fr, fg), bl = x3_frag_x(sx + kk * 32 * 256, xcol + 32, fr, fg);
+          acc[sl] = x3_mfma(ah, al, bh, bl, acc[sl]);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+      }
+    }
+    DWA_STAMP(3);
+    // slab sums in apply_kernel's order, per lane: acc[.][r] = dW[m0 + 16 tm + 4 fg + r][n0 + 16 tn + fr]
+    f32x4 gsum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < NSLAB; s0 += 8)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        gsum[k] += ((acc[s0][k] + acc[s0 + 1][k]) + (acc[s0 + 2][k] + acc[s0 + 3][k])) + ((acc[s0 + 4][k] + acc[s0 + 5][k]) + (acc[s0 + 6][k] + acc[s0 + 7][k]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // every consumer has read its last stage: the ring is idle
+    {
+      float* img = (float*)lds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(tm * 16 + fg * 4 + r) * TP + tn * 16 + fr] = gsum[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    DWA_STAMP(4);
+    const f32x4 gv = *(const f32x4*)((const float*)lds + em * TP + enq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = gv[k];
+  } else {
+    f32x4 acc[SPW][2][4];
+  #pragma unroll
+    for (int s = 0; s < SPW; ++s)
+  #pragma unroll
+      for (int i = 0; i < 2; ++i)
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses inside a chunk (constant over the stages): k row of the lane = fg * 8 + half * 4 + (fr >> 2)
+    int offa[2][2], offb[4][2];
+  #pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kr = fg * 8 + half * 4 + (fr >> 2);
+      const int f = ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1);
+  #pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const int pos = tm ^ ((kr >> 3) & 1);
+        offa[tm][half] = CH_X + kr * 64 + (pos * 2 + ((fr & 3) >> 1)) * 16 + (fr & 1) * 8;
+      }
+  #pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int c = 2 * tn + ((fr & 3) >> 1);
+        const int sl = (((c >> 1) ^ f) << 1) | (c & 1);
+        offb[tn][half] = kr * 128 + sl * 16 + (fr & 1) * 8;
+      }
+    }
+    const int per_slab = nstep / SPW;
+    int slot = 0;
+  #pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+      for (int tt = 0; tt < per_slab; ++tt) {
+        __builtin_amdgcn_s_barrier();              // stage t is in LDS (every loader waited for its part)
+        if (s == 0 && tt == 0) DWA_STAMP(2);
+        const unsigned char* ch = lds + slot * STAGE + cw * CHUNK;
+        v4s16 fa[2][2], fb[4][2];
+  #pragma unroll
+        for (int half = 0; half < 2; ++half) {
+  #pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            fa[tm][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ch + offa[tm][half]));
+  #pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            fb[tn][half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(ch + offb[tn][half]));
+        }
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            struct { v4s16 lo, hi; } av = {fa[tm][0], fa[tm][1]}, bv = {fb[tn][0], fb[tn][1]};
+            acc[s][tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[s][tm][tn], 0, 0, 0);
+          }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+      }
+    }
+    DWA_STAMP(3);
+    // ---- the partial tiles meet in LDS (the ring is idle once every consumer has read its last stage)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      float* part = (float*)lds;
+  #pragma unroll
+      for (int s = 0; s < SPW; ++s) {
+        float* ps = part + (cw * SPW + s) * (PART / 4);
+  #pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+  #pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) ps[(tm * 16 + fg * 4 + r) * TP + tn * 16 + fr] = acc[s][tm][tn][r];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    DWA_STAMP(4);
+    constexpr int NG = NC * SPW;
+    {
+      const float* pe = (const float*)lds + em * TP + enq;
+  #pragma unroll
+      for (int s0 = 0; s0 < NG; s0 += 8) {         // slab_grads' order: eight slabs as a balanced tree, added to the running sum
+        f32x4 v[8];
+  #pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(pe + (s0 + j) * (PART / 4));
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] += ((v[0][k] + v[1][k]) + (v[2][k] + v[3][k])) + ((v[4][k] + v[5][k]) + (v[6][k] + v[7][k]));
+      }
     }
   }
   const OptScalars S = *(const OptScalars*)(lds + SCAL_OFF);
@@ -292,7 +426,21 @@ __device__ __forceinline__ void tile_role(const DwAdamNet& N, const DwAdamProb& 
     }
   }
   DWA_STAMP(5);
-  if (t_sh_off >= 0) {                           // the bf16 compute shadow(s): 8 bytes per thread (4 when the row ends inside the quad)
+  if (X3 && t_sh_off >= 0) {                      // split-bf16 shadow(s): hi at the mapped column, lo 32 elements further (x3.h)
+    const int c0 = n0 + enq;
+    const int64_t se = t_sh_off + (int64_t)row * t_sh_ld;
+    if (ok[1]) {
+      uint2 hi, lo;
+      if (a_sh) { x3_split4(pn, hi, lo); *(uint2*)(a_sh + se + x3_col(c0)) = hi; *(uint2*)(a_sh + se + x3_col(c0) + 32) = lo; }
+      if (a_tp && a_tsh) { x3_split4(tn4, hi, lo); *(uint2*)(a_tsh + se + x3_col(c0)) = hi; *(uint2*)(a_tsh + se + x3_col(c0) + 32) = lo; }
+    } else if (ok[0]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (a_sh) x3_store(a_sh + se, c0 + j, pn[j]);
+        if (a_tp && a_tsh) x3_store(a_tsh + se, c0 + j, tn4[j]);
+      }
+    }
+  } else if (t_sh_off >= 0) {                    // the bf16 compute shadow(s): 8 bytes per thread (4 when the row ends inside the quad)
     const int64_t se = t_sh_off + (int64_t)row * t_sh_ld + n0 + enq;
     if (ok[1]) {
       if (a_sh) *(uint2*)(a_sh + se) = make_uint2(pack_bf2(pn[0], pn[1]), pack_bf2(pn[2], pn[3]));
@@ -330,8 +478,11 @@ __global__ __launch_bounds__((NC + NL) * 64) void dw_adam_kernel(const DwAdamBat
   const int wi = t0 < N.ntile[0] ? 0 : 1;
   const DwAdamProb& P = N.w[wi];
   const int tile = wi == 0 ? t0 : t0 - N.ntile[0];
-  if (P.nslab == 8) tile_role<1>(N, P, tile, lds, trow);
-  else tile_role<2>(N, P, tile, lds, trow);
+  if (N.x3) {
+    if (P.nslab == 8) tile_role<1, true>(N, P, tile, lds, trow);
+    else tile_role<2, true>(N, P, tile, lds, trow);
+  } else if (P.nslab == 8) tile_role<1, false>(N, P, tile, lds, trow);
+  else tile_role<2, false>(N, P, tile, lds, trow);
 }
 
 unsigned long long* g_dwadam_trace = nullptr;
@@ -343,15 +494,22 @@ int dwadam_init() {
   return recnn_check_hip(hipFuncSetAttribute((const void*)dw_adam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "dw_adam attr");
 }
 
-bool dwadam_tensor_ok(const NetLayout& L, int ti, int rows) {
+bool dwadam_tensor_ok(const NetLayout& L, int ti, int rows, int x3) {
   const TensorSeg& T = L.t[ti];
   if (rows < 256 || rows % 256) return false;                       // every consumer wave multiplies whole 32-row steps
   if (T.nslab != 8 && T.nslab != 16) return false;
-  // the slabs of the two-launch path must be the waves' ranges (gemm.hip: chunk = roundup(ceil(rows / nslab), 64))
-  const int chunk = (((rows + T.nslab - 1) / T.nslab) + 63) / 64 * 64;
-  if (chunk * T.nslab != rows || (rows / 8) % chunk) return false;
+  if (x3) {
+    // split bf16: slabs are whole 128-row stages (x3.hip: chunk = roundup(ceil(rows / nslab), 32))
+    const int chunk = (((rows + T.nslab - 1) / T.nslab) + 31) / 32 * 32;
+    if (chunk * T.nslab != rows || chunk % 128) return false;
+    if (T.sh_ld < 2 * ((T.cols + 63) / 64 * 64)) return false;
+  } else {
+    // the slabs of the two-launch path must be the waves' ranges (gemm.hip: chunk = roundup(ceil(rows / nslab), 64))
+    const int chunk = (((rows + T.nslab - 1) / T.nslab) + 63) / 64 * 64;
+    if (chunk * T.nslab != rows || (rows / 8) % chunk) return false;
+    if (T.sh_ld < (T.cols + 63) / 64 * 64) return false;            // a 64-column tile is readable inside the shadow / batch row pitch
+  }
   if (T.rows % 32 || (T.cols & 1) || (T.col_rot & 1) || (T.p_off & 1) || T.sh_off < 0 || (T.sh_off & 3) || (T.sh_ld & 3)) return false;
-  if (T.sh_ld < (T.cols + 63) / 64 * 64) return false;              // a 64-column tile is readable inside the shadow / batch row pitch
   return true;
 }
 
@@ -361,18 +519,21 @@ int dwadam_launch(DwAdamBatch& b, int nnet, hipStream_t s) {
   for (int i = 0; i < nnet; ++i) {
     DwAdamNet& n = b.n[i];
     apply_args_finish(&n.a);
-    RECNN_REQUIRE(n.a.do_adam && n.a.from_slabs && !n.a.comm.world && n.a.n_l1 == 0 && n.a.tc_bf16 == RECNN_BF16 && n.a.p && n.a.m && n.a.v,
-                  "dw_adam: single-GPU bf16 optimizer steps without the clip quirk only");
+    RECNN_REQUIRE(n.a.do_adam && n.a.from_slabs && !n.a.comm.world && n.a.n_l1 == 0 && (n.a.tc_bf16 == RECNN_BF16 || n.a.tc_bf16 == RECNN_BF16X3) &&
+                      n.a.p && n.a.m && n.a.v,
+                  "dw_adam: single-GPU bf16 / split-bf16 optimizer steps without the clip quirk only");
+    n.x3 = n.a.tc_bf16 == RECNN_BF16X3;
     RECNN_REQUIRE(!(((uintptr_t)n.a.p | (uintptr_t)n.a.m | (uintptr_t)n.a.v | (uintptr_t)n.a.g_out | (uintptr_t)n.a.tgt_p | (uintptr_t)n.a.slow) & 7),
                   "dw_adam: the flat arenas must be 8-byte aligned");
     RECNN_REQUIRE(!(((uintptr_t)n.a.shadow | (uintptr_t)n.a.tgt_shadow) & 7), "dw_adam: the shadow arenas must be 8-byte aligned");
     RECNN_REQUIRE(n.a.opt_kind != RECNN_OPT_RANGER || n.a.slow, "dw_adam: Ranger needs the slow-weight arena");
     for (int w = 0; w < 2; ++w) {
       DwAdamProb& p = n.w[w];
-      RECNN_REQUIRE(dwadam_tensor_ok(n.L, p.tensor, n.rows), "dw_adam: tensor %d of network %d does not fit the tile plan at %d rows", p.tensor, i, n.rows);
+      RECNN_REQUIRE(dwadam_tensor_ok(n.L, p.tensor, n.rows, n.x3), "dw_adam: tensor %d of network %d does not fit the tile plan at %d rows", p.tensor, i, n.rows);
       const TensorSeg& T = n.L.t[p.tensor];
-      RECNN_REQUIRE(p.dz && p.x && p.ldz >= T.rows && p.ldx >= (T.cols + 63) / 64 * 64 && !(((uintptr_t)p.dz | (uintptr_t)p.x) & 15) && p.ldz % 8 == 0 &&
-                        p.ldx % 8 == 0 && (int64_t)n.rows * p.ldx * 2 < (1ll << 31),
+      const int ph = n.x3 ? 2 : 1;                // physical elements per logical column
+      RECNN_REQUIRE(p.dz && p.x && p.ldz >= ph * T.rows && p.ldx >= ph * ((T.cols + 63) / 64 * 64) && !(((uintptr_t)p.dz | (uintptr_t)p.x) & 15) &&
+                        p.ldz % 8 == 0 && p.ldx % 8 == 0 && (int64_t)n.rows * p.ldx * 2 < (1ll << 31),
                     "dw_adam: bad operands");
       p.nslab = T.nslab;
       p.tiles_m = T.rows / 32;

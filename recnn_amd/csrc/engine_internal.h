@@ -92,6 +92,7 @@ struct recnn_engine {
   float *reward0 = nullptr, *done0 = nullptr;  // the bound reward / done arrays (set 0)
   int cur_set = 0;
   const GatherArgs* pregather = nullptr;   // set while the critic's optimizer launch should carry the next gather
+  const GatherArgs* head_gather = nullptr; // ... or (split bf16 with the fused dW + optimizer launch) the critic head launch; NULL once consumed
   // run graphs: the device counters (mask-key step, Adam steps, sampler cursor) are ticked ONCE, by the finalize of
   // the run's last step; step i of the run is captured with these offsets on top of them
   int run_off = 0;                         // steps of the run before this one
@@ -234,7 +235,7 @@ GatherArgs gather_args(const recnn_engine* e, int rows, int set, int cursor_add)
 int ph_gather_cycle(recnn_engine* e, int rows, int n, int run_off0, int b, hipStream_t s);
 int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_t s);
 int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool value_bwd, hipStream_t s);
-int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s);
+int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, bool dx_only = false);
 int ph_policy(recnn_engine* e, int rows, bool backward, bool with_l1, hipStream_t s, bool need_rows = true);
 int ph_policy_l1(recnn_engine* e, hipStream_t s);
 int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, hipStream_t s);

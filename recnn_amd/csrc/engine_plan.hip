@@ -743,7 +743,11 @@ int ph_forward_x3(recnn_engine* e, int rows, bool value_side, bool actor_side, b
         h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
       }
     }
-    if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
+    {
+      const GatherArgs* hg = (value_bwd && e->head_gather) ? e->head_gather : nullptr;   // (armed by step_impl: the next step's gather rides here)
+      if ((rc = slot(e, hg ? "head_td_target+gather" : "head_td_target", 0, s, [&] { return head_launch(h, s, hg); }, hg == nullptr))) return rc;
+      if (hg) e->head_gather = nullptr;         // consumed
+    }
   }
   return 0;
 }
@@ -1025,14 +1029,18 @@ int ph_forward(recnn_engine* e, int rows, bool value_side, bool actor_side, bool
         h.dz2[c] = e->dzc2[c]; h.dw3_part[c] = v.gp[W3]; h.db2_part[c] = v.gp[B2]; h.db3_part[c] = v.gp[B3];
       }
     }
-    if ((rc = slot(e, "head_td_target", 0, s, [&] { return head_launch(h, s); }))) return rc;
+    {
+      const GatherArgs* hg = (value_bwd && e->head_gather) ? e->head_gather : nullptr;   // (armed by step_impl: the next step's gather rides here)
+      if ((rc = slot(e, hg ? "head_td_target+gather" : "head_td_target", 0, s, [&] { return head_launch(h, s, hg); }, hg == nullptr))) return rc;
+      if (hg) e->head_gather = nullptr;         // consumed
+    }
   }
   return 0;
 }
 
 // Backward of the critic(s): dz1 (unless the forward launch produced it), then the weight-gradient GEMMs as split-batch slabs
 // (summed by the slab-reducing Adam launch, or by grad_reduce into the flat arenas when `reduce`: the phase API / data parallel).
-int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
+int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s, bool dx_only) {
   const int Hp = e->Hp, H = e->H, nc = e->n_critic;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   int rc;
@@ -1042,6 +1050,7 @@ int ph_value_backward(recnn_engine* e, int rows, bool reduce, hipStream_t s) {
       g.flops += fill_dx(e, g.add(), rows, e->dzc2[c], Hp, Hp, VAL[c], W2, 0, H, e->dzc1[c], Hp, e->cv[c].h1, Hp, e->net[VAL[c]].gp[B1]);
     if ((rc = g.run(s, "dx_critic_l2"))) return rc;
   }
+  if (dx_only) return 0;     // (the weight gradients follow in dw_adam_kernel: ph_value_dwadam)
   NetLayout L0 = make_layout(e, VAL[0], rows);
   {
     Group g(e, GEMM_DW, 0, 0);  // dW2 = dz2^T h1 and dW1 = dz1^T [a|s], split over the batch into slabs
@@ -1283,13 +1292,18 @@ int value_apply(recnn_engine* e, bool soft, float grad_scale, hipStream_t s, int
 // value_apply, no gradient slabs.  Taken when the step's backward tensors came from the split forward's tail (mlpt.hip: dz2 / dz1
 // already carry the per-row loss seed, the small tensors' panel sums exist) on the single-GPU bf16 step; bit-identical to the two launches.
 bool dwadam_ok(const recnn_engine* e, int rows) {
-  if (!e->tune.dw_fuse || e->comm || e->cfg.dtype != RECNN_BF16 || !e->panel_bwd_done || e->unit_bwd || e->H != 256 || e->Hp != 256) return false;
+  if (!e->tune.dw_fuse || e->comm || e->unit_bwd || e->H != 256) return false;
+  if (e->x3) {
+    // split bf16: the head launch wrote dz2 (times the loss seed) and the small tensors' partial sums; dz1 comes from the dX launch that
+    // ph_value_dwadam issues first.  (The generic split-bf16 forward only: Hp = 512 physical.)
+    if (e->cfg.dtype != RECNN_BF16X3 || e->panel_bwd_done || e->Hp != 512) return false;
+  } else if (e->cfg.dtype != RECNN_BF16 || !e->panel_bwd_done || e->Hp != 256) return false;
   const int VAL[2] = {RECNN_NET_VALUE1, RECNN_NET_VALUE2};
   for (int c = 0; c < e->n_critic; ++c) {
     const Net& n = e->net[VAL[c]];
     if (!n.g || !n.m || !n.v || !n.critic) return false;
     const NetLayout L = make_layout(e, VAL[c], rows);
-    if (!dwadam_tensor_ok(L, W1, rows) || !dwadam_tensor_ok(L, W2, rows)) return false;
+    if (!dwadam_tensor_ok(L, W1, rows, e->x3) || !dwadam_tensor_ok(L, W2, rows, e->x3)) return false;
     if (!L.t[B1].small || !L.t[B2].small || !L.t[W3].small || !L.t[B3].small) return false;
   }
   return true;
@@ -1301,6 +1315,7 @@ int ph_value_dwadam(recnn_engine* e, int rows, bool soft, hipStream_t s) {
   memset(&b, 0, sizeof(b));
   double fl = 0;
   int rc;
+  if (!e->panel_bwd_done && (rc = ph_value_backward(e, rows, false, s, true))) return rc;   // (split bf16: the critics' dX launch)
   for (int c = 0; c < e->n_critic; ++c) {
     DwAdamNet& n = b.n[c];
     n.L = make_layout(e, VAL[c], rows);
@@ -1613,6 +1628,19 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
               bool defer_policy_fwd, bool frozen_done) {
   int rc;
   if (!pregathered && (rc = stage_batch(e, rows, s))) return rc;
+  // Split bf16 with the fused dW + optimizer launch: that launch (147 KB of LDS per workgroup) cannot carry the look-ahead gather the
+  // way apply_gather_kernel does, so the critic HEAD launch does -- armed here, consumed inside ph_forward (if no head launch takes it,
+  // the optimizer launch carries it as before and the two-launch form stays)
+  GatherArgs ga_head;
+  bool head_ride = false;
+  if (learn && gather_next && e->x3 && !e->comm && e->tune.dw_fuse && e->H == 256 && e->Hp == 512) {
+    const NetLayout L0 = make_layout(e, RECNN_NET_VALUE1, rows);
+    if (dwadam_tensor_ok(L0, W1, rows, 1) && dwadam_tensor_ok(L0, W2, rows, 1)) {
+      ga_head = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1);
+      e->head_gather = &ga_head;
+      head_ride = true;
+    }
+  }
   if (frozen_done) {   // cycle mode: the batch is in place and the frozen networks have been applied to it (ph_frozen_batched)
     if ((rc = ph_forward_split(e, rows, true, true, learn, s, true))) return rc;
   } else if ((rc = ph_forward(e, rows, true, true, learn, s))) return rc;
@@ -1621,7 +1649,9 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
     // next step, so on policy steps it is fused into the critic's optimizer pass (ddpg.py:95-97) -- which itself is the
     // epilogue of the weight-gradient launch on the bf16 unit-backward path (dwopt.hip), a separate Adam launch otherwise.
     GatherArgs ga;
-    if (gather_next) { ga = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1); e->pregather = &ga; }
+    const bool rode = head_ride && e->head_gather == nullptr;     // the head launch took the next step's gather
+    e->head_gather = nullptr;
+    if (gather_next && !rode) { ga = gather_args(e, rows, e->cur_set ^ 1, e->run_off + 1); e->pregather = &ga; }
     if (e->comm) {
       // data parallel: finished gradients into the flat arenas, summed over the ranks by one launch per arena, then the
       // replicated optimizer step on grad / world (recnn_amd/parallel.py; the arithmetic of the global batch mean)
@@ -1636,7 +1666,7 @@ int step_impl(recnn_engine* e, int rows, bool learn, bool policy_step, hipStream
         for (int c = 0; c < e->n_critic && !rc; ++c) rc = net_allreduce(e, VAL[c], "allreduce_critic", s);
         if (!rc) rc = value_apply(e, policy_step, e->comm_scale, s);
       }
-    } else if (!gather_next && dwadam_ok(e, rows)) {
+    } else if ((!gather_next || rode) && dwadam_ok(e, rows)) {
       rc = ph_value_dwadam(e, rows, policy_step, s);
     } else {
       rc = ph_value_backward(e, rows, false, s);

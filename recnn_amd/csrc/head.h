@@ -77,5 +77,7 @@ struct LossHistoryArgs {
 };
 int loss_history_launch(const LossHistoryArgs& a, hipStream_t s);
 
-int head_launch(const HeadArgs& a, hipStream_t s);
+struct GatherArgs;
+// pregather != NULL: the sampler + gather of the NEXT step runs as extra workgroups of this launch
+int head_launch(const HeadArgs& a, hipStream_t s, const GatherArgs* pregather = nullptr);
 int loss_finalize_launch(const LossFinalizeArgs& a, hipStream_t s);

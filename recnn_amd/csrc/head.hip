@@ -9,6 +9,7 @@
 // and the first step of autograd's backward through linear3 of the critic.
 #include <type_traits>
 #include "head.h"
+#include "gather_dev.h"
 #include "x3.h"
 
 // compute-type tags of the templates below: float, bf16_t, or x3_t = split-bf16 rows (x3.h: the column index is mapped, a value is hi + lo)
@@ -43,7 +44,17 @@ template <class TC> __device__ inline float dot4(const typename HeadStore<TC>::t
 // so the loads of all 4 x (NT + NC) row segments (and of reward / done / biases) are in flight together -- the kernel
 // is a chain of memory latencies, not bandwidth.  TD target, Q, dQ, loss partial.  Phase 2 (do_bwd): dz2 and the
 // partial sums of dW3 / db2 / db3.  One launch instead of two, dQ never leaves the CU.
-template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a, const GatherArgs ga, const int n_gather) {
+  if (n_gather > 0) {
+    // the sampler + gather of the NEXT step as extra, last-dispatched workgroups of this launch (round 6: the split-bf16 step's weight
+    // gradients + optimizer became one big-LDS launch that cannot carry them as apply_gather_kernel did)
+    const int nhead = (a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK;
+    if ((int)blockIdx.x >= nhead) {
+      extern __shared__ __attribute__((aligned(16))) unsigned char smem_gather[];
+      frame_gather_body<4, 4>(ga, (int)blockIdx.x - nhead, smem_gather);
+      return;
+    }
+  }
   kernarg_prefetch<(int)sizeof(HeadArgs)>();
   using ST = typename HeadStore<TC>::type;
   constexpr bool X3 = std::is_same<TC, x3_t>::value;
@@ -236,19 +247,32 @@ template <class TC, int NT, int NC, bool PRE> __global__ __launch_bounds__(256) 
   }
 }
 
-int head_launch(const HeadArgs& a, hipStream_t s) {
+int head_launch(const HeadArgs& a, hipStream_t s, const GatherArgs* pregather) {
   if (a.rows <= 0) return 0;
+  GatherArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  int ng = 0;
+  size_t glds = 0;
+  if (pregather) {
+    ga = *pregather;
+    glds = frame_gather_lds_bytes(ga, 4);
+    if (glds > 48 * 1024 || !ga.state_h || ga.state || (ga.emb % 4) || ga.rows <= 0) {
+      recnn_set_error("head + gather: needs the compute-type-only gather with a tile that fits 48 KB of LDS");
+      return RECNN_E_UNSUPPORTED;
+    }
+    ng = (ga.rows + 3) / 4;
+  }
   if (a.H % 8 || a.ld_h % 8) { recnn_set_error("head: hidden size and pitch must be multiples of 8"); return RECNN_E_INVALID; }
   if (a.tc_bf16 == 2 && a.ld_h < x3_ld(a.H)) { recnn_set_error("head (bf16x3): pitch below the split row width"); return RECNN_E_INVALID; }
-  dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK), block(256);
+  dim3 grid((a.rows + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK + ng), block(256);
   if (a.n_target < 0 || a.n_target > 2 || a.n_critic < 1 || a.n_critic > HEAD_MAX_CRITIC) {
     recnn_set_error("head: n_target must be 0..2 and n_critic 1..2");
     return RECNN_E_INVALID;
   }
   const bool pre = a.n_target > 0 && a.tq_in[0] != nullptr;
   if (pre && a.n_target > 1 && !a.tq_in[1]) { recnn_set_error("head: tq_in[1] missing"); return RECNN_E_INVALID; }
-#define HEAD_GO(TC, NT, NC) do { if (pre) hipLaunchKernelGGL((head_kernel<TC, NT, NC, true>), grid, block, 0, s, a); \
-                                 else hipLaunchKernelGGL((head_kernel<TC, NT, NC, false>), grid, block, 0, s, a); } while (0)
+#define HEAD_GO(TC, NT, NC) do { if (pre) hipLaunchKernelGGL((head_kernel<TC, NT, NC, true>), grid, block, glds, s, a, ga, ng); \
+                                 else hipLaunchKernelGGL((head_kernel<TC, NT, NC, false>), grid, block, glds, s, a, ga, ng); } while (0)
 #define HEAD_TC(NT, NC) do { if (a.tc_bf16 == 2) HEAD_GO(x3_t, NT, NC); else if (a.tc_bf16) HEAD_GO(bf16_t, NT, NC); else HEAD_GO(float, NT, NC); } while (0)
   switch (a.n_target * 2 + (a.n_critic - 1)) {
     case 0: HEAD_TC(0, 1); break;

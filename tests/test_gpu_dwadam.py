@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 S, A, H = 1290, 128, 256
 
 
-def _run(algo, B, fuse, steps, L, opt="adam", policy_every=2):
+def _run(algo, B, fuse, steps, L, opt="adam", policy_every=2, dtype="bf16"):
     td3 = algo == "td3"
     actor, critics = _init_nets(8, S, A, H, 2 if td3 else 1)
-    eng = _engine(algo, S, A, H, B, "bf16", mask_mode="hash", seed=17)
+    eng = _engine(algo, S, A, H, B, dtype, mask_mode="hash", seed=17)
     eng.set_tuning(split_fwd=2, dw_fuse=fuse)      # split forward for eager steps too: the tail's backward tensors feed either path
     nets = [(L.NET_POLICY, actor), (L.NET_TARGET_POLICY, actor), (L.NET_VALUE1, critics[0]), (L.NET_TARGET_VALUE1, critics[0])]
     if td3:
@@ -66,3 +66,21 @@ def test_two_launch_path_is_kept_where_the_tile_plan_does_not_fit(cuda):
     _, eng = _run("ddpg", 333, 1, 2, L)
     prof = [n for n, _, _ in eng.profile(333, policy=False, n_steps=1)]
     assert "dwadam_critic" not in prof and "dw_critic" in prof, prof
+
+
+@pytest.mark.parametrize("algo,B,opt,steps", [("ddpg", 2048, "adam", 5), ("td3", 4096, "adam", 3), ("ddpg", 1024, "ranger", 7)])
+def test_fused_dw_adam_in_split_bf16_equals_the_two_launches(cuda, algo, B, opt, steps):
+    """The split-bf16 (bf16x3) form of dw_adam_kernel: one 16 x 16 block per consumer wave over all slabs, three MFMAs per product in
+    x3_dw_kernel's order, the slabs summed per lane in apply_kernel's order, split shadows written from the epilogue -- against
+    x3_dw_kernel + apply_kernel, bit for bit (parameters, moments, gradient arenas, targets; the shadows through the next step's forward)."""
+    from recnn_amd import _lib as L
+    ref, _ = _run(algo, B, 0, steps, L, opt, dtype="bf16x3")
+    new, eng = _run(algo, B, 1, steps, L, opt, dtype="bf16x3")
+    prof = [n for n, _, _ in eng.profile(B, policy=False, n_steps=1)]
+    assert "dwadam_critic" in prof and "dw_critic" not in prof and "adam_critic" not in prof, prof
+    for t, (a, b) in enumerate(zip(ref, new)):
+        assert a["loss"] == b["loss"], (t, a["loss"], b["loss"])
+        for key in ("g", "p", "m", "v", "slow"):
+            for ni in a[key]:
+                d = (a[key][ni] - b[key][ni]).abs().max().item()
+                assert torch.equal(a[key][ni], b[key][ni]), (t, key, ni, d, int((a[key][ni] != b[key][ni]).sum()))
