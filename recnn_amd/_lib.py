@@ -201,6 +201,7 @@ DEBUG_SIGNATURES = {
     "recnn_debug_mlp_probe": (None, [_I]),
     "recnn_debug_mlp_trace": (None, [_P]),
     "recnn_debug_tail_trace": (None, [_P]),
+    "recnn_debug_frozen_trace": (None, [_P]),
     "recnn_debug_l1_trace": (None, [_P]),
     "recnn_debug_x3_fwd": (None, [_I]),
     "recnn_debug_x3_ws_probe": (None, [_I]),

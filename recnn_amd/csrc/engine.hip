@@ -247,6 +247,10 @@ extern "C" int recnn_engine_create(const recnn_engine_config* cfg, void* workspa
   e->net[RECNN_NET_VALUE1].t_ptr = e->counters + 2;
   e->net[RECNN_NET_VALUE2].t_ptr = e->counters + 3;
   memset(&e->hy, 0, sizeof(e->hy));
+  // the pinned words loss_finalize_kernel mirrors the losses into (recnn_engine_read_losses): host-coherent, written from the device
+  rc = recnn_check_hip(hipHostMalloc((void**)&e->h_stage, 16 * sizeof(float), hipHostMallocCoherent), "engine_create: pinned loss mirror");
+  if (rc) { delete e; return rc; }
+  memset(e->h_stage, 0, 16 * sizeof(float));
   *out = e;
   return 0;
 }
@@ -478,13 +482,13 @@ extern "C" int recnn_engine_read_counters(recnn_engine* e, int32_t* h_out, void*
 
 extern "C" int recnn_engine_read_losses(recnn_engine* e, float* h_out, void* stream) {
   RECNN_REQUIRE(e && h_out, "read_losses: null pointer");
-  if (!e->h_stage) RECNN_HIP(hipHostMalloc((void**)&e->h_stage, 16 * sizeof(float), hipHostMallocDefault));
-  float* h = e->h_stage;
-  RECNN_HIP(hipMemcpyAsync(h, e->losses, 5 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  // loss_finalize_kernel -- the last launch of every step and run graph -- writes the losses and the error word into the pinned mirror
+  // itself: no device-to-host copy behind the graph (that copy was a blit kernel + a second boundary: 16 us per read, round 6)
   RECNN_HIP(hipStreamSynchronize((hipStream_t)stream));
-  memcpy(h_out, h, 4 * sizeof(float));
-  int32_t word;
-  memcpy(&word, h + 4, sizeof(word));
+  volatile float* h = e->h_stage;
+  for (int i = 0; i < 4; ++i) h_out[i] = h[i];
+  const int32_t word = ((volatile int32_t*)e->h_stage)[4];
+  if (word) ((volatile int32_t*)e->h_stage)[4] = 0;
   return report_handoff_error(e, word, (hipStream_t)stream);
 }
 

@@ -144,7 +144,7 @@ struct recnn_engine {
   float* l1_scratch;
   // step scalars of the optimizers (bias corrections ...: fp64 chains, optim.h) for every step of the run being issued:
   // [RUN_MAX][3] = {policy, value1, value2}; filled by one small launch at the start of a run graph / an eager step
-  float* h_stage = nullptr;                // pinned host words for the read-backs (a pageable destination is staged by the runtime: +30 us)
+  float* h_stage = nullptr;                // pinned, host-coherent: losses[0..3] + the hand-off error word, written by loss_finalize_kernel
   recnn_comm* comm = nullptr;              // data parallel: the gradient arenas are all-reduced in-stream (comm.hip)
   float comm_scale = 1.0f;                 // 1 / world
   bool comm_region = false;                // the arenas have regions of their own inside the communicator's buffers:

@@ -1234,6 +1234,7 @@ int ph_finish(recnn_engine* e, int rows, bool ticked_value, bool ticked_policy, 
   }
   a.n = nc + 1;
   a.out = e->losses;
+  a.host_out = e->h_stage;
   // run_tick = {1, 1, 1} outside run graphs; the last step of a run adds the whole run's counts
   a.tick_inc[a.n_tick] = e->run_tick[0]; a.tick[a.n_tick++] = e->counters;  // mask-key step
   if (ticked_value) {

@@ -47,6 +47,7 @@ struct LossFinalizeArgs {
   const float* add_ptr[4];  // optional: out[c] += add_scale[c] * (*add_ptr[c])
   float add_scale[4];
   float* out;  // [4]
+  float* host_out;    // optional pinned host mirror: [0..3] = out[0..3], [4] = the hand-off error word out[4] as it stands when this kernel runs
   int n_tick;
   int32_t* tick[6];
   int tick_inc[6];     // *tick[i] += tick_inc[i]

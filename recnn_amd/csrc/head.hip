@@ -348,8 +348,12 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeAr
     const float s = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
     const float v = s * a.scale[c] + (a.add_ptr[c] ? a.add_scale[c] * a.add_ptr[c][0] : 0.f);
     a.out[c] = v;
+    if (a.host_out) a.host_out[c] = v;
     if (a.ring && a.n_tick > 0) a.ring[(int64_t)((s_old + a.tick_inc[0] - 1) & a.ring_mask) * 4 + c] = v;
   }
+  // (the error word is written by kernels EARLIER in the stream: whatever they left is what the host should see with these losses)
+  if (threadIdx.x == 4 && a.host_out) ((uint32_t*)a.host_out)[4] = ((const volatile uint32_t*)a.out)[4];
+  if (a.host_out && threadIdx.x <= 4) __threadfence_system();
 }
 
 __global__ __launch_bounds__(256) void loss_history_kernel(const LossHistoryArgs a) {

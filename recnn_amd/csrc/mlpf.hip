@@ -54,6 +54,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const unsigned lds0 = (unsigned)(size_t)lds;
   const int tid = threadIdx.x, lane = tid & 63;
+  // (debug: phase stamps by thread 0 -- tools/frozen_trace.py)
+  unsigned long long* const trw = batch.trace ? batch.trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+  auto stamp = [&](int k) { if (trw && tid == 0) trw[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;       // rows 32 wm .. + 31, hidden columns 64 wn .. + 63
   const int fr = lane & 15, fg = lane >> 4;
@@ -116,6 +120,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // slab t landed for every wave; the stage of slab t - 1 (= slab t + 2's) is free
+    if (t == 0) stamp(1);
+    if (t == 8) stamp(2);
+    if (t == 16) stamp(3);
     if (t + 2 < nt) issue_l1();
     const unsigned char* sa = lds + (t % NST1) * STAGE1;
     const unsigned char* sb = sa + A_BYTES;
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // every wave is done with layer 1's ring: the second LDS plan takes over
+  stamp(4);
 
   // ---- the later layers' stream: slab c = W2's k-slab c (c < 4), then (actor) W3's two double slabs; ring stage c % 3
   const unsigned voff_sq = (unsigned)(l_row * (int)P.ldw2 * 2 + l_c);   // W2 / W3 share the pitch (mlpf_launch)
@@ -188,6 +196,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
     }
     hidden_epilogue<4>(acc, b1v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key1, spanel);
   }
+  stamp(5);
   // the later layers' constants (after the epilogue: the accumulators' registers are free again)
   f32x4 b2v[4];
 #pragma unroll
@@ -239,7 +248,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // everyone is done reading the h1 panel
+  stamp(6);
   hidden_epilogue<4>(acc, b2v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key2, spanel);
+  stamp(7);
 
   if (actor) {
     // ---------------------------------------------------------------- layer 3: 128 x 128 outputs, wave tile 32 x 32
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
         }
       }
     }
+    stamp(8);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int m = sm0 + tm * 16 + fr;
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
         }
       }
     }
+    stamp(9);
     return;
   }
 
@@ -333,7 +346,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
     s = wave_sum(s);
     if (lane == 0 && m0 + prow < P.rows && P.q) P.q[m0 + prow] = s + b3s;
   }
+  stamp(9);
 }
+static unsigned long long* g_frozen_trace = nullptr;
+extern "C" void recnn_debug_frozen_trace(void* p) { g_frozen_trace = (unsigned long long*)p; }   // read at launch (= graph capture) time
 
 int mlpf_init() {
   return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_frozen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlp_frozen attr");
@@ -361,6 +377,8 @@ int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s) {
     if (p.W3) RECNN_REQUIRE(p.out && p.ldw3 == p.ldw2 && (((uintptr_t)p.W3) & 15) == 0 && p.ldo % 4 == 0, "mlp_frozen: actor needs W3 (same pitch as W2) and an output");
     else RECNN_REQUIRE(p.w3row && p.q, "mlp_frozen: critic needs its last layer's row and a Q output");
   }
-  hipLaunchKernelGGL(mlp_frozen_kernel, dim3((rows + FR - 1) / FR, nprob), dim3(NW * 64), LDS_TOTAL, s, b);
+  FrozenBatch bb = b;
+  bb.trace = g_frozen_trace;
+  hipLaunchKernelGGL(mlp_frozen_kernel, dim3((rows + FR - 1) / FR, nprob), dim3(NW * 64), LDS_TOTAL, s, bb);
   return recnn_check_hip(hipGetLastError(), "mlp_frozen_kernel");
 }

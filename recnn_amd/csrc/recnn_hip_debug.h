@@ -14,6 +14,7 @@ void recnn_debug_mlp_probe(int bits);
 /* shader-clock stamps of a kernel's phases: device uint64 [workgroup][32] (mlps_fwd_kernel) / [workgroup][16]; NULL = off */
 void recnn_debug_mlp_trace(void* device_u64_wg32);
 void recnn_debug_tail_trace(void* device_u64_wg16);
+void recnn_debug_frozen_trace(void* device_u64_wg16);   /* mlp_frozen_kernel: read at launch (= capture) time */
 void recnn_debug_l1_trace(void* device_u64_wg16);
 /* kernel variant of the split-bf16 forward GEMM for the single-problem entry point recnn_gemm_fwd (engines carry their own:
  * recnn_engine_tuning::x3_fwd); -1 = off */

@@ -134,6 +134,9 @@ struct FrozenProb {
   float* q;                       // critic output, fp32 [rows] (b3 included)
 };
 constexpr int FROZEN_MAX_GROUP = 4;
-struct FrozenBatch { FrozenProb p[FROZEN_MAX_GROUP]; };
+struct FrozenBatch {
+  FrozenProb p[FROZEN_MAX_GROUP];
+  unsigned long long* trace;      // debug: [workgroup][16] shader-clock stamps (set by mlpf_launch from recnn_debug_frozen_trace)
+};
 int mlpf_init();
 int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s);
