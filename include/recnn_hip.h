@@ -582,7 +582,10 @@ typedef struct recnn_engine_tuning {
                                per-workgroup epilogue work (its phases are bound by the CU's vector issue); 0: 32-row panels.  Bit-identical */
   int l1_ws;                /* 1: the per-step layer-1 GEMM (csrc/l1gemm.hip, 64 x 64 tiles) runs with 4 loader + 8 consumer waves; 0: all 16 waves
                                load and multiply.  Bit-identical */
-  int reserved[4];
+  int frozen_half;          /* 1: a cycle segment's frozen-network launch (csrc/mlpf.hip) runs 64-row workgroups instead of 128-row ones while
+                               it then still fits one round of workgroups (short segments: a request that starts or ends inside a policy
+                               cycle); 0: always 128 rows.  Bit-identical */
+  int reserved[3];
 } recnn_engine_tuning;
 void recnn_engine_tuning_init(recnn_engine_tuning* h_t);
 int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* h_t);

@@ -91,12 +91,12 @@ class Sampler(C.Structure):
 
 TUNING_FIELDS = ("fused_mlp", "chain_target_critic", "bwd_panel", "policy_chain", "split_fwd", "cycle_min_len", "cycle_min_seg",
                  "frozen_fused", "frozen_gemm", "graph_run", "pregather", "defer_policy_fwd", "sampler_f32_rows", "dw_splits", "comm_fused",
-                 "l1_big", "gemm_variant", "gemm_v0_threshold", "gemm_dma", "gemm_dma_depth", "gemm_dma_waves", "gemm_waves", "dw_dma", "x3_tail", "x3_fwd", "dw_fuse", "tail_half", "l1_ws")
+                 "l1_big", "gemm_variant", "gemm_v0_threshold", "gemm_dma", "gemm_dma_depth", "gemm_dma_waves", "gemm_waves", "dw_dma", "x3_tail", "x3_fwd", "dw_fuse", "tail_half", "l1_ws", "frozen_half")
 
 
 class EngineTuning(C.Structure):
     """include/recnn_hip.h recnn_engine_tuning: schedule / tile choices of ONE engine (all compute the same numbers)."""
-    _fields_ = [(f, C.c_int) for f in TUNING_FIELDS] + [("reserved", C.c_int * 4)]
+    _fields_ = [(f, C.c_int) for f in TUNING_FIELDS] + [("reserved", C.c_int * 3)]
 
 
 _P = C.c_void_p

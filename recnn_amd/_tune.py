@@ -18,7 +18,7 @@ ENV_FIELDS = {
     "RECNN_SAMPLER_F32": "sampler_f32_rows", "RECNN_DW_SPLITS": "dw_splits", "RECNN_COMM_FUSED": "comm_fused", "RECNN_L1_BIG": "l1_big",
     "RECNN_GEMM_VARIANT": "gemm_variant", "RECNN_V0_MIN_WG": "gemm_v0_threshold", "RECNN_GEMM_DMA": "gemm_dma",
     "RECNN_DMA_DEEP": "gemm_dma_depth", "RECNN_DMA_WAVES": "gemm_dma_waves", "RECNN_GEMM_WAVES": "gemm_waves", "RECNN_DW_DMA": "dw_dma",
-    "RECNN_X3_TAIL": "x3_tail", "RECNN_X3_FWD": "x3_fwd", "RECNN_DW_FUSE": "dw_fuse", "RECNN_TAIL_HALF": "tail_half", "RECNN_L1_WS": "l1_ws",
+    "RECNN_X3_TAIL": "x3_tail", "RECNN_X3_FWD": "x3_fwd", "RECNN_DW_FUSE": "dw_fuse", "RECNN_TAIL_HALF": "tail_half", "RECNN_L1_WS": "l1_ws", "RECNN_FROZEN_HALF": "frozen_half",
 }
 # process-level settings of the peer communicators (shared by engines: not part of an engine's tuning) and debug hooks
 # (RECNN_COMM_MEMORY / RECNN_COMM_WORKGROUPS are read by each PeerComm for ITSELF: recnn_amd/parallel.py)

@@ -268,7 +268,7 @@ extern "C" void recnn_engine_tuning_init(recnn_engine_tuning* t) {
   t->graph_run = -1; t->pregather = 1; t->defer_policy_fwd = 1;
   t->sampler_f32_rows = 0; t->dw_splits = 8; t->comm_fused = 1; t->l1_big = 1;
   t->gemm_variant = -1; t->gemm_v0_threshold = 512; t->gemm_dma = 1; t->gemm_dma_depth = 1; t->gemm_dma_waves = 8;
-  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1; t->tail_half = 1; t->l1_ws = 1;
+  t->gemm_waves = 8; t->dw_dma = 2; t->x3_tail = 1; t->x3_fwd = 2; t->dw_fuse = 1; t->tail_half = 1; t->l1_ws = 1; t->frozen_half = 1;
 }
 extern "C" int recnn_engine_set_tuning(recnn_engine* e, const recnn_engine_tuning* t) {
   RECNN_REQUIRE(e && t, "set_tuning: null pointer");
@@ -1488,14 +1488,23 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
     // with the second three quarters empty.  The actor depends on nothing here, so its batches are dealt out over both
     // launches to fill them: as many whole batches next to the target actor as fit the first round, the rest next to the
     // target critics (DDPG, 10 x 2048 rows: 160 + 96 and 160 + 64 workgroups = two full rounds instead of three).
+    // Short segments (round 6; a run that starts or ends inside a policy cycle): a launch lasts as long as ONE workgroup does, whatever
+    // the segment's length -- with 64-row workgroups that is 0.7 of the time, as long as the launch still fits one round.
+    const int cus = 256;
     const int wg_set = (rows + 127) / 128;                            // workgroups per batch (batches start on panel boundaries
-    int sets_a = n;                                                   //  when rows is a multiple of 128: else no dealing)
+    const int wg_set64 = rows / 64;                                   //  when rows is a multiple of 128: else no dealing)
+    int sets_a = n, fr_a = 128, fr_b = 128;
     if (rows % 128 == 0) {
-      const int cus = 256;
-      const int free1 = ((n * wg_set + cus - 1) / cus) * cus - n * wg_set;   // idle slots of the target actor's last round
-      sets_a = free1 / wg_set;
+      if (e->tune.frozen_half && n * wg_set64 <= cus) {
+        fr_a = 64;
+        sets_a = (cus - n * wg_set64) / wg_set64;
+      } else {
+        const int free1 = ((n * wg_set + cus - 1) / cus) * cus - n * wg_set;   // idle slots of the target actor's last round
+        sets_a = free1 / wg_set;
+      }
       if (sets_a > n) sets_a = n;
       if (sets_a < 0) sets_a = 0;
+      if (e->tune.frozen_half && (nc * n + (n - sets_a)) * wg_set64 <= cus) fr_b = 64;
     }
     auto actor_part = [&](FrozenProb* p, int set0, int nsets) {      // the actor on batches set0 .. set0 + nsets - 1
       const int64_t r0 = (int64_t)set0 * rows;
@@ -1512,7 +1521,7 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
     if (e->td3) { fb.p[np].addend = e->m_noise; fb.p[np].ld_add = A; fb.p[np].add_clip = e->hy.noise_clip; }
     ++np;
     if (sets_a > 0) actor_part(&fb.p[np++], 0, sets_a);              // actor on s -> gen_action, activations kept for the policy step
-    if ((rc = slot(e, "frozen_actors", l1_fl_a + t_fl_a + (l1_fl_a + t_fl_a) * sets_a / n, s, [&] { return mlpf_launch(fb, np, s); }))) return rc;
+    if ((rc = slot(e, "frozen_actors", l1_fl_a + t_fl_a + (l1_fl_a + t_fl_a) * sets_a / n, s, [&] { return mlpf_launch(fb, np, s, fr_a); }))) return rc;
     FrozenBatch fc;
     int nq = 0;
     for (int c = 0; c < nc; ++c) {                                  // target critics on [s' | next_action]: state part first
@@ -1522,7 +1531,7 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
       ++nq;
     }
     if (sets_a < n) actor_part(&fc.p[nq++], sets_a, n - sets_a);
-    return slot(e, "frozen_target_critics", nc * (l1_fl_c + t_fl_c) + (l1_fl_a + t_fl_a) * (n - sets_a) / n, s, [&] { return mlpf_launch(fc, nq, s); });
+    return slot(e, "frozen_target_critics", nc * (l1_fl_c + t_fl_c) + (l1_fl_a + t_fl_a) * (n - sets_a) / n, s, [&] { return mlpf_launch(fc, nq, s, fr_b); });
   }
 
   {

@@ -21,23 +21,37 @@
 
 namespace {
 constexpr int NW = 16;
-constexpr int FR = 128;                          // rows per workgroup
-constexpr int A_BYTES = FR * 128;                // 16 KB: one 64-k slab of the rows
 constexpr int W_BYTES = HP * 128;                // 32 KB: one 64-k slab of a 256-row weight matrix
-constexpr int STAGE1 = A_BYTES + W_BYTES;        // 48 KB
 constexpr int NST1 = 3;
-constexpr int PANEL_BYTES = 4 * 2 * PANEL_HALF;  // 64 KB: four 32-row sub-panels
-constexpr int WR_OFF = PANEL_BYTES;              // the later layers' ring: 3 x 32 KB behind the panel
-constexpr int CONST_OFF = NST1 * STAGE1;         // 144 KB: b1 | b2 | b3 or w3 (fp32, 1 KB each) while layer 1 runs
-constexpr int LDS_TOTAL = NST1 * STAGE1 + 16 * 1024;   // 160 KB (= panel + 3 x 32 KB)
-static_assert(LDS_TOTAL == PANEL_BYTES + 3 * W_BYTES, "the two LDS plans share one allocation");
+constexpr int LDS_TOTAL = 160 * 1024;
+// FR = rows per workgroup: 128 (waves as 4 row groups x 4 column groups, wave tile 32 x 64), or 64 (2 x 8, wave tile 32 x 32) for the
+// launches of SHORT cycle segments (round 6): a launch lasts as long as one workgroup does (one workgroup per CU, <= 256 of them), and a
+// request that starts or ends inside a policy cycle -- the driver's 20 steps are segments of 6 + 10 + 4 -- pays two launches per
+// segment whatever its length; half the rows per workgroup is 0.7 of the time (tools/frozen_trace.py: 48.5k against 69.6k clocks) while
+// the launch still fits one round.
+template <int FR> struct FrozenPlan {
+  static constexpr int WMG = FR / 32, WNG = NW / WMG;            // row groups x column groups of the 16 waves
+  static constexpr int TNH = HP / WNG / 16;                      // 16-column blocks per wave in the hidden layers: 4 | 2
+  static constexpr int TN3 = 128 / WNG / 16;                     // ... in the actor's output layer: 2 | 1
+  static constexpr int A_BYTES = FR * 128;                       // one 64-k slab of the rows: 16 | 8 KB
+  static constexpr int STAGE1 = A_BYTES + W_BYTES;               // 48 | 40 KB
+  static constexpr int PANEL_BYTES = WMG * 2 * PANEL_HALF;       // 32-row sub-panels: 64 | 32 KB
+  static constexpr int WR_OFF = PANEL_BYTES;                     // the later layers' ring: 3 x 32 KB behind the panel
+  static constexpr int CONST_OFF = NST1 * STAGE1;                // 144 | 120 KB: b1 | b2 | b3 or w3 (fp32, 1 KB each) while layer 1 runs --
+  static constexpr int A_WAVES = FR / 8;                         //   inside the later ring's third stage in both plans
+  static_assert(CONST_OFF + 3 * 1024 <= LDS_TOTAL && PANEL_BYTES + 3 * W_BYTES <= LDS_TOTAL, "the two LDS plans share one allocation");
+  static_assert(CONST_OFF >= WR_OFF + 2 * W_BYTES, "the constants must survive the later layers' first two slabs");
+};
 
 __device__ __forceinline__ void dma_s(unsigned voff, const void* sbase, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "m0");
 }
 }  // namespace
 
+template <int FR>
 __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch batch) {
+  using PL = FrozenPlan<FR>;
+  constexpr int WNG = PL::WNG, TNH = PL::TNH, TN3 = PL::TN3, A_BYTES = PL::A_BYTES, STAGE1 = PL::STAGE1, WR_OFF = PL::WR_OFF, CONST_OFF = PL::CONST_OFF;
   const FrozenProb& P = batch.p[blockIdx.y];
   const int m0 = blockIdx.x * FR;
   if (m0 >= P.rows) return;
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   auto stamp = [&](int k) { if (trw && tid == 0) trw[k] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;       // rows 32 wm .. + 31, hidden columns 64 wn .. + 63
+  const int wm = wave / WNG, wn = wave % WNG;    // rows 32 wm .. + 31, hidden columns 16 TNH wn .. + 16 TNH - 1
   const int fr = lane & 15, fg = lane >> 4;
   const bool actor = P.W3 != nullptr;
   const int sw = (fr >> 1) & 7;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
     }
     const unsigned sb = lds0 + (issued % NST1) * STAGE1 + wave_kb;
     ++issued;
-    dma_s(voff_a, a_base, sb);
+    if (FR == 128 || wave < PL::A_WAVES) dma_s(voff_a, a_base, sb);      // (64 rows: one instruction each from waves 0..7)
     dma_s(voff_w, w_base, sb + A_BYTES);
     dma_s(voff_w, w_base + w_half, sb + A_BYTES + NW * 1024);
     a_base += 128;
@@ -110,15 +124,16 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   issue_l1();
   issue_l1();                                     // (layer 1 has at least 2 slabs)
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][TNH];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 >= nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (FR == 128 || wave < PL::A_WAVES) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // (waves 8..15 of the 64-row plan issue two instructions per slab)
     __builtin_amdgcn_s_barrier();                 // slab t landed for every wave; the stage of slab t - 1 (= slab t + 2's) is free
     if (t == 0) stamp(1);
     if (t == 8) stamp(2);
@@ -129,15 +144,15 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int pos = ((ks * 4 + fg) ^ sw) * 16;
-      uint4 a[2], b[4];
+      uint4 a[2], b[TNH];
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (wm * 32 + tm * 16 + fr) * 128 + pos);
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) b[tn] = *(const uint4*)(sb + (wn * 64 + tn * 16 + fr) * 128 + pos);
+      for (int tn = 0; tn < TNH; ++tn) b[tn] = *(const uint4*)(sb + (wn * (16 * TNH) + tn * 16 + fr) * 128 + pos);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < TNH; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]), acc[tm][tn], 0, 0, 0);
     }
   }
@@ -188,29 +203,29 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   const uint32_t key2 = P.mask_mode == RECNN_MASK_HASH ? mask_key(P.seed, step0, P.stream2) : 0u;
   const float* cst = (const float*)(lds + CONST_OFF);
   {
-    f32x4 b1v[4];
+    f32x4 b1v[TNH];
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = wn * 64 + tn * 16 + fg * 4;
+    for (int tn = 0; tn < TNH; ++tn) {
+      const int n = wn * (16 * TNH) + tn * 16 + fg * 4;
       b1v[tn] = (n + 3 < P.H) ? *(const f32x4*)(cst + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    hidden_epilogue<4>(acc, b1v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key1, spanel);
+    hidden_epilogue<TNH>(acc, b1v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key1, spanel);
   }
   stamp(5);
   // the later layers' constants (after the epilogue: the accumulators' registers are free again)
-  f32x4 b2v[4];
+  f32x4 b2v[TNH];
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int n = wn * 64 + tn * 16 + fg * 4;
+  for (int tn = 0; tn < TNH; ++tn) {
+    const int n = wn * (16 * TNH) + tn * 16 + fg * 4;
     b2v[tn] = (n + 3 < P.H) ? *(const f32x4*)(cst + 256 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float v3[2][4];                                 // actor: b3 of this lane's output columns 32 wn + 16 tn + 4 fg + r
+  float v3[TN3][4];                               // actor: b3 of this lane's output columns 16 TN3 wn + 16 tn + 4 fg + r
   float w3v[4];                                   // critic: w3 of columns 4 lane .. 4 lane + 3
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
+  for (int tn = 0; tn < TN3; ++tn)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int no = wn * 32 + tn * 16 + fg * 4 + r;
+      const int no = wn * (16 * TN3) + tn * 16 + fg * 4 + r;
       v3[tn][r] = (actor && no < P.out_dim) ? cst[512 + no] : 0.f;
     }
 #pragma unroll
@@ -222,48 +237,48 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int q = 0; q < 4; ++q) {
     const unsigned char* st = next_post();        // (its barrier also completes the h1 panel for q = 0)
     if (q == 0 && P.h1) {
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h1, P.ldh, m0 + sp * 32, P.rows, tid);
+      for (int sp = 0; sp < PL::WMG; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h1, P.ldh, m0 + sp * 32, P.rows, tid);
     }
     const unsigned char* sa = spanel + (q >> 1) * PANEL_HALF;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int posa = ((((q & 1) * 8) + ks * 4 + fg) ^ fr) * 16;
       const int posb = ((ks * 4 + fg) ^ sw) * 16;
-      uint4 a[2], b[4];
+      uint4 a[2], b[TNH];
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + posa);
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) b[tn] = *(const uint4*)(st + (wn * 64 + tn * 16 + fr) * 128 + posb);
+      for (int tn = 0; tn < TNH; ++tn) b[tn] = *(const uint4*)(st + (wn * (16 * TNH) + tn * 16 + fr) * 128 + posb);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < TNH; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]), acc[tm][tn], 0, 0, 0);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // everyone is done reading the h1 panel
   stamp(6);
-  hidden_epilogue<4>(acc, b2v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key2, spanel);
+  hidden_epilogue<TNH>(acc, b2v, P.H, P.rows - (sm0 - mrow0), mrow0, wn, fr, fg, P.mask_mode, nullptr, 0, key2, spanel);
   stamp(7);
 
   if (actor) {
     // ---------------------------------------------------------------- layer 3: 128 x 128 outputs, wave tile 32 x 32
-    f32x4 o[2][2];
+    f32x4 o[2][TN3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN3; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < 2; ++p) {
       const unsigned char* st = next_post();      // (completes the h2 panel for p = 0)
       if (p == 0 && P.h2) {
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h2, P.ldh, m0 + sp * 32, P.rows, tid);
+        for (int sp = 0; sp < PL::WMG; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h2, P.ldh, m0 + sp * 32, P.rows, tid);
       }
 #pragma unroll
       for (int hq = 0; hq < 2; ++hq) {            // k quarter q = 2 p + hq of the panel against image rows hq * 128 + output column
@@ -273,15 +288,15 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
         for (int ks = 0; ks < 2; ++ks) {
           const int posa = ((((q & 1) * 8) + ks * 4 + fg) ^ fr) * 16;
           const int posb = ((ks * 4 + fg) ^ sw) * 16;
-          uint4 a[2], b[2];
+          uint4 a[2], b[TN3];
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm) a[tm] = *(const uint4*)(sa + (tm * 16 + fr) * 256 + posa);
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) b[tn] = *(const uint4*)(st + (hq * 128 + wn * 32 + tn * 16 + fr) * 128 + posb);
+          for (int tn = 0; tn < TN3; ++tn) b[tn] = *(const uint4*)(st + (hq * 128 + wn * (16 * TN3) + tn * 16 + fr) * 128 + posb);
 #pragma unroll
           for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < TN3; ++tn)
               o[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[tn]), __builtin_bit_cast(bf16x8, a[tm]), o[tm][tn], 0, 0, 0);
         }
       }
@@ -291,8 +306,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
     for (int tm = 0; tm < 2; ++tm) {
       const int m = sm0 + tm * 16 + fr;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int no = wn * 32 + tn * 16 + fg * 4;
+      for (int tn = 0; tn < TN3; ++tn) {
+        const int no = wn * (16 * TN3) + tn * 16 + fg * 4;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_frozen_kernel(const FrozenBatch b
   __builtin_amdgcn_s_barrier();                   // h2 panel complete
   if (P.h2) {
 #pragma unroll
-    for (int sp = 0; sp < 4; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h2, P.ldh, m0 + sp * 32, P.rows, tid);
+    for (int sp = 0; sp < PL::WMG; ++sp) panel_to_global<NW>(lds + sp * (2 * PANEL_HALF), (bf16_t*)P.h2, P.ldh, m0 + sp * 32, P.rows, tid);
   }
   for (int i = 0; i < FR / NW; ++i) {
     const int prow = wave * (FR / NW) + i;        // row of the 128-row panel
@@ -352,11 +367,14 @@ static unsigned long long* g_frozen_trace = nullptr;
 extern "C" void recnn_debug_frozen_trace(void* p) { g_frozen_trace = (unsigned long long*)p; }   // read at launch (= graph capture) time
 
 int mlpf_init() {
-  return recnn_check_hip(hipFuncSetAttribute((const void*)mlp_frozen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlp_frozen attr");
+  int rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_frozen_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlp_frozen attr");
+  if (!rc) rc = recnn_check_hip(hipFuncSetAttribute((const void*)mlp_frozen_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL), "mlp_frozen<64> attr");
+  return rc;
 }
 
-int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s) {
+int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s, int panel_rows) {
   RECNN_REQUIRE(nprob >= 1 && nprob <= FROZEN_MAX_GROUP, "mlp_frozen: 1..%d problems per launch", FROZEN_MAX_GROUP);
+  RECNN_REQUIRE(panel_rows == 128 || panel_rows == 64, "mlp_frozen: 128 or 64 rows per workgroup");
   int rows = 0;
   for (int i = 0; i < nprob; ++i) {
     const FrozenProb& p = b.p[i];
@@ -379,6 +397,7 @@ int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s) {
   }
   FrozenBatch bb = b;
   bb.trace = g_frozen_trace;
-  hipLaunchKernelGGL(mlp_frozen_kernel, dim3((rows + FR - 1) / FR, nprob), dim3(NW * 64), LDS_TOTAL, s, bb);
+  if (panel_rows == 64) hipLaunchKernelGGL(mlp_frozen_kernel<64>, dim3((rows + 63) / 64, nprob), dim3(NW * 64), LDS_TOTAL, s, bb);
+  else hipLaunchKernelGGL(mlp_frozen_kernel<128>, dim3((rows + 127) / 128, nprob), dim3(NW * 64), LDS_TOTAL, s, bb);
   return recnn_check_hip(hipGetLastError(), "mlp_frozen_kernel");
 }

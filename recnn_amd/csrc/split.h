@@ -139,4 +139,5 @@ struct FrozenBatch {
   unsigned long long* trace;      // debug: [workgroup][16] shader-clock stamps (set by mlpf_launch from recnn_debug_frozen_trace)
 };
 int mlpf_init();
-int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s);
+// panel_rows: rows per workgroup, 128 | 64 (the same numbers: the launches of short cycle segments take 64 while they fit one round)
+int mlpf_launch(const FrozenBatch& b, int nprob, hipStream_t s, int panel_rows = 128);

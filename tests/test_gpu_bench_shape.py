@@ -176,6 +176,38 @@ def test_bench_shape_run_equals_loop_and_oracle(cuda, dtype, n):
     print("bench-shape parity:", json.dumps(report))
 
 
+def test_short_segment_frozen_launches_on_64_row_workgroups(cuda):
+    """tuning.frozen_half (round 6): a request that starts and ends inside policy cycles -- the driver's 5 + 20 steps are cycle segments of
+    6 + 10 + 4 -- runs the frozen networks of its short segments on 64-row workgroups (csrc/mlpf.hip, wave tile 32 x 32) instead of
+    128-row ones: every parameter and the loss history bit for bit, for several request lengths (segments of 1..10 steps)."""
+    import recnn_amd
+    from recnn_amd._tune import set_default_tuning
+    env, _ = _bench_env(recnn_amd, cuda, n_users=80 * UPB, n_items=3000)
+
+    def run(half):
+        set_default_tuning(frozen_half=half)
+        try:
+            ddpg = _make_algo(recnn_amd, cuda, env, "bf16")
+            assert ddpg._fused_ctx.engine.tuning.frozen_half == half
+            hist = []
+            first = 0
+            for k in (5, 20, 23, 27):                      # 20 from step 5: 6 + 10 + 4; 23 from 25: 6 + 10 + 7; 27 from 48: 3 + 10 + 10 + 4
+                if k >= 20:
+                    ddpg.prepare_run(k, first_step=first)
+                _, h = ddpg.run(k, history=True)
+                hist += h
+                first += k
+            torch.cuda.synchronize()
+            return hist, _snapshot(ddpg)
+        finally:
+            set_default_tuning(frozen_half=None)
+    (h0, p0), (h1, p1) = run(0), run(1)
+    for net, sd in p0.items():
+        for k, v in sd.items():
+            assert torch.equal(v, p1[net][k]), (net, k)
+    assert h0 == h1
+
+
 def test_run_interleaved_with_test_updates(cuda):
     """`algo.update(env.test_batch(), learn=False)` between two `run()` calls evaluates the batch it was given (not a
     sampler batch), leaves the sampler cursor and the optimizer counters alone, and the next `run()` picks up where the

@@ -1,5 +1,5 @@
 """In-kernel phase timeline (shader-clock stamps by thread 0 of every workgroup) of mlp_frozen_kernel in the cycle schedule's run graphs
-(the trace pointer is captured into the graphs: armed BEFORE attach_env builds them).  usage: python tools/frozen_trace.py"""
+(the trace pointer is captured into the graphs: armed BEFORE attach_env builds them).  usage: [DRIVER=1] python tools/frozen_trace.py"""
 import os, sys
 import numpy as np
 import torch
@@ -25,7 +25,12 @@ lib.recnn_debug_frozen_trace(L.ptr(tr))
 algo.attach_env(env, rows_per_batch=2048, users_per_batch=None, shard=(0, 1))
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
-    algo.run(200)
+    if os.environ.get("DRIVER"):     # the driver's request: 5 warm-up steps, then 20 = segments of 6 + 10 + 4 (the short ones on 64-row workgroups)
+        algo.run(5)
+        algo.prepare_run(20, first_step=5)
+        algo.run(20)
+    else:
+        algo.run(200)
     torch.cuda.synchronize()
 lib.recnn_debug_frozen_trace(None)
 t = tr.cpu().numpy()
