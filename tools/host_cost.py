@@ -1,3 +1,5 @@
+"""Host-side cost of one timed `run(20)` region (the driver's command): Python in front of the graph launch, hipGraphLaunch itself, the wait for
+the GPU in read_losses, and the per-call cost of the context's checks.  usage: python tools/host_cost.py"""
 import os, sys, time
 import numpy as np
 import torch
