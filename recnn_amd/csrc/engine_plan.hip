@@ -1488,23 +1488,21 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
     // with the second three quarters empty.  The actor depends on nothing here, so its batches are dealt out over both
     // launches to fill them: as many whole batches next to the target actor as fit the first round, the rest next to the
     // target critics (DDPG, 10 x 2048 rows: 160 + 96 and 160 + 64 workgroups = two full rounds instead of three).
-    // Short segments (round 6; a run that starts or ends inside a policy cycle): a launch lasts as long as ONE workgroup does, whatever
-    // the segment's length -- with 64-row workgroups that is 0.7 of the time, as long as the launch still fits one round.
+    // Round 6: 64-row workgroups last 0.70 of a 128-row one's time (tools/frozen_trace.py: 48.5k against 69.6k clocks) -- a gain while the
+    // launch still fits the same number of rounds, i.e. for the SHORT segments of a run that starts or ends inside a policy cycle (the
+    // driver's 20 steps: 6 + 10 + 4).  All (rows per workgroup of launch 1, actor batches in launch 1, rows per workgroup of launch 2)
+    // are priced as rounds x duration; ties go to the 128-row form and to the larger first share.
     const int cus = 256;
-    const int wg_set = (rows + 127) / 128;                            // workgroups per batch (batches start on panel boundaries
-    const int wg_set64 = rows / 64;                                   //  when rows is a multiple of 128: else no dealing)
     int sets_a = n, fr_a = 128, fr_b = 128;
     if (rows % 128 == 0) {
-      if (e->tune.frozen_half && n * wg_set64 <= cus) {
-        fr_a = 64;
-        sets_a = (cus - n * wg_set64) / wg_set64;
-      } else {
-        const int free1 = ((n * wg_set + cus - 1) / cus) * cus - n * wg_set;   // idle slots of the target actor's last round
-        sets_a = free1 / wg_set;
-      }
-      if (sets_a > n) sets_a = n;
-      if (sets_a < 0) sets_a = 0;
-      if (e->tune.frozen_half && (nc * n + (n - sets_a)) * wg_set64 <= cus) fr_b = 64;
+      float best = 1e30f;
+      for (int fa = 128; fa >= (e->tune.frozen_half ? 64 : 128); fa -= 64)
+        for (int fb = 128; fb >= (e->tune.frozen_half ? 64 : 128); fb -= 64)
+          for (int sa = n; sa >= 0; --sa) {
+            const int wa = (n + sa) * (rows / fa), wb = (nc * n + (n - sa)) * (rows / fb);
+            const float cost = (float)((wa + cus - 1) / cus) * (fa == 64 ? 0.70f : 1.0f) + (float)((wb + cus - 1) / cus) * (fb == 64 ? 0.70f : 1.0f);
+            if (cost < best - 1e-6f) { best = cost; sets_a = sa; fr_a = fa; fr_b = fb; }
+          }
     }
     auto actor_part = [&](FrozenProb* p, int set0, int nsets) {      // the actor on batches set0 .. set0 + nsets - 1
       const int64_t r0 = (int64_t)set0 * rows;
