@@ -23,7 +23,8 @@
 
 constexpr int LOSS_RING = 1024;   // loss history ring entries (power of two)
 
-int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s);
+// n_sets > 1: consecutive batches of n elements each, batch j under the key of step + step_add + j
+int noise_fill_launch(float* out, int64_t n, float stddev, uint32_t seed, const int32_t* step_ptr, int step_add, hipStream_t s, int n_sets = 1);
 int rows_to_bf16_launch(const float* xs, const float* xn, bf16_t* hs, bf16_t* hn, int rows, int64_t ld, hipStream_t s);
 
 static inline int64_t ru(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -1459,9 +1459,8 @@ int ph_frozen_batched(recnn_engine* e, int rows, int n, int run_off0, hipStream_
   const int64_t aoff = (int64_t)A * 2;
   const int M = n * rows;
   int rc;
-  if (e->td3 && !e->ext_noise)
-    for (int j = 0; j < n; ++j)
-      if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->m_noise + (int64_t)j * rows * A, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, run_off0 + j, s); }))) return rc;
+  if (e->td3 && !e->ext_noise)     // the cycle's batches in one launch (batch j: the key of step run_off0 + j)
+    if ((rc = slot(e, "td3_noise", 0, s, [&] { return noise_fill_launch(e->m_noise, (int64_t)rows * A, e->hy.noise_std, e->cfg.seed, e->counters, run_off0, s, n); }))) return rc;
   const double l1_fl_a = 2.0 * M * (double)e->H * e->S, l1_fl_c = 2.0 * M * (double)e->H * (e->S + A);
   const double t_fl_a = 2.0 * M * ((double)e->H * e->H + (double)A * e->H), t_fl_c = 2.0 * M * ((double)e->H * e->H + e->H);
   if (e->tune.frozen_fused) {
