@@ -489,7 +489,11 @@ int ph_forward_split(recnn_engine* e, int rows, bool value_side, bool actor_side
       fl += l1_fl_c; tfl += t_fl_c;
       e->pending_pc.on = false;
     }
-    if ((rc = slot(e, "l1_critic", fl, s, [&] { return l1gemm_launch(lb, np, 0, s, e->tune.l1_ws); }))) return rc;
+    // 64 x 64 tiles while they fit two rounds of workgroups; beyond that (TD3 at 4096 rows: 3 problems x 256 tiles = three rounds of 8 us)
+    // the 128 x 128 form -- a quarter of the workgroups, twice the stream each: one round (122.35 -> 120.1 us/step, A/B in one call)
+    const int tiles64 = np * ((rows + 63) / 64) * 4;
+    const int big = tiles64 > 512 ? 1 : 0;
+    if ((rc = slot(e, "l1_critic", fl, s, [&] { return l1gemm_launch(lb, np, big, s, e->tune.l1_ws); }))) return rc;
     if ((rc = slot(e, "tail_critic", tfl, s, [&] { return mlpt_launch(tb, np, s); }))) return rc;
   }
   e->panel_bwd_done = true;     // dz2 / dz1 (already times the per-row loss seed) and the small tensors' panel sums exist
